@@ -1,0 +1,135 @@
+/*
+ * libsaicv_hip.so -- C-ABI of the MI355X (gfx950) kernels behind the SimpleAICV DDP
+ * forward/backward hot path.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer borrowed for the call (allocated by the caller, e.g.
+ *    PyTorch's caching allocator); the library allocates nothing and frees nothing;
+ *  - `stream` is a hipStream_t passed as void*; every launch goes on it, no implicit syncs,
+ *    so calls are capturable in a hipGraph and safe on the communication side stream;
+ *  - return 0 on success, negative on error; the message is in saicv_last_error_string()
+ *    (thread local).  Nothing throws across the ABI;
+ *  - dtype: SAICV_BF16 = perf mode (bf16 storage, fp32 accumulate / statistics),
+ *           SAICV_F32  = parity mode (fp32 everywhere, exact-f32 MFMA);
+ *  - activations are dense NHWC ([N,H,W,C], C fastest); conv weights are "KRSC"
+ *    ([Cout][R][S][Cin], Cin fastest); C and Cout must be multiples of 8 (bf16) / 4 (f32).
+ *
+ * Each entry point names the reference call it replaces (paths relative to the reference
+ * repository zgcr/SimpleAICV_pytorch_training_examples).
+ */
+#ifndef SAICV_HIP_H
+#define SAICV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAICV_BF16 0
+#define SAICV_F32 1
+
+typedef struct saicv_conv_desc {
+    int N, H, W, C;      /* input  [N,H,W,C]                       */
+    int K, R, S;         /* weight [K][R][S][C]                    */
+    int stride, pad;
+    int OH, OW;          /* output [N,OH,OW,K]                     */
+    int dtype;           /* SAICV_BF16 | SAICV_F32                 */
+} saicv_conv_desc;
+
+int saicv_version(void);
+const char* saicv_last_error_string(void);
+
+/* ---- layout packing ------------------------------------------------------------------ */
+/* NCHW-shaped fp32 batch with element strides (sN,sC,sH,sW) -> dense NHWC [N,H,W,Cp],
+ * channels zero-padded.  Input contract: SimpleAICV/classification/common.py:645-665
+ * (ClassificationCollater returns an NHWC-strided, NCHW-shaped fp32 tensor). */
+int saicv_pack_input(int dtype, const float* src, long sN, long sC, long sH, long sW, void* dst,
+                     int N, int C, int H, int W, int Cp, void* stream);
+/* fp32 master weight [O,I,R,S] (element strides) -> Wf[O][R][S][Ip] and optionally the
+ * data-gradient matrix Wd[I][R][S][O] (NULL to skip).  nn.Conv2d / nn.Linear weights of
+ * resnet.py:33-39, :204. */
+int saicv_pack_weight(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I,
+                      int R, int S, int Ip, void* wf, void* wd, void* stream);
+/* fp32 dW[O][R][S][Ip] -> gradient tensor [O,I,R,S] with element strides. */
+int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, float* grad, long sO,
+                       long sI, long sR, long sS, int accumulate, void* stream);
+
+/* ---- convolution / linear (implicit GEMM on MFMA) ------------------------------------- */
+/* rows of BN partial statistics saicv_conv2d_fwd writes when stat_sum != NULL */
+int saicv_conv2d_stat_rows(const saicv_conv_desc* d);
+/* y = conv(x, wf) [+ bias]; optionally per-channel partial sum / sum-of-squares of y
+ * ([rows][K] each) for the following BatchNorm.  ATen `convolution` under
+ * ConvBnActBlock.forward, resnet.py:45-48.  out_f32: write y as fp32 (logits). */
+int saicv_conv2d_fwd(const saicv_conv_desc* d, const void* x, const void* wf, const float* bias,
+                     void* y, int out_f32, float* stat_sum, float* stat_sq, void* stream);
+/* dx = conv_transpose(dy, w) via Wd[C][R][S][K]   (`convolution_backward`, grad_input) */
+int saicv_conv2d_dgrad(const saicv_conv_desc* d, const void* dy, const void* wd, void* dx,
+                       void* stream);
+/* dw[K][R][S][C] (fp32) += dy^T * im2col(x)       (`convolution_backward`, grad_weight).
+ * Accumulates with fp32 atomics: zero dw first for a plain gradient. */
+int saicv_conv2d_wgrad(const saicv_conv_desc* d, const void* dy, const void* x, float* dw,
+                       void* stream);
+/* dbias[N] (fp32) += column sums of dy[M][N] */
+int saicv_colsum(int dtype, const void* dy, int M, int N, float* dbias, void* stream);
+
+/* ---- BatchNorm2d + ReLU + residual ---------------------------------------------------- */
+size_t saicv_bn_ws_floats(int C);
+/* partial sums -> mean/invstd/scale/shift, running-stat update (momentum, unbiased var).
+ * `native_batch_norm` (training) under resnet.py:41. */
+int saicv_bn_finalize_fwd(const float* sum, const float* sq, int rows, int C, double count,
+                          const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, double momentum, double eps, float* mean,
+                          float* invstd, float* scale, float* shift, float* ws, void* stream);
+/* eval mode: scale/shift from running statistics */
+int saicv_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, double eps, float* scale, float* shift,
+                         void* stream);
+/* z = [relu](y*scale + shift [+ res])   (resnet.py:41-42, :94-95, :152-153) */
+int saicv_bn_act_fwd(int dtype, const void* y, const void* res, void* z, const float* scale,
+                     const float* shift, size_t M, int C, int relu, void* stream);
+size_t saicv_bn_bwd_ws_floats(size_t M, int C, int dtype);
+/* backward of the fused block: g = dz*[z>0]; dy, dres(=g, optional), dgamma, dbeta.
+ * `threshold_backward` + `native_batch_norm_backward` (+ residual `add` backward). */
+int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
+                     const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
+                     float* dbeta, size_t M, int C, int relu, float* ws, void* stream);
+
+/* ---- pooling --------------------------------------------------------------------------- */
+/* nn.MaxPool2d(3,2,1), resnet.py:184; idx = window position of the first maximum */
+int saicv_maxpool_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C,
+                      int OH, int OW, int K, int stride, int pad, void* stream);
+int saicv_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W,
+                      int C, int OH, int OW, int K, int stride, int pad, void* stream);
+/* nn.AdaptiveAvgPool2d((1,1)), resnet.py:203 */
+int saicv_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream);
+int saicv_avgpool_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, void* stream);
+
+/* ---- loss ------------------------------------------------------------------------------ */
+/* CELoss (soft=0, label int64[B]) / OneHotLabelCELoss (soft=1, label fp32[B][C]);
+ * SimpleAICV/classification/losses.py:21-28, :86-91.  loss[0] = mean; dlogits (optional) =
+ * d loss / d logits for upstream gradient 1. */
+int saicv_softmax_ce_fwd(const float* logits, const void* label, int soft, int B, int C,
+                         float* row_loss, float* loss, float* dlogits, void* stream);
+/* out = in * scale[0] (device scalar), out dtype selectable */
+int saicv_scale_by_scalar(int out_dtype, const float* in, const float* scale, void* out, size_t n,
+                          void* stream);
+
+/* ---- flat-arena optimizers / GradScaler (tools/utils.py:292-679, :199-200) ------------- */
+int saicv_sgd_flat(float* p, const float* g, float* mom, const int32_t* block_group,
+                   const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
+                   void* stream);
+int saicv_adamw_flat(float* p, const float* g, float* m, float* v, const int32_t* block_group,
+                     const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
+                     void* stream);
+int saicv_grad_stats(const float* g, size_t n, float* found_inf, float* sumsq, void* stream);
+int saicv_grad_clip_scale(float* g, size_t n, const float* sumsq, const float* inv_scale,
+                          double max_norm, void* stream);
+int saicv_scaler_update(float* state, const float* found_inf, double growth, double backoff,
+                        int interval, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAICV_HIP_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of libsaicv_hip.so (include/saicv_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a tensor is not on a
+HIP device, the call raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_uint8, c_void_p
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libsaicv_hip.so')
+
+BF16, F32 = 0, 1
+
+
+class ConvDesc(Structure):
+    _fields_ = [('N', c_int), ('H', c_int), ('W', c_int), ('C', c_int), ('K', c_int), ('R', c_int),
+                ('S', c_int), ('stride', c_int), ('pad', c_int), ('OH', c_int), ('OW', c_int),
+                ('dtype', c_int)]
+
+
+_P = c_void_p
+_PD = POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/saicv_hip.h one to one
+SIGNATURES = {
+    'saicv_version': (c_int, []),
+    'saicv_last_error_string': (c_char_p, []),
+    'saicv_pack_input': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_pack_weight': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'saicv_unpack_wgrad': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_long, c_long, c_long, c_long, c_int, _P]),
+    'saicv_conv2d_stat_rows': (c_int, [_PD]),
+    'saicv_conv2d_fwd': (c_int, [_PD, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    'saicv_conv2d_dgrad': (c_int, [_PD, _P, _P, _P, _P]),
+    'saicv_conv2d_wgrad': (c_int, [_PD, _P, _P, _P, _P]),
+    'saicv_colsum': (c_int, [c_int, _P, c_int, c_int, _P, _P]),
+    'saicv_bn_ws_floats': (c_size_t, [c_int]),
+    'saicv_bn_finalize_fwd': (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P, _P, c_double, c_double, _P, _P, _P, _P, _P, _P]),
+    'saicv_bn_eval_coeffs': (c_int, [c_int, _P, _P, _P, _P, c_double, _P, _P, _P]),
+    'saicv_bn_act_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
+    'saicv_bn_bwd_ws_floats': (c_size_t, [c_size_t, c_int, c_int]),
+    'saicv_bn_act_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P, _P]),
+    'saicv_maxpool_fwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_maxpool_bwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_avgpool_fwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_avgpool_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    'saicv_scale_by_scalar': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
+    'saicv_sgd_flat': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'saicv_adamw_flat': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'saicv_grad_stats': (c_int, [_P, c_size_t, _P, _P, _P]),
+    'saicv_grad_clip_scale': (c_int, [_P, c_size_t, _P, _P, c_double, _P]),
+    'saicv_scaler_update': (c_int, [_P, _P, c_double, c_double, c_int, _P]),
+    # transformer kernels (tfm.hip)
+    'saicv_layernorm_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
+    'saicv_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    'saicv_layernorm_bwd_ws_floats': (c_size_t, [c_int, c_int]),
+    'saicv_gelu_fwd': (c_int, [c_int, _P, _P, c_size_t, _P]),
+    'saicv_gelu_bwd': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
+    'saicv_attention_fwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
+    'saicv_attention_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
+}
+
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Loads the library (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first. '
+                'The MI355X HIP extension is required; there is no CPU/eager fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().saicv_last_error_string()
+        raise RuntimeError(f'libsaicv_hip {what} failed ({rc}): {msg.decode() if msg else "?"}')
+
+
+def dtype_code(dt):
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise TypeError(f'saicv kernels support bfloat16 and float32, got {dt}')
+
+
+def epc(dt):
+    return 8 if dt == torch.bfloat16 else 4
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('saicv HIP kernels need tensors on an MI355X device (got a CPU tensor); '
+                               'there is no CPU fallback in the product path')

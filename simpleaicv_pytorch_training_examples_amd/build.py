@@ -1,0 +1,65 @@
+"""Builds libsaicv_hip.so (gfx950) in-tree with hipcc.  No torch dependency in the library."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libsaicv_hip.so')
+SOURCES = ['igemm.hip', 'bn.hip', 'pool.hip', 'loss.hip', 'pack.hip', 'optim.hip', 'tfm.hip', 'capi.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
+         '-Wno-unused-result', '-Wno-unused-value']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return 'hipcc'
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.h')]
+    headers.append(os.path.join(os.path.dirname(HERE), 'include', 'saicv_hip.h'))
+    objdir = os.path.join(CSRC, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(objdir, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print('[saicv build]', ' '.join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(out.decode(errors='replace'))
+    if failed:
+        raise RuntimeError('hipcc failed building libsaicv_hip.so')
+    if force or procs or not os.path.exists(LIB):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print('[saicv build]', ' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

@@ -1,0 +1,376 @@
+// BatchNorm2d (training + eval) fused with ReLU and the residual add, NHWC, gfx950.
+//
+// Replaces `native_batch_norm` + `relu_` (+ `add`) and their backward ATen dispatches of
+// reference SimpleAICV/classification/backbones/resnet.py:41-42 (ConvBnActBlock),
+// :94-95 (BasicBlock tail), :152-153 (Bottleneck tail).
+//
+// Forward:  per-channel sum / sum-of-squares partials come from the conv epilogue
+//           (igemm.hip); `bn_reduce_partials` + `bn_finalize_fwd` turn them into
+//           mean / invstd / (scale, shift) and update running stats; `bn_act_fwd`
+//           streams y -> z = relu(y*scale + shift [+ res]) with 16-byte accesses.
+// Backward: `bn_bwd_reduce` streams (dz, z, y) once for sum(g), sum(g*xhat);
+//           `bn_finalize_bwd` produces dgamma/dbeta and the per-channel coefficients;
+//           `bn_bwd_apply` streams (dz, z, y) again and writes dy (and dres = g).
+// All statistics are fp32; activations are bf16 (perf mode) or fp32 (parity mode).
+// These kernels are HBM-bound: algorithmic bytes are listed in DESIGN.md.
+#include "common.h"
+#include "saicv_internal.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+
+// ---------------------------------------------------------------- partial reduce [P][C] -> [Y][C]
+__global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __restrict__ a,
+                                                                 const float* __restrict__ b, int P,
+                                                                 int C, float* __restrict__ oa,
+                                                                 float* __restrict__ ob, int rows_per) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = threadIdx.x >> 6;
+    const int p0 = blockIdx.y * rows_per;
+    const int p1 = min(P, p0 + rows_per);
+    float sa = 0.f, sb = 0.f;
+    if (c < C) {
+        for (int p = p0 + ty; p < p1; p += 4) {
+            sa += a[(size_t)p * C + c];
+            sb += b[(size_t)p * C + c];
+        }
+    }
+    __shared__ float la[4][64], lb[4][64];
+    la[ty][threadIdx.x & 63] = sa;
+    lb[ty][threadIdx.x & 63] = sb;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        const int x = threadIdx.x;
+        oa[(size_t)blockIdx.y * C + c] = la[0][x] + la[1][x] + la[2][x] + la[3][x];
+        ob[(size_t)blockIdx.y * C + c] = lb[0][x] + lb[1][x] + lb[2][x] + lb[3][x];
+    }
+}
+
+// ---------------------------------------------------------------- forward finalize
+// Follows torch.nn.BatchNorm2d training semantics (biased var for normalisation, unbiased
+// var into running_var, momentum 0.1) as used by reference resnet.py:41.
+__global__ void bn_finalize_fwd_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
+                                       int P, int C, float count, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* running_mean,
+                                       float* running_var, float momentum, float eps,
+                                       float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                       float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < P; ++p) {
+        s += sum[(size_t)p * C + c];
+        q += sq[(size_t)p * C + c];
+    }
+    const float mean = s / count;
+    float var = q / count - mean * mean;
+    var = fmaxf(var, 0.f);
+    const float invstd = rsqrtf(var + eps);
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    const float g = gamma ? gamma[c] : 1.f;
+    const float bt = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = bt - mean * g * invstd;
+    if (running_mean) {
+        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// eval mode: scale/shift from running statistics
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean,
+                                      const float* __restrict__ running_var, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = rsqrtf(running_var[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    const float bt = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = bt - running_mean[c] * g * invstd;
+}
+
+// ---------------------------------------------------------------- forward apply
+template <typename T, bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y,
+                                                         const T* __restrict__ res, T* __restrict__ z,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         size_t nchunks, int C) {
+    constexpr int N = Chunk<T>::N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const int c0 = (int)((i * N) % (size_t)C);
+        float v[N], sc[N], sh[N];
+        Chunk<T>::unpack(ld_chunk(y + i * N), v);
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c0 + j);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(shift + c0 + j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sc[j + k] = a[k]; sh[j + k] = b[k]; }
+        }
+        float rr[N];
+        if (RES) Chunk<T>::unpack(ld_chunk(res + i * N), rr);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float o = fmaf(v[j], sc[j], sh[j]);
+            if (RES) o += rr[j];
+            if (RELU) o = fmaxf(o, 0.f);
+            v[j] = o;
+        }
+        st_chunk(z + i * N, Chunk<T>::pack(v));
+    }
+}
+
+// ---------------------------------------------------------------- backward reduce
+// Block handles a slab of rows; thread owns one chunk column (N channels) and strides over
+// rows; per-block partials [slab][C].  Requires C/N to divide 256 or be a multiple of 256.
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz,
+                                                            const T* __restrict__ z,
+                                                            const T* __restrict__ y,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int M,
+                                                            int C, int rows_per,
+                                                            float* __restrict__ part_g,
+                                                            float* __restrict__ part_gx) {
+    constexpr int N = Chunk<T>::N;
+    const int cpr = C / N;                       // chunk columns per row
+    const int cols = cpr < 256 ? cpr : 256;      // columns handled per pass by this block
+    const int rpp = 256 / cols;                  // rows per pass
+    const int tx = threadIdx.x % cols;
+    const int ty = threadIdx.x / cols;
+    const int r0 = blockIdx.x * rows_per;
+    const int r1 = min(M, r0 + rows_per);
+    __shared__ float lg_[256 * 8], lx_[256 * 8];
+    for (int cb = tx; cb < cpr; cb += cols) {
+        const int c0 = cb * N;
+        float mu[N], is[N], ag[N], ax[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; ag[j] = 0.f; ax[j] = 0.f; }
+        for (int r = r0 + ty; r < r1; r += rpp) {
+            const size_t e = (size_t)r * C + c0;
+            float g[N], yy[N], zz[N];
+            Chunk<T>::unpack(ld_chunk(dz + e), g);
+            Chunk<T>::unpack(ld_chunk(y + e), yy);
+            if (RELU) Chunk<T>::unpack(ld_chunk(z + e), zz);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float gj = (RELU && !(zz[j] > 0.f)) ? 0.f : g[j];
+                ag[j] += gj;
+                ax[j] += gj * (yy[j] - mu[j]) * is[j];
+            }
+        }
+        // combine the rpp row-lanes of this column through LDS
+#pragma unroll
+        for (int j = 0; j < N; ++j) { lg_[threadIdx.x * N + j] = ag[j]; lx_[threadIdx.x * N + j] = ax[j]; }
+        __syncthreads();
+        if (ty == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float sg = 0.f, sx = 0.f;
+                for (int t = 0; t < rpp; ++t) {
+                    sg += lg_[(t * cols + tx) * N + j];
+                    sx += lx_[(t * cols + tx) * N + j];
+                }
+                part_g[(size_t)blockIdx.x * C + c0 + j] = sg;
+                part_gx[(size_t)blockIdx.x * C + c0 + j] = sx;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- backward finalize
+// dy = A*(g - mg) - A*xhat*mgx  with A = gamma*invstd, mg = sum(g)/M, mgx = sum(g*xhat)/M
+// written as dy = ca*g + cb*y + cc per channel.
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ pg, const float* __restrict__ pgx,
+                                       int P, int C, float count, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ ca,
+                                       float* __restrict__ cb, float* __restrict__ cc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sg = 0.f, sx = 0.f;
+    for (int p = 0; p < P; ++p) {
+        sg += pg[(size_t)p * C + c];
+        sx += pgx[(size_t)p * C + c];
+    }
+    if (dgamma) dgamma[c] = sx;
+    if (dbeta) dbeta[c] = sg;
+    const float g = gamma ? gamma[c] : 1.f;
+    const float A = g * invstd[c];
+    const float mg = sg / count, mgx = sx / count;
+    const float B = -A * invstd[c] * mgx;      // coefficient on y
+    ca[c] = A;
+    cb[c] = B;
+    cc[c] = -A * mg - B * mean[c];
+}
+
+// ---------------------------------------------------------------- backward apply
+template <typename T, bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz,
+                                                           const T* __restrict__ z,
+                                                           const T* __restrict__ y,
+                                                           const float* __restrict__ ca,
+                                                           const float* __restrict__ cb,
+                                                           const float* __restrict__ cc,
+                                                           T* __restrict__ dy, T* __restrict__ dres,
+                                                           size_t nchunks, int C) {
+    constexpr int N = Chunk<T>::N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const int c0 = (int)((i * N) % (size_t)C);
+        float g[N], yy[N], zz[N], o[N];
+        Chunk<T>::unpack(ld_chunk(dz + i * N), g);
+        Chunk<T>::unpack(ld_chunk(y + i * N), yy);
+        if (RELU) Chunk<T>::unpack(ld_chunk(z + i * N), zz);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float gj = (RELU && !(zz[j] > 0.f)) ? 0.f : g[j];
+            g[j] = gj;
+            o[j] = fmaf(ca[c0 + j], gj, fmaf(cb[c0 + j], yy[j], cc[c0 + j]));
+        }
+        st_chunk(dy + i * N, Chunk<T>::pack(o));
+        if (RES) st_chunk(dres + i * N, Chunk<T>::pack(g));
+    }
+}
+
+inline int stream_grid(size_t nchunks) {
+    size_t b = (nchunks + 255) / 256;
+    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// reduce [P][C] partial pairs down to at most 32 rows (in place into ws), returns new P
+int reduce_partials(const float*& a, const float*& b, int P, int C, float* ws, hipStream_t st) {
+    if (P <= 32) return P;
+    const int Y = 32;
+    const int rows_per = (P + Y - 1) / Y;
+    const int y_used = (P + rows_per - 1) / rows_per;
+    float* oa = ws;
+    float* ob = ws + (size_t)Y * C;
+    dim3 grid((C + 63) / 64, y_used);
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, grid, dim3(256), 0, st, a, b, P, C, oa, ob, rows_per);
+    a = oa;
+    b = ob;
+    return y_used;
+}
+
+}  // namespace
+
+namespace saicv {
+
+// workspace floats needed by bn_finalize (two [32][C] slabs)
+size_t bn_ws_floats(int C) { return (size_t)64 * C; }
+
+int bn_finalize_fwd(const float* sum, const float* sq, int P, int C, double count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, double momentum,
+                    double eps, float* mean, float* invstd, float* scale, float* shift, float* ws,
+                    hipStream_t st) {
+    P = reduce_partials(sum, sq, P, C, ws, st);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sum, sq, P, C,
+                       (float)count, gamma, beta, running_mean, running_var, (float)momentum, (float)eps,
+                       mean, invstd, scale, shift);
+    return check_launch("bn_finalize_fwd");
+}
+
+int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, double eps, float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, gamma, beta,
+                       running_mean, running_var, (float)eps, scale, shift);
+    return check_launch("bn_eval_coeffs");
+}
+
+template <typename T>
+static int bn_act_fwd_t(const void* y, const void* res, void* z, const float* scale,
+                        const float* shift, size_t M, int C, int relu, hipStream_t st) {
+    constexpr int N = Chunk<T>::N;
+    const size_t nchunks = M * (size_t)C / N;
+    const int grid = stream_grid(nchunks);
+    const T* yy = (const T*)y; const T* rr = (const T*)res; T* zz = (T*)z;
+#define LAUNCH(R, S) hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C)
+    if (relu) { if (res) LAUNCH(true, true); else LAUNCH(true, false); }
+    else      { if (res) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    return check_launch("bn_act_fwd");
+}
+
+int bn_act_fwd(int dtype, const void* y, const void* res, void* z, const float* scale,
+               const float* shift, size_t M, int C, int relu, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0, "bn_act_fwd: C=%d must be a multiple of %d", C, n);
+    if (dtype == SAICV_DTYPE_BF16) return bn_act_fwd_t<bf16_t>(y, res, z, scale, shift, M, C, relu, st);
+    return bn_act_fwd_t<float>(y, res, z, scale, shift, M, C, relu, st);
+}
+
+// rows of partials produced by bn_bwd (so the caller can size the workspace)
+int bn_bwd_slabs(size_t M, int C, int dtype) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    const int cpr = C / n;
+    const int rpp = cpr >= 256 ? 1 : 256 / cpr;
+    size_t s = M / ((size_t)rpp * 8);      // >= 8 passes per slab
+    if (s > 1024) s = 1024;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+// workspace: [2][slabs][C] partials + [2][32][C] second stage + 3*C coefficients
+size_t bn_bwd_ws_floats(size_t M, int C, int dtype) {
+    return (size_t)2 * bn_bwd_slabs(M, C, dtype) * C + (size_t)64 * C + (size_t)3 * C;
+}
+
+template <typename T>
+static int bn_bwd_t(const void* dz, const void* z, const void* y, const float* gamma,
+                    const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
+                    float* dbeta, size_t M, int C, int relu, float* ws, hipStream_t st) {
+    constexpr int N = Chunk<T>::N;
+    const int slabs = bn_bwd_slabs(M, C, sizeof(T) == 2 ? SAICV_DTYPE_BF16 : SAICV_DTYPE_F32);
+    const int rows_per = (int)((M + slabs - 1) / slabs);
+    const int used = (int)((M + rows_per - 1) / rows_per);
+    float* pg = ws;
+    float* pgx = ws + (size_t)slabs * C;
+    float* ws2 = ws + (size_t)2 * slabs * C;
+    float* coef = ws2 + (size_t)64 * C;
+    const T* dzz = (const T*)dz; const T* zz = (const T*)z; const T* yy = (const T*)y;
+    if (relu)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(used), dim3(256), 0, st, dzz, zz, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(used), dim3(256), 0, st, dzz, zz, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
+    const float* a = pg; const float* b = pgx;
+    const int P = reduce_partials(a, b, used, C, ws2, st);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, a, b, P, C,
+                       (float)M, gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C);
+    const size_t nchunks = M * (size_t)C / N;
+    const int grid = stream_grid(nchunks);
+    T* dyy = (T*)dy; T* drr = (T*)dres;
+#define LAUNCH(R, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C)
+    if (relu) { if (dres) LAUNCH(true, true); else LAUNCH(true, false); }
+    else      { if (dres) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    return check_launch("bn_bwd");
+}
+
+int bn_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
+           const float* mean, const float* invstd, void* dy, void* dres, float* dgamma, float* dbeta,
+           size_t M, int C, int relu, float* ws, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    const int cpr = C / n;
+    SAICV_REQUIRE(C % n == 0, "bn_bwd: C=%d must be a multiple of %d", C, n);
+    SAICV_REQUIRE((cpr <= 256 && 256 % cpr == 0) || (cpr % 256 == 0),
+                  "bn_bwd: C/%d=%d must divide 256 or be a multiple of 256", n, cpr);
+    SAICV_REQUIRE(!relu || z != nullptr, "bn_bwd: relu needs the forward output z");
+    if (dtype == SAICV_DTYPE_BF16)
+        return bn_bwd_t<bf16_t>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, ws, st);
+    return bn_bwd_t<float>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, ws, st);
+}
+
+}  // namespace saicv

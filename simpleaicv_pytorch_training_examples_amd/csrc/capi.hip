@@ -1,0 +1,202 @@
+// extern "C" surface of libsaicv_hip.so (declared in include/saicv_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+#include "saicv_internal.h"
+#include "../../include/saicv_hip.h"
+
+namespace saicv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+// declared in the other translation units
+size_t bn_ws_floats(int C);
+int bn_finalize_fwd(const float*, const float*, int, int, double, const float*, const float*, float*,
+                    float*, double, double, float*, float*, float*, float*, float*, hipStream_t);
+int bn_eval_coeffs(int, const float*, const float*, const float*, const float*, double, float*, float*,
+                   hipStream_t);
+int bn_act_fwd(int, const void*, const void*, void*, const float*, const float*, size_t, int, int,
+               hipStream_t);
+size_t bn_bwd_ws_floats(size_t, int, int);
+int bn_bwd(int, const void*, const void*, const void*, const float*, const float*, const float*, void*,
+           void*, float*, float*, size_t, int, int, float*, hipStream_t);
+int maxpool_fwd(int, const void*, void*, uint8_t*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int maxpool_bwd(int, const void*, const uint8_t*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int avgpool_fwd(int, const void*, void*, int, int, int, hipStream_t);
+int avgpool_bwd(int, const void*, void*, int, int, int, hipStream_t);
+int softmax_ce_fwd(const float*, const void*, int, int, int, float*, float*, float*, hipStream_t);
+int scale_by_scalar(int, const float*, const float*, void*, size_t, hipStream_t);
+int pack_input(int, const float*, long, long, long, long, void*, int, int, int, int, int, hipStream_t);
+int pack_weight(int, const float*, long, long, long, long, int, int, int, int, int, void*, void*, hipStream_t);
+int unpack_wgrad(const float*, int, int, int, int, int, float*, long, long, long, long, int, hipStream_t);
+int colsum(int, const void*, int, int, float*, hipStream_t);
+int sgd_flat(float*, const float*, float*, const int32_t*, const float*, const float*, const float*, size_t, hipStream_t);
+int adamw_flat(float*, const float*, float*, float*, const int32_t*, const float*, const float*, const float*, size_t, hipStream_t);
+int grad_stats(const float*, size_t, float*, float*, hipStream_t);
+int grad_clip_scale(float*, size_t, const float*, const float*, double, hipStream_t);
+int scaler_update(float*, const float*, double, double, int, hipStream_t);
+
+}  // namespace saicv
+
+using namespace saicv;
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int check_desc(const saicv_conv_desc* d, const char* who) {
+    SAICV_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    SAICV_REQUIRE(d->dtype == SAICV_BF16 || d->dtype == SAICV_F32, "%s: bad dtype %d", who, d->dtype);
+    SAICV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0,
+                  "%s: non-positive dimension", who);
+    SAICV_REQUIRE(d->stride >= 1 && d->pad >= 0, "%s: bad stride/pad", who);
+    const int oh = (d->H + 2 * d->pad - d->R) / d->stride + 1;
+    const int ow = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+    SAICV_REQUIRE(oh == d->OH && ow == d->OW, "%s: OH/OW (%d,%d) inconsistent with geometry (%d,%d)",
+                  who, d->OH, d->OW, oh, ow);
+    SAICV_REQUIRE((long long)d->N * d->H * d->W * (long long)d->C < (1ll << 31) &&
+                      (long long)d->N * d->OH * d->OW * (long long)d->K < (1ll << 31),
+                  "%s: tensor exceeds 2^31 elements", who);
+    return 0;
+}
+
+extern "C" {
+
+int saicv_version(void) { return 100; }
+const char* saicv_last_error_string(void) { return g_err; }
+
+int saicv_pack_input(int dtype, const float* src, long sN, long sC, long sH, long sW, void* dst,
+                     int N, int C, int H, int W, int Cp, void* stream) {
+    return pack_input(dtype, src, sN, sC, sH, sW, dst, N, C, H, W, Cp, S(stream));
+}
+int saicv_pack_weight(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I,
+                      int R, int Sx, int Ip, void* wf, void* wd, void* stream) {
+    return pack_weight(dtype, w, sO, sI, sR, sS, O, I, R, Sx, Ip, wf, wd, S(stream));
+}
+int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int Sx, int Ip, float* grad, long sO,
+                       long sI, long sR, long sS, int accumulate, void* stream) {
+    return unpack_wgrad(dw, O, I, R, Sx, Ip, grad, sO, sI, sR, sS, accumulate, S(stream));
+}
+
+int saicv_conv2d_stat_rows(const saicv_conv_desc* d) {
+    if (!d) return -1;
+    return conv_stat_rows(d->N * d->OH * d->OW);
+}
+
+int saicv_conv2d_fwd(const saicv_conv_desc* d, const void* x, const void* wf, const float* bias,
+                     void* y, int out_f32, float* stat_sum, float* stat_sq, void* stream) {
+    if (check_desc(d, "saicv_conv2d_fwd")) return -1;
+    const int M = d->N * d->OH * d->OW;
+    return igemm_nt(d->dtype, 0, x, wf, y, bias, stat_sum, stat_sq, d->H, d->W, d->C, d->OH, d->OW,
+                    d->R, d->S, d->stride, d->pad, M, d->K, d->R * d->S * d->C, d->K, out_f32, S(stream));
+}
+
+int saicv_conv2d_dgrad(const saicv_conv_desc* d, const void* dy, const void* wd, void* dx,
+                       void* stream) {
+    if (check_desc(d, "saicv_conv2d_dgrad")) return -1;
+    // rows = input pixels; gather source = dy [N,OH,OW,K]; k = (r,s,kout)
+    const int M = d->N * d->H * d->W;
+    return igemm_nt(d->dtype, 1, dy, wd, dx, nullptr, nullptr, nullptr, d->OH, d->OW, d->K, d->H, d->W,
+                    d->R, d->S, d->stride, d->pad, M, d->C, d->R * d->S * d->K, d->C, 0, S(stream));
+}
+
+int saicv_conv2d_wgrad(const saicv_conv_desc* d, const void* dy, const void* x, float* dw,
+                       void* stream) {
+    if (check_desc(d, "saicv_conv2d_wgrad")) return -1;
+    const int M = d->N * d->OH * d->OW;
+    return igemm_tn(d->dtype, dy, x, dw, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad,
+                    M, d->K, d->R * d->S * d->C, S(stream));
+}
+
+int saicv_colsum(int dtype, const void* dy, int M, int N, float* dbias, void* stream) {
+    return colsum(dtype, dy, M, N, dbias, S(stream));
+}
+
+size_t saicv_bn_ws_floats(int C) { return bn_ws_floats(C); }
+
+int saicv_bn_finalize_fwd(const float* sum, const float* sq, int rows, int C, double count,
+                          const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, double momentum, double eps, float* mean,
+                          float* invstd, float* scale, float* shift, float* ws, void* stream) {
+    return bn_finalize_fwd(sum, sq, rows, C, count, gamma, beta, running_mean, running_var, momentum,
+                           eps, mean, invstd, scale, shift, ws, S(stream));
+}
+int saicv_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, double eps, float* scale, float* shift,
+                         void* stream) {
+    return bn_eval_coeffs(C, gamma, beta, running_mean, running_var, eps, scale, shift, S(stream));
+}
+int saicv_bn_act_fwd(int dtype, const void* y, const void* res, void* z, const float* scale,
+                     const float* shift, size_t M, int C, int relu, void* stream) {
+    return bn_act_fwd(dtype, y, res, z, scale, shift, M, C, relu, S(stream));
+}
+size_t saicv_bn_bwd_ws_floats(size_t M, int C, int dtype) { return bn_bwd_ws_floats(M, C, dtype); }
+int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
+                     const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
+                     float* dbeta, size_t M, int C, int relu, float* ws, void* stream) {
+    return bn_bwd(dtype, dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, ws, S(stream));
+}
+
+int saicv_maxpool_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C,
+                      int OH, int OW, int K, int stride, int pad, void* stream) {
+    return maxpool_fwd(dtype, x, out, idx, N, H, W, C, OH, OW, K, stride, pad, S(stream));
+}
+int saicv_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W,
+                      int C, int OH, int OW, int K, int stride, int pad, void* stream) {
+    return maxpool_bwd(dtype, dout, idx, dx, N, H, W, C, OH, OW, K, stride, pad, S(stream));
+}
+int saicv_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream) {
+    return avgpool_fwd(dtype, x, out, N, HW, C, S(stream));
+}
+int saicv_avgpool_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, void* stream) {
+    return avgpool_bwd(dtype, dout, dx, N, HW, C, S(stream));
+}
+
+int saicv_softmax_ce_fwd(const float* logits, const void* label, int soft, int B, int C,
+                         float* row_loss, float* loss, float* dlogits, void* stream) {
+    return softmax_ce_fwd(logits, label, soft, B, C, row_loss, loss, dlogits, S(stream));
+}
+int saicv_scale_by_scalar(int out_dtype, const float* in, const float* scale, void* out, size_t n,
+                          void* stream) {
+    return scale_by_scalar(out_dtype, in, scale, out, n, S(stream));
+}
+
+int saicv_sgd_flat(float* p, const float* g, float* mom, const int32_t* block_group,
+                   const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
+                   void* stream) {
+    return sgd_flat(p, g, mom, block_group, hyper, inv_scale, found_inf, n, S(stream));
+}
+int saicv_adamw_flat(float* p, const float* g, float* m, float* v, const int32_t* block_group,
+                     const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
+                     void* stream) {
+    return adamw_flat(p, g, m, v, block_group, hyper, inv_scale, found_inf, n, S(stream));
+}
+int saicv_grad_stats(const float* g, size_t n, float* found_inf, float* sumsq, void* stream) {
+    return grad_stats(g, n, found_inf, sumsq, S(stream));
+}
+int saicv_grad_clip_scale(float* g, size_t n, const float* sumsq, const float* inv_scale,
+                          double max_norm, void* stream) {
+    return grad_clip_scale(g, n, sumsq, inv_scale, max_norm, S(stream));
+}
+int saicv_scaler_update(float* state, const float* found_inf, double growth, double backoff,
+                        int interval, void* stream) {
+    return scaler_update(state, found_inf, growth, backoff, interval, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// Device-side helpers shared by every gfx950 kernel in this library.
+// CDNA4 only: 64-wide wavefronts, MFMA 16x16x32 bf16 / 16x16x4 f32, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define SAICV_DTYPE_BF16 0
+#define SAICV_DTYPE_F32 1
+
+#define DEVINL __device__ __forceinline__
+
+// ---------------------------------------------------------------- error state
+namespace saicv {
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}  // namespace saicv
+
+#define SAICV_REQUIRE(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            saicv::set_error(__VA_ARGS__);  \
+            return -1;                      \
+        }                                   \
+    } while (0)
+
+// ---------------------------------------------------------------- 16-byte chunks
+// Every tiled kernel moves data in 16-byte chunks: 8 bf16 or 4 f32.
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<bf16_t> { static constexpr int EPC = 8; };
+template <> struct ElemTraits<float>  { static constexpr int EPC = 4; };
+
+DEVINL u32x4 zero_chunk() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
+
+DEVINL u32x4 ld_chunk(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+DEVINL void st_chunk(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+DEVINL float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+
+DEVINL float to_f32(bf16_t v) { return (float)v; }
+DEVINL float to_f32(float v) { return v; }
+
+template <typename T> DEVINL T from_f32(float v);
+template <> DEVINL bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> DEVINL float from_f32<float>(float v) { return v; }
+
+// round a float through T (used so BN statistics see what is stored in HBM)
+template <typename T> DEVINL float round_through(float v) { return to_f32(from_f32<T>(v)); }
+
+// unpack a chunk into EPC floats / pack back
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16_t> {
+    static constexpr int N = 8;
+    static DEVINL void unpack(u32x4 c, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i]     = __uint_as_float(c[i] << 16);
+            f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+        }
+    }
+    static DEVINL u32x4 pack(const float* f) {
+        u32x4 c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x2 p;
+            p[0] = (bf16_t)f[2 * i];
+            p[1] = (bf16_t)f[2 * i + 1];
+            c[i] = __builtin_bit_cast(uint32_t, p);
+        }
+        return c;
+    }
+};
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    static DEVINL void unpack(u32x4 c, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(c[i]);
+    }
+    static DEVINL u32x4 pack(const float* f) {
+        u32x4 c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(f[i]);
+        return c;
+    }
+};
+
+// ---------------------------------------------------------------- MFMA wrappers
+// D(16x16) += A(16xk) * B(kx16).  Lane l supplies row (l&15) of A and column (l&15) of B,
+// k-group (l>>4).  C/D: col = l&15, row = (l>>4)*4 + reg   (guide §3).
+// One call consumes one 16-byte chunk per operand: 32 k for bf16, 16 k for f32
+// (the f32 form issues four 16x16x4 MFMAs, one per float of the chunk; the k order
+//  is a permutation shared by A and B, which a dot product does not care about).
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static DEVINL void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                     __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static DEVINL void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]),
+                                                       acc, 0, 0, 0);
+    }
+};
+
+// ---------------------------------------------------------------- reductions
+DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware bijective block remap (guide T1): block b runs on XCD b%8; give each XCD a
+// contiguous range of logical tiles so neighbouring tiles share that XCD's L2.
+DEVINL int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,597 @@
+// Implicit-GEMM convolution / linear kernels for gfx950 (MI355X), NHWC.
+//
+//   igemm_nt : OUT[m][n] = sum_k GATHER(src)[m][k] * WGT[n][k]
+//              conv forward (rows = output pixels, k = (r,s,c)), conv data-gradient
+//              (rows = input pixels, k = (r,s,cout)) and nn.Linear forward / input-grad.
+//   igemm_tn : DW[n][kk] += sum_m DY[m][n] * GATHER(src)[m][kk]
+//              conv / linear weight-gradient; both operands are reduction-major in HBM,
+//              so bf16 fragments are built with the LDS transpose read
+//              (ds_read_b64_tr_b16) and the reduction over pixels is split across
+//              workgroups with fp32 hardware atomics into a pre-zeroed fp32 gradient.
+//
+// Replaces the ATen `convolution` / `convolution_backward` / `addmm` / `mm` dispatches of
+// reference SimpleAICV/classification/backbones/resnet.py:33-43 (ConvBnActBlock) and
+// resnet.py:204 (fc).  Tiles are 128x{64,128} with 128-byte K slices, 4 wavefronts (2x2),
+// MFMA 16x16x32 bf16 (perf mode) or 16x16x4 f32 (parity mode), register-staged double
+// buffered LDS with an XOR swizzle that makes ds_read_b128 fragment reads conflict free.
+#include "common.h"
+#include "saicv_internal.h"
+
+namespace {
+
+struct NTParams {
+    const void* src;
+    const void* wgt;
+    void* out;
+    const float* bias;
+    float* stat_sum;
+    float* stat_sq;
+    int H, W, C;        // gather-source spatial dims / channels
+    int OH, OW;         // pixel grid that indexes the GEMM rows
+    int R, S, stride, pad;
+    int M, Nn, Kd;
+    int ldo;
+    int tiles_n;
+    int nblk;
+};
+
+// LDS row = 128 bytes = 8 chunks; chunk c of row r lives at slot c ^ ((r>>1)&7).
+DEVINL int lds_off(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
+
+template <typename T, int BN_T, int MODE, bool OUT_F32>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int BM_T = 128;
+    constexpr int WN = BN_T / 2;
+    constexpr int NT_ = WN / 16;
+    constexpr int MT_ = 4;
+    constexpr int WROWS = BN_T / 32;             // weight rows per thread
+    constexpr int A_BYTES = BM_T * 128;
+    constexpr int W_BYTES = BN_T * 128;
+    constexpr int STAGE = A_BYTES + W_BYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1;
+    const int wn = wave >> 1;
+
+    const int bid = xcd_remap(blockIdx.x, p.nblk);
+    const int tile_n = bid % p.tiles_n;
+    const int tile_m = bid / p.tiles_n;
+
+    // ---- per-thread gather state: chunk column cc, rows rb + 32*i
+    const int cc = tid & 7;
+    const int rb = tid >> 3;
+    int pixbase[4], a0[4], b0[4];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = tile_m * BM_T + rb + 32 * i;
+        if (m < p.M) {
+            const int img = m / ohw;
+            const int rem = m - img * ohw;
+            const int oh = rem / p.OW;
+            const int ow = rem - oh * p.OW;
+            pixbase[i] = img * p.H * p.W;
+            if (MODE == 0) {
+                a0[i] = oh * p.stride - p.pad;
+                b0[i] = ow * p.stride - p.pad;
+            } else {
+                a0[i] = oh + p.pad;
+                b0[i] = ow + p.pad;
+            }
+        } else {
+            pixbase[i] = 0;
+            a0[i] = -(1 << 24);
+            b0[i] = -(1 << 24);
+        }
+    }
+    const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
+
+    u32x4 ra[4], rw[WROWS];
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + cc * EPC;
+        const bool kvalid = k < p.Kd;
+        const int tap = k / p.C;
+        const int c0 = k - tap * p.C;
+        const int r = tap / p.S;
+        const int s = tap - r * p.S;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ih, iw;
+            bool ok = kvalid;
+            if (MODE == 0) {
+                ih = a0[i] + r;
+                iw = b0[i] + s;
+            } else {
+                const int th = a0[i] - r;
+                const int tw = b0[i] - s;
+                ok = ok && (th >= 0) && (tw >= 0);
+                if (p.stride == 1) {
+                    ih = th;
+                    iw = tw;
+                } else {
+                    ih = th / p.stride;
+                    iw = tw / p.stride;
+                    ok = ok && (ih * p.stride == th) && (iw * p.stride == tw);
+                }
+            }
+            ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+            if (ok) {
+                const size_t e = (size_t)(pixbase[i] + ih * p.W + iw) * (size_t)p.C + (size_t)c0;
+                ra[i] = ld_chunk(src + e);
+            } else {
+                ra[i] = zero_chunk();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WROWS; ++j) {
+            const int n = tile_n * BN_T + rb + 32 * j;
+            if (kvalid && n < p.Nn) {
+                rw[j] = ld_chunk(wgt + (size_t)n * (size_t)p.Kd + (size_t)k);
+            } else {
+                rw[j] = zero_chunk();
+            }
+        }
+    };
+
+    auto store_tile = [&](int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st_chunk(sa + lds_off(rb + 32 * i, cc), ra[i]);
+#pragma unroll
+        for (int j = 0; j < WROWS; ++j) st_chunk(sw + lds_off(rb + 32 * j, cc), rw[j]);
+    };
+
+    f32x4 acc[NT_][MT_];
+#pragma unroll
+    for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MT_; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE;
+        const char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[MT_], wf[NT_];
+            const int chunk = ks * 4 + lg;
+#pragma unroll
+            for (int mi = 0; mi < MT_; ++mi)
+                af[mi] = ld_chunk(sa + lds_off(wm * 64 + mi * 16 + l15, chunk));
+#pragma unroll
+            for (int ni = 0; ni < NT_; ++ni)
+                wf[ni] = ld_chunk(sw + lds_off(wn * WN + ni * 16 + l15, chunk));
+#pragma unroll
+            for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
+        }
+    };
+
+    const int nkt = (p.Kd + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nkt;
+        if (more) load_tile(kt + 1);
+        compute(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*16 + lg*4 + r ; m = m_base + mi*16 + l15
+    const int m_base = tile_m * BM_T + wm * 64;
+    const int n_base = tile_n * BN_T + wn * WN;
+    const bool do_stats = p.stat_sum != nullptr;
+#pragma unroll
+    for (int ni = 0; ni < NT_; ++ni) {
+        const int n0 = n_base + ni * 16 + lg * 4;
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.Nn) bs[r] = p.bias[n0 + r];
+        }
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < MT_; ++mi) {
+            const int m = m_base + mi * 16 + l15;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bs[r];
+            if (do_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vr = OUT_F32 ? v[r] : round_through<T>(v[r]);
+                    ssum[r] += vr;
+                    ssq[r] += vr * vr;
+                }
+            }
+            if (m < p.M) {
+                if (OUT_F32) {
+                    float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n0;
+                    if (n0 + 3 < p.Nn && (p.ldo & 3) == 0) {
+                        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n0 + r < p.Nn) o[r] = v[r];
+                    }
+                } else {
+                    T* o = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n0;
+                    if (n0 + 3 < p.Nn && (p.ldo & 3) == 0) {
+                        if (sizeof(T) == 2) {
+                            bf16x4 pk;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
+                            *reinterpret_cast<bf16x4*>(o) = pk;
+                        } else {
+                            *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n0 + r < p.Nn) o[r] = from_f32<T>(v[r]);
+                    }
+                }
+            }
+        }
+        if (do_stats) {
+            // rows m >= M were gathered as zeros (no bias when stats are requested) -> add 0.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    ssum[r] += __shfl_xor(ssum[r], o, 64);
+                    ssq[r] += __shfl_xor(ssq[r], o, 64);
+                }
+            }
+            if (l15 == 0) {
+                const size_t prow = (size_t)(tile_m * 2 + wm) * (size_t)p.Nn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < p.Nn) {
+                        p.stat_sum[prow + n0 + r] = ssum[r];
+                        p.stat_sq[prow + n0 + r] = ssq[r];
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ TN
+struct TNParams {
+    const void* dy;     // [M][Cout]
+    const void* src;    // [Nimg,H,W,C] gather source (layer input)
+    float* dw;          // [Cout][Kd] fp32, accumulated with atomics
+    int H, W, C;
+    int OH, OW;
+    int R, S, stride, pad;
+    int M, Cout, Kd;
+    int tiles_a, tiles_b;       // tiles over Cout / over Kd
+    int m_per_split;            // multiple of BR
+    int d_img, d_oh, d_ow;      // mixed-radix digits of BR in (img, oh, ow)
+};
+
+template <typename T, int BA, int BB>
+__global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BR = 8 * EPC;                  // reduction rows per tile (64 bf16 / 32 f32)
+    constexpr int PITCH_A = (BA + 16) * (int)sizeof(T);
+    constexpr int PITCH_B = (BB + 16) * (int)sizeof(T);
+    constexpr int A_BYTES = BR * PITCH_A;
+    constexpr int B_BYTES = BR * PITCH_B;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int CPR_A = BA / EPC, CPR_B = BB / EPC;     // chunks per row
+    constexpr int RPP_A = 256 / CPR_A, RPP_B = 256 / CPR_B;
+    constexpr int NA = BR / RPP_A, NB = BR / RPP_B;       // chunks per thread
+    constexpr int WA = BA / 2, WB = BB / 2;
+    constexpr int AT = WA / 16, BT = WB / 16;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wa = wave & 1, wb = wave >> 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int tile = blockIdx.x;
+    const int tile_a = tile % p.tiles_a;
+    const int tile_b = tile / p.tiles_a;
+    const int m_begin = blockIdx.y * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+    if (m_begin >= m_end) return;
+
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+    const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+
+    // dY loader state
+    const int ca = tid % CPR_A, rba = tid / CPR_A;
+    const int n_ld = tile_a * BA + ca * EPC;
+    const bool n_ok = n_ld < p.Cout;
+    // gather loader state
+    const int cb = tid % CPR_B, rbb = tid / CPR_B;
+    const int kk_ld = tile_b * BB + cb * EPC;
+    const bool kk_ok = kk_ld < p.Kd;
+    const int tap = kk_ld / p.C;
+    const int c0 = kk_ld - tap * p.C;
+    const int fr = tap / p.S;
+    const int fs = tap - fr * p.S;
+    int g_img[NB], g_oh[NB], g_ow[NB];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int m = m_begin + rbb + RPP_B * i;
+        const int img = m / ohw;
+        const int rem = m - img * ohw;
+        g_img[i] = img;
+        g_oh[i] = rem / p.OW;
+        g_ow[i] = rem - g_oh[i] * p.OW;
+    }
+
+    u32x4 ra[NA], rbv[NB];
+    auto load_tile = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + rba + RPP_A * i;
+            if (n_ok && m < m_end) ra[i] = ld_chunk(dy + (size_t)m * (size_t)p.Cout + n_ld);
+            else ra[i] = zero_chunk();
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = m0 + rbb + RPP_B * i;
+            const int ih = g_oh[i] * p.stride - p.pad + fr;
+            const int iw = g_ow[i] * p.stride - p.pad + fs;
+            const bool ok = kk_ok && (m < m_end) && ((unsigned)ih < (unsigned)p.H) &&
+                            ((unsigned)iw < (unsigned)p.W);
+            if (ok) {
+                const size_t e = ((size_t)(g_img[i] * p.H + ih) * p.W + iw) * (size_t)p.C + c0;
+                rbv[i] = ld_chunk(src + e);
+            } else {
+                rbv[i] = zero_chunk();
+            }
+            // advance this row by BR pixels (mixed radix add with carries)
+            int ow = g_ow[i] + p.d_ow;
+            int cy = ow >= p.OW;
+            ow -= cy ? p.OW : 0;
+            int oh = g_oh[i] + p.d_oh + cy;
+            cy = oh >= p.OH;
+            oh -= cy ? p.OH : 0;
+            g_ow[i] = ow;
+            g_oh[i] = oh;
+            g_img[i] += p.d_img + cy;
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            st_chunk(sa + (rba + RPP_A * i) * PITCH_A + ca * 16, ra[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            st_chunk(sb + (rbb + RPP_B * i) * PITCH_B + cb * 16, rbv[i]);
+    };
+
+    f32x4 acc[AT][BT];
+#pragma unroll
+    for (int ai = 0; ai < AT; ++ai)
+#pragma unroll
+        for (int bi = 0; bi < BT; ++bi) acc[ai][bi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+        if constexpr (sizeof(T) == 2) {
+            // BR = 64 rows -> two 32-deep k-steps.  ds_read_b64_tr_b16: a 16-lane group reads a
+            // [4 rows][16 cols] block; lane t supplies the 8-byte address of row (t>>2),
+            // cols (t&3)*4.. and receives column t of the four rows.
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 af[AT], bf[BT];
+                const int row0 = ks * 32 + lg * 8 + (l15 >> 2);
+#pragma unroll
+                for (int ai = 0; ai < AT; ++ai) {
+                    const int col = wa * WA + ai * 16 + (l15 & 3) * 4;
+                    const char* q = sa + row0 * PITCH_A + col * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * PITCH_A));
+                    u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    af[ai] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+                }
+#pragma unroll
+                for (int bi = 0; bi < BT; ++bi) {
+                    const int col = wb * WB + bi * 16 + (l15 & 3) * 4;
+                    const char* q = sb + row0 * PITCH_B + col * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * PITCH_B));
+                    u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    bf[bi] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+                }
+#pragma unroll
+                for (int ai = 0; ai < AT; ++ai)
+#pragma unroll
+                    for (int bi = 0; bi < BT; ++bi)
+                        acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, af[ai]), __builtin_bit_cast(bf16x8, bf[bi]),
+                            acc[ai][bi], 0, 0, 0);
+            }
+        } else {
+            // f32: BR = 32 rows -> eight 4-deep k-steps of mfma 16x16x4 (lane: row/col l15, k = lg)
+#pragma unroll
+            for (int ks = 0; ks < BR / 4; ++ks) {
+                float af[AT], bf[BT];
+                const int row = ks * 4 + lg;
+#pragma unroll
+                for (int ai = 0; ai < AT; ++ai)
+                    af[ai] = *reinterpret_cast<const float*>(sa + row * PITCH_A +
+                                                             (wa * WA + ai * 16 + l15) * 4);
+#pragma unroll
+                for (int bi = 0; bi < BT; ++bi)
+                    bf[bi] = *reinterpret_cast<const float*>(sb + row * PITCH_B +
+                                                             (wb * WB + bi * 16 + l15) * 4);
+#pragma unroll
+                for (int ai = 0; ai < AT; ++ai)
+#pragma unroll
+                    for (int bi = 0; bi < BT; ++bi)
+                        acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ai], bf[bi],
+                                                                          acc[ai][bi], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nt = (m_end - m_begin + BR - 1) / BR;
+    load_tile(m_begin);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1) < nt;
+        if (more) load_tile(m_begin + (t + 1) * BR);
+        compute(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D row -> n = .. + lg*4 + r ; D col -> kk = .. + l15
+#pragma unroll
+    for (int ai = 0; ai < AT; ++ai) {
+        const int n0 = tile_a * BA + wa * WA + ai * 16 + lg * 4;
+#pragma unroll
+        for (int bi = 0; bi < BT; ++bi) {
+            const int kk = tile_b * BB + wb * WB + bi * 16 + l15;
+            if (kk < p.Kd) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < p.Cout)
+                        unsafeAtomicAdd(p.dw + (size_t)(n0 + r) * (size_t)p.Kd + kk, acc[ai][bi][r]);
+            }
+        }
+    }
+}
+
+template <typename K>
+void allow_lds(K k, size_t smem) {
+    // one-time opt-in for > 64 KiB dynamic LDS (idempotent; cheap enough to repeat)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+
+template <typename T, int BN_T, int MODE>
+int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
+    constexpr size_t smem = 2 * (128 * 128 + BN_T * 128);
+    dim3 grid(p.nblk), block(256);
+    if (out_f32) {
+        auto k = igemm_nt_kernel<T, BN_T, MODE, true>;
+        static bool once = (allow_lds(k, smem), true);
+        (void)once;
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    } else {
+        auto k = igemm_nt_kernel<T, BN_T, MODE, false>;
+        static bool once = (allow_lds(k, smem), true);
+        (void)once;
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    }
+    return saicv::check_launch("igemm_nt");
+}
+
+template <typename T, int BA, int BB>
+int launch_tn(const TNParams& p, int splits, hipStream_t st) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BR = 8 * EPC;
+    constexpr size_t smem = 2 * (size_t)BR * ((BA + 16) + (BB + 16)) * sizeof(T);
+    dim3 grid(p.tiles_a * p.tiles_b, splits), block(256);
+    auto k = igemm_tn_kernel<T, BA, BB>;
+    static bool once = (allow_lds(k, smem), true);
+    (void)once;
+    hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    return saicv::check_launch("igemm_tn");
+}
+
+}  // namespace
+
+namespace saicv {
+
+// rows of per-wave BN partial statistics written by the forward kernel
+int conv_stat_rows(int M) { return ((M + 127) / 128) * 2; }
+
+int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
+             float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
+             int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st) {
+    const int epc = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % epc == 0, "igemm_nt: C=%d must be a multiple of %d", C, epc);
+    SAICV_REQUIRE(Kd % epc == 0, "igemm_nt: Kd=%d must be a multiple of %d", Kd, epc);
+    SAICV_REQUIRE(M > 0 && Nn > 0 && Kd > 0, "igemm_nt: empty problem");
+    SAICV_REQUIRE(!(bias && stat_sum), "igemm_nt: bias and BN statistics are exclusive");
+    NTParams p;
+    p.src = src; p.wgt = wgt; p.out = out; p.bias = bias; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.M = M; p.Nn = Nn; p.Kd = Kd; p.ldo = ldo;
+    const bool narrow = Nn <= 64;
+    const int bn = narrow ? 64 : 128;
+    p.tiles_n = (Nn + bn - 1) / bn;
+    p.nblk = p.tiles_n * ((M + 127) / 128);
+    const bool f32o = out_f32 != 0;
+    if (dtype == SAICV_DTYPE_BF16) {
+        if (mode == 0) return narrow ? launch_nt<bf16_t, 64, 0>(p, f32o, st) : launch_nt<bf16_t, 128, 0>(p, f32o, st);
+        return narrow ? launch_nt<bf16_t, 64, 1>(p, f32o, st) : launch_nt<bf16_t, 128, 1>(p, f32o, st);
+    } else {
+        if (mode == 0) return narrow ? launch_nt<float, 64, 0>(p, true, st) : launch_nt<float, 128, 0>(p, true, st);
+        return narrow ? launch_nt<float, 64, 1>(p, true, st) : launch_nt<float, 128, 1>(p, true, st);
+    }
+}
+
+int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W, int C, int OH,
+             int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st) {
+    const int epc = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % epc == 0 && Cout % epc == 0, "igemm_tn: C=%d, Cout=%d must be multiples of %d", C, Cout, epc);
+    SAICV_REQUIRE(M > 0 && Cout > 0 && Kd > 0, "igemm_tn: empty problem");
+    TNParams p;
+    p.dy = dy; p.src = src; p.dw = dw; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.M = M; p.Cout = Cout; p.Kd = Kd;
+    const int BR = 8 * epc;
+    const int ba = Cout <= 64 ? 64 : 128;
+    const int bb = Kd <= 64 ? 64 : 128;
+    p.tiles_a = (Cout + ba - 1) / ba;
+    p.tiles_b = (Kd + bb - 1) / bb;
+    const int tiles = p.tiles_a * p.tiles_b;
+    // split the pixel reduction so that ~4 workgroups per CU are in flight
+    const int total_rt = (M + BR - 1) / BR;
+    int splits = (1024 + tiles - 1) / tiles;
+    if (splits > total_rt) splits = total_rt;
+    if (splits < 1) splits = 1;
+    int rt_per = (total_rt + splits - 1) / splits;
+    splits = (total_rt + rt_per - 1) / rt_per;
+    p.m_per_split = rt_per * BR;
+    const int ohw = OH * OW;
+    p.d_img = BR / ohw;
+    const int rem = BR - p.d_img * ohw;
+    p.d_oh = rem / OW;
+    p.d_ow = rem - p.d_oh * OW;
+    if (dtype == SAICV_DTYPE_BF16) {
+        if (ba == 64 && bb == 64) return launch_tn<bf16_t, 64, 64>(p, splits, st);
+        if (ba == 64) return launch_tn<bf16_t, 64, 128>(p, splits, st);
+        if (bb == 64) return launch_tn<bf16_t, 128, 64>(p, splits, st);
+        return launch_tn<bf16_t, 128, 128>(p, splits, st);
+    } else {
+        if (ba == 64 && bb == 64) return launch_tn<float, 64, 64>(p, splits, st);
+        if (ba == 64) return launch_tn<float, 64, 128>(p, splits, st);
+        if (bb == 64) return launch_tn<float, 128, 64>(p, splits, st);
+        return launch_tn<float, 128, 128>(p, splits, st);
+    }
+}
+
+}  // namespace saicv

@@ -1,0 +1,134 @@
+// Layout / dtype packing kernels (HBM-bound, tiny next to the activations).
+//  - pack_input : NCHW-shaped image batch (any strides, fp32) -> dense NHWC [N,H,W,Cp] in the
+//                 compute dtype, channels zero-padded to Cp (the 3-channel stem becomes C=8
+//                 so every implicit-GEMM gather is a 16-byte chunk).  The reference collater
+//                 hands over NHWC-strided fp32 (SimpleAICV/classification/common.py:645-665).
+//  - pack_weight: fp32 master weight [O,I,R,S] (any strides) -> compute-dtype forward matrix
+//                 Wf[O][R][S][Ip] and, optionally, the data-gradient matrix Wd[I][R][S][O].
+//  - unpack_wgrad: fp32 dW[O][R][S][Ip] -> gradient tensor [O,I,R,S] with arbitrary strides.
+#include "common.h"
+#include "saicv_internal.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, long sN,
+                                                         long sC, long sH, long sW, T* __restrict__ dst,
+                                                         int Nimg, int C, int H, int W, int Cp) {
+    const size_t total = (size_t)Nimg * H * W;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        size_t pix = i;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const int n = (int)(pix / H);
+        const float* s = src + (size_t)n * sN + (size_t)h * sH + (size_t)w * sW;
+        T* d = dst + i * Cp;
+        for (int c = 0; c < Cp; ++c) d[c] = from_f32<T>(c < C ? s[(size_t)c * sC] : 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, long sO, long sI,
+                                                          long sR, long sS, int O, int I, int R, int S,
+                                                          int Ip, T* __restrict__ wf, T* __restrict__ wd) {
+    const size_t total = (size_t)O * R * S * Ip;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gstride) {
+        size_t t = e;
+        const int i = (int)(t % Ip); t /= Ip;
+        const int s = (int)(t % S); t /= S;
+        const int r = (int)(t % R);
+        const int o = (int)(t / R);
+        const float v = i < I ? w[(size_t)o * sO + (size_t)i * sI + (size_t)r * sR + (size_t)s * sS] : 0.f;
+        if (wf) wf[e] = from_f32<T>(v);
+        if (wd && i < I) wd[(((size_t)i * R + r) * S + s) * O + o] = from_f32<T>(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dw, int O, int I,
+                                                           int R, int S, int Ip, float* __restrict__ g,
+                                                           long sO, long sI, long sR, long sS,
+                                                           int accumulate) {
+    const size_t total = (size_t)O * R * S * I;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gstride) {
+        size_t t = e;
+        const int i = (int)(t % I); t /= I;
+        const int s = (int)(t % S); t /= S;
+        const int r = (int)(t % R);
+        const int o = (int)(t / R);
+        const float v = dw[(((size_t)o * R + r) * S + s) * Ip + i];
+        float* d = g + (size_t)o * sO + (size_t)i * sI + (size_t)r * sR + (size_t)s * sS;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+
+// column sums of a [M][N] matrix (bias gradient), T in, fp32 out (accumulating atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int M, int N,
+                                                     int rows_per, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * rows_per;
+    const int r1 = min(M, r0 + rows_per);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += to_f32(x[(size_t)r * N + c]);
+    unsafeAtomicAdd(out + c, s);
+}
+
+inline int sgrid(size_t total) {
+    size_t b = (total + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+namespace saicv {
+
+int pack_input(int dtype, const float* src, long sN, long sC, long sH, long sW, void* dst, int Nimg,
+               int C, int H, int W, int Cp, hipStream_t st) {
+    SAICV_REQUIRE(Cp >= C, "pack_input: Cp=%d < C=%d", Cp, C);
+    const size_t total = (size_t)Nimg * H * W;
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_input_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, src, sN, sC, sH, sW, (bf16_t*)dst, Nimg, C, H, W, Cp);
+    else
+        hipLaunchKernelGGL(pack_input_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, src, sN, sC, sH, sW, (float*)dst, Nimg, C, H, W, Cp);
+    return check_launch("pack_input");
+}
+
+int pack_weight(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I, int R,
+                int S, int Ip, void* wf, void* wd, hipStream_t st) {
+    SAICV_REQUIRE(Ip >= I, "pack_weight: Ip=%d < I=%d", Ip, I);
+    SAICV_REQUIRE(wd == nullptr || Ip == I, "pack_weight: data-gradient matrix needs unpadded I");
+    const size_t total = (size_t)O * R * S * Ip;
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, Ip, (bf16_t*)wf, (bf16_t*)wd);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, Ip, (float*)wf, (float*)wd);
+    return check_launch("pack_weight");
+}
+
+int unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, float* g, long sO, long sI,
+                 long sR, long sS, int accumulate, hipStream_t st) {
+    const size_t total = (size_t)O * R * S * I;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(sgrid(total)), dim3(256), 0, st, dw, O, I, R, S, Ip, g, sO, sI, sR, sS, accumulate);
+    return check_launch("unpack_wgrad");
+}
+
+int colsum(int dtype, const void* x, int M, int N, float* out, hipStream_t st) {
+    int ysplit = (M + 63) / 64;
+    if (ysplit > 64) ysplit = 64;
+    const int rows_per = (M + ysplit - 1) / ysplit;
+    ysplit = (M + rows_per - 1) / rows_per;
+    dim3 grid((N + 255) / 256, ysplit);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, M, N, rows_per, out);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, M, N, rows_per, out);
+    return check_launch("colsum");
+}
+
+}  // namespace saicv

@@ -1,0 +1,18 @@
+// Internal C++ declarations shared between the .hip translation units and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace saicv {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// igemm.hip
+int conv_stat_rows(int M);
+int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
+             float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
+             int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st);
+int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W, int C, int OH,
+             int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st);
+
+}  // namespace saicv

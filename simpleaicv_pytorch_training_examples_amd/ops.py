@@ -1,0 +1,377 @@
+"""torch.autograd.Functions over the C-ABI of libsaicv_hip.so.
+
+Activations are NCHW-shaped, NHWC-strided (torch.channels_last) tensors in the compute dtype
+(bf16 under autocast = perf mode, fp32 otherwise = parity mode).  Statistics, logits, losses
+and every parameter gradient are fp32, as under the reference's autocast region
+(reference tools/scripts.py:153-156).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, dtype_code, lib, ptr, require_gpu, stream
+
+_weights_epoch = [0]
+
+
+def bump_weights_epoch():
+    """Called by the flat-arena optimizer after it rewrote parameters through raw pointers."""
+    _weights_epoch[0] += 1
+
+
+def compute_dtype():
+    if torch.is_autocast_enabled('cuda'):
+        dt = torch.get_autocast_dtype('cuda')
+        if dt != torch.bfloat16:
+            raise RuntimeError(f'saicv kernels run bf16 or fp32; autocast dtype {dt} is not supported '
+                               '(MI355X perf mode is bf16)')
+        return dt
+    return torch.float32
+
+
+def _nhwc(x):
+    """Returns x as a dense NHWC-strided tensor (no copy when it already is)."""
+    if x.dim() != 4:
+        raise ValueError('expected a 4-d NCHW-shaped tensor')
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    return x
+
+
+def _empty_nhwc(n, c, h, w, dtype, device):
+    return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+_desc_cache = {}
+
+
+def _desc(N, H, W, C, K, R, S, stride, pad, dt):
+    key = (N, H, W, C, K, R, S, stride, pad, dt)
+    d = _desc_cache.get(key)
+    if d is None:
+        OH = (H + 2 * pad - R) // stride + 1
+        OW = (W + 2 * pad - S) // stride + 1
+        d = ConvDesc(N, H, W, C, K, R, S, stride, pad, OH, OW, dtype_code(dt))
+        _desc_cache[key] = d
+    return d
+
+
+# ------------------------------------------------------------------------------ packing
+def pack_input(x, dtype=None, cp=8):
+    """NCHW-shaped image batch (any strides) -> NHWC compute-dtype tensor with C padded to cp."""
+    require_gpu(x)
+    if dtype is None:
+        dtype = compute_dtype()
+    if x.dtype != torch.float32:
+        x = x.float()
+    n, c, h, w = x.shape
+    cp = max(cp, ((c + _lib.epc(dtype) - 1) // _lib.epc(dtype)) * _lib.epc(dtype))
+    out = torch.empty((n, h, w, cp), dtype=dtype, device=x.device)
+    sn, sc, sh, sw = x.stride()
+    check(lib().saicv_pack_input(dtype_code(dtype), ptr(x), sn, sc, sh, sw, ptr(out), n, c, h, w, cp,
+                                 stream()), 'pack_input')
+    return out.permute(0, 3, 1, 2)
+
+
+def packed_weight(weight, dtype, cin_padded, need_wd):
+    """Compute-dtype copies of a conv / linear master weight, cached until the weight changes.
+
+    Returns (wf [O][R][S][Ip], wd [I][R][S][O] or None)."""
+    key = (weight._version, _weights_epoch[0], dtype, cin_padded, weight.data_ptr())
+    cache = getattr(weight, '_saicv_pack', None)
+    if cache is not None and cache[0] == key and (cache[2] is not None or not need_wd):
+        return cache[1], cache[2]
+    w = weight.detach()
+    if w.dim() == 2:
+        o, i = w.shape
+        r = s = 1
+        so, si = w.stride()
+        sr = ss = 0
+    else:
+        o, i, r, s = w.shape
+        so, si, sr, ss = w.stride()
+    wf = torch.empty((o, r, s, cin_padded), dtype=dtype, device=w.device)
+    wd = torch.empty((i, r, s, o), dtype=dtype, device=w.device) if need_wd else None
+    check(lib().saicv_pack_weight(dtype_code(dtype), ptr(w), so, si, sr, ss, o, i, r, s, cin_padded,
+                                  ptr(wf), ptr(wd), stream()), 'pack_weight')
+    weight._saicv_pack = (key, wf, wd)
+    return wf, wd
+
+
+def _weight_grad(dw, weight, cin_padded):
+    """fp32 dW[O][R][S][Ip] -> gradient laid out like `weight`."""
+    if weight.dim() == 2:
+        return dw.view(weight.shape[0], cin_padded)[:, :weight.shape[1]] if cin_padded != weight.shape[1] else dw.view(weight.shape)
+    o, i, r, s = weight.shape
+    if cin_padded == i and weight.is_contiguous(memory_format=torch.channels_last):
+        return dw.permute(0, 3, 1, 2)
+    g = torch.empty_strided(weight.shape, weight.stride(), dtype=torch.float32, device=weight.device)
+    so, si, sr, ss = g.stride()
+    check(lib().saicv_unpack_wgrad(ptr(dw), o, i, r, s, cin_padded, ptr(g), so, si, sr, ss, 0, stream()),
+          'unpack_wgrad')
+    return g
+
+
+# ------------------------------------------------------------------------------ conv + BN + act
+class ConvBnActFn(torch.autograd.Function):
+    """conv -> [BatchNorm2d (train: batch stats, eval: running stats)] -> [+residual] -> [ReLU].
+
+    Mirrors reference ConvBnActBlock (classification/backbones/resnet.py:19-48) plus the
+    residual tail of BasicBlock / Bottleneck (:94-95, :152-153)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, pad, relu):
+        require_gpu(x, weight)
+        x = _nhwc(x)
+        dt = x.dtype
+        n, c, h, w = x.shape
+        k, ci, r, s = weight.shape
+        if c < ci:
+            raise ValueError(f'input has {c} channels, weight expects {ci}')
+        need_dx = ctx.needs_input_grad[0]
+        wf, wd = packed_weight(weight, dt, c, need_dx and c == ci)
+        d = _desc(n, h, w, c, k, r, s, stride, pad, dt)
+        L = lib()
+        st = stream()
+        dev = x.device
+        y = _empty_nhwc(n, k, d.OH, d.OW, dt, dev)
+        M = n * d.OH * d.OW
+        training = bn.training
+        scale = torch.empty(k, dtype=torch.float32, device=dev)
+        shift = torch.empty(k, dtype=torch.float32, device=dev)
+        mean = invstd = None
+        if training:
+            rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
+            stats = torch.empty((2, rows, k), dtype=torch.float32, device=dev)
+            check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, ptr(stats[0]),
+                                     ptr(stats[1]), st), 'conv2d_fwd')
+            mean = torch.empty(k, dtype=torch.float32, device=dev)
+            invstd = torch.empty(k, dtype=torch.float32, device=dev)
+            ws = torch.empty(L.saicv_bn_ws_floats(k), dtype=torch.float32, device=dev)
+            if bn.momentum is None:
+                raise NotImplementedError('BatchNorm2d(momentum=None) is not supported')
+            track = bn.track_running_stats and bn.running_mean is not None
+            check(L.saicv_bn_finalize_fwd(ptr(stats[0]), ptr(stats[1]), rows, k, float(M), ptr(gamma),
+                                          ptr(beta), ptr(bn.running_mean) if track else 0,
+                                          ptr(bn.running_var) if track else 0, float(bn.momentum),
+                                          float(bn.eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                          ptr(ws), st), 'bn_finalize_fwd')
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+        else:
+            check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, 0, 0, st), 'conv2d_fwd')
+            check(L.saicv_bn_eval_coeffs(k, ptr(gamma), ptr(beta), ptr(bn.running_mean),
+                                         ptr(bn.running_var), float(bn.eps), ptr(scale), ptr(shift), st),
+                  'bn_eval_coeffs')
+        if residual is not None:
+            residual = _nhwc(residual)
+            if residual.dtype != dt:
+                residual = residual.to(dt)
+        z = _empty_nhwc(n, k, d.OH, d.OW, dt, dev)
+        check(L.saicv_bn_act_fwd(dtype_code(dt), ptr(y), ptr(residual), ptr(z), ptr(scale), ptr(shift), M,
+                                 k, int(relu), st), 'bn_act_fwd')
+        if training:
+            ctx.save_for_backward(x, weight, gamma, y, z if relu else None, mean, invstd)
+        else:
+            # eval-mode backward (frozen statistics) is linear: dy = scale * g
+            ctx.save_for_backward(x, weight, gamma, y, z if relu else None, None, scale)
+        ctx.cfg = (stride, pad, bool(relu), residual is not None, training, d, wd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight, gamma, y, z, mean, invstd = ctx.saved_tensors
+        stride, pad, relu, has_res, training, d, wd = ctx.cfg
+        if not training:
+            raise NotImplementedError('backward through eval-mode BatchNorm is not implemented')
+        L = lib()
+        st = stream()
+        dt = y.dtype
+        dev = y.device
+        dz = _nhwc(dz)
+        if dz.dtype != dt:
+            dz = dz.to(dt)
+        n, k, oh, ow = y.shape
+        M = n * oh * ow
+        dy = _empty_nhwc(n, k, oh, ow, dt, dev)
+        dres = _empty_nhwc(n, k, oh, ow, dt, dev) if (has_res and ctx.needs_input_grad[4]) else None
+        dgamma = torch.empty(k, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(k, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, k, dtype_code(dt)), dtype=torch.float32, device=dev)
+        check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), ptr(z), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
+                                 ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), M, k, int(relu), ptr(ws), st),
+              'bn_act_bwd')
+        c = x.shape[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if wd is None:
+                _, wd = packed_weight(weight, dt, c, True)
+            dx = _empty_nhwc(n, c, x.shape[2], x.shape[3], dt, dev)
+            check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
+        dwt = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=dev)
+            check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
+            dwt = _weight_grad(dw, weight, c)
+        return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
+                dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None)
+
+
+def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None):
+    return ConvBnActFn.apply(x, weight, bn.weight, bn.bias, residual, bn, stride, pad, relu)
+
+
+# ------------------------------------------------------------------------------ plain conv / linear
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b on the implicit-GEMM kernel (1x1 geometry).  nn.Linear of resnet.py:204."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_f32):
+        require_gpu(x, weight)
+        if x.dim() != 2:
+            raise ValueError('LinearFn expects a 2-d input')
+        x = x.contiguous()
+        dt = x.dtype
+        b, ci = x.shape
+        o = weight.shape[0]
+        wf, wd = packed_weight(weight, dt, ci, ctx.needs_input_grad[0])
+        d = _desc(b, 1, 1, ci, o, 1, 1, 1, 0, dt)
+        odt = torch.float32 if (out_f32 or dt == torch.float32) else dt
+        y = torch.empty((b, o), dtype=odt, device=x.device)
+        check(lib().saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), ptr(bias), ptr(y),
+                                     int(odt == torch.float32), 0, 0, stream()), 'linear_fwd')
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (d, wd, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        d, wd, has_bias = ctx.cfg
+        dt = x.dtype
+        L = lib()
+        st = stream()
+        dy = dy.contiguous()
+        if dy.dtype != dt:
+            dy = dy.to(dt)
+        b, ci = x.shape
+        o = weight.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if wd is None:
+                _, wd = packed_weight(weight, dt, ci, True)
+            dx = torch.empty((b, ci), dtype=dt, device=x.device)
+            check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'linear_dgrad')
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((o, ci), dtype=torch.float32, device=x.device)
+            check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'linear_wgrad')
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(o, dtype=torch.float32, device=x.device)
+            check(L.saicv_colsum(dtype_code(dt), ptr(dy), b, o, ptr(db), st), 'colsum')
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, out_f32=False):
+    return LinearFn.apply(x, weight, bias, out_f32)
+
+
+# ------------------------------------------------------------------------------ pooling
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(k, s, p) on NHWC (reference resnet.py:184)."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        require_gpu(x)
+        x = _nhwc(x)
+        n, c, h, w = x.shape
+        oh = (h + 2 * pad - k) // stride + 1
+        ow = (w + 2 * pad - k) // stride + 1
+        out = _empty_nhwc(n, c, oh, ow, x.dtype, x.device)
+        idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
+        check(lib().saicv_maxpool_fwd(dtype_code(x.dtype), ptr(x), ptr(out), ptr(idx), n, h, w, c, oh, ow, k,
+                                      stride, pad, stream()), 'maxpool_fwd')
+        ctx.save_for_backward(idx)
+        ctx.cfg = (n, c, h, w, oh, ow, k, stride, pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w, oh, ow, k, stride, pad = ctx.cfg
+        dout = _nhwc(dout)
+        dx = _empty_nhwc(n, c, h, w, dout.dtype, dout.device)
+        check(lib().saicv_maxpool_bwd(dtype_code(dout.dtype), ptr(dout), ptr(idx), ptr(dx), n, h, w, c, oh, ow,
+                                      k, stride, pad, stream()), 'maxpool_bwd')
+        return dx, None, None, None
+
+
+def max_pool2d(x, k, stride, pad):
+    return MaxPoolFn.apply(x, k, stride, pad)
+
+
+class GlobalAvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d((1,1)) + flatten -> [N, C] (reference resnet.py:203,243-244)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_gpu(x)
+        x = _nhwc(x)
+        n, c, h, w = x.shape
+        out = torch.empty((n, c), dtype=x.dtype, device=x.device)
+        check(lib().saicv_avgpool_fwd(dtype_code(x.dtype), ptr(x), ptr(out), n, h * w, c, stream()), 'avgpool_fwd')
+        ctx.cfg = (n, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, c, h, w = ctx.cfg
+        dout = dout.contiguous()
+        dx = _empty_nhwc(n, c, h, w, dout.dtype, dout.device)
+        check(lib().saicv_avgpool_bwd(dtype_code(dout.dtype), ptr(dout), ptr(dx), n, h * w, c, stream()),
+              'avgpool_bwd')
+        return dx
+
+
+def global_avg_pool(x):
+    return GlobalAvgPoolFn.apply(x)
+
+
+# ------------------------------------------------------------------------------ losses
+class SoftmaxCEFn(torch.autograd.Function):
+    """mean softmax cross-entropy on fp32 logits; hard (int64) or soft (fp32 [B,C]) labels.
+
+    Reference SimpleAICV/classification/losses.py:21-28 (CELoss), :86-91 (OneHotLabelCELoss)."""
+
+    @staticmethod
+    def forward(ctx, logits, label, soft):
+        require_gpu(logits, label)
+        logits = logits.float().contiguous()
+        b, c = logits.shape
+        if soft:
+            label = label.float().contiguous()
+        else:
+            label = label.long().contiguous()
+        dev = logits.device
+        row = torch.empty(b, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[0]
+        dlog = torch.empty((b, c), dtype=torch.float32, device=dev) if need else None
+        check(lib().saicv_softmax_ce_fwd(ptr(logits), ptr(label), int(soft), b, c, ptr(row), ptr(loss), ptr(dlog),
+                                         stream()), 'softmax_ce_fwd')
+        if need:
+            ctx.save_for_backward(dlog)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dlog,) = ctx.saved_tensors
+        gout = gout.float().contiguous()
+        out = torch.empty_like(dlog)
+        check(lib().saicv_scale_by_scalar(_lib.F32, ptr(dlog), ptr(gout), ptr(out), dlog.numel(), stream()),
+              'scale_by_scalar')
+        return out, None, None
+
+
+def softmax_cross_entropy(logits, label, soft=False):
+    return SoftmaxCEFn.apply(logits, label, soft)
