@@ -48,10 +48,11 @@ const char* saicv_last_error_string(void);
 int saicv_pack_input(int dtype, const float* src, long sN, long sC, long sH, long sW, void* dst,
                      int N, int C, int H, int W, int Cp, void* stream);
 /* fp32 master weight [O,I,R,S] (element strides) -> Wf[O][R][S][Ip] and optionally the
- * data-gradient matrix Wd[I][R][S][O] (NULL to skip).  nn.Conv2d / nn.Linear weights of
- * resnet.py:33-39, :204. */
+ * data-gradient matrix Wd[I][R][S][Op] (NULL to skip; Op >= O is its leading dimension, rows
+ * O..Op-1 of Wf / columns O..Op-1 of Wd are the caller's zero padding).  nn.Conv2d / nn.Linear
+ * weights of resnet.py:33-39, :204. */
 int saicv_pack_weight(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I,
-                      int R, int S, int Ip, void* wf, void* wd, void* stream);
+                      int R, int S, int Ip, int Op, void* wf, void* wd, void* stream);
 /* fp32 dW[O][R][S][Ip] -> gradient tensor [O,I,R,S] with element strides. */
 int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, float* grad, long sO,
                        long sI, long sR, long sS, int accumulate, void* stream);

@@ -29,7 +29,7 @@ SIGNATURES = {
     'saicv_version': (c_int, []),
     'saicv_last_error_string': (c_char_p, []),
     'saicv_pack_input': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    'saicv_pack_weight': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'saicv_pack_weight': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'saicv_unpack_wgrad': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_long, c_long, c_long, c_long, c_int, _P]),
     'saicv_conv2d_stat_rows': (c_int, [_PD]),
     'saicv_conv2d_fwd': (c_int, [_PD, _P, _P, _P, _P, c_int, _P, _P, _P]),

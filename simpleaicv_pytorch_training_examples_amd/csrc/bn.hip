@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 
 // ---------------------------------------------------------------- backward reduce
 // Block handles a slab of rows; thread owns one chunk column (N channels) and strides over
-// rows; per-block partials [slab][C].  Requires C/N to divide 256 or be a multiple of 256.
+// rows; per-block partials [slab][C].  Any C that is a multiple of N works.
 template <typename T, bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz,
                                                             const T* __restrict__ z,
@@ -143,35 +143,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     constexpr int N = Chunk<T>::N;
     const int cpr = C / N;                       // chunk columns per row
     const int cols = cpr < 256 ? cpr : 256;      // columns handled per pass by this block
-    const int rpp = 256 / cols;                  // rows per pass
+    const int rpp = 256 / cols;                  // row lanes per pass
     const int tx = threadIdx.x % cols;
-    const int ty = threadIdx.x / cols;
+    const int ty = threadIdx.x / cols;           // may be >= rpp for the few left-over threads
     const int r0 = blockIdx.x * rows_per;
     const int r1 = min(M, r0 + rows_per);
     __shared__ float lg_[256 * 8], lx_[256 * 8];
-    for (int cb = tx; cb < cpr; cb += cols) {
-        const int c0 = cb * N;
+    for (int base = 0; base < cpr; base += cols) {           // uniform trip count
+        const int cb = base + tx;
+        const bool active = (cb < cpr) && (ty < rpp);
+        const int c0 = active ? cb * N : 0;
         float mu[N], is[N], ag[N], ax[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; ag[j] = 0.f; ax[j] = 0.f; }
-        for (int r = r0 + ty; r < r1; r += rpp) {
-            const size_t e = (size_t)r * C + c0;
-            float g[N], yy[N], zz[N];
-            Chunk<T>::unpack(ld_chunk(dz + e), g);
-            Chunk<T>::unpack(ld_chunk(y + e), yy);
-            if (RELU) Chunk<T>::unpack(ld_chunk(z + e), zz);
+        if (active) {
+            for (int r = r0 + ty; r < r1; r += rpp) {
+                const size_t e = (size_t)r * C + c0;
+                float g[N], yy[N], zz[N];
+                Chunk<T>::unpack(ld_chunk(dz + e), g);
+                Chunk<T>::unpack(ld_chunk(y + e), yy);
+                if (RELU) Chunk<T>::unpack(ld_chunk(z + e), zz);
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const float gj = (RELU && !(zz[j] > 0.f)) ? 0.f : g[j];
-                ag[j] += gj;
-                ax[j] += gj * (yy[j] - mu[j]) * is[j];
+                for (int j = 0; j < N; ++j) {
+                    const float gj = (RELU && !(zz[j] > 0.f)) ? 0.f : g[j];
+                    ag[j] += gj;
+                    ax[j] += gj * (yy[j] - mu[j]) * is[j];
+                }
             }
         }
         // combine the rpp row-lanes of this column through LDS
 #pragma unroll
         for (int j = 0; j < N; ++j) { lg_[threadIdx.x * N + j] = ag[j]; lx_[threadIdx.x * N + j] = ax[j]; }
         __syncthreads();
-        if (ty == 0) {
+        if (active && ty == 0) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float sg = 0.f, sx = 0.f;
@@ -363,10 +367,7 @@ int bn_bwd(int dtype, const void* dz, const void* z, const void* y, const float*
            const float* mean, const float* invstd, void* dy, void* dres, float* dgamma, float* dbeta,
            size_t M, int C, int relu, float* ws, hipStream_t st) {
     const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
-    const int cpr = C / n;
     SAICV_REQUIRE(C % n == 0, "bn_bwd: C=%d must be a multiple of %d", C, n);
-    SAICV_REQUIRE((cpr <= 256 && 256 % cpr == 0) || (cpr % 256 == 0),
-                  "bn_bwd: C/%d=%d must divide 256 or be a multiple of 256", n, cpr);
     SAICV_REQUIRE(!relu || z != nullptr, "bn_bwd: relu needs the forward output z");
     if (dtype == SAICV_DTYPE_BF16)
         return bn_bwd_t<bf16_t>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, ws, st);

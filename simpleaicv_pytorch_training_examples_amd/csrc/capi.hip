@@ -45,7 +45,7 @@ int avgpool_bwd(int, const void*, void*, int, int, int, hipStream_t);
 int softmax_ce_fwd(const float*, const void*, int, int, int, float*, float*, float*, hipStream_t);
 int scale_by_scalar(int, const float*, const float*, void*, size_t, hipStream_t);
 int pack_input(int, const float*, long, long, long, long, void*, int, int, int, int, int, hipStream_t);
-int pack_weight(int, const float*, long, long, long, long, int, int, int, int, int, void*, void*, hipStream_t);
+int pack_weight(int, const float*, long, long, long, long, int, int, int, int, int, int, void*, void*, hipStream_t);
 int unpack_wgrad(const float*, int, int, int, int, int, float*, long, long, long, long, int, hipStream_t);
 int colsum(int, const void*, int, int, float*, hipStream_t);
 int sgd_flat(float*, const float*, float*, const int32_t*, const float*, const float*, const float*, size_t, hipStream_t);
@@ -86,8 +86,8 @@ int saicv_pack_input(int dtype, const float* src, long sN, long sC, long sH, lon
     return pack_input(dtype, src, sN, sC, sH, sW, dst, N, C, H, W, Cp, S(stream));
 }
 int saicv_pack_weight(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I,
-                      int R, int Sx, int Ip, void* wf, void* wd, void* stream) {
-    return pack_weight(dtype, w, sO, sI, sR, sS, O, I, R, Sx, Ip, wf, wd, S(stream));
+                      int R, int Sx, int Ip, int Op, void* wf, void* wd, void* stream) {
+    return pack_weight(dtype, w, sO, sI, sR, sS, O, I, R, Sx, Ip, Op, wf, wd, S(stream));
 }
 int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int Sx, int Ip, float* grad, long sO,
                        long sI, long sR, long sS, int accumulate, void* stream) {

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, long sO, long sI,
                                                           long sR, long sS, int O, int I, int R, int S,
-                                                          int Ip, T* __restrict__ wf, T* __restrict__ wd) {
+                                                          int Ip, int Op, T* __restrict__ wf, T* __restrict__ wd) {
     const size_t total = (size_t)O * R * S * Ip;
     const size_t gstride = (size_t)gridDim.x * blockDim.x;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gstride) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         const int o = (int)(t / R);
         const float v = i < I ? w[(size_t)o * sO + (size_t)i * sI + (size_t)r * sR + (size_t)s * sS] : 0.f;
         if (wf) wf[e] = from_f32<T>(v);
-        if (wd && i < I) wd[(((size_t)i * R + r) * S + s) * O + o] = from_f32<T>(v);
+        if (wd && i < I) wd[(((size_t)i * R + r) * S + s) * Op + o] = from_f32<T>(v);
     }
 }
 
@@ -100,14 +100,15 @@ int pack_input(int dtype, const float* src, long sN, long sC, long sH, long sW, 
 }
 
 int pack_weight(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I, int R,
-                int S, int Ip, void* wf, void* wd, hipStream_t st) {
+                int S, int Ip, int Op, void* wf, void* wd, hipStream_t st) {
     SAICV_REQUIRE(Ip >= I, "pack_weight: Ip=%d < I=%d", Ip, I);
     SAICV_REQUIRE(wd == nullptr || Ip == I, "pack_weight: data-gradient matrix needs unpadded I");
+    SAICV_REQUIRE(Op >= O, "pack_weight: Op=%d < O=%d", Op, O);
     const size_t total = (size_t)O * R * S * Ip;
     if (dtype == SAICV_DTYPE_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, Ip, (bf16_t*)wf, (bf16_t*)wd);
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, Ip, Op, (bf16_t*)wf, (bf16_t*)wd);
     else
-        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, Ip, (float*)wf, (float*)wd);
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, Ip, Op, (float*)wf, (float*)wd);
     return check_launch("pack_weight");
 }
 

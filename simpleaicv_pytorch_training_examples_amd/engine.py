@@ -1,0 +1,405 @@
+"""Data-parallel training engine for MI355X: flat fp32 arenas, bucketed RCCL gradient
+all-reduce overlapped with backward, fused flat optimizers and a sync-free GradScaler.
+
+Replaces, behind the same call surface, what the reference gets from
+  * nn.parallel.DistributedDataParallel        (tools/utils.py:193-197, build_training_mode)
+  * torch.optim.SGD / AdamW                     (tools/utils.py:292-679, build_optimizer)
+  * torch.amp.GradScaler                        (tools/utils.py:199-200)
+and removes their per-step host synchronisation: the inf/nan decision, the unscale, the
+clip and the parameter update all stay on the device.
+
+Design (MI355X-first, one process per GPU):
+  * every parameter is re-pointed into ONE flat fp32 arena (each parameter starts on a
+    1024-element boundary), its .grad into a second arena; channels_last conv weights keep
+    their strides (as_strided views), so state_dict()/load_state_dict() are unchanged;
+  * gradient buckets are contiguous slices of the gradient arena in reverse registration
+    order (the order backward produces them); a post-accumulate hook counts parameters and,
+    when a bucket is complete, enqueues one torch.distributed all_reduce (backend "nccl" ==
+    RCCL over xGMI) asynchronously -- ProcessGroupNCCL runs it on its own HIP stream, ordered
+    after the producing kernels by an event, so it overlaps the rest of backward;
+  * xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce moves 1.75x the bucket
+    over one link per GPU, so buckets are large (default 48 MiB) and only the LAST bucket to
+    complete (stem + first stage) is small (4 MiB) to shorten the exposed tail;
+  * `no_sync()` only suppresses the enqueue; gradients keep accumulating in the arena.
+"""
+import contextlib
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops
+from ._lib import check, lib, ptr
+
+ALIGN = 1024          # elements; one optimizer workgroup never straddles two parameters
+HYPER = 8             # floats per param group in the device hyper-parameter table
+
+
+def _dense_numel(p):
+    return p.numel()
+
+
+class FlatArena:
+    """Owns the flat fp32 parameter and gradient arenas of a model."""
+
+    def __init__(self, named_params, device):
+        self.names, self.params = [], []
+        seen = set()
+        for n, p in named_params:
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            if p.dtype != torch.float32:
+                raise TypeError(f'{n}: master parameters must be fp32, got {p.dtype}')
+            self.names.append(n)
+            self.params.append(p)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += ((p.numel() + ALIGN - 1) // ALIGN) * ALIGN
+        self.total = off
+        self.device = device
+        self.flat_param = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):
+                    p.data = p.data.contiguous()
+                view = self.flat_param.as_strided(p.shape, p.stride(), o)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad.as_strided(p.shape, p.stride(), o)
+        ops.bump_weights_epoch()
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        # re-attach views in case someone set .grad = None (optimizer.zero_grad(set_to_none=True))
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad.as_strided(p.shape, p.stride(), o)
+
+    def block_groups(self, group_of_param):
+        """int32 [total/ALIGN] table: optimizer param-group index of each 1024-element block."""
+        table = torch.full((self.total // ALIGN,), -1, dtype=torch.int32)
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            g = group_of_param.get(id(p), -1)
+            nb = (p.numel() + ALIGN - 1) // ALIGN
+            table[o // ALIGN:o // ALIGN + nb] = g
+        return table.to(self.device)
+
+
+def _arena_of(model):
+    arena = getattr(model, '_saicv_arena', None)
+    if arena is None:
+        dev = next(model.parameters()).device
+        arena = FlatArena(list(model.named_parameters()), dev)
+        model._saicv_arena = arena
+    return arena
+
+
+# ------------------------------------------------------------------------------ optimizers
+class _FlatOptimizer:
+    """torch.optim-compatible surface (param_groups, step, zero_grad, state_dict) on the fused
+    flat kernels.  `param_groups[i]['lr']` may be rewritten every iteration by the reference
+    Scheduler (tools/utils.py:223-260); values are uploaded to the device table at step()."""
+
+    def __init__(self, model, param_groups):
+        self.arena = _arena_of(model)
+        self.param_groups = []
+        group_of = {}
+        for gi, g in enumerate(param_groups):
+            g = dict(g)
+            g['params'] = list(g['params'])
+            for p in g['params']:
+                group_of[id(p)] = gi
+            self.param_groups.append(g)
+        self.block_group = self.arena.block_groups(group_of)
+        self._hyper_host = torch.zeros(len(self.param_groups) * HYPER, dtype=torch.float32).pin_memory() \
+            if self.arena.device.type == 'cuda' else torch.zeros(len(self.param_groups) * HYPER)
+        self._hyper_dev = torch.zeros(len(self.param_groups) * HYPER, dtype=torch.float32, device=self.arena.device)
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
+        self.steps = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def _upload(self, rows):
+        for gi, row in enumerate(rows):
+            for k, v in enumerate(row):
+                self._hyper_host[gi * HYPER + k] = v
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def _launch(self, inv_scale, found_inf):
+        raise NotImplementedError
+
+    def check_finite(self):
+        """found_inf[0] = 1 if any gradient is inf / nan (device side, no host sync)."""
+        self.found_inf.zero_()
+        check(lib().saicv_grad_stats(ptr(self.arena.flat_grad), self.arena.total, ptr(self.found_inf), 0,
+                                     _lib.stream()), 'grad_stats')
+
+    def clip_grad_norm_(self, max_norm, inv_scale=None):
+        """torch.nn.utils.clip_grad_norm_ over the whole arena, fused with the unscale."""
+        self.sumsq.zero_()
+        check(lib().saicv_grad_stats(ptr(self.arena.flat_grad), self.arena.total, 0, ptr(self.sumsq),
+                                     _lib.stream()), 'grad_stats')
+        check(lib().saicv_grad_clip_scale(ptr(self.arena.flat_grad), self.arena.total, ptr(self.sumsq),
+                                          ptr(inv_scale), float(max_norm), _lib.stream()), 'grad_clip_scale')
+
+    def step(self, inv_scale=None, found_inf=None):
+        self.steps += 1
+        self._launch(inv_scale, found_inf)
+        ops.bump_weights_epoch()
+
+    def state_dict(self):
+        return {'steps': self.steps,
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups],
+                'state': {k: v.detach().cpu() for k, v in self._state_tensors().items()}}
+
+    def load_state_dict(self, sd):
+        self.steps = sd['steps']
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update(s)
+        for k, v in self._state_tensors().items():
+            v.copy_(sd['state'][k])
+
+
+class SGD(_FlatOptimizer):
+    """torch.optim.SGD(momentum, weight_decay, nesterov) semantics, one launch for all params."""
+
+    def __init__(self, model, param_groups, lr, momentum=0.0, weight_decay=0.0, nesterov=False):
+        defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov)
+        super().__init__(model, [{**defaults, **g} for g in param_groups])
+        self.momentum_buf = torch.zeros_like(self.arena.flat_param)
+
+    def _state_tensors(self):
+        return {'momentum_buffer': self.momentum_buf}
+
+    def _launch(self, inv_scale, found_inf):
+        self._upload([[g['lr'], g['weight_decay'], g['momentum'], 0, 0, 0, 0, 1.0 if g['nesterov'] else 0.0]
+                      for g in self.param_groups])
+        a = self.arena
+        check(lib().saicv_sgd_flat(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.momentum_buf),
+                                   ptr(self.block_group), ptr(self._hyper_dev), ptr(inv_scale), ptr(found_inf),
+                                   a.total, _lib.stream()), 'sgd_flat')
+
+
+class AdamW(_FlatOptimizer):
+    """torch.optim.AdamW semantics (decoupled decay, bias correction), one launch."""
+
+    def __init__(self, model, param_groups, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(model, [{**defaults, **g} for g in param_groups])
+        self.exp_avg = torch.zeros_like(self.arena.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.arena.flat_param)
+
+    def _state_tensors(self):
+        return {'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
+
+    def _launch(self, inv_scale, found_inf):
+        t = self.steps
+        self._upload([[g['lr'], g['weight_decay'], g['betas'][0], g['betas'][1], g['eps'],
+                       1 - g['betas'][0] ** t, 1 - g['betas'][1] ** t, 0] for g in self.param_groups])
+        a = self.arena
+        check(lib().saicv_adamw_flat(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                     ptr(self.block_group), ptr(self._hyper_dev), ptr(inv_scale), ptr(found_inf),
+                                     a.total, _lib.stream()), 'adamw_flat')
+
+
+# ------------------------------------------------------------------------------ GradScaler
+class GradScaler:
+    """torch.amp.GradScaler surface without host syncs: the scale lives on the device, the
+    inf/nan test sets a device flag that the optimizer kernel honours, update() is a kernel."""
+
+    def __init__(self, device='cuda', init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5,
+                 growth_interval=2000, enabled=True):
+        self.enabled = enabled
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        # state = [scale, growth_tracker, 1/scale]
+        self.state = torch.tensor([init_scale, 0.0, 1.0 / init_scale], dtype=torch.float32, device=device)
+        self._unscaled = False
+
+    def scale(self, loss):
+        return loss * self.state[0] if self.enabled else loss
+
+    def get_scale(self):
+        return float(self.state[0])
+
+    def unscale_(self, optimizer, max_norm=None):
+        """Folds 1/scale (and, if given, clip_grad_norm_) into the gradient arena."""
+        if not self.enabled:
+            return
+        optimizer.check_finite()
+        optimizer.clip_grad_norm_(max_norm if max_norm is not None else float('inf'), self.state[2:3])
+        self._unscaled = True
+
+    def step(self, optimizer):
+        if not self.enabled:
+            optimizer.step()
+            return
+        if self._unscaled:
+            optimizer.step(None, optimizer.found_inf)
+        else:
+            optimizer.check_finite()
+            optimizer.step(self.state[2:3], optimizer.found_inf)
+        self._found_inf = optimizer.found_inf
+
+    def update(self):
+        if not self.enabled:
+            return
+        check(lib().saicv_scaler_update(ptr(self.state), ptr(self._found_inf), self.growth_factor,
+                                        self.backoff_factor, self.growth_interval, _lib.stream()), 'scaler_update')
+        self._unscaled = False
+
+    def state_dict(self):
+        s = self.state.detach().cpu()
+        return {'scale': float(s[0]), 'growth_tracker': int(s[1]), 'growth_factor': self.growth_factor,
+                'backoff_factor': self.backoff_factor, 'growth_interval': self.growth_interval}
+
+    def load_state_dict(self, sd):
+        self.state.copy_(torch.tensor([sd['scale'], float(sd['growth_tracker']), 1.0 / sd['scale']]))
+
+
+# ------------------------------------------------------------------------------ DDP engine
+class DistributedDataParallel(torch.nn.Module):
+    """Drop-in for nn.parallel.DistributedDataParallel on the flat gradient arena.
+
+    Honours the surface the reference loop uses (tools/scripts.py:124,155,173,185,219;
+    tools/train_classification_model.py:217-227): forward pass-through, `.module`, `no_sync()`,
+    `module.`-prefixed state_dict keys, mean-over-ranks gradients, rank-0 buffer broadcast
+    before forward (`broadcast_buffers`), tolerance of parameters that receive no gradient."""
+
+    def __init__(self, module, device_ids=None, output_device=None, find_unused_parameters=False,
+                 process_group=None, bucket_cap_mb=48, last_bucket_cap_mb=4, broadcast_buffers=True):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.find_unused_parameters = find_unused_parameters
+        self.broadcast_buffers = broadcast_buffers
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.arena = _arena_of(module)
+        self._sync = True
+        self._works = []
+        self._build_buckets(int(bucket_cap_mb * 2 ** 20 // 4), int(last_bucket_cap_mb * 2 ** 20 // 4))
+        self._flatten_buffers()
+        if self.world > 1:
+            # identical start on every rank (DDP ctor broadcast, C3 in SURVEY.md section 2.4)
+            dist.broadcast(self.arena.flat_param, 0, group=process_group)
+            if self.flat_buffers is not None:
+                dist.broadcast(self.flat_buffers, 0, group=process_group)
+            for b in self.module.buffers():
+                if not b.dtype.is_floating_point:
+                    dist.broadcast(b, 0, group=process_group)
+            ops.bump_weights_epoch()
+        for i, p in enumerate(self.arena.params):
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    # buckets are contiguous arena ranges; walking parameters in REVERSE registration order
+    def _build_buckets(self, cap, last_cap):
+        a = self.arena
+        size = lambda i: ((a.params[i].numel() + ALIGN - 1) // ALIGN) * ALIGN
+        idxs = [i for i, p in enumerate(a.params) if p.requires_grad]
+        # the parameters inside the first `last_cap` elements of the arena (stem + first layers,
+        # whose gradients arrive last) form their own small bucket
+        tail = [i for i in idxs if a.offsets[i] + size(i) <= last_cap]
+        main = [i for i in idxs if i not in set(tail)]
+        self.buckets = []          # dicts: start, end (arena range), params (indices), count
+        for group in (main, tail):
+            cur, used = None, 0
+            for i in reversed(group):
+                if cur is None or used + size(i) > cap:
+                    cur = {'start': a.offsets[i], 'end': a.offsets[i] + size(i), 'params': [], 'count': 0}
+                    self.buckets.append(cur)
+                    used = 0
+                cur['start'] = min(cur['start'], a.offsets[i])
+                cur['end'] = max(cur['end'], a.offsets[i] + size(i))
+                cur['params'].append(i)
+                used += size(i)
+        self.bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for i in b['params']:
+                self.bucket_of[i] = bi
+
+    def _make_hook(self, i):
+        def hook(param):
+            if not self._sync or self.world == 1:
+                return
+            b = self.buckets[self.bucket_of[i]]
+            b['count'] += 1
+            if b['count'] == len(b['params']):
+                self._reduce_bucket(b)
+        return hook
+
+    def _reduce_bucket(self, b):
+        view = self.arena.flat_grad[b['start']:b['end']]
+        backend = dist.get_backend(self.process_group)
+        if backend == 'nccl':
+            w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)
+            self._works.append((w, None))
+        else:
+            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            self._works.append((w, view))
+        b['count'] = -1 << 30        # reduced for this step
+
+    def finish_gradient_sync(self):
+        """Waits (stream-wise on HIP) for every in-flight bucket; reduces buckets whose
+        parameters produced no gradient this step (find_unused_parameters semantics)."""
+        if self.world > 1 and self._sync:
+            for b in self.buckets:
+                if b['count'] >= 0:
+                    self._reduce_bucket(b)
+        for w, view in self._works:
+            w.wait()
+            if view is not None:
+                view.div_(self.world)
+        self._works = []
+        for b in self.buckets:
+            b['count'] = 0
+
+    def allreduce_grads(self):
+        """Stand-in for the reference's manual per-parameter all_reduce loop
+        (tools/interactive_segmentation_scripts.py:446-449): one bucketed pass."""
+        if self.world > 1:
+            for b in self.buckets:
+                b['count'] = 0
+                self._reduce_bucket(b)
+        self.finish_gradient_sync()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        old = self._sync
+        self._sync = False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def _flatten_buffers(self):
+        """Re-points every floating-point buffer (BN running statistics) into one flat tensor so
+        the per-forward rank-0 buffer sync (DDP broadcast_buffers, C2 in SURVEY.md) is ONE
+        broadcast instead of one per buffer."""
+        entries = []
+        for mod in self.module.modules():
+            for name, b in mod._buffers.items():
+                if b is not None and b.dtype == torch.float32:
+                    entries.append((mod, name, b))
+        if not entries:
+            self.flat_buffers = None
+            return
+        total = sum(((b.numel() + 3) // 4) * 4 for _, _, b in entries)
+        self.flat_buffers = torch.zeros(total, dtype=torch.float32, device=entries[0][2].device)
+        o = 0
+        with torch.no_grad():
+            for mod, name, b in entries:
+                view = self.flat_buffers[o:o + b.numel()].view(b.shape)
+                view.copy_(b)
+                mod._buffers[name] = view
+                o += ((b.numel() + 3) // 4) * 4
+
+    def forward(self, *args, **kwargs):
+        if self.world > 1 and self.broadcast_buffers and self.module.training and self.flat_buffers is not None:
+            dist.broadcast(self.flat_buffers, 0, group=self.process_group)
+        return self.module(*args, **kwargs)

@@ -15,6 +15,42 @@ from ._lib import ConvDesc, check, dtype_code, lib, ptr, require_gpu, stream
 _weights_epoch = [0]
 
 
+class KernelTimer:
+    """HIP-event bracketing of selected launches on torch's current stream (the stream every
+    saicv kernel is launched on).  bench.py enables it to price the dominant kernel against
+    its roofline from live measurements; it is off by default (zero overhead)."""
+    enabled = False
+    records = []          # (tag, start_event, end_event, algorithmic_flops, algorithmic_bytes)
+
+    @classmethod
+    def begin(cls):
+        if not cls.enabled:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    @classmethod
+    def end(cls, e0, tag, flops, nbytes):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        cls.records.append((tag, e0, e1, flops, nbytes))
+
+    @classmethod
+    def summary(cls):
+        """{tag: dict(calls, ms, flops, bytes)}; call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, e0, e1, fl, by in cls.records:
+            d = out.setdefault(tag, {'calls': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            d['calls'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += fl
+            d['bytes'] += by
+        return out
+
+
 def bump_weights_epoch():
     """Called by the flat-arena optimizer after it rewrote parameters through raw pointers."""
     _weights_epoch[0] += 1
@@ -74,11 +110,12 @@ def pack_input(x, dtype=None, cp=8):
     return out.permute(0, 3, 1, 2)
 
 
-def packed_weight(weight, dtype, cin_padded, need_wd):
+def packed_weight(weight, dtype, cin_padded, need_wd, cout_padded=None):
     """Compute-dtype copies of a conv / linear master weight, cached until the weight changes.
 
-    Returns (wf [O][R][S][Ip], wd [I][R][S][O] or None)."""
-    key = (weight._version, _weights_epoch[0], dtype, cin_padded, weight.data_ptr())
+    Returns (wf [Op][R][S][Ip], wd [I][R][S][Op] or None); rows/cols beyond O are zero."""
+    cout_padded = cout_padded or weight.shape[0]
+    key = (weight._version, _weights_epoch[0], dtype, cin_padded, cout_padded, weight.data_ptr())
     cache = getattr(weight, '_saicv_pack', None)
     if cache is not None and cache[0] == key and (cache[2] is not None or not need_wd):
         return cache[1], cache[2]
@@ -91,9 +128,11 @@ def packed_weight(weight, dtype, cin_padded, need_wd):
     else:
         o, i, r, s = w.shape
         so, si, sr, ss = w.stride()
-    wf = torch.empty((o, r, s, cin_padded), dtype=dtype, device=w.device)
-    wd = torch.empty((i, r, s, o), dtype=dtype, device=w.device) if need_wd else None
-    check(lib().saicv_pack_weight(dtype_code(dtype), ptr(w), so, si, sr, ss, o, i, r, s, cin_padded,
+    op = cout_padded
+    alloc = torch.empty if op == o else torch.zeros
+    wf = alloc((op, r, s, cin_padded), dtype=dtype, device=w.device)
+    wd = alloc((i, r, s, op), dtype=dtype, device=w.device) if need_wd else None
+    check(lib().saicv_pack_weight(dtype_code(dtype), ptr(w), so, si, sr, ss, o, i, r, s, cin_padded, op,
                                   ptr(wf), ptr(wd), stream()), 'pack_weight')
     weight._saicv_pack = (key, wf, wd)
     return wf, wd
@@ -144,8 +183,10 @@ class ConvBnActFn(torch.autograd.Function):
         if training:
             rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
             stats = torch.empty((2, rows, k), dtype=torch.float32, device=dev)
+            t0 = KernelTimer.begin()
             check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, ptr(stats[0]),
                                      ptr(stats[1]), st), 'conv2d_fwd')
+            KernelTimer.end(t0, 'igemm_nt', 2.0 * M * k * r * s * min(c, ci), 0)
             mean = torch.empty(k, dtype=torch.float32, device=dev)
             invstd = torch.empty(k, dtype=torch.float32, device=dev)
             ws = torch.empty(L.saicv_bn_ws_floats(k), dtype=torch.float32, device=dev)
@@ -169,8 +210,10 @@ class ConvBnActFn(torch.autograd.Function):
             if residual.dtype != dt:
                 residual = residual.to(dt)
         z = _empty_nhwc(n, k, d.OH, d.OW, dt, dev)
+        t0 = KernelTimer.begin()
         check(L.saicv_bn_act_fwd(dtype_code(dt), ptr(y), ptr(residual), ptr(z), ptr(scale), ptr(shift), M,
                                  k, int(relu), st), 'bn_act_fwd')
+        KernelTimer.end(t0, 'bn_act_fwd', 0, float(M) * k * y.element_size() * (3 if residual is not None else 2))
         if training:
             ctx.save_for_backward(x, weight, gamma, y, z if relu else None, mean, invstd)
         else:
@@ -199,20 +242,29 @@ class ConvBnActFn(torch.autograd.Function):
         dgamma = torch.empty(k, dtype=torch.float32, device=dev)
         dbeta = torch.empty(k, dtype=torch.float32, device=dev)
         ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, k, dtype_code(dt)), dtype=torch.float32, device=dev)
+        t0 = KernelTimer.begin()
         check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), ptr(z), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
                                  ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), M, k, int(relu), ptr(ws), st),
               'bn_act_bwd')
+        # two streaming passes: (dz, y[, z]) read twice, dy (and dres) written once
+        KernelTimer.end(t0, 'bn_act_bwd', 0, float(M) * k * y.element_size() *
+                        (2 * (3 if relu else 2) + (2 if dres is not None else 1)))
         c = x.shape[1]
+        flops = 2.0 * M * k * d.R * d.S * min(c, weight.shape[1])
         dx = None
         if ctx.needs_input_grad[0]:
             if wd is None:
                 _, wd = packed_weight(weight, dt, c, True)
             dx = _empty_nhwc(n, c, x.shape[2], x.shape[3], dt, dev)
+            t0 = KernelTimer.begin()
             check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
+            KernelTimer.end(t0, 'igemm_nt', flops, 0)
         dwt = None
         if ctx.needs_input_grad[1]:
             dw = torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=dev)
+            t0 = KernelTimer.begin()
             check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
+            KernelTimer.end(t0, 'igemm_tn', flops, 0)
             dwt = _weight_grad(dw, weight, c)
         return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
                 dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None)
@@ -235,40 +287,54 @@ class LinearFn(torch.autograd.Function):
         dt = x.dtype
         b, ci = x.shape
         o = weight.shape[0]
-        wf, wd = packed_weight(weight, dt, ci, ctx.needs_input_grad[0])
-        d = _desc(b, 1, 1, ci, o, 1, 1, 1, 0, dt)
+        e = _lib.epc(dt)
+        if ci % e:
+            raise ValueError(f'linear: in_features={ci} must be a multiple of {e}')
+        op = ((o + e - 1) // e) * e              # out_features padded to the 16-byte chunk
+        wf, wd = packed_weight(weight, dt, ci, ctx.needs_input_grad[0], op)
+        d = _desc(b, 1, 1, ci, op, 1, 1, 1, 0, dt)
         odt = torch.float32 if (out_f32 or dt == torch.float32) else dt
-        y = torch.empty((b, o), dtype=odt, device=x.device)
-        check(lib().saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), ptr(bias), ptr(y),
+        y = torch.empty((b, op), dtype=odt, device=x.device)
+        bp = bias
+        if bias is not None and op != o:
+            bp = torch.zeros(op, dtype=torch.float32, device=x.device)
+            bp[:o] = bias.detach()
+        check(lib().saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), ptr(bp), ptr(y),
                                      int(odt == torch.float32), 0, 0, stream()), 'linear_fwd')
         ctx.save_for_backward(x, weight)
-        ctx.cfg = (d, wd, bias is not None)
-        return y
+        ctx.cfg = (d, wd, bias is not None, o, op)
+        return y if op == o else y[:, :o]
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        d, wd, has_bias = ctx.cfg
+        d, wd, has_bias, o, op = ctx.cfg
         dt = x.dtype
         L = lib()
         st = stream()
-        dy = dy.contiguous()
-        if dy.dtype != dt:
-            dy = dy.to(dt)
+        if op != o:
+            dyp = torch.zeros((dy.shape[0], op), dtype=dt, device=dy.device)
+            dyp[:, :o] = dy
+            dy = dyp
+        else:
+            dy = dy.contiguous()
+            if dy.dtype != dt:
+                dy = dy.to(dt)
         b, ci = x.shape
-        o = weight.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if wd is None:
-                _, wd = packed_weight(weight, dt, ci, True)
+                _, wd = packed_weight(weight, dt, ci, True, op)
             dx = torch.empty((b, ci), dtype=dt, device=x.device)
             check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'linear_dgrad')
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((o, ci), dtype=torch.float32, device=x.device)
+            dw = torch.zeros((op, ci), dtype=torch.float32, device=x.device)
             check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'linear_wgrad')
+            dw = dw[:o]
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(o, dtype=torch.float32, device=x.device)
-            check(L.saicv_colsum(dtype_code(dt), ptr(dy), b, o, ptr(db), st), 'colsum')
+            db = torch.zeros(op, dtype=torch.float32, device=x.device)
+            check(L.saicv_colsum(dtype_code(dt), ptr(dy), b, op, ptr(db), st), 'colsum')
+            db = db[:o]
         return dx, dw, db, None
 
 

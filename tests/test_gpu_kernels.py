@@ -1,0 +1,225 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel, through the C-ABI / autograd Functions,
+against a plain PyTorch fp32 CPU computation of the same op on identical seeded inputs.
+
+Tolerances (scale-relative, conftest.rel_err):
+  fp32 parity mode : 1e-4  (exact-f32 MFMA, fp32 statistics; only summation order differs)
+  bf16 perf mode   : 2e-2  (inputs rounded to bf16 BEFORE the reference op, so the remaining
+                            error is bf16 rounding of the stored outputs, 2^-8 relative)
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+
+def _ops():
+    from simpleaicv_pytorch_training_examples_amd import ops
+    return ops
+
+
+def _q(t, dt):
+    """round a CPU fp32 tensor through the compute dtype"""
+    return t.to(dt).float()
+
+
+def _nhwc_dev(t, dt):
+    return t.to(dt).cuda().contiguous(memory_format=torch.channels_last)
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, stride, pad
+    (2, 64, 14, 14, 64, 3, 1, 1),
+    (3, 64, 15, 13, 128, 3, 2, 1),      # odd spatial, stride 2
+    (2, 128, 9, 9, 256, 1, 1, 0),
+    (2, 256, 10, 10, 64, 1, 2, 0),      # 1x1 stride 2 (downsample), narrow N tile
+    (2, 8, 20, 20, 64, 7, 2, 3),        # stem geometry with padded channels
+    (1, 32, 7, 7, 40, 3, 1, 1),         # K not a multiple of the tile, small M
+    (5, 512, 7, 7, 512, 3, 1, 1),       # deep K = 4608
+]
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_bn_act_block(case, dt):
+    """ConvBnActFn forward + backward (conv fwd/dgrad/wgrad + BN + residual + ReLU)."""
+    ops = _ops()
+    n, c, h, w, k, r, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _q(torch.randn(n, c, h, w, generator=g), dt)
+    wt = torch.randn(k, c, r, r, generator=g) * (2.0 / (c * r * r)) ** 0.5
+    gamma = torch.rand(k, generator=g) + 0.5
+    beta = torch.randn(k, generator=g) * 0.1
+    oh = (h + 2 * pad - r) // stride + 1
+    ow = (w + 2 * pad - r) // stride + 1
+    res = _q(torch.randn(n, k, oh, ow, generator=g), dt)
+    dz = _q(torch.randn(n, k, oh, ow, generator=g), dt)
+
+    for use_res, relu in [(True, True), (False, True), (False, False)]:
+        # ---- reference (CPU fp32; weights rounded like the kernel sees them)
+        xr = x.clone().requires_grad_(True)
+        wr = wt.clone().requires_grad_(True)
+        gr = gamma.clone().requires_grad_(True)
+        br = beta.clone().requires_grad_(True)
+        rr = res.clone().requires_grad_(True)
+        y = F.conv2d(xr, _q(wr, dt) if dt == torch.bfloat16 else wr, None, stride, pad)
+        if dt == torch.bfloat16:
+            y = y + (_q(y.detach(), dt) - y.detach())        # straight-through bf16 storage of y
+        rm, rv = torch.zeros(k), torch.ones(k)
+        z = F.batch_norm(y, rm, rv, gr, br, True, 0.1, 1e-5)
+        if use_res:
+            z = z + rr
+        if relu:
+            z = F.relu(z)
+        z.backward(dz)
+
+        # ---- device
+        bn = torch.nn.BatchNorm2d(k).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(gamma)
+            bn.bias.copy_(beta)
+        xd = _nhwc_dev(x, dt).requires_grad_(True)
+        wd = wt.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        rd = _nhwc_dev(res, dt).requires_grad_(True) if use_res else None
+        zd = ops.conv_bn_act(xd, wd, bn, stride, pad, relu, rd)
+        zd.backward(_nhwc_dev(dz, dt))
+        torch.cuda.synchronize()
+        tol = TOL[dt]
+        tag = f'{case} res={use_res} relu={relu}'
+        assert rel_err(zd.float(), z) < tol, 'z ' + tag
+        assert rel_err(bn.running_mean, rm) < max(tol, 1e-4), 'running_mean ' + tag
+        assert rel_err(bn.running_var, rv) < max(tol, 1e-4), 'running_var ' + tag
+        assert int(bn.num_batches_tracked) == 1
+        # gradients: the BN backward amplifies storage rounding; compare on the gradient scale
+        gtol = tol * 4
+        assert rel_err(xd.grad.float(), xr.grad) < gtol, 'dx ' + tag
+        assert rel_err(wd.grad, wr.grad) < gtol, 'dw ' + tag
+        assert rel_err(bn.weight.grad, gr.grad) < gtol, 'dgamma ' + tag
+        assert rel_err(bn.bias.grad, br.grad) < gtol, 'dbeta ' + tag
+        if use_res:
+            assert rel_err(rd.grad.float(), rr.grad) < gtol, 'dres ' + tag
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_conv_bn_eval_mode(dt):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = _q(torch.randn(2, 64, 12, 12, generator=g), dt)
+    wt = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    bn = torch.nn.BatchNorm2d(128)
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(128, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(128, generator=g) + 0.5)
+        bn.weight.copy_(torch.rand(128, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(128, generator=g) * 0.1)
+    bn.eval()
+    ref = F.relu(bn(F.conv2d(x, _q(wt, dt) if dt == torch.bfloat16 else wt, None, 1, 1)))
+    bnd = torch.nn.BatchNorm2d(128)
+    bnd.load_state_dict(bn.state_dict())
+    bnd = bnd.cuda().eval()
+    with torch.no_grad():
+        out = ops.conv_bn_act(_nhwc_dev(x, dt), wt.cuda(), bnd, 1, 1, True, None)
+    assert rel_err(out.float(), ref) < TOL[dt]
+    assert int(bnd.num_batches_tracked) == 0
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(4, 512, 1000), (256, 2048, 1000), (7, 64, 12), (130, 200, 136)])
+def test_linear(shape, dt):
+    ops = _ops()
+    b, ci, co = shape
+    g = torch.Generator().manual_seed(b + ci)
+    x = _q(torch.randn(b, ci, generator=g), dt)
+    wt = torch.randn(co, ci, generator=g) * ci ** -0.5
+    bias = torch.randn(co, generator=g)
+    dy = torch.randn(b, co, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = F.linear(xr, _q(wr, dt) if dt == torch.bfloat16 else wr, br)
+    yr.backward(_q(dy, dt))
+    xd = x.to(dt).cuda().requires_grad_(True)
+    wd = wt.cuda().requires_grad_(True)
+    bd = bias.cuda().requires_grad_(True)
+    yd = ops.linear(xd, wd, bd, out_f32=True)
+    assert yd.dtype == torch.float32
+    yd.backward(dy.cuda())
+    tol = TOL[dt]
+    assert rel_err(yd, yr) < tol
+    assert rel_err(xd.grad.float(), xr.grad) < tol * 2
+    assert rel_err(wd.grad, wr.grad) < tol * 2
+    assert rel_err(bd.grad, br.grad) < tol * 2
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 64, 16, 16), (3, 64, 15, 17), (1, 8, 5, 5)])
+def test_maxpool(shape, dt):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    x = _q(F.relu(torch.randn(*shape, generator=g)), dt)     # post-ReLU zeros -> many ties
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = _q(torch.randn(yr.shape, generator=g), dt)
+    yr.backward(dy)
+    xd = _nhwc_dev(x, dt).requires_grad_(True)
+    yd = ops.max_pool2d(xd, 3, 2, 1)
+    yd.backward(_nhwc_dev(dy, dt))
+    assert rel_err(yd.float(), yr) == 0.0
+    assert rel_err(xd.grad.float(), xr.grad) < TOL[dt]      # tie-break rule = ATen's first max
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_global_avgpool(dt):
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    x = _q(torch.randn(3, 256, 7, 7, generator=g), dt)
+    xr = x.clone().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, (1, 1)).flatten(1)
+    dy = _q(torch.randn(3, 256, generator=g), dt)
+    yr.backward(dy)
+    xd = _nhwc_dev(x, dt).requires_grad_(True)
+    yd = ops.global_avg_pool(xd)
+    yd.backward(dy.to(dt).cuda())
+    assert rel_err(yd.float(), yr) < TOL[dt]
+    assert rel_err(xd.grad.float(), xr.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize('b,c', [(8, 100), (256, 1000), (3, 7)])
+def test_softmax_ce(b, c):
+    ops = _ops()
+    g = torch.Generator().manual_seed(b * c)
+    logits = torch.randn(b, c, generator=g) * 3
+    label = torch.randint(0, c, (b,), generator=g)
+    soft = torch.softmax(torch.randn(b, c, generator=g), -1)
+    for is_soft, lab in [(False, label), (True, soft)]:
+        lr_ = logits.clone().requires_grad_(True)
+        if is_soft:
+            ref = torch.sum(-lab * F.log_softmax(lr_, -1), -1).mean()
+        else:
+            ref = F.cross_entropy(lr_, lab)
+        (ref * 7.0).backward()
+        ld = logits.cuda().requires_grad_(True)
+        out = ops.softmax_cross_entropy(ld, lab.cuda(), soft=is_soft)
+        (out * 7.0).backward()
+        assert abs(float(out) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+        assert rel_err(ld.grad, lr_.grad) < 1e-5
+
+
+def test_pack_input_layouts():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    nhwc = torch.randn(2, 9, 11, 3, generator=g)
+    for src in (nhwc.permute(0, 3, 1, 2), nhwc.permute(0, 3, 1, 2).contiguous()):   # NHWC-strided and true NCHW
+        for dt in (torch.float32, torch.bfloat16):
+            out = ops.pack_input(src.cuda(), dt)
+            assert out.shape == (2, 8, 9, 11) and out.is_contiguous(memory_format=torch.channels_last)
+            assert torch.equal(out[:, :3].float().cpu(), src.to(dt).float())
+            assert float(out[:, 3:].abs().sum()) == 0.0
+
+
+def test_product_path_has_no_cpu_fallback():
+    ops = _ops()
+    with pytest.raises(RuntimeError):
+        ops.pack_input(torch.randn(1, 3, 8, 8), torch.float32)

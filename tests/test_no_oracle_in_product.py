@@ -1,0 +1,29 @@
+"""The product package must never import, call or shell out to anything under oracle/, and must
+not silently fall back to CPU."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+PKG = os.path.join(ROOT, 'simpleaicv_pytorch_training_examples_amd')
+
+
+def test_product_never_references_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f), errors='replace').read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M) or 'torch_oracle' in src:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones
+    model = backbones.resnet18cifar(num_classes=10)
+    with pytest.raises(RuntimeError):
+        model(torch.randn(2, 3, 32, 32))
