@@ -115,8 +115,7 @@ class _FlatOptimizer:
                 group_of[id(p)] = gi
             self.param_groups.append(g)
         self.block_group = self.arena.block_groups(group_of)
-        self._hyper_host = torch.zeros(len(self.param_groups) * HYPER, dtype=torch.float32).pin_memory() \
-            if self.arena.device.type == 'cuda' else torch.zeros(len(self.param_groups) * HYPER)
+        self._last_hyper = None
         self._hyper_dev = torch.zeros(len(self.param_groups) * HYPER, dtype=torch.float32, device=self.arena.device)
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
@@ -126,10 +125,16 @@ class _FlatOptimizer:
         self.arena.zero_grad()
 
     def _upload(self, rows):
-        for gi, row in enumerate(rows):
-            for k, v in enumerate(row):
-                self._hyper_host[gi * HYPER + k] = v
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        flat = [float(v) for row in rows for v in row]
+        if flat == self._last_hyper:
+            return
+        self._last_hyper = flat
+        host = torch.tensor(flat, dtype=torch.float32)
+        if self.arena.device.type == 'cuda':
+            # a fresh pinned staging tensor per change: the caching host allocator keeps it alive
+            # until the async copy has run, so the host may run ahead of the stream safely
+            host = host.pin_memory()
+        self._hyper_dev.copy_(host, non_blocking=True)
 
     def _launch(self, inv_scale, found_inf):
         raise NotImplementedError
