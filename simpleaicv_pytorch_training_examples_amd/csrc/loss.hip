@@ -21,16 +21,16 @@ __global__ __launch_bounds__(256) void ce_hard_kernel(const float* __restrict__ 
     for (int c = lane; c < C; c += 64) mx = fmaxf(mx, x[c]);
     mx = wave_max(mx);
     float se = 0.f;
-    for (int c = lane; c < C; c += 64) se += __expf(x[c] - mx);
+    for (int c = lane; c < C; c += 64) se += expf(x[c] - mx);
     se = wave_sum(se);
-    const float lse = mx + __logf(se);
+    const float lse = mx + logf(se);
     const int64_t t = label[row];
     if (lane == 0) row_loss[row] = (t >= 0 && t < C) ? (lse - x[t]) : 0.f;
     if (dlogits) {
         const float invB = 1.f / (float)B;
         float* d = dlogits + (size_t)row * C;
         for (int c = lane; c < C; c += 64) {
-            float pr = __expf(x[c] - lse);
+            float pr = expf(x[c] - lse);
             if (c == t) pr -= 1.f;
             d[c] = pr * invB;
         }
@@ -52,19 +52,19 @@ __global__ __launch_bounds__(256) void ce_soft_kernel(const float* __restrict__ 
     mx = wave_max(mx);
     float se = 0.f, sy = 0.f, sxy = 0.f;
     for (int c = lane; c < C; c += 64) {
-        se += __expf(x[c] - mx);
+        se += expf(x[c] - mx);
         sy += yy[c];
         sxy += yy[c] * x[c];
     }
     se = wave_sum(se);
     sy = wave_sum(sy);
     sxy = wave_sum(sxy);
-    const float lse = mx + __logf(se);
+    const float lse = mx + logf(se);
     if (lane == 0) row_loss[row] = lse * sy - sxy;
     if (dlogits) {
         const float invB = 1.f / (float)B;
         float* d = dlogits + (size_t)row * C;
-        for (int c = lane; c < C; c += 64) d[c] = (__expf(x[c] - lse) * sy - yy[c]) * invB;
+        for (int c = lane; c < C; c += 64) d[c] = (expf(x[c] - lse) * sy - yy[c]) * invB;
     }
 }
 

@@ -8,7 +8,7 @@ from oracle import torch_oracle as O
 from oracle.make_golden import make_batch
 from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones
 
-RESNET_CASES = [('resnet18cifar_b8', 'resnet18cifar'), ('resnet50_b4_64', 'resnet50'),
+RESNET_CASES = [('resnet18cifar_b8', 'resnet18cifar'), ('resnet18cifar_b64', 'resnet18cifar'), ('resnet50_b4_64', 'resnet50'),
                 ('resnet34_b2_96', 'resnet34'), ('resnet50_b2_224', 'resnet50')]
 
 
