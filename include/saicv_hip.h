@@ -91,11 +91,13 @@ int saicv_bn_eval_coeffs(int C, const float* gamma, const float* beta, const flo
 int saicv_bn_act_fwd(int dtype, const void* y, const void* res, void* z, const float* scale,
                      const float* shift, size_t M, int C, int relu, void* stream);
 size_t saicv_bn_bwd_ws_floats(size_t M, int C, int dtype);
-/* backward of the fused block: g = dz*[z>0]; dy, dres(=g, optional), dgamma, dbeta.
+/* backward of the fused block: g = dz*[z>0]; dy, dres(=g, optional), dgamma, dbeta
+ * (accumulate != 0: dgamma/dbeta are added to, e.g. straight into the gradient arena).
  * `threshold_backward` + `native_batch_norm_backward` (+ residual `add` backward). */
 int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
                      const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
-                     float* dbeta, size_t M, int C, int relu, float* ws, void* stream);
+                     float* dbeta, size_t M, int C, int relu, int accumulate, float* ws,
+                     void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------- */
 /* nn.MaxPool2d(3,2,1), resnet.py:184; idx = window position of the first maximum */

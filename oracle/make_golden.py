@@ -48,7 +48,7 @@ def _rel(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
 
 
-def measure_reference_noise(factory, kwargs, x, y, criterion, model_seed, samples, logits, loss):
+def measure_reference_noise(factory, kwargs, x, y, criterion, model_seed, samples, full, logits, loss):
     """How much the REFERENCE ITSELF moves under (a) a different fp32 summation order (its own
     modules run in channels_last on CPU) and (b) its own bf16 autocast (CPU).  Whole-model parity
     tolerances in tests/test_gpu_models.py are derived from these numbers: a deep BN network at
@@ -67,6 +67,8 @@ def measure_reference_noise(factory, kwargs, x, y, criterion, model_seed, sample
         for n, p in m.named_parameters():
             if float(p.grad.norm()) > 1e-7:
                 worst = max(worst, _rel(p.grad.flatten()[:64], samples[n]))
+                if n in full:
+                    worst = max(worst, _rel(p.grad, full[n]))
         out['fp32_reorder_logits'] = _rel(lg.detach(), logits)
         out['fp32_reorder_grad_sample'] = worst
     torch.manual_seed(model_seed)
@@ -98,7 +100,7 @@ def run_case(name, factory, kwargs, shape, num_classes, criterion, soft, model_s
     model.eval()
     with torch.no_grad():
         eval_logits = model(x)
-    noise = measure_reference_noise(factory, kwargs, x, y, criterion, model_seed, samples, logits.detach(), float(loss))
+    noise = measure_reference_noise(factory, kwargs, x, y, criterion, model_seed, samples, full, logits.detach(), float(loss))
     fx = {
         'name': name, 'kwargs': kwargs, 'shape': list(shape), 'num_classes': num_classes, 'soft': soft,
         'model_seed': model_seed, 'data_seed': data_seed,

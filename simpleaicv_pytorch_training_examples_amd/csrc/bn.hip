@@ -96,7 +96,9 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma,
 }
 
 // ---------------------------------------------------------------- forward apply
-template <typename T, bool RELU, bool RES>
+// HOIST: the launch guarantees (gridDim.x*256) % (C/N) == 0, so a thread sees the same N
+// channels on every grid-stride iteration and keeps scale/shift in registers.
+template <typename T, bool RELU, bool RES, bool HOIST>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y,
                                                          const T* __restrict__ res, T* __restrict__ z,
                                                          const float* __restrict__ scale,
@@ -104,10 +106,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
                                                          size_t nchunks, int C) {
     constexpr int N = Chunk<T>::N;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
-        const int c0 = (int)((i * N) % (size_t)C);
-        float v[N], sc[N], sh[N];
-        Chunk<T>::unpack(ld_chunk(y + i * N), v);
+    const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sc[N], sh[N];
+    auto load_coeffs = [&](int c0) {
 #pragma unroll
         for (int j = 0; j < N; j += 4) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c0 + j);
@@ -115,6 +116,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 #pragma unroll
             for (int k = 0; k < 4; ++k) { sc[j + k] = a[k]; sh[j + k] = b[k]; }
         }
+    };
+    if (HOIST) load_coeffs((int)((first * N) % (size_t)C));
+    for (size_t i = first; i < nchunks; i += stride) {
+        if (!HOIST) load_coeffs((int)((i * N) % (size_t)C));
+        float v[N];
+        Chunk<T>::unpack(ld_chunk(y + i * N), v);
         float rr[N];
         if (RES) Chunk<T>::unpack(ld_chunk(res + i * N), rr);
 #pragma unroll
@@ -199,7 +206,7 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ pg, const float
                                        const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ ca,
-                                       float* __restrict__ cb, float* __restrict__ cc) {
+                                       float* __restrict__ cb, float* __restrict__ cc, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float sg = 0.f, sx = 0.f;
@@ -207,8 +214,8 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ pg, const float
         sg += pg[(size_t)p * C + c];
         sx += pgx[(size_t)p * C + c];
     }
-    if (dgamma) dgamma[c] = sx;
-    if (dbeta) dbeta[c] = sg;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sx : sx;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sg : sg;
     const float g = gamma ? gamma[c] : 1.f;
     const float A = g * invstd[c];
     const float mg = sg / count, mgx = sx / count;
@@ -219,7 +226,7 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ pg, const float
 }
 
 // ---------------------------------------------------------------- backward apply
-template <typename T, bool RELU, bool RES>
+template <typename T, bool RELU, bool RES, bool HOIST>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz,
                                                            const T* __restrict__ z,
                                                            const T* __restrict__ y,
@@ -230,8 +237,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            size_t nchunks, int C) {
     constexpr int N = Chunk<T>::N;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
-        const int c0 = (int)((i * N) % (size_t)C);
+    const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float ka[N], kb[N], kc[N];
+    auto load_coeffs = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ca + c0 + j);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cb + c0 + j);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(cc + c0 + j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ka[j + k] = a[k]; kb[j + k] = b[k]; kc[j + k] = c[k]; }
+        }
+    };
+    if (HOIST) load_coeffs((int)((first * N) % (size_t)C));
+    for (size_t i = first; i < nchunks; i += stride) {
+        if (!HOIST) load_coeffs((int)((i * N) % (size_t)C));
         float g[N], yy[N], zz[N], o[N];
         Chunk<T>::unpack(ld_chunk(dz + i * N), g);
         Chunk<T>::unpack(ld_chunk(y + i * N), yy);
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int j = 0; j < N; ++j) {
             const float gj = (RELU && !(zz[j] > 0.f)) ? 0.f : g[j];
             g[j] = gj;
-            o[j] = fmaf(ca[c0 + j], gj, fmaf(cb[c0 + j], yy[j], cc[c0 + j]));
+            o[j] = fmaf(ka[j], gj, fmaf(kb[j], yy[j], kc[j]));
         }
         st_chunk(dy + i * N, Chunk<T>::pack(o));
         if (RES) st_chunk(dres + i * N, Chunk<T>::pack(g));
@@ -301,7 +321,9 @@ static int bn_act_fwd_t(const void* y, const void* res, void* z, const float* sc
     const size_t nchunks = M * (size_t)C / N;
     const int grid = stream_grid(nchunks);
     const T* yy = (const T*)y; const T* rr = (const T*)res; T* zz = (T*)z;
-#define LAUNCH(R, S) hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C)
+    const bool hoist = ((size_t)grid * 256) % (size_t)(C / N) == 0;
+#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, true>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C); \
+                          else hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, false>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C); } while (0)
     if (relu) { if (res) LAUNCH(true, true); else LAUNCH(true, false); }
     else      { if (res) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -335,7 +357,7 @@ size_t bn_bwd_ws_floats(size_t M, int C, int dtype) {
 template <typename T>
 static int bn_bwd_t(const void* dz, const void* z, const void* y, const float* gamma,
                     const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
-                    float* dbeta, size_t M, int C, int relu, float* ws, hipStream_t st) {
+                    float* dbeta, size_t M, int C, int relu, int accumulate, float* ws, hipStream_t st) {
     constexpr int N = Chunk<T>::N;
     const int slabs = bn_bwd_slabs(M, C, sizeof(T) == 2 ? SAICV_DTYPE_BF16 : SAICV_DTYPE_F32);
     const int rows_per = (int)((M + slabs - 1) / slabs);
@@ -352,11 +374,13 @@ static int bn_bwd_t(const void* dz, const void* z, const void* y, const float* g
     const float* a = pg; const float* b = pgx;
     const int P = reduce_partials(a, b, used, C, ws2, st);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, a, b, P, C,
-                       (float)M, gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C);
+                       (float)M, gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, accumulate);
     const size_t nchunks = M * (size_t)C / N;
     const int grid = stream_grid(nchunks);
     T* dyy = (T*)dy; T* drr = (T*)dres;
-#define LAUNCH(R, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C)
+    const bool hoist = ((size_t)grid * 256) % (size_t)(C / N) == 0;
+#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, true>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C); \
+                          else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, false>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C); } while (0)
     if (relu) { if (dres) LAUNCH(true, true); else LAUNCH(true, false); }
     else      { if (dres) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -365,13 +389,13 @@ static int bn_bwd_t(const void* dz, const void* z, const void* y, const float* g
 
 int bn_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
            const float* mean, const float* invstd, void* dy, void* dres, float* dgamma, float* dbeta,
-           size_t M, int C, int relu, float* ws, hipStream_t st) {
+           size_t M, int C, int relu, int accumulate, float* ws, hipStream_t st) {
     const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     SAICV_REQUIRE(C % n == 0, "bn_bwd: C=%d must be a multiple of %d", C, n);
     SAICV_REQUIRE(!relu || z != nullptr, "bn_bwd: relu needs the forward output z");
     if (dtype == SAICV_DTYPE_BF16)
-        return bn_bwd_t<bf16_t>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, ws, st);
-    return bn_bwd_t<float>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, ws, st);
+        return bn_bwd_t<bf16_t>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, st);
+    return bn_bwd_t<float>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, st);
 }
 
 }  // namespace saicv

@@ -37,7 +37,7 @@ int bn_act_fwd(int, const void*, const void*, void*, const float*, const float*,
                hipStream_t);
 size_t bn_bwd_ws_floats(size_t, int, int);
 int bn_bwd(int, const void*, const void*, const void*, const float*, const float*, const float*, void*,
-           void*, float*, float*, size_t, int, int, float*, hipStream_t);
+           void*, float*, float*, size_t, int, int, int, float*, hipStream_t);
 int maxpool_fwd(int, const void*, void*, uint8_t*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int maxpool_bwd(int, const void*, const uint8_t*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int avgpool_fwd(int, const void*, void*, int, int, int, hipStream_t);
@@ -149,8 +149,8 @@ int saicv_bn_act_fwd(int dtype, const void* y, const void* res, void* z, const f
 size_t saicv_bn_bwd_ws_floats(size_t M, int C, int dtype) { return bn_bwd_ws_floats(M, C, dtype); }
 int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
                      const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
-                     float* dbeta, size_t M, int C, int relu, float* ws, void* stream) {
-    return bn_bwd(dtype, dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, ws, S(stream));
+                     float* dbeta, size_t M, int C, int relu, int accumulate, float* ws, void* stream) {
+    return bn_bwd(dtype, dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, S(stream));
 }
 
 int saicv_maxpool_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C,

@@ -59,7 +59,27 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     const int wm = wave & 1;
     const int wn = wave >> 1;
 
-    const int bid = xcd_remap(blockIdx.x, p.nblk);
+    // ---- data-gradient with stride s > 1: the input pixels split into s*s parity classes
+    // (h % s, w % s); a class only ever meets the taps r == (h + pad) mod s, so each class is a
+    // dense GEMM over its own tap subset (no multiply-by-zero work).  blockIdx.y = class.
+    int cs = 1, ph = 0, pw = 0, r0 = 0, s0 = 0, Sc = p.S, Hc = p.OH, Wc = p.OW, Mc = p.M, Kc = p.Kd;
+    int nblk = p.nblk;
+    if (MODE == 1 && p.stride > 1) {
+        cs = p.stride;
+        ph = blockIdx.y / cs;
+        pw = blockIdx.y - ph * cs;
+        Hc = (p.OH - ph + cs - 1) / cs;
+        Wc = (p.OW - pw + cs - 1) / cs;
+        Mc = (p.M / (p.OH * p.OW)) * Hc * Wc;
+        r0 = (ph + p.pad) % cs;
+        s0 = (pw + p.pad) % cs;
+        const int Rc = r0 < p.R ? (p.R - r0 + cs - 1) / cs : 0;
+        Sc = s0 < p.S ? (p.S - s0 + cs - 1) / cs : 0;
+        Kc = Rc * Sc * p.C;
+        nblk = ((Mc + BM_T - 1) / BM_T) * p.tiles_n;
+        if ((int)blockIdx.x >= nblk) return;
+    }
+    const int bid = xcd_remap(blockIdx.x, nblk);
     const int tile_n = bid % p.tiles_n;
     const int tile_m = bid / p.tiles_n;
 
@@ -67,22 +87,22 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     const int cc = tid & 7;
     const int rb = tid >> 3;
     int pixbase[4], a0[4], b0[4];
-    const int ohw = p.OH * p.OW;
+    const int ohw = Hc * Wc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = tile_m * BM_T + rb + 32 * i;
-        if (m < p.M) {
+        if (m < Mc) {
             const int img = m / ohw;
             const int rem = m - img * ohw;
-            const int oh = rem / p.OW;
-            const int ow = rem - oh * p.OW;
+            const int oh = rem / Wc;
+            const int ow = rem - oh * Wc;
             pixbase[i] = img * p.H * p.W;
             if (MODE == 0) {
                 a0[i] = oh * p.stride - p.pad;
                 b0[i] = ow * p.stride - p.pad;
             } else {
-                a0[i] = oh + p.pad;
-                b0[i] = ow + p.pad;
+                a0[i] = oh * cs + ph + p.pad;
+                b0[i] = ow * cs + pw + p.pad;
             }
         } else {
             pixbase[i] = 0;
@@ -97,11 +117,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
 
     auto load_tile = [&](int kt) {
         const int k = kt * BK + cc * EPC;
-        const bool kvalid = k < p.Kd;
+        const bool kvalid = k < Kc;
         const int tap = k / p.C;
         const int c0 = k - tap * p.C;
-        const int r = tap / p.S;
-        const int s = tap - r * p.S;
+        int r = tap / Sc;
+        int s = tap - r * Sc;
+        if (MODE == 1) {            // class-local tap -> real tap
+            r = r0 + r * cs;
+            s = s0 + s * cs;
+        }
+        const int kw = (MODE == 1) ? (r * p.S + s) * p.C + c0 : k;      // column in the weight matrix
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int ih, iw;
@@ -110,17 +135,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
                 ih = a0[i] + r;
                 iw = b0[i] + s;
             } else {
-                const int th = a0[i] - r;
+                const int th = a0[i] - r;       // multiples of cs by construction of the class
                 const int tw = b0[i] - s;
                 ok = ok && (th >= 0) && (tw >= 0);
-                if (p.stride == 1) {
-                    ih = th;
-                    iw = tw;
-                } else {
-                    ih = th / p.stride;
-                    iw = tw / p.stride;
-                    ok = ok && (ih * p.stride == th) && (iw * p.stride == tw);
-                }
+                ih = (cs == 1) ? th : th / cs;
+                iw = (cs == 1) ? tw : tw / cs;
             }
             ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
             if (ok) {
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         for (int j = 0; j < WROWS; ++j) {
             const int n = tile_n * BN_T + rb + 32 * j;
             if (kvalid && n < p.Nn) {
-                rw[j] = ld_chunk(wgt + (size_t)n * (size_t)p.Kd + (size_t)k);
+                rw[j] = ld_chunk(wgt + (size_t)n * (size_t)p.Kd + (size_t)kw);
             } else {
                 rw[j] = zero_chunk();
             }
@@ -179,9 +198,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         }
     };
 
-    const int nkt = (p.Kd + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    const int nkt = (Kc + BK - 1) / BK;        // 0 for a class without taps: the output is zero
+    if (nkt > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
@@ -208,7 +229,15 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < MT_; ++mi) {
-            const int m = m_base + mi * 16 + l15;
+            const int mrow = m_base + mi * 16 + l15;
+            int m = mrow;                        // output row (pixel index)
+            if (MODE == 1 && cs > 1 && mrow < Mc) {
+                const int img = mrow / ohw;
+                const int rem = mrow - img * ohw;
+                const int hc = rem / Wc;
+                const int wc = rem - hc * Wc;
+                m = (img * p.OH + hc * cs + ph) * p.OW + wc * cs + pw;
+            }
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bs[r];
@@ -220,7 +249,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
                     ssq[r] += vr * vr;
                 }
             }
-            if (m < p.M) {
+            if (mrow < Mc) {
                 if (OUT_F32) {
                     float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n0;
                     if (n0 + 3 < p.Nn && (p.ldo & 3) == 0) {
@@ -492,16 +521,20 @@ void allow_lds(K k, size_t smem) {
 
 template <typename T, int BN_T, int MODE>
 int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
-    constexpr size_t smem = 2 * (128 * 128 + BN_T * 128);
-    dim3 grid(p.nblk), block(256);
+    constexpr size_t smem_full = 2 * (128 * 128 + BN_T * 128);
+    constexpr int BK = 8 * ElemTraits<T>::EPC;
+    // a single K tile never touches the second LDS stage: ask for half the LDS so that more
+    // workgroups are resident per CU (the K=64 1x1 convolutions are latency/HBM bound)
+    const size_t smem = (p.Kd <= BK) ? smem_full / 2 : smem_full;
+    dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(256);
     if (out_f32) {
         auto k = igemm_nt_kernel<T, BN_T, MODE, true>;
-        static bool once = (allow_lds(k, smem), true);
+        static bool once = (allow_lds(k, smem_full), true);
         (void)once;
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
     } else {
         auto k = igemm_nt_kernel<T, BN_T, MODE, false>;
-        static bool once = (allow_lds(k, smem), true);
+        static bool once = (allow_lds(k, smem_full), true);
         (void)once;
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
     }
@@ -544,6 +577,12 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     const int bn = narrow ? 64 : 128;
     p.tiles_n = (Nn + bn - 1) / bn;
     p.nblk = p.tiles_n * ((M + 127) / 128);
+    if (mode == 1 && stride > 1) {
+        // grid.x must cover the largest parity class (class (0,0))
+        const int nimg = M / (OH * OW);
+        const int mc = nimg * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);
+        p.nblk = p.tiles_n * ((mc + 127) / 128);
+    }
     const bool f32o = out_f32 != 0;
     if (dtype == SAICV_DTYPE_BF16) {
         if (mode == 0) return narrow ? launch_nt<bf16_t, 64, 0>(p, f32o, st) : launch_nt<bf16_t, 128, 0>(p, f32o, st);

@@ -70,6 +70,7 @@ class FlatArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad.as_strided(p.shape, p.stride(), o)
+                p._saicv_direct = True      # kernels may accumulate into p.grad in place (ops._arena_grad)
         ops.bump_weights_epoch()
 
     def zero_grad(self):
@@ -300,7 +301,9 @@ class DistributedDataParallel(torch.nn.Module):
             ops.bump_weights_epoch()
         for i, p in enumerate(self.arena.params):
             if p.requires_grad:
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                hook = self._make_hook(i)
+                p.register_post_accumulate_grad_hook(hook)      # gradients that arrive through autograd
+                p._saicv_grad_ready = hook                      # gradients written in place by the kernels
 
     # buckets are contiguous arena ranges; walking parameters in REVERSE registration order
     def _build_buckets(self, cap, last_cap):

@@ -56,6 +56,25 @@ def bump_weights_epoch():
     _weights_epoch[0] += 1
 
 
+def _arena_grad(t):
+    """t.grad when it is a persistent view into the engine's flat gradient arena that kernels
+    may accumulate into directly (set up by engine.FlatArena), else None."""
+    if t is None or not getattr(t, '_saicv_direct', False):
+        return None
+    g = t.grad
+    if g is None or g.dtype != torch.float32 or g.stride() != t.stride():
+        return None
+    return g
+
+
+def _grad_ready(t):
+    """Tells the DDP engine that t.grad received this step's contribution (the kernel wrote it
+    in place, so autograd's AccumulateGrad hook will not run for t)."""
+    cb = getattr(t, '_saicv_grad_ready', None)
+    if cb is not None:
+        cb(t)
+
+
 def compute_dtype():
     if torch.is_autocast_enabled('cuda'):
         dt = torch.get_autocast_dtype('cuda')
@@ -220,6 +239,7 @@ class ConvBnActFn(torch.autograd.Function):
             # eval-mode backward (frozen statistics) is linear: dy = scale * g
             ctx.save_for_backward(x, weight, gamma, y, z if relu else None, None, scale)
         ctx.cfg = (stride, pad, bool(relu), residual is not None, training, d, wd)
+        ctx.beta_ref = beta
         return z
 
     @staticmethod
@@ -239,13 +259,23 @@ class ConvBnActFn(torch.autograd.Function):
         M = n * oh * ow
         dy = _empty_nhwc(n, k, oh, ow, dt, dev)
         dres = _empty_nhwc(n, k, oh, ow, dt, dev) if (has_res and ctx.needs_input_grad[4]) else None
-        dgamma = torch.empty(k, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(k, dtype=torch.float32, device=dev)
+        beta = ctx.beta_ref
+        gg, gb = _arena_grad(gamma), _arena_grad(beta)
+        direct_bn = gg is not None and gb is not None
+        if direct_bn:
+            dgamma, dbeta = gg, gb
+        else:
+            dgamma = torch.empty(k, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(k, dtype=torch.float32, device=dev)
         ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, k, dtype_code(dt)), dtype=torch.float32, device=dev)
         t0 = KernelTimer.begin()
         check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), ptr(z), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
-                                 ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), M, k, int(relu), ptr(ws), st),
-              'bn_act_bwd')
+                                 ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), M, k, int(relu), int(direct_bn),
+                                 ptr(ws), st), 'bn_act_bwd')
+        if direct_bn:
+            _grad_ready(gamma)
+            _grad_ready(beta)
+            dgamma = dbeta = None
         # two streaming passes: (dz, y[, z]) read twice, dy (and dres) written once
         KernelTimer.end(t0, 'bn_act_bwd', 0, float(M) * k * y.element_size() *
                         (2 * (3 if relu else 2) + (2 if dres is not None else 1)))
@@ -261,11 +291,18 @@ class ConvBnActFn(torch.autograd.Function):
             KernelTimer.end(t0, 'igemm_nt', flops, 0)
         dwt = None
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=dev)
+            gw = _arena_grad(weight)
+            direct = (gw is not None and c == weight.shape[1] and
+                      weight.is_contiguous(memory_format=torch.channels_last))
+            # KRSC fp32 gradient: straight into the arena (atomics accumulate), else a temporary
+            dw = gw if direct else torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=dev)
             t0 = KernelTimer.begin()
             check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
             KernelTimer.end(t0, 'igemm_tn', flops, 0)
-            dwt = _weight_grad(dw, weight, c)
+            if direct:
+                _grad_ready(weight)
+            else:
+                dwt = _weight_grad(dw, weight, c)
         return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
                 dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None)
 
