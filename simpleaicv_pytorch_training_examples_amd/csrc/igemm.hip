@@ -14,10 +14,20 @@
 // resnet.py:204 (fc).  Tiles are 128x{64,128} with 128-byte K slices, 4 wavefronts (2x2),
 // MFMA 16x16x32 bf16 (perf mode) or 16x16x4 f32 (parity mode), register-staged double
 // buffered LDS with an XOR swizzle that makes ds_read_b128 fragment reads conflict free.
+#include <type_traits>
+
 #include "common.h"
 #include "saicv_internal.h"
 
 namespace {
+
+struct FastDiv {           // exact unsigned division by a runtime constant (Granlund-Montgomery)
+    uint32_t mul, s1, s2;
+};
+DEVINL uint32_t fdiv(uint32_t n, FastDiv d) {
+    const uint32_t t = __umulhi(d.mul, n);
+    return (t + ((n - t) >> d.s1)) >> d.s2;
+}
 
 struct NTParams {
     const void* src;
@@ -26,6 +36,7 @@ struct NTParams {
     const float* bias;
     float* stat_sum;
     float* stat_sq;
+    uint32_t src_bytes, wgt_bytes;
     int H, W, C;        // gather-source spatial dims / channels
     int OH, OW;         // pixel grid that indexes the GEMM rows
     int R, S, stride, pad;
@@ -33,11 +44,22 @@ struct NTParams {
     int ldo;
     int tiles_n;
     int nblk;
+    FastDiv fd_ohw, fd_ow;   // for OH*OW and OW (unit-stride row decomposition)
 };
 
 // LDS row = 128 bytes = 8 chunks; chunk c of row r lives at slot c ^ ((r>>1)&7).
 DEVINL int lds_off(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
 
+DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+}
+
+// The main loop is bound by MFMA issue only if the integer work per K tile is tiny, so:
+//  * all gathers are raw buffer loads: an out-of-range lane (padding halo, M/N/K tails) gets
+//    offset 0xffffffff and the hardware returns zeros -- no branches, no exec masking;
+//  * the (r, s, c) position of a thread's K chunk advances incrementally (no divisions);
+//  * per-row constants fold image base and top-left corner, so a gather address is one add;
+//  * LDS fragment addresses (with the XOR swizzle) are computed once.
 template <typename T, int BN_T, int MODE, bool OUT_F32>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
@@ -50,6 +72,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     constexpr int A_BYTES = BM_T * 128;
     constexpr int W_BYTES = BN_T * 128;
     constexpr int STAGE = A_BYTES + W_BYTES;
+    constexpr uint32_t OOB = 0xfffffff0u;   // 16-byte aligned, beyond any operand (host checks sizes)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -62,7 +85,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     // ---- data-gradient with stride s > 1: the input pixels split into s*s parity classes
     // (h % s, w % s); a class only ever meets the taps r == (h + pad) mod s, so each class is a
     // dense GEMM over its own tap subset (no multiply-by-zero work).  blockIdx.y = class.
-    int cs = 1, ph = 0, pw = 0, r0 = 0, s0 = 0, Sc = p.S, Hc = p.OH, Wc = p.OW, Mc = p.M, Kc = p.Kd;
+    // In class-local terms the source pixel of (row, tap) is (A0 - tr, B0 - ts).
+    int cs = 1, ph = 0, pw = 0, r0 = 0, s0 = 0, q0h = p.pad, q0w = p.pad;
+    int Sc = p.S, Hc = p.OH, Wc = p.OW, Mc = p.M, Kc = p.Kd;
     int nblk = p.nblk;
     if (MODE == 1 && p.stride > 1) {
         cs = p.stride;
@@ -73,6 +98,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         Mc = (p.M / (p.OH * p.OW)) * Hc * Wc;
         r0 = (ph + p.pad) % cs;
         s0 = (pw + p.pad) % cs;
+        q0h = (ph + p.pad - r0) / cs;
+        q0w = (pw + p.pad - s0) / cs;
         const int Rc = r0 < p.R ? (p.R - r0 + cs - 1) / cs : 0;
         Sc = s0 < p.S ? (p.S - s0 + cs - 1) / cs : 0;
         Kc = Rc * Sc * p.C;
@@ -83,90 +110,110 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     const int tile_n = bid % p.tiles_n;
     const int tile_m = bid / p.tiles_n;
 
+    const __amdgpu_buffer_rsrc_t src_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+
     // ---- per-thread gather state: chunk column cc, rows rb + 32*i
     const int cc = tid & 7;
     const int rb = tid >> 3;
-    int pixbase[4], a0[4], b0[4];
+    int rowc[4], a0[4], b0[4];          // rowc = (image base + A0*W + B0) * C  [elements]
     const int ohw = Hc * Wc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = tile_m * BM_T + rb + 32 * i;
         if (m < Mc) {
-            const int img = m / ohw;
-            const int rem = m - img * ohw;
-            const int oh = rem / Wc;
-            const int ow = rem - oh * Wc;
-            pixbase[i] = img * p.H * p.W;
+            int img, oh, ow;
+            if (cs == 1) {
+                img = (int)fdiv((uint32_t)m, p.fd_ohw);
+                const int rem = m - img * ohw;
+                oh = (int)fdiv((uint32_t)rem, p.fd_ow);
+                ow = rem - oh * Wc;
+            } else {
+                img = m / ohw;
+                const int rem = m - img * ohw;
+                oh = rem / Wc;
+                ow = rem - oh * Wc;
+            }
             if (MODE == 0) {
                 a0[i] = oh * p.stride - p.pad;
                 b0[i] = ow * p.stride - p.pad;
             } else {
-                a0[i] = oh * cs + ph + p.pad;
-                b0[i] = ow * cs + pw + p.pad;
+                a0[i] = oh + q0h;
+                b0[i] = ow + q0w;
             }
+            rowc[i] = ((img * p.H + a0[i]) * p.W + b0[i]) * p.C;
         } else {
-            pixbase[i] = 0;
+            rowc[i] = 0;
             a0[i] = -(1 << 24);
             b0[i] = -(1 << 24);
         }
     }
-    const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
-    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
+    int wrow[WROWS];                    // weight row base [elements], or -1
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) {
+        const int n = tile_n * BN_T + rb + 32 * j;
+        wrow[j] = n < p.Nn ? n * p.Kd : -1;
+    }
+
+    // K-chunk walker: k = kt*BK + cc*EPC  ->  (tr, ts, c0), advanced by BK per tile
+    int kpos = cc * EPC;
+    int tc0, ttr, tts;
+    {
+        const int tap = kpos / p.C;
+        tc0 = kpos - tap * p.C;
+        ttr = Sc > 0 ? tap / Sc : 0;
+        tts = tap - ttr * Sc;
+    }
 
     u32x4 ra[4], rw[WROWS];
 
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + cc * EPC;
-        const bool kvalid = k < Kc;
-        const int tap = k / p.C;
-        const int c0 = k - tap * p.C;
-        int r = tap / Sc;
-        int s = tap - r * Sc;
-        if (MODE == 1) {            // class-local tap -> real tap
-            r = r0 + r * cs;
-            s = s0 + s * cs;
+    auto load_tile = [&]() {
+        const bool kvalid = kpos < Kc;
+        int tapoff, kw;
+        if (MODE == 0) {
+            tapoff = (ttr * p.W + tts) * p.C + tc0;
+            kw = kpos;
+        } else {
+            tapoff = tc0 - (ttr * p.W + tts) * p.C;
+            kw = ((r0 + ttr * cs) * p.S + (s0 + tts * cs)) * p.C + tc0;
         }
-        const int kw = (MODE == 1) ? (r * p.S + s) * p.C + c0 : k;      // column in the weight matrix
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int ih, iw;
-            bool ok = kvalid;
-            if (MODE == 0) {
-                ih = a0[i] + r;
-                iw = b0[i] + s;
-            } else {
-                const int th = a0[i] - r;       // multiples of cs by construction of the class
-                const int tw = b0[i] - s;
-                ok = ok && (th >= 0) && (tw >= 0);
-                ih = (cs == 1) ? th : th / cs;
-                iw = (cs == 1) ? tw : tw / cs;
-            }
-            ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-            if (ok) {
-                const size_t e = (size_t)(pixbase[i] + ih * p.W + iw) * (size_t)p.C + (size_t)c0;
-                ra[i] = ld_chunk(src + e);
-            } else {
-                ra[i] = zero_chunk();
-            }
+            const int ih = (MODE == 0) ? a0[i] + ttr : a0[i] - ttr;
+            const int iw = (MODE == 0) ? b0[i] + tts : b0[i] - tts;
+            const bool ok = kvalid && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+            const uint32_t off = ok ? (uint32_t)(rowc[i] + tapoff) * (uint32_t)sizeof(T) : OOB;
+            ra[i] = buf_ld(src_rs, off);
         }
 #pragma unroll
         for (int j = 0; j < WROWS; ++j) {
-            const int n = tile_n * BN_T + rb + 32 * j;
-            if (kvalid && n < p.Nn) {
-                rw[j] = ld_chunk(wgt + (size_t)n * (size_t)p.Kd + (size_t)kw);
-            } else {
-                rw[j] = zero_chunk();
-            }
+            const bool ok = kvalid && (wrow[j] >= 0);
+            const uint32_t off = ok ? (uint32_t)(wrow[j] + kw) * (uint32_t)sizeof(T) : OOB;
+            rw[j] = buf_ld(wgt_rs, off);
+        }
+        // advance to the next K tile
+        kpos += BK;
+        tc0 += BK;
+        while (tc0 >= p.C) {
+            tc0 -= p.C;
+            if (++tts == Sc) { tts = 0; ++ttr; }
         }
     };
 
+    int st_a[4], st_w[WROWS];           // LDS store offsets (stage 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st_a[i] = lds_off(rb + 32 * i, cc);
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) st_w[j] = A_BYTES + lds_off(rb + 32 * j, cc);
+
     auto store_tile = [&](int stage) {
-        char* sa = smem + stage * STAGE;
-        char* sw = sa + A_BYTES;
+        char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st_chunk(sa + lds_off(rb + 32 * i, cc), ra[i]);
+        for (int i = 0; i < 4; ++i) st_chunk(base + st_a[i], ra[i]);
 #pragma unroll
-        for (int j = 0; j < WROWS; ++j) st_chunk(sw + lds_off(rb + 32 * j, cc), rw[j]);
+        for (int j = 0; j < WROWS; ++j) st_chunk(base + st_w[j], rw[j]);
     };
 
     f32x4 acc[NT_][MT_];
@@ -177,20 +224,24 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
 
     const int l15 = lane & 15;
     const int lg = lane >> 4;
+    int fa[2][MT_], fw[2][NT_];         // LDS fragment offsets (stage 0), hoisted out of the K loop
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < MT_; ++mi) fa[ks][mi] = lds_off(wm * 64 + mi * 16 + l15, ks * 4 + lg);
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni) fw[ks][ni] = A_BYTES + lds_off(wn * WN + ni * 16 + l15, ks * 4 + lg);
+    }
 
     auto compute = [&](int stage) {
-        const char* sa = smem + stage * STAGE;
-        const char* sw = sa + A_BYTES;
+        const char* base = smem + stage * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 af[MT_], wf[NT_];
-            const int chunk = ks * 4 + lg;
 #pragma unroll
-            for (int mi = 0; mi < MT_; ++mi)
-                af[mi] = ld_chunk(sa + lds_off(wm * 64 + mi * 16 + l15, chunk));
+            for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(base + fa[ks][mi]);
 #pragma unroll
-            for (int ni = 0; ni < NT_; ++ni)
-                wf[ni] = ld_chunk(sw + lds_off(wn * WN + ni * 16 + l15, chunk));
+            for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(base + fw[ks][ni]);
 #pragma unroll
             for (int ni = 0; ni < NT_; ++ni)
 #pragma unroll
@@ -200,23 +251,31 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
 
     const int nkt = (Kc + BK - 1) / BK;        // 0 for a class without taps: the output is zero
     if (nkt > 0) {
-        load_tile(0);
+        load_tile();
         store_tile(0);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1) < nkt;
-        if (more) load_tile(kt + 1);
+        if (more) load_tile();
         compute(cur);
         if (more) store_tile(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*16 + lg*4 + r ; m = m_base + mi*16 + l15
+    // BN statistics come straight from the accumulators; the output tile is staged through LDS
+    // so that HBM sees whole rows written 16 bytes per lane (a lane's fragment is only 4 values
+    // of one row: storing it directly gives 32-byte row segments and half the write bandwidth).
+    typedef typename std::conditional<OUT_F32, float, T>::type TO;
+    constexpr int OPITCH = BN_T * (int)sizeof(TO) + 16;         // bytes; +16 staggers banks
+    constexpr int OCPR = BN_T * (int)sizeof(TO) / 16;           // 16-byte chunks per tile row
+    constexpr int OEPC = 16 / (int)sizeof(TO);
     const int m_base = tile_m * BM_T + wm * 64;
     const int n_base = tile_n * BN_T + wn * WN;
     const bool do_stats = p.stat_sum != nullptr;
+    const bool staged = ((p.ldo * (int)sizeof(TO)) & 15) == 0;
 #pragma unroll
     for (int ni = 0; ni < NT_; ++ni) {
         const int n0 = n_base + ni * 16 + lg * 4;
@@ -229,15 +288,6 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < MT_; ++mi) {
-            const int mrow = m_base + mi * 16 + l15;
-            int m = mrow;                        // output row (pixel index)
-            if (MODE == 1 && cs > 1 && mrow < Mc) {
-                const int img = mrow / ohw;
-                const int rem = mrow - img * ohw;
-                const int hc = rem / Wc;
-                const int wc = rem - hc * Wc;
-                m = (img * p.OH + hc * cs + ph) * p.OW + wc * cs + pw;
-            }
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bs[r];
@@ -249,32 +299,31 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
                     ssq[r] += vr * vr;
                 }
             }
-            if (mrow < Mc) {
-                if (OUT_F32) {
-                    float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n0;
-                    if (n0 + 3 < p.Nn && (p.ldo & 3) == 0) {
-                        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-                    } else {
+            if (staged) {
+                char* q = smem + (wm * 64 + mi * 16 + l15) * OPITCH + (wn * WN + ni * 16 + lg * 4) * (int)sizeof(TO);
+                if (sizeof(TO) == 2) {
+                    bf16x4 pk;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n0 + r < p.Nn) o[r] = v[r];
-                    }
+                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4*>(q) = pk;
                 } else {
-                    T* o = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n0;
-                    if (n0 + 3 < p.Nn && (p.ldo & 3) == 0) {
-                        if (sizeof(T) == 2) {
-                            bf16x4 pk;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                            *reinterpret_cast<bf16x4*>(o) = pk;
-                        } else {
-                            *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n0 + r < p.Nn) o[r] = from_f32<T>(v[r]);
+                    *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
+                }
+            } else {
+                // unaligned leading dimension: scalar stores straight from the fragment
+                const int mrow = m_base + mi * 16 + l15;
+                if (mrow < Mc) {
+                    int m = mrow;
+                    if (MODE == 1 && cs > 1) {
+                        const int img = mrow / ohw;
+                        const int rem = mrow - img * ohw;
+                        const int hc = rem / Wc;
+                        m = (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
                     }
+                    TO* o = reinterpret_cast<TO*>(p.out) + (size_t)m * p.ldo + n0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < p.Nn) o[r] = from_f32<TO>(v[r]);
                 }
             }
         }
@@ -296,6 +345,37 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
                         p.stat_sum[prow + n0 + r] = ssum[r];
                         p.stat_sq[prow + n0 + r] = ssq[r];
                     }
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        const int oc = tid % OCPR;               // chunk within the tile row
+        const int orow0 = tid / OCPR;
+        constexpr int RPP = 256 / OCPR;          // tile rows per pass
+        const int ncol = tile_n * BN_T + oc * OEPC;
+        if (ncol < p.Nn) {
+            const bool whole = ncol + OEPC <= p.Nn;
+#pragma unroll 4
+            for (int rr = orow0; rr < BM_T; rr += RPP) {
+                const int mrow = tile_m * BM_T + rr;
+                if (mrow >= Mc) break;
+                int m = mrow;
+                if (MODE == 1 && cs > 1) {
+                    const int img = mrow / ohw;
+                    const int rem = mrow - img * ohw;
+                    const int hc = rem / Wc;
+                    m = (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
+                }
+                const u32x4 v = ld_chunk(smem + rr * OPITCH + oc * 16);
+                TO* o = reinterpret_cast<TO*>(p.out) + (size_t)m * p.ldo + ncol;
+                if (whole) {
+                    st_chunk(o, v);
+                } else {
+                    const TO* e = reinterpret_cast<const TO*>(&v);
+                    for (int j = 0; j < OEPC; ++j)
+                        if (ncol + j < p.Nn) o[j] = e[j];
+                }
             }
         }
     }
@@ -513,6 +593,16 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
     }
 }
 
+FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;                       // l = ceil(log2 d)
+    f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+
 template <typename K>
 void allow_lds(K k, size_t smem) {
     // one-time opt-in for > 64 KiB dynamic LDS (idempotent; cheap enough to repeat)
@@ -525,16 +615,18 @@ int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
     constexpr int BK = 8 * ElemTraits<T>::EPC;
     // a single K tile never touches the second LDS stage: ask for half the LDS so that more
     // workgroups are resident per CU (the K=64 1x1 convolutions are latency/HBM bound)
-    const size_t smem = (p.Kd <= BK) ? smem_full / 2 : smem_full;
+    const size_t epi = 128 * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16);
+    size_t smem = (p.Kd <= BK) ? smem_full / 2 : smem_full;
+    if (smem < epi) smem = epi;
     dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(256);
     if (out_f32) {
         auto k = igemm_nt_kernel<T, BN_T, MODE, true>;
-        static bool once = (allow_lds(k, smem_full), true);
+        static bool once = (allow_lds(k, smem_full + 4096), true);
         (void)once;
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
     } else {
         auto k = igemm_nt_kernel<T, BN_T, MODE, false>;
-        static bool once = (allow_lds(k, smem_full), true);
+        static bool once = (allow_lds(k, smem_full + 4096), true);
         (void)once;
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
     }
@@ -573,6 +665,15 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.src = src; p.wgt = wgt; p.out = out; p.bias = bias; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = M; p.Nn = Nn; p.Kd = Kd; p.ldo = ldo;
+    const size_t esz = dtype == SAICV_DTYPE_BF16 ? 2 : 4;
+    const size_t src_bytes = (size_t)(M / (OH * OW)) * H * W * C * esz;
+    const size_t wgt_bytes = (size_t)Nn * Kd * esz;
+    SAICV_REQUIRE(src_bytes < 0xfffffff0ull && wgt_bytes < 0xfffffff0ull,
+                  "igemm_nt: operand larger than 4 GiB (buffer addressing)");
+    p.src_bytes = (uint32_t)src_bytes;
+    p.wgt_bytes = (uint32_t)wgt_bytes;
+    p.fd_ohw = make_fastdiv((uint32_t)(OH * OW));
+    p.fd_ow = make_fastdiv((uint32_t)OW);
     const bool narrow = Nn <= 64;
     const int bn = narrow ? 64 : 128;
     p.tiles_n = (Nn + bn - 1) / bn;
