@@ -183,22 +183,32 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         for (int i = 0; i < 4; ++i) {
             const int ih = (MODE == 0) ? a0[i] + ttr : a0[i] - ttr;
             const int iw = (MODE == 0) ? b0[i] + tts : b0[i] - tts;
-            const bool ok = kvalid && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+            // bitwise (not short-circuit) logic keeps this branch-free
+            const bool ok = kvalid & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
             const uint32_t off = ok ? (uint32_t)(rowc[i] + tapoff) * (uint32_t)sizeof(T) : OOB;
             ra[i] = buf_ld(src_rs, off);
         }
 #pragma unroll
         for (int j = 0; j < WROWS; ++j) {
-            const bool ok = kvalid && (wrow[j] >= 0);
+            const bool ok = kvalid & (wrow[j] >= 0);
             const uint32_t off = ok ? (uint32_t)(wrow[j] + kw) * (uint32_t)sizeof(T) : OOB;
             rw[j] = buf_ld(wgt_rs, off);
         }
         // advance to the next K tile
         kpos += BK;
         tc0 += BK;
-        while (tc0 >= p.C) {
-            tc0 -= p.C;
-            if (++tts == Sc) { tts = 0; ++ttr; }
+        if (p.C >= BK) {                 // at most one tap boundary per tile (uniform branch)
+            const bool wrap = tc0 >= p.C;
+            tc0 -= wrap ? p.C : 0;
+            tts += wrap ? 1 : 0;
+            const bool wrap2 = tts == Sc;
+            tts = wrap2 ? 0 : tts;
+            ttr += wrap2 ? 1 : 0;
+        } else {
+            while (tc0 >= p.C) {
+                tc0 -= p.C;
+                if (++tts == Sc) { tts = 0; ++ttr; }
+            }
         }
     };
 
@@ -386,6 +396,7 @@ struct TNParams {
     const void* dy;     // [M][Cout]
     const void* src;    // [Nimg,H,W,C] gather source (layer input)
     float* dw;          // [Cout][Kd] fp32, accumulated with atomics
+    uint32_t dy_bytes, src_bytes;
     int H, W, C;
     int OH, OW;
     int R, S, stride, pad;
@@ -393,6 +404,7 @@ struct TNParams {
     int tiles_a, tiles_b;       // tiles over Cout / over Kd
     int m_per_split;            // multiple of BR
     int d_img, d_oh, d_ow;      // mixed-radix digits of BR in (img, oh, ow)
+    FastDiv fd_ohw, fd_ow;
 };
 
 template <typename T, int BA, int BB>
@@ -409,6 +421,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
     constexpr int NA = BR / RPP_A, NB = BR / RPP_B;       // chunks per thread
     constexpr int WA = BA / 2, WB = BB / 2;
     constexpr int AT = WA / 16, BT = WB / 16;
+    constexpr uint32_t OOB = 0xfffffff0u;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -424,54 +437,57 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
     const int m_end = min(p.M, m_begin + p.m_per_split);
     if (m_begin >= m_end) return;
 
-    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
-    const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+    const __amdgpu_buffer_rsrc_t dy_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t src_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
 
-    // dY loader state
+    // dY loader state: byte offset of this thread's chunk in row (m_begin + rba), advanced per tile
     const int ca = tid % CPR_A, rba = tid / CPR_A;
     const int n_ld = tile_a * BA + ca * EPC;
     const bool n_ok = n_ld < p.Cout;
+    uint32_t dy_off = (uint32_t)((m_begin + rba) * p.Cout + n_ld) * (uint32_t)sizeof(T);
+    const uint32_t dy_row_step = (uint32_t)(RPP_A * p.Cout) * (uint32_t)sizeof(T);
+    const uint32_t dy_tile_step = (uint32_t)(BR * p.Cout) * (uint32_t)sizeof(T);
+    int m_a = m_begin + rba;
     // gather loader state
     const int cb = tid % CPR_B, rbb = tid / CPR_B;
     const int kk_ld = tile_b * BB + cb * EPC;
     const bool kk_ok = kk_ld < p.Kd;
     const int tap = kk_ld / p.C;
     const int c0 = kk_ld - tap * p.C;
-    const int fr = tap / p.S;
-    const int fs = tap - fr * p.S;
+    const int fr = tap / p.S - p.pad;            // tap offsets with the padding folded in
+    const int fs = tap - (tap / p.S) * p.S - p.pad;
     int g_img[NB], g_oh[NB], g_ow[NB];
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int m = m_begin + rbb + RPP_B * i;
-        const int img = m / ohw;
+        const int img = (int)fdiv((uint32_t)m, p.fd_ohw);
         const int rem = m - img * ohw;
         g_img[i] = img;
-        g_oh[i] = rem / p.OW;
+        g_oh[i] = (int)fdiv((uint32_t)rem, p.fd_ow);
         g_ow[i] = rem - g_oh[i] * p.OW;
     }
+    int m_b = m_begin + rbb;
 
     u32x4 ra[NA], rbv[NB];
-    auto load_tile = [&](int m0) {
+    auto load_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int m = m0 + rba + RPP_A * i;
-            if (n_ok && m < m_end) ra[i] = ld_chunk(dy + (size_t)m * (size_t)p.Cout + n_ld);
-            else ra[i] = zero_chunk();
+            const bool ok = n_ok & (m_a + RPP_A * i < m_end);
+            ra[i] = buf_ld(dy_rs, ok ? dy_off + (uint32_t)i * dy_row_step : OOB);
         }
+        dy_off += dy_tile_step;
+        m_a += BR;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int m = m0 + rbb + RPP_B * i;
-            const int ih = g_oh[i] * p.stride - p.pad + fr;
-            const int iw = g_ow[i] * p.stride - p.pad + fs;
-            const bool ok = kk_ok && (m < m_end) && ((unsigned)ih < (unsigned)p.H) &&
+            const int ih = g_oh[i] * p.stride + fr;
+            const int iw = g_ow[i] * p.stride + fs;
+            const bool ok = kk_ok & (m_b + RPP_B * i < m_end) & ((unsigned)ih < (unsigned)p.H) &
                             ((unsigned)iw < (unsigned)p.W);
-            if (ok) {
-                const size_t e = ((size_t)(g_img[i] * p.H + ih) * p.W + iw) * (size_t)p.C + c0;
-                rbv[i] = ld_chunk(src + e);
-            } else {
-                rbv[i] = zero_chunk();
-            }
+            const uint32_t off = (uint32_t)(((g_img[i] * p.H + ih) * p.W + iw) * p.C + c0) * (uint32_t)sizeof(T);
+            rbv[i] = buf_ld(src_rs, ok ? off : OOB);
             // advance this row by BR pixels (mixed radix add with carries)
             int ow = g_ow[i] + p.d_ow;
             int cy = ow >= p.OW;
@@ -483,16 +499,19 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
             g_oh[i] = oh;
             g_img[i] += p.d_img + cy;
         }
+        m_b += BR;
     };
+    int st_a[NA], st_b[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) st_a[i] = (rba + RPP_A * i) * PITCH_A + ca * 16;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) st_b[i] = A_BYTES + (rbb + RPP_B * i) * PITCH_B + cb * 16;
     auto store_tile = [&](int stage) {
-        char* sa = smem + stage * STAGE;
-        char* sb = sa + A_BYTES;
+        char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-            st_chunk(sa + (rba + RPP_A * i) * PITCH_A + ca * 16, ra[i]);
+        for (int i = 0; i < NA; ++i) st_chunk(base + st_a[i], ra[i]);
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            st_chunk(sb + (rbb + RPP_B * i) * PITCH_B + cb * 16, rbv[i]);
+        for (int i = 0; i < NB; ++i) st_chunk(base + st_b[i], rbv[i]);
     };
 
     f32x4 acc[AT][BT];
@@ -501,22 +520,34 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
 #pragma unroll
         for (int bi = 0; bi < BT; ++bi) acc[ai][bi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // LDS fragment offsets (stage 0), hoisted out of the reduction loop
+    int fa_off[AT], fb_off[BT];
+    if constexpr (sizeof(T) == 2) {
+        // ds_read_b64_tr_b16: a 16-lane group reads a [4 rows][16 cols] block; lane t supplies the
+        // 8-byte address of row (t>>2), cols (t&3)*4.. and receives column t of the four rows.
+        const int row0 = lg * 8 + (l15 >> 2);
+#pragma unroll
+        for (int ai = 0; ai < AT; ++ai) fa_off[ai] = row0 * PITCH_A + (wa * WA + ai * 16 + (l15 & 3) * 4) * 2;
+#pragma unroll
+        for (int bi = 0; bi < BT; ++bi) fb_off[bi] = A_BYTES + row0 * PITCH_B + (wb * WB + bi * 16 + (l15 & 3) * 4) * 2;
+    } else {
+#pragma unroll
+        for (int ai = 0; ai < AT; ++ai) fa_off[ai] = lg * PITCH_A + (wa * WA + ai * 16 + l15) * 4;
+#pragma unroll
+        for (int bi = 0; bi < BT; ++bi) fb_off[bi] = A_BYTES + lg * PITCH_B + (wb * WB + bi * 16 + l15) * 4;
+    }
+
     auto compute = [&](int stage) {
-        const char* sa = smem + stage * STAGE;
-        const char* sb = sa + A_BYTES;
+        const char* base = smem + stage * STAGE;
         if constexpr (sizeof(T) == 2) {
-            // BR = 64 rows -> two 32-deep k-steps.  ds_read_b64_tr_b16: a 16-lane group reads a
-            // [4 rows][16 cols] block; lane t supplies the 8-byte address of row (t>>2),
-            // cols (t&3)*4.. and receives column t of the four rows.
+            // BR = 64 rows -> two 32-deep k-steps
             typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 af[AT], bf[BT];
-                const int row0 = ks * 32 + lg * 8 + (l15 >> 2);
 #pragma unroll
                 for (int ai = 0; ai < AT; ++ai) {
-                    const int col = wa * WA + ai * 16 + (l15 & 3) * 4;
-                    const char* q = sa + row0 * PITCH_A + col * 2;
+                    const char* q = base + fa_off[ai] + ks * 32 * PITCH_A;
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * PITCH_A));
                     u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
@@ -524,8 +555,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
                 }
 #pragma unroll
                 for (int bi = 0; bi < BT; ++bi) {
-                    const int col = wb * WB + bi * 16 + (l15 & 3) * 4;
-                    const char* q = sb + row0 * PITCH_B + col * 2;
+                    const char* q = base + fb_off[bi] + ks * 32 * PITCH_B;
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * PITCH_B));
                     u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
@@ -544,15 +574,12 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
 #pragma unroll
             for (int ks = 0; ks < BR / 4; ++ks) {
                 float af[AT], bf[BT];
-                const int row = ks * 4 + lg;
 #pragma unroll
                 for (int ai = 0; ai < AT; ++ai)
-                    af[ai] = *reinterpret_cast<const float*>(sa + row * PITCH_A +
-                                                             (wa * WA + ai * 16 + l15) * 4);
+                    af[ai] = *reinterpret_cast<const float*>(base + fa_off[ai] + ks * 4 * PITCH_A);
 #pragma unroll
                 for (int bi = 0; bi < BT; ++bi)
-                    bf[bi] = *reinterpret_cast<const float*>(sb + row * PITCH_B +
-                                                             (wb * WB + bi * 16 + l15) * 4);
+                    bf[bi] = *reinterpret_cast<const float*>(base + fb_off[bi] + ks * 4 * PITCH_B);
 #pragma unroll
                 for (int ai = 0; ai < AT; ++ai)
 #pragma unroll
@@ -564,13 +591,13 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
     };
 
     const int nt = (m_end - m_begin + BR - 1) / BR;
-    load_tile(m_begin);
+    load_tile();
     store_tile(0);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         const bool more = (t + 1) < nt;
-        if (more) load_tile(m_begin + (t + 1) * BR);
+        if (more) load_tile();
         compute(cur);
         if (more) store_tile(cur ^ 1);
         __syncthreads();
@@ -702,6 +729,15 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     TNParams p;
     p.dy = dy; p.src = src; p.dw = dw; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.M = M; p.Cout = Cout; p.Kd = Kd;
+    const size_t esz = dtype == SAICV_DTYPE_BF16 ? 2 : 4;
+    const size_t dy_bytes = (size_t)M * Cout * esz;
+    const size_t src_bytes = (size_t)(M / (OH * OW)) * H * W * C * esz;
+    SAICV_REQUIRE(dy_bytes < 0xfffffff0ull && src_bytes < 0xfffffff0ull,
+                  "igemm_tn: operand larger than 4 GiB (buffer addressing)");
+    p.dy_bytes = (uint32_t)dy_bytes;
+    p.src_bytes = (uint32_t)src_bytes;
+    p.fd_ohw = make_fastdiv((uint32_t)(OH * OW));
+    p.fd_ow = make_fastdiv((uint32_t)OW);
     const int BR = 8 * epc;
     const int ba = Cout <= 64 ? 64 : 128;
     const int bb = Kd <= 64 ? 64 : 128;
@@ -710,7 +746,7 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     const int tiles = p.tiles_a * p.tiles_b;
     // split the pixel reduction so that ~4 workgroups per CU are in flight
     const int total_rt = (M + BR - 1) / BR;
-    int splits = (1024 + tiles - 1) / tiles;
+    int splits = (512 + tiles - 1) / tiles;     // 2 workgroups per CU are resident (73 KiB LDS each)
     if (splits > total_rt) splits = total_rt;
     if (splits < 1) splits = 1;
     int rt_per = (total_rt + splits - 1) / splits;
