@@ -107,6 +107,9 @@ class _FlatOptimizer:
 
     def __init__(self, model, param_groups):
         self.arena = _arena_of(model)
+        if self.arena.device.type != 'cuda':
+            raise RuntimeError('the fused flat optimizers run on MI355X only (HIP kernels, no CPU fallback); '
+                               'move the model to the GPU before building the optimizer')
         self.param_groups = []
         group_of = {}
         for gi, g in enumerate(param_groups):

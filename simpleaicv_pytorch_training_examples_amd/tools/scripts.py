@@ -1,0 +1,183 @@
+"""Per-iteration train / eval loops of the reference tools/scripts.py on the MI355X engine.
+
+  all_reduce_operation_in_group_for_variables  (reference :26-33)
+  test_classification                          (reference :36-113)
+  train_classification                         (reference :116-275)
+
+Loop semantics are kept -- skip a batch when ANY rank saw inf/nan input or a zero/inf/nan loss,
+gradient accumulation with `no_sync()`, optional clipping, GradScaler step/update, EMA, mean-
+over-ranks loss meter, per-iteration scheduler on the fractional epoch, identical log lines --
+but the reference's four host synchronisations and the barrier per iteration (C5-C7 in
+SURVEY.md section 2.4) collapse into ONE 2-element all-reduce whose result the host reads a few
+iterations late:
+  * the skip decision is taken on the device: the flag is all-reduced and handed to the fused
+    optimizer kernel as `found_inf`, which then leaves parameters and optimizer state untouched
+    (what `optimizer.zero_grad(); continue` achieves in the reference);
+  * the loss meter, the "skip this batch!" log line and the iteration counter are updated when
+    the (flag, loss) pair of an iteration is popped from a short queue (`config.host_sync_lag`
+    iterations later, default 2; 0 restores a blocking read every iteration), so the host never
+    stalls the HIP stream.
+"""
+import collections
+import time
+
+import torch
+import torch.distributed as dist
+from torch.amp.autocast_mode import autocast
+
+from ..SimpleAICV.classification.common import AccMeter, AverageMeter, get_amp_type
+
+
+def _device_of(model):
+    return next(model.parameters()).device
+
+
+def _dist_on(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def all_reduce_operation_in_group_for_variables(variables, operator, group):
+    """python scalars / 0-d tensors -> all-reduced python scalars (blocking; eval path only)."""
+    device = 'cuda' if torch.cuda.is_available() else 'cpu'
+    for i in range(len(variables)):
+        if not torch.is_tensor(variables[i]):
+            variables[i] = torch.tensor(variables[i], device=device)
+        if _dist_on(group):
+            dist.all_reduce(variables[i], op=operator, group=group)
+        variables[i] = variables[i].item()
+    return variables
+
+
+def test_classification(test_loader, model, criterion, config):
+    batch_time, data_time, losses, accs = AverageMeter(), AverageMeter(), AverageMeter(), AccMeter()
+    if getattr(config, 'use_ema_model', False):
+        model = config.ema_model.ema_model
+    model.eval()
+    device = _device_of(model)
+    sync = torch.cuda.synchronize if device.type == 'cuda' else (lambda: None)
+    with torch.no_grad():
+        end = time.time()
+        for data in test_loader:
+            images, labels = data['image'].to(device), data['label'].to(device)
+            sync()
+            data_time.update(time.time() - end)
+            end = time.time()
+            outputs = model(images)
+            sync()
+            batch_time.update(time.time() - end)
+            loss = criterion(outputs, labels)
+            _, topk = torch.topk(outputs, k=5, dim=1, largest=True, sorted=True)
+            correct = topk.eq(labels.unsqueeze(-1).expand_as(topk)).float()
+            # one fused all-reduce instead of the reference's 1 + 3 scalar ones (C8)
+            packed = torch.stack([loss.float(), correct[:, :1].sum(), correct[:, :5].sum(),
+                                  torch.tensor(float(images.size(0)), device=device)])
+            if _dist_on(config.group):
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=config.group)
+            loss_sum, acc1_n, acc5_n, n = packed.tolist()
+            losses.update(loss_sum / float(config.gpus_num), images.size(0))
+            accs.update(acc1_n, acc5_n, n)
+            end = time.time()
+    accs.compute()
+    per_gpu = config.batch_size // config.gpus_num
+    return (accs.acc1 * 100, accs.acc5 * 100, losses.avg, data_time.avg / per_gpu * 1000,
+            batch_time.avg / per_gpu * 1000)
+
+
+def train_classification(train_loader, model, criterion, optimizer, scheduler, epoch, logger, config):
+    '''train classification model for one epoch'''
+    losses = AverageMeter()
+    model.train()
+    device = _device_of(model)
+    amp_type = get_amp_type(model)
+    local_rank = config.local_rank
+    total_rank = getattr(config, 'total_rank', 0)
+    main = local_rank == 0 and total_rank == 0
+    if main:
+        logger.info(f'use_amp: {config.use_amp}, amp_type: {amp_type}!')
+    iters = len(train_loader.dataset) // config.batch_size
+    iter_index = 1
+    acc_steps = config.accumulation_steps
+    assert acc_steps >= 1, 'illegal accumulation_steps!'
+    lag = getattr(config, 'host_sync_lag', 2)
+    scaler = getattr(config, 'scaler', None) if config.use_amp else None
+    clip_value = getattr(config, 'clip_grad_value', 0) or 0
+    clip_norm = getattr(config, 'clip_max_norm', 0) or 0
+    pending = collections.deque()      # (packed [skip, loss] device tensor, batch size, log line or None)
+    carried_bad = None                 # skip flag of earlier micro-steps of this accumulation window
+
+    def drain(keep):
+        nonlocal iter_index
+        while len(pending) > keep:
+            packed, n, log_fmt = pending.popleft()
+            skip, loss_sum = packed.tolist()
+            if skip:
+                if main:
+                    logger.info('skip this batch!')
+                iter_index -= 1            # the reference does not count a skipped iteration
+                continue
+            loss = loss_sum / float(config.gpus_num)
+            losses.update(loss, n)
+            if log_fmt is not None and main:
+                logger.info(log_fmt.format(loss=loss * acc_steps))
+
+    for data in train_loader:
+        images, labels = data['image'].to(device, non_blocking=True), data['label'].to(device, non_blocking=True)
+        # device-side replacement of the reference's isinf/isnan python branches (:147-151)
+        bad = ~torch.isfinite(images).all()
+        if labels.dtype.is_floating_point:
+            bad = bad | ~torch.isfinite(labels).all()
+        if config.use_amp:
+            with autocast(device_type=device.type, dtype=amp_type):
+                outputs = model(images)
+                loss = criterion(outputs, labels)
+        else:
+            outputs = model(images)
+            loss = criterion(outputs, labels)
+        bad = bad | (loss == 0.) | ~torch.isfinite(loss)
+        loss = loss / acc_steps
+        boundary = iter_index % acc_steps == 0
+        scaled = scaler.scale(loss) if scaler is not None else loss
+        if boundary:
+            scaled.backward()
+        else:
+            with model.no_sync():       # no gradient exchange on non-boundary micro-steps
+                scaled.backward()
+
+        # one tiny all-reduce carries the skip flag (any rank) and the loss (sum over ranks)
+        packed = torch.stack([bad.float(), loss.detach().float()])
+        if _dist_on(config.group):
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=config.group)
+        if carried_bad is not None:
+            packed = torch.stack([torch.maximum(packed[0], carried_bad), packed[1]])
+        carried_bad = None if boundary else packed[0]
+
+        if boundary:
+            if hasattr(model, 'finish_gradient_sync'):
+                model.finish_gradient_sync()
+            skip_flag = packed[0:1]
+            if getattr(config, 'skip_inf_nan_grad', False) or scaler is not None:
+                optimizer.check_finite()
+                skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
+            inv_scale = scaler.state[2:3] if scaler is not None else None
+            if clip_value > 0:
+                raise NotImplementedError('clip_grad_value is not used by the hot-path configs')
+            if clip_norm > 0:
+                optimizer.clip_grad_norm_(clip_norm, inv_scale)
+                inv_scale = None
+            optimizer.step(inv_scale, skip_flag)
+            if scaler is not None:
+                scaler._found_inf = optimizer.found_inf
+                scaler.update()
+            optimizer.zero_grad()
+            if config.use_ema_model:
+                config.ema_model.update(model)
+            scheduler.step(optimizer, iter_index / iters + (epoch - 1))
+            log_fmt = None
+            if iter_index % int(config.print_interval * acc_steps) == 0:
+                log_fmt = (f'train: epoch {epoch:0>4d}, iter [{int(iter_index // acc_steps):0>5d}, '
+                           f'{int(iters // acc_steps):0>5d}], lr: {scheduler.current_lr:.6f}, ' + 'loss: {loss:.4f}')
+            pending.append((packed, images.size(0), log_fmt))
+        drain(lag)
+        iter_index += 1
+    drain(0)
+    return losses.avg * acc_steps
