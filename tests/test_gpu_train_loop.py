@@ -17,16 +17,17 @@ pytestmark = pytest.mark.gpu
 
 
 class SyntheticSet(torch.utils.data.Dataset):
-    """HWC float images whose label is recoverable from the pixels (quadrant brightness)."""
+    """HWC float images whose label is recoverable from the pixels (which quadrant is brighter /
+    darker); 8 classes because the reference's eval loop takes top-5 (tools/scripts.py:73)."""
 
-    def __init__(self, n=512, classes=4, size=32, seed=0, poison=()):
+    def __init__(self, n=512, classes=8, size=32, seed=0, poison=()):
         g = torch.Generator().manual_seed(seed)
         self.labels = torch.randint(0, classes, (n,), generator=g)
         self.images = torch.randn(n, size, size, 3, generator=g) * 0.5
         h = size // 2
         for i, l in enumerate(self.labels.tolist()):
-            r, c = divmod(l, 2)
-            self.images[i, r * h:(r + 1) * h, c * h:(c + 1) * h] += 1.5
+            r, c = divmod(l % 4, 2)
+            self.images[i, r * h:(r + 1) * h, c * h:(c + 1) * h] += 1.5 if l < 4 else -1.5
         for i in poison:
             self.images[i, 0, 0, 0] = float('nan')
 
@@ -44,7 +45,7 @@ def _config(dataset, batch=64, acc=1):
         pass
     torch.manual_seed(0)
     config.network = 'resnet18cifar'
-    config.model = backbones.resnet18cifar(num_classes=4)
+    config.model = backbones.resnet18cifar(num_classes=8)
     config.train_criterion = losses.CELoss()
     config.train_dataset = dataset
     config.batch_size = batch
@@ -119,7 +120,7 @@ def test_entry_script_checkpoints_and_resumes(tmp_path):
 
         class config:
             network = 'resnet18cifar'
-            num_classes = 4
+            num_classes = 8
             input_image_size = 32
             model = backbones.__dict__[network](**{{'num_classes': num_classes}})
             train_criterion = losses.CELoss()
