@@ -132,6 +132,27 @@ int saicv_grad_clip_scale(float* g, size_t n, const float* sumsq, const float* i
 int saicv_scaler_update(float* state, const float* found_inf, double growth, double backoff,
                         int interval, void* stream);
 
+/* ---- transformer blocks (SimpleAICV/classification/backbones/vit.py) -------------------- */
+/* nn.LayerNorm over the last dim C of x[M][C]; saves mean / rstd (fp32 [M]).  vit.py:147,151,225 */
+int saicv_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int M, int C, double eps, void* stream);
+size_t saicv_layernorm_bwd_ws_floats(int M, int C);
+/* dx, dgamma, dbeta (accumulate != 0: added to) */
+int saicv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C,
+                        int accumulate, void* stream);
+/* nn.GELU() (exact erf form), vit.py:87-99 */
+int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream);
+int saicv_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, void* stream);
+/* softmax(q k^T * scale) v per (batch, head) straight from the packed qkv GEMM output
+ * qkv[B*N][3*H*D] (column = which*H*D + head*D + d, as vit.py:65-68 views it) into the head-merged
+ * out[B*N][H*D]; lse[B][H][N] is kept for the backward.  MultiHeadAttention.forward, vit.py:61-80.
+ * D = 64, N <= 256. */
+int saicv_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int N, int H, int D,
+                        double scale, void* stream);
+int saicv_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
+                        void* dqkv, int B, int N, int H, int D, double scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,12 +55,12 @@ SIGNATURES = {
     'saicv_scaler_update': (c_int, [_P, _P, c_double, c_double, c_int, _P]),
     # transformer kernels (tfm.hip)
     'saicv_layernorm_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
-    'saicv_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    'saicv_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_layernorm_bwd_ws_floats': (c_size_t, [c_int, c_int]),
     'saicv_gelu_fwd': (c_int, [c_int, _P, _P, c_size_t, _P]),
     'saicv_gelu_bwd': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
     'saicv_attention_fwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
-    'saicv_attention_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
+    'saicv_attention_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
 }
 
 _lib = None

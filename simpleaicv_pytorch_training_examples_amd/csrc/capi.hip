@@ -53,6 +53,15 @@ int adamw_flat(float*, const float*, float*, float*, const int32_t*, const float
 int grad_stats(const float*, size_t, float*, float*, hipStream_t);
 int grad_clip_scale(float*, size_t, const float*, const float*, double, hipStream_t);
 int scaler_update(float*, const float*, double, double, int, hipStream_t);
+int layernorm_fwd(int, const void*, const float*, const float*, void*, float*, float*, int, int, double, hipStream_t);
+size_t layernorm_bwd_ws_floats(int, int);
+int layernorm_bwd(int, const void*, const void*, const float*, const float*, const float*, void*, float*, float*,
+                  float*, int, int, int, hipStream_t);
+int gelu_fwd(int, const void*, void*, size_t, hipStream_t);
+int gelu_bwd(int, const void*, const void*, void*, size_t, hipStream_t);
+int attention_fwd(int, const void*, void*, float*, int, int, int, int, double, hipStream_t);
+int attention_bwd(int, const void*, const void*, const void*, const float*, void*, int, int, int, int, double,
+                  hipStream_t);
 
 }  // namespace saicv
 
@@ -197,6 +206,31 @@ int saicv_grad_clip_scale(float* g, size_t n, const float* sumsq, const float* i
 int saicv_scaler_update(float* state, const float* found_inf, double growth, double backoff,
                         int interval, void* stream) {
     return scaler_update(state, found_inf, growth, backoff, interval, S(stream));
+}
+
+int saicv_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int M, int C, double eps, void* stream) {
+    return layernorm_fwd(dtype, x, gamma, beta, y, mean, rstd, M, C, eps, S(stream));
+}
+size_t saicv_layernorm_bwd_ws_floats(int M, int C) { return layernorm_bwd_ws_floats(M, C); }
+int saicv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C,
+                        int accumulate, void* stream) {
+    return layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, M, C, accumulate, S(stream));
+}
+int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream) {
+    return gelu_fwd(dtype, x, y, n, S(stream));
+}
+int saicv_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, void* stream) {
+    return gelu_bwd(dtype, dy, x, dx, n, S(stream));
+}
+int saicv_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int N, int H, int D,
+                        double scale, void* stream) {
+    return attention_fwd(dtype, qkv, out, lse, B, N, H, D, scale, S(stream));
+}
+int saicv_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
+                        void* dqkv, int B, int N, int H, int D, double scale, void* stream) {
+    return attention_bwd(dtype, qkv, out, dout, lse, dqkv, B, N, H, D, scale, S(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,690 @@
+// Transformer-block kernels for gfx950: LayerNorm, GELU, fused multi-head attention.
+//
+// Replaces the ATen dispatches of reference SimpleAICV/classification/backbones/vit.py:
+//   native_layer_norm (+backward)            TransformerEncoderLayer.norm1/norm2 :147,:151, ViT.norm :225
+//   gelu (+backward)                         FeedForward.gelu :87-99
+//   bmm, mul, _softmax, bmm (+backwards)     MultiHeadAttention.forward :61-80
+// LayerNorm / GELU are HBM-bound streaming kernels (wavefront reductions, 16-byte accesses).
+// Attention never materialises the [N,N] matrix in HBM: one workgroup owns one (batch, head),
+// keeps K and V (backward: two operands per phase) in LDS and walks 16-query tiles per
+// wavefront with MFMA 16x16x32 bf16 / 16x16x4 f32.  It reads q,k,v straight out of the packed
+// qkv GEMM output [B*N, 3*C] and writes the head-merged [B*N, C] layout, so none of the
+// reference's permute / contiguous copies exist.  Sequence length N <= 256 (ViT-B: 197; SAM
+// windows: 196); the 4096-token global attention of SAM needs the streaming variant (next).
+#include "common.h"
+#include "saicv_internal.h"
+
+namespace {
+
+// ======================================================================== LayerNorm
+// one wavefront per row; a lane holds NCH chunks (columns lane, lane+64, ...) in registers
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            T* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int M, int C, float eps) {
+    constexpr int N = Chunk<T>::N;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int cpr = C / N;
+    float v[NCH][N];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+        if (c < cpr) {
+            Chunk<T>::unpack(ld_chunk(x + (size_t)row * C + c * N), v[j]);
+#pragma unroll
+            for (int k = 0; k < N; ++k) s += v[j][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[j][k] = 0.f;
+        }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (lane + 64 * j < cpr) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) { const float d = v[j][k] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+        if (c < cpr) {
+            float o[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) o[k] = (v[j][k] - mu) * rs * gamma[c * N + k] + beta[c * N + k];
+            st_chunk(y + (size_t)row * C + c * N, Chunk<T>::pack(o));
+        }
+    }
+}
+
+// backward: dx per row; per-block partial dgamma / dbeta (a wavefront walks rows_per rows)
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, T* __restrict__ dx,
+                                                            float* __restrict__ part_g, float* __restrict__ part_b,
+                                                            int M, int C, int rows_per) {
+    constexpr int N = Chunk<T>::N;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cpr = C / N;
+    float gam[NCH][N], ag[NCH][N], ab[NCH][N];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            gam[j][k] = c < cpr ? gamma[c * N + k] : 0.f;
+            ag[j][k] = 0.f;
+            ab[j][k] = 0.f;
+        }
+    }
+    const int r0 = blockIdx.x * rows_per * 4;
+    for (int i = 0; i < rows_per; ++i) {
+        const int row = r0 + i * 4 + wave;
+        if (row >= M) break;
+        const float mu = mean[row], rs = rstd[row];
+        float g[NCH][N], xh[NCH][N];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cpr) {
+                float d[N], xv[N];
+                Chunk<T>::unpack(ld_chunk(dy + (size_t)row * C + c * N), d);
+                Chunk<T>::unpack(ld_chunk(x + (size_t)row * C + c * N), xv);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    xh[j][k] = (xv[k] - mu) * rs;
+                    g[j][k] = d[k] * gam[j][k];
+                    s1 += g[j][k];
+                    s2 += g[j][k] * xh[j][k];
+                    ag[j][k] += d[k] * xh[j][k];
+                    ab[j][k] += d[k];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cpr) {
+                float o[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) o[k] = rs * (g[j][k] - s1 - xh[j][k] * s2);
+                st_chunk(dx + (size_t)row * C + c * N, Chunk<T>::pack(o));
+            }
+        }
+    }
+    // combine the four wavefronts of the block: one column at a time through LDS
+    __shared__ float red[4][64 * 8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) red[wave][lane * N + k] = pass == 0 ? ag[j][k] : ab[j][k];
+            __syncthreads();
+            if (wave == 0 && c < cpr) {
+                float* dst = (pass == 0 ? part_g : part_b) + (size_t)blockIdx.x * C + c * N;
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    dst[k] = red[0][lane * N + k] + red[1][lane * N + k] + red[2][lane * N + k] + red[3][lane * N + k];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// out[c] (=|+=) sum_p part[p][c]
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int P, int C,
+                                                        float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int p = ty; p < P; p += 4) s += part[(size_t)p * C + c];
+    __shared__ float l[4][64];
+    l[ty][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        const int t = threadIdx.x;
+        const float v = l[0][t] + l[1][t] + l[2][t] + l[3][t];
+        out[c] = accumulate ? out[c] + v : v;
+    }
+}
+
+// ======================================================================== GELU (exact erf form)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t nchunks) {
+    constexpr int N = Chunk<T>::N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        float v[N];
+        Chunk<T>::unpack(ld_chunk(x + i * N), v);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+        st_chunk(y + i * N, Chunk<T>::pack(v));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                       T* __restrict__ dx, size_t nchunks) {
+    constexpr int N = Chunk<T>::N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        float v[N], g[N];
+        Chunk<T>::unpack(ld_chunk(x + i * N), v);
+        Chunk<T>::unpack(ld_chunk(dy + i * N), g);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float cdf = 0.5f * (1.f + erff(v[k] * 0.70710678118654752f));
+            const float pdf = 0.39894228040143268f * expf(-0.5f * v[k] * v[k]);
+            g[k] *= cdf + v[k] * pdf;
+        }
+        st_chunk(dx + i * N, Chunk<T>::pack(g));
+    }
+}
+
+// ======================================================================== attention
+// LDS image of a [rows][64] operand: 16-byte chunks, chunk c of row r at slot c ^ swz(r), which
+// keeps both the row-fragment reads (ds_read_b128, 16 rows x one chunk) and the transposing
+// reads (ds_read_b64_tr_b16, 4 rows x 32 bytes) conflict-light.
+template <typename T> struct AttnLds;
+template <> struct AttnLds<bf16_t> {
+    static constexpr int ROWB = 128;                        // 64 d * 2 B
+    static constexpr int DCH = 8;                           // chunks per row
+    static DEVINL int off(int row, int chunk) { return row * ROWB + (((chunk ^ (row >> 1)) & 7) << 4); }
+};
+template <> struct AttnLds<float> {
+    static constexpr int ROWB = 256;
+    static constexpr int DCH = 16;
+    static DEVINL int off(int row, int chunk) { return row * ROWB + (((chunk ^ row) & 15) << 4); }
+};
+
+// cooperative copy of `rows` x 64 elements (row stride `rs` elements in HBM) into the LDS image;
+// rows >= nvalid are zero filled
+template <typename T>
+DEVINL void attn_stage(char* lds, const T* __restrict__ g, int rs, int nvalid, int rows) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int DCH = AttnLds<T>::DCH;
+    for (int i = threadIdx.x; i < rows * DCH; i += 256) {
+        const int r = i / DCH, c = i - r * DCH;
+        const u32x4 v = r < nvalid ? ld_chunk(g + (size_t)r * rs + c * EPC) : zero_chunk();
+        st_chunk(lds + AttnLds<T>::off(r, c), v);
+    }
+}
+
+// B-operand fragment for D = A(16 x k) * B(k x 16) where B[k][col] = M[kbase + kperm][cbase + col]
+// and M is an LDS image with rows = k.  bf16: two transposing reads (k = 8 rows per lane group,
+// taken as rows g*4..g*4+3 of the first 16-row tile and of the second); f32: four plain reads.
+template <typename T> struct TrFrag;
+template <> struct TrFrag<bf16_t> {
+    // rows kbase + g*4 + j (j<4) and kbase + 16 + g*4 + j
+    static DEVINL u32x4 load(const char* lds, int kbase, int cbase, int l15, int lg) {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const int col = cbase + (l15 & 3) * 4;
+        const int r0 = kbase + lg * 4 + (l15 >> 2);
+        const int r1 = r0 + 16;
+        const char* q0 = lds + r0 * 128 + ((((col >> 3) ^ (r0 >> 1)) & 7) << 4) + ((col & 4) << 1);
+        const char* q1 = lds + r1 * 128 + ((((col >> 3) ^ (r1 >> 1)) & 7) << 4) + ((col & 4) << 1);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q1);
+        const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+        return u32x4{a[0], a[1], b[0], b[1]};
+    }
+};
+
+// pack probabilities of two adjacent 16-key tiles (fragment rows g*4+r) into a bf16 A operand
+DEVINL u32x4 pack_p(const f32x4& t0, const f32x4& t1) {
+    float f[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+    return Chunk<bf16_t>::pack(f);
+}
+
+// O(16 x 64) += P(16 x keys) * M(keys x 64) with P given as C-layout tiles pt[kt] (lane: row-of-A =
+// l15, k = kt*16 + g*4 + r) and M an LDS image with rows = keys.
+template <typename T, int NKT>
+DEVINL void pv_accumulate(f32x4 (&o)[4], const f32x4 (&pt)[NKT], int nkt, const char* lds, int l15, int lg) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int blk = 0; blk < NKT / 2; ++blk) {
+            if (blk * 2 < nkt) {
+                const u32x4 pa = pack_p(pt[2 * blk], pt[2 * blk + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x4 vb = TrFrag<bf16_t>::load(lds, blk * 32, dt * 16, l15, lg);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa),
+                                                                   __builtin_bit_cast(bf16x8, vb), o[dt], 0, 0, 0);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = kt * 16 + lg * 4 + r;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const int d = dt * 16 + l15;
+                        const float b = *reinterpret_cast<const float*>(lds + AttnLds<float>::off(row, d >> 2) + (d & 3) * 4);
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pt[kt][r], b, o[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// row fragments (A or B operand with k = d) of 16 rows starting at `row0` of an LDS image
+template <typename T>
+DEVINL void lds_row_frags(u32x4 (&f)[4], const char* lds, int row0, int l15, int lg) {
+    constexpr int STEPS = AttnLds<T>::DCH / 4;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) f[s] = ld_chunk(lds + AttnLds<T>::off(row0 + l15, s * 4 + lg));
+}
+// the same straight from HBM (row stride rs elements); rows >= nvalid give zeros
+template <typename T>
+DEVINL void gmem_row_frags(u32x4 (&f)[4], const T* __restrict__ g, int rs, int row0, int nvalid, int l15, int lg) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int STEPS = AttnLds<T>::DCH / 4;
+    const int r = row0 + l15;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+        f[s] = r < nvalid ? ld_chunk(g + (size_t)r * rs + (s * 4 + lg) * EPC) : zero_chunk();
+}
+template <typename T>
+DEVINL f32x4 tile_mma(const u32x4 (&a)[4], const u32x4 (&b)[4]) {
+    constexpr int STEPS = AttnLds<T>::DCH / 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) Mma<T>::run(acc, a[s], b[s]);
+    return acc;
+}
+
+constexpr int MAXKT = 16;          // up to 256 keys
+
+// ------------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                            float* __restrict__ lse, int B, int N, int H,
+                                                            float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H;
+    const int C = H * 64, RS = 3 * C;
+    const int Np = (N + 31) & ~31;
+    const int nkt = Np / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    char* Ks = smem;
+    char* Vs = smem + Np * AttnLds<T>::ROWB;
+    const T* base = qkv + (size_t)b * N * RS + h * 64;
+    attn_stage<T>(Ks, base + C, RS, N, Np);
+    attn_stage<T>(Vs, base + 2 * C, RS, N, Np);
+    __syncthreads();
+    const int nqt = (N + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        u32x4 qf[4];
+        gmem_row_frags<T>(qf, base, RS, qt * 16, N, l15, lg);
+        // S^T tiles: rows = keys (kt*16 + lg*4 + r), col = query l15
+        f32x4 st[MAXKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+                u32x4 kf[4];
+                lds_row_frags<T>(kf, Ks, kt * 16, l15, lg);
+                st[kt] = tile_mma<T>(kf, qf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + lg * 4 + r;
+                    st[kt][r] = key < N ? st[kt][r] * scale : -INFINITY;
+                    mx = fmaxf(mx, st[kt][r]);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[kt][r] = expf(st[kt][r] - mx);
+                    sum += st[kt][r];
+                }
+            } else {
+                st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (lg == 0 && qt * 16 + l15 < N) lse[((size_t)b * H + h) * N + qt * 16 + l15] = mx + logf(sum);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pv_accumulate<T, MAXKT>(o, st, nkt, Vs, l15, lg);
+        // O tile: col d = dt*16 + l15, rows = queries lg*4 + r; 1/sum lives on lanes with l15 == query
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float iq = __shfl(inv, lg * 4 + r, 64);
+            const int q = qt * 16 + lg * 4 + r;
+            if (q < N) {
+                T* dst = out + ((size_t)b * N + q) * C + h * 64 + l15;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = from_f32<T>(o[dt][r] * iq);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ backward
+// phase 0: D[q] = sum_d dO[q][d] * O[q][d] -> LDS;  LSE -> LDS
+// phase A: LDS = {K, V}:  per 16-query tile  dQ  = scale * dS K        (dS in "S^T" layout)
+// phase B: LDS = {Q, dO}: per 16-key tile    dV  = P^T dO ,  dK = scale * dS^T Q
+template <typename T>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                            const T* __restrict__ dout, const float* __restrict__ lse,
+                                                            T* __restrict__ dqkv, int B, int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H;
+    const int C = H * 64, RS = 3 * C;
+    const int Np = (N + 31) & ~31;
+    const int nkt = Np / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    char* M0 = smem;
+    char* M1 = smem + Np * AttnLds<T>::ROWB;
+    float* Dq = reinterpret_cast<float*>(smem + 2 * Np * AttnLds<T>::ROWB);
+    float* Ls = Dq + Np;
+    const T* qb = qkv + (size_t)b * N * RS + h * 64;
+    const T* ob = out + (size_t)b * N * C + h * 64;
+    const T* dob = dout + (size_t)b * N * C + h * 64;
+    T* dqb = dqkv + (size_t)b * N * RS + h * 64;
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int DCH = AttnLds<T>::DCH;
+
+    // ---- phase 0
+    for (int q = threadIdx.x; q < Np; q += 256) {
+        float d = 0.f;
+        if (q < N) {
+            for (int c = 0; c < DCH; ++c) {
+                float a[Chunk<T>::N], o[Chunk<T>::N];
+                Chunk<T>::unpack(ld_chunk(dob + (size_t)q * C + c * EPC), a);
+                Chunk<T>::unpack(ld_chunk(ob + (size_t)q * C + c * EPC), o);
+#pragma unroll
+                for (int k = 0; k < Chunk<T>::N; ++k) d += a[k] * o[k];
+            }
+        }
+        Dq[q] = d;
+        Ls[q] = q < N ? lse[((size_t)b * H + h) * N + q] : 0.f;
+    }
+    attn_stage<T>(M0, qb + C, RS, N, Np);          // K
+    attn_stage<T>(M1, qb + 2 * C, RS, N, Np);      // V
+    __syncthreads();
+
+    // ---- phase A: dQ
+    const int nqt = (N + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        u32x4 qf[4], dof[4];
+        gmem_row_frags<T>(qf, qb, RS, qt * 16, N, l15, lg);
+        gmem_row_frags<T>(dof, dob, C, qt * 16, N, l15, lg);
+        const int q = qt * 16 + l15;
+        const float lq = Ls[q < Np ? q : 0], dq_ = Dq[q < Np ? q : 0];
+        f32x4 ds[MAXKT];
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+                u32x4 kf[4], vf[4];
+                lds_row_frags<T>(kf, M0, kt * 16, l15, lg);
+                lds_row_frags<T>(vf, M1, kt * 16, l15, lg);
+                const f32x4 s = tile_mma<T>(kf, qf);       // rows keys, col query
+                const f32x4 dp = tile_mma<T>(vf, dof);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + lg * 4 + r;
+                    const float p = (key < N && q < N) ? expf(s[r] * scale - lq) : 0.f;
+                    ds[kt][r] = p * (dp[r] - dq_) * scale;
+                }
+            } else {
+                ds[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pv_accumulate<T, MAXKT>(o, ds, nkt, M0, l15, lg);      // dQ = dS * K
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = qt * 16 + lg * 4 + r;
+            if (qq < N) {
+                T* dst = dqb + (size_t)qq * RS + l15;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = from_f32<T>(o[dt][r]);
+            }
+        }
+    }
+    __syncthreads();
+    attn_stage<T>(M0, qb, RS, N, Np);              // Q
+    attn_stage<T>(M1, dob, C, N, Np);              // dO
+    __syncthreads();
+
+    // ---- phase B: dK, dV per key tile; P / dS tiles in the un-swapped layout
+    // (col = key l15, rows = queries lg*4 + r), accumulated over all query tiles
+    for (int kt = wave; kt < (N + 15) / 16; kt += 4) {
+        u32x4 kf[4], vf[4];
+        gmem_row_frags<T>(kf, qb + C, RS, kt * 16, N, l15, lg);
+        gmem_row_frags<T>(vf, qb + 2 * C, RS, kt * 16, N, l15, lg);
+        const int key = kt * 16 + l15;
+        f32x4 pt[MAXKT], dst_[MAXKT];
+#pragma unroll
+        for (int qt = 0; qt < MAXKT; ++qt) {
+            if (qt < nkt) {
+                u32x4 qf[4], dof[4];
+                lds_row_frags<T>(qf, M0, qt * 16, l15, lg);
+                lds_row_frags<T>(dof, M1, qt * 16, l15, lg);
+                const f32x4 s = tile_mma<T>(qf, kf);       // rows queries, col key
+                const f32x4 dp = tile_mma<T>(dof, vf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = qt * 16 + lg * 4 + r;
+                    const float p = (qq < N && key < N) ? expf(s[r] * scale - Ls[qq]) : 0.f;
+                    pt[qt][r] = p;
+                    dst_[qt][r] = p * (dp[r] - Dq[qq]) * scale;
+                }
+            } else {
+                pt[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dst_[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // the A operand wants row = key; the tiles hold key on l15 and queries on (lg, r): exactly the
+        // layout pv_accumulate expects with "keys" := queries
+        pv_accumulate<T, MAXKT>(dv, pt, nkt, M1, l15, lg);      // dV = P^T dO
+        pv_accumulate<T, MAXKT>(dk, dst_, nkt, M0, l15, lg);    // dK = dS^T Q
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = kt * 16 + lg * 4 + r;
+            if (kk < N) {
+                T* dkp = dqb + (size_t)kk * RS + C + l15;
+                T* dvp = dqb + (size_t)kk * RS + 2 * C + l15;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dkp[dt * 16] = from_f32<T>(dk[dt][r]);
+                    dvp[dt * 16] = from_f32<T>(dv[dt][r]);
+                }
+            }
+        }
+    }
+}
+
+inline int sgrid(size_t n) {
+    size_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename K>
+void allow_lds(K k, size_t bytes) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+namespace saicv {
+
+template <typename T>
+static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                           float* rstd, int M, int C, double eps, hipStream_t st) {
+    constexpr int N = Chunk<T>::N;
+    const int nch = (C / N + 63) / 64;
+    dim3 grid((M + 3) / 4), block(256);
+#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), grid, block, 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, M, C, (float)eps)
+    if (nch <= 1) LN_LAUNCH(1);
+    else if (nch <= 2) LN_LAUNCH(2);
+    else if (nch <= 4) LN_LAUNCH(4);
+    else if (nch <= 8) LN_LAUNCH(8);
+    else { set_error("layernorm_fwd: C=%d too wide", C); return -1; }
+#undef LN_LAUNCH
+    return check_launch("layernorm_fwd");
+}
+
+int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                  float* rstd, int M, int C, double eps, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && M > 0, "layernorm_fwd: C=%d must be a multiple of %d", C, n);
+    if (dtype == SAICV_DTYPE_BF16) return layernorm_fwd_t<bf16_t>(x, gamma, beta, y, mean, rstd, M, C, eps, st);
+    return layernorm_fwd_t<float>(x, gamma, beta, y, mean, rstd, M, C, eps, st);
+}
+
+static int ln_bwd_blocks(int M, int* rows_per) {
+    int rp = (M + 4 * 512 - 1) / (4 * 512);        // <= 512 blocks
+    if (rp < 1) rp = 1;
+    *rows_per = rp;
+    return (M + 4 * rp - 1) / (4 * rp);
+}
+
+size_t layernorm_bwd_ws_floats(int M, int C) {
+    int rp;
+    return (size_t)2 * ln_bwd_blocks(M, &rp) * C;
+}
+
+template <typename T>
+static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, const float* mean,
+                           const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C,
+                           int accumulate, hipStream_t st) {
+    constexpr int N = Chunk<T>::N;
+    const int nch = (C / N + 63) / 64;
+    int rp;
+    const int nb = ln_bwd_blocks(M, &rp);
+    float* pg = ws;
+    float* pb = ws + (size_t)nb * C;
+    dim3 grid(nb), block(256);
+#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, pg, pb, M, C, rp)
+    if (nch <= 1) LN_LAUNCH(1);
+    else if (nch <= 2) LN_LAUNCH(2);
+    else if (nch <= 4) LN_LAUNCH(4);
+    else { set_error("layernorm_bwd: C=%d too wide", C); return -1; }
+#undef LN_LAUNCH
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pg, nb, C, dgamma, accumulate);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pb, nb, C, dbeta, accumulate);
+    return check_launch("layernorm_bwd");
+}
+
+int layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                  const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C,
+                  int accumulate, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && M > 0, "layernorm_bwd: C=%d must be a multiple of %d", C, n);
+    if (dtype == SAICV_DTYPE_BF16)
+        return layernorm_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, M, C, accumulate, st);
+    return layernorm_bwd_t<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, M, C, accumulate, st);
+}
+
+int gelu_fwd(int dtype, const void* x, void* y, size_t n, hipStream_t st) {
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(n % e == 0, "gelu_fwd: length must be a multiple of %d", e);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, dim3(sgrid(n / e)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n / e);
+    else
+        hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(sgrid(n / e)), dim3(256), 0, st, (const float*)x, (float*)y, n / e);
+    return check_launch("gelu_fwd");
+}
+
+int gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, hipStream_t st) {
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(n % e == 0, "gelu_bwd: length must be a multiple of %d", e);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(sgrid(n / e)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, n / e);
+    else
+        hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(sgrid(n / e)), dim3(256), 0, st, (const float*)dy, (const float*)x, (float*)dx, n / e);
+    return check_launch("gelu_bwd");
+}
+
+static int attn_check(const char* who, int B, int N, int H, int D) {
+    SAICV_REQUIRE(D == 64, "%s: head dim %d (only 64 is implemented)", who, D);
+    SAICV_REQUIRE(N >= 1 && N <= 256, "%s: sequence length %d outside [1,256] (streaming variant not built yet)", who, N);
+    SAICV_REQUIRE(B >= 1 && H >= 1, "%s: empty problem", who);
+    return 0;
+}
+
+int attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int N, int H, int D, double scale,
+                  hipStream_t st) {
+    if (attn_check("attention_fwd", B, N, H, D)) return -1;
+    const int Np = (N + 31) & ~31;
+    if (dtype == SAICV_DTYPE_BF16) {
+        const size_t smem = (size_t)2 * Np * 128;
+        auto k = attention_fwd_kernel<bf16_t>;
+        static bool once = (allow_lds(k, 2 * 256 * 128), true);
+        (void)once;
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, H, (float)scale);
+    } else {
+        const size_t smem = (size_t)2 * Np * 256;
+        auto k = attention_fwd_kernel<float>;
+        static bool once = (allow_lds(k, 2 * 256 * 256), true);
+        (void)once;
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const float*)qkv, (float*)out, lse, B, N, H, (float)scale);
+    }
+    return check_launch("attention_fwd");
+}
+
+int attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                  int B, int N, int H, int D, double scale, hipStream_t st) {
+    if (attn_check("attention_bwd", B, N, H, D)) return -1;
+    const int Np = (N + 31) & ~31;
+    if (dtype == SAICV_DTYPE_BF16) {
+        const size_t smem = (size_t)2 * Np * 128 + 2 * Np * sizeof(float);
+        auto k = attention_bwd_kernel<bf16_t>;
+        static bool once = (allow_lds(k, 2 * 256 * 128 + 2048), true);
+        (void)once;
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, (float)scale);
+    } else {
+        const size_t smem = (size_t)2 * Np * 256 + 2 * Np * sizeof(float);
+        auto k = attention_bwd_kernel<float>;
+        static bool once = (allow_lds(k, 2 * 256 * 256 + 2048), true);
+        (void)once;
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, B, N, H, (float)scale);
+    }
+    return check_launch("attention_bwd");
+}
+
+}  // namespace saicv
