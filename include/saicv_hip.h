@@ -72,6 +72,20 @@ int saicv_conv2d_dgrad(const saicv_conv_desc* d, const void* dy, const void* wd,
  * Accumulates with fp32 atomics: zero dw first for a plain gradient. */
 int saicv_conv2d_wgrad(const saicv_conv_desc* d, const void* dy, const void* x, float* dw,
                        void* stream);
+/* nn.Linear on the same kernels: y[M][N] = addend + row_scale[m / rows_per_scale] * (x[M][K] wf[N][K]^T + bias)
+ * (addend / row_scale optional: the residual add and drop-path of vit.py:159-163 fused into the
+ * epilogue); dx[M][K] = dy[M][N] wd[K][N]^T (+ addend); dw[N][K] (fp32) += dy^T x. */
+int saicv_linear_fwd(int dtype, const void* x, const void* wf, const float* bias, void* y, int M, int K, int N,
+                     int out_f32, const void* addend, const float* row_scale, int rows_per_scale, void* stream);
+int saicv_linear_dgrad(int dtype, const void* dy, const void* wd, void* dx, int M, int K, int N, const void* addend,
+                       void* stream);
+int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, int M, int K, int N, void* stream);
+/* conv data-gradient that adds an existing gradient (residual branch) in its epilogue */
+int saicv_conv2d_dgrad_add(const saicv_conv_desc* d, const void* dy, const void* wd, const void* addend, void* dx,
+                           void* stream);
+/* out[r][:] = x[r][:] * scale[r / rows_per_scale] */
+int saicv_row_scale(int dtype, const void* x, const float* scale, void* out, size_t rows, int row_len,
+                    int rows_per_scale, void* stream);
 /* dbias[N] (fp32) += column sums of dy[M][N] */
 int saicv_colsum(int dtype, const void* dy, int M, int N, float* dbias, void* stream);
 
@@ -137,10 +151,11 @@ int saicv_scaler_update(float* state, const float* found_inf, double growth, dou
 int saicv_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                         float* rstd, int M, int C, double eps, void* stream);
 size_t saicv_layernorm_bwd_ws_floats(int M, int C);
-/* dx, dgamma, dbeta (accumulate != 0: added to) */
+/* dx (= addend + LN backward; addend optional: the residual-stream gradient of a pre-LN block),
+ * dgamma, dbeta (accumulate != 0: added to) */
 int saicv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
-                        const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C,
-                        int accumulate, void* stream);
+                        const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
+                        int M, int C, int accumulate, void* stream);
 /* nn.GELU() (exact erf form), vit.py:87-99 */
 int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream);
 int saicv_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, void* stream);

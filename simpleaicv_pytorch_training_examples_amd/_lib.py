@@ -36,6 +36,11 @@ SIGNATURES = {
     'saicv_conv2d_dgrad': (c_int, [_PD, _P, _P, _P, _P]),
     'saicv_conv2d_wgrad': (c_int, [_PD, _P, _P, _P, _P]),
     'saicv_colsum': (c_int, [c_int, _P, c_int, c_int, _P, _P]),
+    'saicv_linear_fwd': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    'saicv_linear_dgrad': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    'saicv_linear_wgrad': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_conv2d_dgrad_add': (c_int, [_PD, _P, _P, _P, _P, _P]),
+    'saicv_row_scale': (c_int, [c_int, _P, _P, _P, c_size_t, c_int, c_int, _P]),
     'saicv_bn_ws_floats': (c_size_t, [c_int]),
     'saicv_bn_finalize_fwd': (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P, _P, c_double, c_double, _P, _P, _P, _P, _P, _P]),
     'saicv_bn_eval_coeffs': (c_int, [c_int, _P, _P, _P, _P, c_double, _P, _P, _P]),
@@ -55,7 +60,7 @@ SIGNATURES = {
     'saicv_scaler_update': (c_int, [_P, _P, c_double, c_double, c_int, _P]),
     # transformer kernels (tfm.hip)
     'saicv_layernorm_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
-    'saicv_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_layernorm_bwd_ws_floats': (c_size_t, [c_int, c_int]),
     'saicv_gelu_fwd': (c_int, [c_int, _P, _P, c_size_t, _P]),
     'saicv_gelu_bwd': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),

@@ -48,6 +48,7 @@ int pack_input(int, const float*, long, long, long, long, void*, int, int, int, 
 int pack_weight(int, const float*, long, long, long, long, int, int, int, int, int, int, void*, void*, hipStream_t);
 int unpack_wgrad(const float*, int, int, int, int, int, float*, long, long, long, long, int, hipStream_t);
 int colsum(int, const void*, int, int, float*, hipStream_t);
+int row_scale(int, const void*, const float*, void*, size_t, int, int, hipStream_t);
 int sgd_flat(float*, const float*, float*, const int32_t*, const float*, const float*, const float*, size_t, hipStream_t);
 int adamw_flat(float*, const float*, float*, float*, const int32_t*, const float*, const float*, const float*, size_t, hipStream_t);
 int grad_stats(const float*, size_t, float*, float*, hipStream_t);
@@ -55,8 +56,8 @@ int grad_clip_scale(float*, size_t, const float*, const float*, double, hipStrea
 int scaler_update(float*, const float*, double, double, int, hipStream_t);
 int layernorm_fwd(int, const void*, const float*, const float*, void*, float*, float*, int, int, double, hipStream_t);
 size_t layernorm_bwd_ws_floats(int, int);
-int layernorm_bwd(int, const void*, const void*, const float*, const float*, const float*, void*, float*, float*,
-                  float*, int, int, int, hipStream_t);
+int layernorm_bwd(int, const void*, const void*, const float*, const float*, const float*, const void*, void*,
+                  float*, float*, float*, int, int, int, hipStream_t);
 int gelu_fwd(int, const void*, void*, size_t, hipStream_t);
 int gelu_bwd(int, const void*, const void*, void*, size_t, hipStream_t);
 int attention_fwd(int, const void*, void*, float*, int, int, int, int, double, hipStream_t);
@@ -131,6 +132,38 @@ int saicv_conv2d_wgrad(const saicv_conv_desc* d, const void* dy, const void* x, 
     const int M = d->N * d->OH * d->OW;
     return igemm_tn(d->dtype, dy, x, dw, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad,
                     M, d->K, d->R * d->S * d->C, S(stream));
+}
+
+int saicv_linear_fwd(int dtype, const void* x, const void* wf, const float* bias, void* y, int M, int K, int N,
+                     int out_f32, const void* addend, const float* row_scale, int rows_per_scale, void* stream) {
+    EpiExtra ex;
+    ex.addend = addend; ex.row_scale = row_scale; ex.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    return igemm_nt(dtype, 0, x, wf, y, bias, nullptr, nullptr, 1, 1, K, 1, 1, 1, 1, 1, 0, M, N, K, N, out_f32,
+                    S(stream), (addend || row_scale) ? &ex : nullptr);
+}
+int saicv_linear_dgrad(int dtype, const void* dy, const void* wd, void* dx, int M, int K, int N, const void* addend,
+                       void* stream) {
+    EpiExtra ex;
+    ex.addend = addend;
+    return igemm_nt(dtype, 1, dy, wd, dx, nullptr, nullptr, nullptr, 1, 1, N, 1, 1, 1, 1, 1, 0, M, K, N, K, 0,
+                    S(stream), addend ? &ex : nullptr);
+}
+int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, int M, int K, int N, void* stream) {
+    return igemm_tn(dtype, dy, x, dw, 1, 1, K, 1, 1, 1, 1, 1, 0, M, N, K, S(stream));
+}
+int saicv_conv2d_dgrad_add(const saicv_conv_desc* d, const void* dy, const void* wd, const void* addend, void* dx,
+                           void* stream) {
+    if (check_desc(d, "saicv_conv2d_dgrad_add")) return -1;
+    const int M = d->N * d->H * d->W;
+    EpiExtra ex;
+    ex.addend = addend;
+    return igemm_nt(d->dtype, 1, dy, wd, dx, nullptr, nullptr, nullptr, d->OH, d->OW, d->K, d->H, d->W,
+                    d->R, d->S, d->stride, d->pad, M, d->C, d->R * d->S * d->K, d->C, 0, S(stream),
+                    addend ? &ex : nullptr);
+}
+int saicv_row_scale(int dtype, const void* x, const float* scale, void* out, size_t rows, int row_len,
+                    int rows_per_scale, void* stream) {
+    return row_scale(dtype, x, scale, out, rows, row_len, rows_per_scale, S(stream));
 }
 
 int saicv_colsum(int dtype, const void* dy, int M, int N, float* dbias, void* stream) {
@@ -214,9 +247,9 @@ int saicv_layernorm_fwd(int dtype, const void* x, const float* gamma, const floa
 }
 size_t saicv_layernorm_bwd_ws_floats(int M, int C) { return layernorm_bwd_ws_floats(M, C); }
 int saicv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
-                        const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C,
-                        int accumulate, void* stream) {
-    return layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, M, C, accumulate, S(stream));
+                        const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
+                        int M, int C, int accumulate, void* stream) {
+    return layernorm_bwd(dtype, dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, S(stream));
 }
 int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream) {
     return gelu_fwd(dtype, x, y, n, S(stream));

@@ -36,6 +36,9 @@ struct NTParams {
     const float* bias;
     float* stat_sum;
     float* stat_sq;
+    const void* addend;         // epilogue: out = addend + row_scale * (acc + bias)
+    const float* row_scale;
+    int rows_per_scale;
     uint32_t src_bytes, wgt_bytes;
     int H, W, C;        // gather-source spatial dims / channels
     int OH, OW;         // pixel grid that indexes the GEMM rows
@@ -377,8 +380,23 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
                     const int hc = rem / Wc;
                     m = (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
                 }
-                const u32x4 v = ld_chunk(smem + rr * OPITCH + oc * 16);
+                u32x4 v = ld_chunk(smem + rr * OPITCH + oc * 16);
                 TO* o = reinterpret_cast<TO*>(p.out) + (size_t)m * p.ldo + ncol;
+                if (p.addend != nullptr || p.row_scale != nullptr) {
+                    float f[OEPC], a[OEPC];
+                    Chunk<TO>::unpack(v, f);
+                    const float sc = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.f;
+                    if (p.addend != nullptr && whole) {
+                        Chunk<TO>::unpack(ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol), a);
+                    } else {
+                        for (int j = 0; j < OEPC; ++j)
+                            a[j] = (p.addend != nullptr && ncol + j < p.Nn)
+                                       ? to_f32(reinterpret_cast<const TO*>(p.addend)[(size_t)m * p.ldo + ncol + j]) : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < OEPC; ++j) f[j] = fmaf(sc, f[j], a[j]);
+                    v = Chunk<TO>::pack(f);
+                }
                 if (whole) {
                     st_chunk(o, v);
                 } else {
@@ -682,7 +700,8 @@ int conv_stat_rows(int M) { return ((M + 127) / 128) * 2; }
 
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
-             int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st) {
+             int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st,
+             const EpiExtra* ex) {
     const int epc = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     SAICV_REQUIRE(C % epc == 0, "igemm_nt: C=%d must be a multiple of %d", C, epc);
     SAICV_REQUIRE(Kd % epc == 0, "igemm_nt: Kd=%d must be a multiple of %d", Kd, epc);
@@ -690,6 +709,14 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     SAICV_REQUIRE(!(bias && stat_sum), "igemm_nt: bias and BN statistics are exclusive");
     NTParams p;
     p.src = src; p.wgt = wgt; p.out = out; p.bias = bias; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.addend = ex ? ex->addend : nullptr;
+    p.row_scale = ex ? ex->row_scale : nullptr;
+    p.rows_per_scale = ex ? ex->rows_per_scale : 1;
+    if (p.addend || p.row_scale) {
+        const int osz = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
+        SAICV_REQUIRE((ldo * osz) % 16 == 0, "igemm_nt: fused residual needs a 16-byte aligned leading dimension");
+        SAICV_REQUIRE(p.rows_per_scale >= 1, "igemm_nt: rows_per_scale must be >= 1");
+    }
     p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = M; p.Nn = Nn; p.Kd = Kd; p.ldo = ldo;
     const size_t esz = dtype == SAICV_DTYPE_BF16 ? 2 : 4;

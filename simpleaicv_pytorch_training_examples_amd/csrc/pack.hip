@@ -77,6 +77,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     unsafeAtomicAdd(out + c, s);
 }
 
+// out[r][:] = x[r][:] * scale[r / rows_per_scale]   (drop-path backward, per-sample factors)
+template <typename T>
+__global__ __launch_bounds__(256) void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                        T* __restrict__ out, size_t nchunks, int chunks_per_group) {
+    constexpr int N = Chunk<T>::N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const float s = scale[i / chunks_per_group];
+        float v[N];
+        Chunk<T>::unpack(ld_chunk(x + i * N), v);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] *= s;
+        st_chunk(out + i * N, Chunk<T>::pack(v));
+    }
+}
+
 inline int sgrid(size_t total) {
     size_t b = (total + 255) / 256;
     if (b > 2048) b = 2048;
@@ -117,6 +133,19 @@ int unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, float* g, 
     const size_t total = (size_t)O * R * S * I;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(sgrid(total)), dim3(256), 0, st, dw, O, I, R, S, Ip, g, sO, sI, sR, sS, accumulate);
     return check_launch("unpack_wgrad");
+}
+
+int row_scale(int dtype, const void* x, const float* scale, void* out, size_t rows, int row_len,
+              int rows_per_scale, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(row_len % n == 0 && rows_per_scale >= 1, "row_scale: row length %d must be a multiple of %d", row_len, n);
+    const size_t nchunks = rows * (size_t)(row_len / n);
+    const int cpg = rows_per_scale * (row_len / n);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(row_scale_kernel<bf16_t>, dim3(sgrid(nchunks)), dim3(256), 0, st, (const bf16_t*)x, scale, (bf16_t*)out, nchunks, cpg);
+    else
+        hipLaunchKernelGGL(row_scale_kernel<float>, dim3(sgrid(nchunks)), dim3(256), 0, st, (const float*)x, scale, (float*)out, nchunks, cpg);
+    return check_launch("row_scale");
 }
 
 int colsum(int dtype, const void* x, int M, int N, float* out, hipStream_t st) {

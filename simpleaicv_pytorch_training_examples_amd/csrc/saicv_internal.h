@@ -9,9 +9,16 @@ int check_launch(const char* what);
 
 // igemm.hip
 int conv_stat_rows(int M);
+// optional epilogue extras: out = addend + row_scale[m / rows_per_scale] * (acc + bias)
+struct EpiExtra {
+    const void* addend = nullptr;      // same dtype / layout as out
+    const float* row_scale = nullptr;  // one factor per group of rows_per_scale rows (drop-path)
+    int rows_per_scale = 1;
+};
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
-             int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st);
+             int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st,
+             const EpiExtra* ex = nullptr);
 int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W, int C, int OH,
              int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st);
 

@@ -71,7 +71,8 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, T* __restrict__ dx,
+                                                            const float* __restrict__ rstd,
+                                                            const T* __restrict__ addend, T* __restrict__ dx,
                                                             float* __restrict__ part_g, float* __restrict__ part_b,
                                                             int M, int C, int rows_per) {
     constexpr int N = Chunk<T>::N;
@@ -122,6 +123,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 float o[N];
 #pragma unroll
                 for (int k = 0; k < N; ++k) o[k] = rs * (g[j][k] - s1 - xh[j][k] * s2);
+                if (addend != nullptr) {        // residual-stream gradient joins here (pre-LN blocks)
+                    float a[N];
+                    Chunk<T>::unpack(ld_chunk(addend + (size_t)row * C + c * N), a);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) o[k] += a[k];
+                }
                 st_chunk(dx + (size_t)row * C + c * N, Chunk<T>::pack(o));
             }
         }
@@ -590,8 +597,8 @@ size_t layernorm_bwd_ws_floats(int M, int C) {
 
 template <typename T>
 static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, const float* mean,
-                           const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C,
-                           int accumulate, hipStream_t st) {
+                           const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
+                           int M, int C, int accumulate, hipStream_t st) {
     constexpr int N = Chunk<T>::N;
     const int nch = (C / N + 63) / 64;
     int rp;
@@ -599,7 +606,7 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
     float* pg = ws;
     float* pb = ws + (size_t)nb * C;
     dim3 grid(nb), block(256);
-#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, pg, pb, M, C, rp)
+#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)addend, (T*)dx, pg, pb, M, C, rp)
     if (nch <= 1) LN_LAUNCH(1);
     else if (nch <= 2) LN_LAUNCH(2);
     else if (nch <= 4) LN_LAUNCH(4);
@@ -611,13 +618,13 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
 }
 
 int layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
-                  const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C,
-                  int accumulate, hipStream_t st) {
+                  const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws, int M,
+                  int C, int accumulate, hipStream_t st) {
     const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     SAICV_REQUIRE(C % n == 0 && M > 0, "layernorm_bwd: C=%d must be a multiple of %d", C, n);
     if (dtype == SAICV_DTYPE_BF16)
-        return layernorm_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, M, C, accumulate, st);
-    return layernorm_bwd_t<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, M, C, accumulate, st);
+        return layernorm_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, st);
+    return layernorm_bwd_t<float>(dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, st);
 }
 
 int gelu_fwd(int dtype, const void* x, void* y, size_t n, hipStream_t st) {
