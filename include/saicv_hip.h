@@ -74,12 +74,14 @@ int saicv_conv2d_wgrad(const saicv_conv_desc* d, const void* dy, const void* x, 
                        void* stream);
 /* nn.Linear on the same kernels: y[M][N] = addend + row_scale[m / rows_per_scale] * (x[M][K] wf[N][K]^T + bias)
  * (addend / row_scale optional: the residual add and drop-path of vit.py:159-163 fused into the
- * epilogue); dx[M][K] = dy[M][N] wd[K][N]^T (+ addend); dw[N][K] (fp32) += dy^T x. */
+ * epilogue); dx[M][K] = dy[M][N] wd[K][N]^T (+ addend); dw[N][K] (fp32) += dy^T x and, when dbias
+ * is given, dbias[N] (fp32) += column sums of dy, computed from the tiles the kernel streams anyway. */
 int saicv_linear_fwd(int dtype, const void* x, const void* wf, const float* bias, void* y, int M, int K, int N,
                      int out_f32, const void* addend, const float* row_scale, int rows_per_scale, void* stream);
 int saicv_linear_dgrad(int dtype, const void* dy, const void* wd, void* dx, int M, int K, int N, const void* addend,
                        void* stream);
-int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, int M, int K, int N, void* stream);
+int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int M, int K, int N,
+                       void* stream);
 /* conv data-gradient that adds an existing gradient (residual branch) in its epilogue */
 int saicv_conv2d_dgrad_add(const saicv_conv_desc* d, const void* dy, const void* wd, const void* addend, void* dx,
                            void* stream);

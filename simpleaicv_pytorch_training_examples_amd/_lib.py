@@ -38,7 +38,7 @@ SIGNATURES = {
     'saicv_colsum': (c_int, [c_int, _P, c_int, c_int, _P, _P]),
     'saicv_linear_fwd': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     'saicv_linear_dgrad': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
-    'saicv_linear_wgrad': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_linear_wgrad': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_conv2d_dgrad_add': (c_int, [_PD, _P, _P, _P, _P, _P]),
     'saicv_row_scale': (c_int, [c_int, _P, _P, _P, c_size_t, c_int, c_int, _P]),
     'saicv_bn_ws_floats': (c_size_t, [c_int]),

@@ -148,8 +148,9 @@ int saicv_linear_dgrad(int dtype, const void* dy, const void* wd, void* dx, int 
     return igemm_nt(dtype, 1, dy, wd, dx, nullptr, nullptr, nullptr, 1, 1, N, 1, 1, 1, 1, 1, 0, M, K, N, K, 0,
                     S(stream), addend ? &ex : nullptr);
 }
-int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, int M, int K, int N, void* stream) {
-    return igemm_tn(dtype, dy, x, dw, 1, 1, K, 1, 1, 1, 1, 1, 0, M, N, K, S(stream));
+int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int M, int K, int N,
+                       void* stream) {
+    return igemm_tn(dtype, dy, x, dw, 1, 1, K, 1, 1, 1, 1, 1, 0, M, N, K, S(stream), dbias);
 }
 int saicv_conv2d_dgrad_add(const saicv_conv_desc* d, const void* dy, const void* wd, const void* addend, void* dx,
                            void* stream) {

@@ -414,6 +414,7 @@ struct TNParams {
     const void* dy;     // [M][Cout]
     const void* src;    // [Nimg,H,W,C] gather source (layer input)
     float* dw;          // [Cout][Kd] fp32, accumulated with atomics
+    float* dbias;       // optional [Cout] fp32: column sums of dy (bias gradient), accumulated
     uint32_t dy_bytes, src_bytes;
     int H, W, C;
     int OH, OW;
@@ -490,6 +491,11 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
     int m_b = m_begin + rbb;
 
     u32x4 ra[NA], rbv[NB];
+    // bias gradient for free: the workgroups of the first kk tile also sum the dY chunks they stream
+    const bool do_bias = (p.dbias != nullptr) && (tile_b == 0);
+    float bsum[EPC];
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) bsum[k] = 0.f;
     auto load_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -526,6 +532,15 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
     for (int i = 0; i < NB; ++i) st_b[i] = A_BYTES + (rbb + RPP_B * i) * PITCH_B + cb * 16;
     auto store_tile = [&](int stage) {
         char* base = smem + stage * STAGE;
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                float f[EPC];
+                Chunk<T>::unpack(ra[i], f);
+#pragma unroll
+                for (int k = 0; k < EPC; ++k) bsum[k] += f[k];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) st_chunk(base + st_a[i], ra[i]);
 #pragma unroll
@@ -621,6 +636,20 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
         __syncthreads();
     }
 
+    if (do_bias) {          // combine the RPP_A row lanes of each chunk column through LDS (now free)
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) red[tid * EPC + k] = bsum[k];
+        __syncthreads();
+        if (rba == 0 && n_ok) {
+#pragma unroll
+            for (int k = 0; k < EPC; ++k) {
+                float sgm = 0.f;
+                for (int t = 0; t < RPP_A; ++t) sgm += red[(t * CPR_A + ca) * EPC + k];
+                unsafeAtomicAdd(p.dbias + n_ld + k, sgm);
+            }
+        }
+    }
     // epilogue: D row -> n = .. + lg*4 + r ; D col -> kk = .. + l15
 #pragma unroll
     for (int ai = 0; ai < AT; ++ai) {
@@ -749,12 +778,12 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
 }
 
 int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W, int C, int OH,
-             int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st) {
+             int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st, float* dbias) {
     const int epc = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     SAICV_REQUIRE(C % epc == 0 && Cout % epc == 0, "igemm_tn: C=%d, Cout=%d must be multiples of %d", C, Cout, epc);
     SAICV_REQUIRE(M > 0 && Cout > 0 && Kd > 0, "igemm_tn: empty problem");
     TNParams p;
-    p.dy = dy; p.src = src; p.dw = dw; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW;
+    p.dy = dy; p.src = src; p.dw = dw; p.dbias = dbias; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.M = M; p.Cout = Cout; p.Kd = Kd;
     const size_t esz = dtype == SAICV_DTYPE_BF16 ? 2 : 4;
     const size_t dy_bytes = (size_t)M * Cout * esz;

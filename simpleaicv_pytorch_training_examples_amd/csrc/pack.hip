@@ -64,17 +64,47 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
     }
 }
 
-// column sums of a [M][N] matrix (bias gradient), T in, fp32 out (accumulating atomics)
+// column sums of a [M][N] matrix (bias gradient), T in, fp32 out (accumulating atomics).
+// A workgroup streams a slab of rows with 16-byte loads: a thread owns one chunk column and
+// strides over rows; the row lanes are combined through LDS; one atomic per column per slab.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int M, int N,
                                                      int rows_per, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
-    const int r0 = blockIdx.y * rows_per;
+    constexpr int E = Chunk<T>::N;
+    const int cpr = N / E;
+    const int cols = cpr < 256 ? cpr : 256;
+    const int rpp = 256 / cols;
+    const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+    const int r0 = blockIdx.x * rows_per;
     const int r1 = min(M, r0 + rows_per);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += to_f32(x[(size_t)r * N + c]);
-    unsafeAtomicAdd(out + c, s);
+    __shared__ float red[256 * 8];
+    for (int base = 0; base < cpr; base += cols) {
+        const int cb = base + tx;
+        const bool active = (cb < cpr) && (ty < rpp);
+        float acc[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc[k] = 0.f;
+        if (active) {
+            for (int r = r0 + ty; r < r1; r += rpp) {
+                float v[E];
+                Chunk<T>::unpack(ld_chunk(x + (size_t)r * N + cb * E), v);
+#pragma unroll
+                for (int k = 0; k < E; ++k) acc[k] += v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) red[threadIdx.x * E + k] = acc[k];
+        __syncthreads();
+        if (active && ty == 0) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                float sgm = 0.f;
+                for (int t = 0; t < rpp; ++t) sgm += red[(t * cols + tx) * E + k];
+                unsafeAtomicAdd(out + cb * E + k, sgm);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // out[r][:] = x[r][:] * scale[r / rows_per_scale]   (drop-path backward, per-sample factors)
@@ -149,15 +179,19 @@ int row_scale(int dtype, const void* x, const float* scale, void* out, size_t ro
 }
 
 int colsum(int dtype, const void* x, int M, int N, float* out, hipStream_t st) {
-    int ysplit = (M + 63) / 64;
-    if (ysplit > 64) ysplit = 64;
-    const int rows_per = (M + ysplit - 1) / ysplit;
-    ysplit = (M + rows_per - 1) / rows_per;
-    dim3 grid((N + 255) / 256, ysplit);
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(N % e == 0, "colsum: N=%d must be a multiple of %d", N, e);
+    const int cpr = N / e;
+    const int rpp = cpr >= 256 ? 1 : 256 / cpr;
+    int slabs = M / (rpp * 8);                 // >= 8 passes per slab
+    if (slabs > 1024) slabs = 1024;
+    if (slabs < 1) slabs = 1;
+    const int rows_per = (M + slabs - 1) / slabs;
+    slabs = (M + rows_per - 1) / rows_per;
     if (dtype == SAICV_DTYPE_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, M, N, rows_per, out);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(slabs), dim3(256), 0, st, (const bf16_t*)x, M, N, rows_per, out);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, M, N, rows_per, out);
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(slabs), dim3(256), 0, st, (const float*)x, M, N, rows_per, out);
     return check_launch("colsum");
 }
 

@@ -20,6 +20,7 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
              int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st,
              const EpiExtra* ex = nullptr);
 int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W, int C, int OH,
-             int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st);
+             int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st,
+             float* dbias = nullptr);
 
 }  // namespace saicv

@@ -154,19 +154,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 }
 
 // out[c] (=|+=) sum_p part[p][c]
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int P, int C,
-                                                        float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ part, int P, int C,
+                                                         float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ty = threadIdx.x >> 6;
+    const int ty = threadIdx.x >> 6;              // 16 row lanes
     float s = 0.f;
     if (c < C)
-        for (int p = ty; p < P; p += 4) s += part[(size_t)p * C + c];
-    __shared__ float l[4][64];
+        for (int p = ty; p < P; p += 16) s += part[(size_t)p * C + c];
+    __shared__ float l[16][64];
     l[ty][threadIdx.x & 63] = s;
     __syncthreads();
     if (ty == 0 && c < C) {
         const int t = threadIdx.x;
-        const float v = l[0][t] + l[1][t] + l[2][t] + l[3][t];
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += l[k][t];
         out[c] = accumulate ? out[c] + v : v;
     }
 }
@@ -226,7 +228,7 @@ template <typename T>
 DEVINL void attn_stage(char* lds, const T* __restrict__ g, int rs, int nvalid, int rows) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int DCH = AttnLds<T>::DCH;
-    for (int i = threadIdx.x; i < rows * DCH; i += 256) {
+    for (int i = threadIdx.x; i < rows * DCH; i += blockDim.x) {
         const int r = i / DCH, c = i - r * DCH;
         const u32x4 v = r < nvalid ? ld_chunk(g + (size_t)r * rs + c * EPC) : zero_chunk();
         st_chunk(lds + AttnLds<T>::off(r, c), v);
@@ -259,36 +261,30 @@ DEVINL u32x4 pack_p(const f32x4& t0, const f32x4& t1) {
     return Chunk<bf16_t>::pack(f);
 }
 
-// O(16 x 64) += P(16 x keys) * M(keys x 64) with P given as C-layout tiles pt[kt] (lane: row-of-A =
-// l15, k = kt*16 + g*4 + r) and M an LDS image with rows = keys.
-template <typename T, int NKT>
-DEVINL void pv_accumulate(f32x4 (&o)[4], const f32x4 (&pt)[NKT], int nkt, const char* lds, int l15, int lg) {
+// O(16 x 64) += P(16 x 32 keys) * M(32 keys x 64): P given as two adjacent C-layout tiles t0, t1
+// (lane: row-of-A = l15, k = kbase + {0,16} + g*4 + r) and M an LDS image with rows = keys.
+template <typename T>
+DEVINL void pv_pair(f32x4 (&o)[4], const f32x4& t0, const f32x4& t1, const char* lds, int kbase, int l15, int lg) {
     if constexpr (sizeof(T) == 2) {
+        const u32x4 pa = pack_p(t0, t1);
 #pragma unroll
-        for (int blk = 0; blk < NKT / 2; ++blk) {
-            if (blk * 2 < nkt) {
-                const u32x4 pa = pack_p(pt[2 * blk], pt[2 * blk + 1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const u32x4 vb = TrFrag<bf16_t>::load(lds, blk * 32, dt * 16, l15, lg);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa),
-                                                                   __builtin_bit_cast(bf16x8, vb), o[dt], 0, 0, 0);
-                }
-            }
+        for (int dt = 0; dt < 4; ++dt) {
+            const u32x4 vb = TrFrag<bf16_t>::load(lds, kbase, dt * 16, l15, lg);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa),
+                                                           __builtin_bit_cast(bf16x8, vb), o[dt], 0, 0, 0);
         }
     } else {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            if (kt < nkt) {
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = kt * 16 + lg * 4 + r;
+            for (int r = 0; r < 4; ++r) {
+                const int row = kbase + half * 16 + lg * 4 + r;
+                const float a = half == 0 ? t0[r] : t1[r];
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const int d = dt * 16 + l15;
-                        const float b = *reinterpret_cast<const float*>(lds + AttnLds<float>::off(row, d >> 2) + (d & 3) * 4);
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pt[kt][r], b, o[dt], 0, 0, 0);
-                    }
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int d = dt * 16 + l15;
+                    const float b = *reinterpret_cast<const float*>(lds + AttnLds<float>::off(row, d >> 2) + (d & 3) * 4);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, o[dt], 0, 0, 0);
                 }
             }
         }
@@ -322,12 +318,13 @@ DEVINL f32x4 tile_mma(const u32x4 (&a)[4], const u32x4 (&b)[4]) {
 }
 
 constexpr int MAXKT = 16;          // up to 256 keys
+constexpr int ATT_THREADS = 512;   // 8 wavefronts: 2 per SIMD hide each other's LDS / HBM latency
 
 // ------------------------------------------------------------------------ forward
 template <typename T>
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                            float* __restrict__ lse, int B, int N, int H,
-                                                            float scale) {
+__global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                                    float* __restrict__ lse, int B, int N, int H,
+                                                                    float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bh = blockIdx.x;
     const int b = bh / H, h = bh - b * H;
@@ -343,7 +340,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const T* __restrict_
     attn_stage<T>(Vs, base + 2 * C, RS, N, Np);
     __syncthreads();
     const int nqt = (N + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         u32x4 qf[4];
         gmem_row_frags<T>(qf, base, RS, qt * 16, N, l15, lg);
         // S^T tiles: rows = keys (kt*16 + lg*4 + r), col = query l15
@@ -366,25 +363,24 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const T* __restrict_
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
+        f32x4 o[4];
 #pragma unroll
-        for (int kt = 0; kt < MAXKT; ++kt) {
-            if (kt < nkt) {
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < MAXKT / 2; ++blk) {
+            if (blk * 2 < nkt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    st[kt][r] = expf(st[kt][r] - mx);
-                    sum += st[kt][r];
+                    st[2 * blk][r] = expf(st[2 * blk][r] - mx);
+                    st[2 * blk + 1][r] = expf(st[2 * blk + 1][r] - mx);
+                    sum += st[2 * blk][r] + st[2 * blk + 1][r];
                 }
-            } else {
-                st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pv_pair<T>(o, st[2 * blk], st[2 * blk + 1], Vs, blk * 32, l15, lg);
             }
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         if (lg == 0 && qt * 16 + l15 < N) lse[((size_t)b * H + h) * N + qt * 16 + l15] = mx + logf(sum);
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        pv_accumulate<T, MAXKT>(o, st, nkt, Vs, l15, lg);
         // O tile: col d = dt*16 + l15, rows = queries lg*4 + r; 1/sum lives on lanes with l15 == query
         const float inv = 1.f / sum;
 #pragma unroll
@@ -404,16 +400,18 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const T* __restrict_
 // phase 0: D[q] = sum_d dO[q][d] * O[q][d] -> LDS;  LSE -> LDS
 // phase A: LDS = {K, V}:  per 16-query tile  dQ  = scale * dS K        (dS in "S^T" layout)
 // phase B: LDS = {Q, dO}: per 16-key tile    dV  = P^T dO ,  dK = scale * dS^T Q
+// Both phases stream over pairs of 16-row tiles and feed the MFMAs at once (the log-sum-exp is
+// known), so only two probability tiles are live per wavefront.
 template <typename T>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
-                                                            const T* __restrict__ dout, const float* __restrict__ lse,
-                                                            T* __restrict__ dqkv, int B, int N, int H, float scale) {
+__global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                                    const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                    T* __restrict__ dqkv, int B, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bh = blockIdx.x;
     const int b = bh / H, h = bh - b * H;
     const int C = H * 64, RS = 3 * C;
     const int Np = (N + 31) & ~31;
-    const int nkt = Np / 16;
+    const int nblk = Np / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     char* M0 = smem;
@@ -426,21 +424,27 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
     T* dqb = dqkv + (size_t)b * N * RS + h * 64;
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int DCH = AttnLds<T>::DCH;
+    constexpr int NW = ATT_THREADS / 64;
 
-    // ---- phase 0
-    for (int q = threadIdx.x; q < Np; q += 256) {
+    // ---- phase 0: two threads per query row (half of the d range each)
+    for (int i = threadIdx.x; i < Np * 2; i += ATT_THREADS) {
+        const int q = i >> 1, hf = i & 1;
         float d = 0.f;
         if (q < N) {
-            for (int c = 0; c < DCH; ++c) {
+#pragma unroll
+            for (int c = 0; c < DCH / 2; ++c) {
                 float a[Chunk<T>::N], o[Chunk<T>::N];
-                Chunk<T>::unpack(ld_chunk(dob + (size_t)q * C + c * EPC), a);
-                Chunk<T>::unpack(ld_chunk(ob + (size_t)q * C + c * EPC), o);
+                Chunk<T>::unpack(ld_chunk(dob + (size_t)q * C + (hf * (DCH / 2) + c) * EPC), a);
+                Chunk<T>::unpack(ld_chunk(ob + (size_t)q * C + (hf * (DCH / 2) + c) * EPC), o);
 #pragma unroll
                 for (int k = 0; k < Chunk<T>::N; ++k) d += a[k] * o[k];
             }
         }
-        Dq[q] = d;
-        Ls[q] = q < N ? lse[((size_t)b * H + h) * N + q] : 0.f;
+        d += __shfl_xor(d, 1, 64);
+        if (hf == 0) {
+            Dq[q] = d;
+            Ls[q] = q < N ? lse[((size_t)b * H + h) * N + q] : 0.f;
+        }
     }
     attn_stage<T>(M0, qb + C, RS, N, Np);          // K
     attn_stage<T>(M1, qb + 2 * C, RS, N, Np);      // V
@@ -448,35 +452,35 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 
     // ---- phase A: dQ
     const int nqt = (N + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += NW) {
         u32x4 qf[4], dof[4];
         gmem_row_frags<T>(qf, qb, RS, qt * 16, N, l15, lg);
         gmem_row_frags<T>(dof, dob, C, qt * 16, N, l15, lg);
         const int q = qt * 16 + l15;
-        const float lq = Ls[q < Np ? q : 0], dq_ = Dq[q < Np ? q : 0];
-        f32x4 ds[MAXKT];
+        const float lq = Ls[q], dq_ = Dq[q];
+        const bool qok = q < N;
+        f32x4 o[4];
 #pragma unroll
-        for (int kt = 0; kt < MAXKT; ++kt) {
-            if (kt < nkt) {
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int blk = 0; blk < nblk; ++blk) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = blk * 2 + t;
                 u32x4 kf[4], vf[4];
                 lds_row_frags<T>(kf, M0, kt * 16, l15, lg);
                 lds_row_frags<T>(vf, M1, kt * 16, l15, lg);
-                const f32x4 s = tile_mma<T>(kf, qf);       // rows keys, col query
+                const f32x4 sv = tile_mma<T>(kf, qf);      // rows keys, col query
                 const f32x4 dp = tile_mma<T>(vf, dof);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + lg * 4 + r;
-                    const float p = (key < N && q < N) ? expf(s[r] * scale - lq) : 0.f;
-                    ds[kt][r] = p * (dp[r] - dq_) * scale;
+                    const float p = (key < N && qok) ? expf(sv[r] * scale - lq) : 0.f;
+                    ds[t][r] = p * (dp[r] - dq_) * scale;
                 }
-            } else {
-                ds[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            pv_pair<T>(o, ds[0], ds[1], M0, blk * 32, l15, lg);      // dQ += dS * K
         }
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        pv_accumulate<T, MAXKT>(o, ds, nkt, M0, l15, lg);      // dQ = dS * K
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int qq = qt * 16 + lg * 4 + r;
@@ -494,39 +498,37 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 
     // ---- phase B: dK, dV per key tile; P / dS tiles in the un-swapped layout
     // (col = key l15, rows = queries lg*4 + r), accumulated over all query tiles
-    for (int kt = wave; kt < (N + 15) / 16; kt += 4) {
+    for (int kt = wave; kt < nqt; kt += NW) {
         u32x4 kf[4], vf[4];
         gmem_row_frags<T>(kf, qb + C, RS, kt * 16, N, l15, lg);
         gmem_row_frags<T>(vf, qb + 2 * C, RS, kt * 16, N, l15, lg);
-        const int key = kt * 16 + l15;
-        f32x4 pt[MAXKT], dst_[MAXKT];
+        const bool kok = kt * 16 + l15 < N;
+        f32x4 dv[4], dk[4];
 #pragma unroll
-        for (int qt = 0; qt < MAXKT; ++qt) {
-            if (qt < nkt) {
+        for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int blk = 0; blk < nblk; ++blk) {
+            f32x4 pt[2], dst_[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = blk * 2 + t;
                 u32x4 qf[4], dof[4];
                 lds_row_frags<T>(qf, M0, qt * 16, l15, lg);
                 lds_row_frags<T>(dof, M1, qt * 16, l15, lg);
-                const f32x4 s = tile_mma<T>(qf, kf);       // rows queries, col key
+                const f32x4 sv = tile_mma<T>(qf, kf);      // rows queries, col key
                 const f32x4 dp = tile_mma<T>(dof, vf);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = qt * 16 + lg * 4 + r;
-                    const float p = (qq < N && key < N) ? expf(s[r] * scale - Ls[qq]) : 0.f;
-                    pt[qt][r] = p;
-                    dst_[qt][r] = p * (dp[r] - Dq[qq]) * scale;
+                    const float p = (qq < N && kok) ? expf(sv[r] * scale - Ls[qq]) : 0.f;
+                    pt[t][r] = p;
+                    dst_[t][r] = p * (dp[r] - Dq[qq]) * scale;
                 }
-            } else {
-                pt[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dst_[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            // the A operand wants row = key; the tiles hold key on l15 and queries on (lg, r): the
+            // layout pv_pair expects with "keys" := queries
+            pv_pair<T>(dv, pt[0], pt[1], M1, blk * 32, l15, lg);       // dV += P^T dO
+            pv_pair<T>(dk, dst_[0], dst_[1], M0, blk * 32, l15, lg);   // dK += dS^T Q
         }
-        f32x4 dv[4], dk[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        // the A operand wants row = key; the tiles hold key on l15 and queries on (lg, r): exactly the
-        // layout pv_accumulate expects with "keys" := queries
-        pv_accumulate<T, MAXKT>(dv, pt, nkt, M1, l15, lg);      // dV = P^T dO
-        pv_accumulate<T, MAXKT>(dk, dst_, nkt, M0, l15, lg);    // dK = dS^T Q
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kk = kt * 16 + lg * 4 + r;
@@ -584,7 +586,7 @@ int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* bet
 }
 
 static int ln_bwd_blocks(int M, int* rows_per) {
-    int rp = (M + 4 * 512 - 1) / (4 * 512);        // <= 512 blocks
+    int rp = (M + 4 * 256 - 1) / (4 * 256);        // <= 256 blocks (one per CU)
     if (rp < 1) rp = 1;
     *rows_per = rp;
     return (M + 4 * rp - 1) / (4 * rp);
@@ -612,8 +614,8 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
     else if (nch <= 4) LN_LAUNCH(4);
     else { set_error("layernorm_bwd: C=%d too wide", C); return -1; }
 #undef LN_LAUNCH
-    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pg, nb, C, dgamma, accumulate);
-    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pb, nb, C, dbeta, accumulate);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, pg, nb, C, dgamma, accumulate);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, pb, nb, C, dbeta, accumulate);
     return check_launch("layernorm_bwd");
 }
 
@@ -663,13 +665,13 @@ int attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int 
         auto k = attention_fwd_kernel<bf16_t>;
         static bool once = (allow_lds(k, 2 * 256 * 128), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, H, (float)scale);
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(ATT_THREADS), smem, st, (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, H, (float)scale);
     } else {
         const size_t smem = (size_t)2 * Np * 256;
         auto k = attention_fwd_kernel<float>;
         static bool once = (allow_lds(k, 2 * 256 * 256), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const float*)qkv, (float*)out, lse, B, N, H, (float)scale);
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(ATT_THREADS), smem, st, (const float*)qkv, (float*)out, lse, B, N, H, (float)scale);
     }
     return check_launch("attention_fwd");
 }
@@ -683,13 +685,13 @@ int attention_bwd(int dtype, const void* qkv, const void* out, const void* dout,
         auto k = attention_bwd_kernel<bf16_t>;
         static bool once = (allow_lds(k, 2 * 256 * 128 + 2048), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, (float)scale);
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(ATT_THREADS), smem, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, (float)scale);
     } else {
         const size_t smem = (size_t)2 * Np * 256 + 2 * Np * sizeof(float);
         auto k = attention_bwd_kernel<float>;
         static bool once = (allow_lds(k, 2 * 256 * 256 + 2048), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, B, N, H, (float)scale);
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(ATT_THREADS), smem, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, B, N, H, (float)scale);
     }
     return check_launch("attention_bwd");
 }

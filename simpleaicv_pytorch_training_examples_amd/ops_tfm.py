@@ -63,22 +63,25 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None):
         _, wd = packed_weight(weight, dt, k, True, op)
         dx = torch.empty((m, k), dtype=dt, device=x2.device)
         check(L.saicv_linear_dgrad(dtype_code(dt), ptr(dy), ptr(wd), ptr(dx), m, k, op, ptr(addend), st), 'linear_dgrad')
+    want_b = bias is not None and bias.requires_grad
+    gb = _arena_grad(bias) if (want_b and op == o) else None
+    tb = (gb if gb is not None else torch.zeros(op, dtype=torch.float32, device=x2.device)) if want_b else None
     if weight.requires_grad:
         gw = _arena_grad(weight) if (op == o and weight.is_contiguous()) else None
         tgt = gw if gw is not None else torch.zeros((op, k), dtype=torch.float32, device=x2.device)
-        check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), m, k, op, st), 'linear_wgrad')
+        # the weight-gradient kernel also emits the bias gradient from the dY tiles it streams
+        check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), ptr(tb), m, k, op, st), 'linear_wgrad')
         if gw is not None:
             _grad_ready(weight)
         else:
             dw = tgt[:o]
-    if bias is not None and bias.requires_grad:
-        gb = _arena_grad(bias) if op == o else None
-        tgt = gb if gb is not None else torch.zeros(op, dtype=torch.float32, device=x2.device)
-        check(L.saicv_colsum(dtype_code(dt), ptr(dy), m, op, ptr(tgt), st), 'colsum')
+    elif want_b:
+        check(L.saicv_colsum(dtype_code(dt), ptr(dy), m, op, ptr(tb), st), 'colsum')
+    if want_b:
         if gb is not None:
             _grad_ready(bias)
         else:
-            db = tgt[:o]
+            db = tb[:o]
     return dx, dw, db
 
 
