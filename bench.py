@@ -29,6 +29,17 @@ PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 TRAIN_GFLOP_PER_IMG = {'resnet50': 24.54, 'vit_base_patch16': 105.38}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes); None when the
+    summary is absent.  Counters cannot be collected inside the timed run itself."""
+    path = os.path.join(ROOT, 'profiles', 'r01c_pmc_hbm_traffic.json')
+    try:
+        return json.load(open(path))['kernels'][kernel]['bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -191,7 +202,7 @@ def main():
             achieved = k['flops'] / (k['ms'] * 1e-3) / 1e12
             out['roofline'] = {'kernel': 'igemm_nt_kernel (implicit-GEMM conv fwd + dgrad)', 'bound': 'mfma',
                                'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                               'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic('igemm_nt'),
                                'launches': k['calls'], 'avg_launch_us': round(k['ms'] * 1e3 / k['calls'], 2)}
             out['kernel_breakdown_ms_per_step'] = {t: round(v['ms'] / args.steps, 3) for t, v in summ.items()}
             for t, v in summ.items():
