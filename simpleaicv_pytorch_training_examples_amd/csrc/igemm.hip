@@ -50,30 +50,45 @@ struct NTParams {
     FastDiv fd_ohw, fd_ow;   // for OH*OW and OW (unit-stride row decomposition)
 };
 
-// LDS row = 128 bytes = 8 chunks; chunk c of row r lives at slot c ^ ((r>>1)&7).
-DEVINL int lds_off(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
+// NT kernel LDS image: one K tile = 64-byte rows = 4 chunks; chunk c of row r lives at slot
+// c ^ f((r>>2)&3), f = {0,2,3,1}.  ds_read_b128 is served in 16-lane groups that mix rows 0-3 /
+// 12-15 of chunk c with rows 4-11 of chunk c^1 (MI355X_MICROARCH.md, LDS table): with this f
+// the 16 lanes of every group hit 16 distinct 16-byte bank groups.
+DEVINL int lds_swz(int q) { return ((q & 1) << 1) ^ ((q >> 1) * 3); }
+DEVINL int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ lds_swz((row >> 2) & 3)) << 4); }
 
 DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
 }
 
-// The main loop is bound by MFMA issue only if the integer work per K tile is tiny, so:
+// Main loop = LDS-DMA ring: `buffer_load ... lds` writes global chunks straight into a 4-stage
+// LDS ring (no staging registers, no ds_write), three K tiles are in flight across the single
+// raw s_barrier of each tile, and the wait is a COUNTED s_waitcnt vmcnt(N) that only retires the
+// tile about to be consumed (guide section 5, T3/T4).  The DMA destination is wave-linear
+// (base + lane*16), so the XOR swizzle is applied to the SOURCE: lane l fetches the chunk that
+// belongs in the slot it will fill.
+// The loop is bound by MFMA issue only if the integer work per K tile is tiny, so:
 //  * all gathers are raw buffer loads: an out-of-range lane (padding halo, M/N/K tails) gets
-//    offset 0xffffffff and the hardware returns zeros -- no branches, no exec masking;
+//    an offset beyond the buffer and the hardware writes zeros -- no branches, no exec masking;
 //  * the (r, s, c) position of a thread's K chunk advances incrementally (no divisions);
 //  * per-row constants fold image base and top-left corner, so a gather address is one add;
 //  * LDS fragment addresses (with the XOR swizzle) are computed once.
-template <typename T, int BN_T, int MODE, bool OUT_F32>
+// PLAIN: 1x1 taps without padding (pointwise conv, nn.Linear and their data-gradients): the K
+// index IS the channel offset, no tap walker and no halo tests in the loop.
+template <typename T, int BN_T, int MODE, bool OUT_F32, bool PLAIN>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
-    constexpr int BK = 8 * EPC;
+    constexpr int BK = 4 * EPC;                  // one 64-byte row per K tile
     constexpr int BM_T = 128;
     constexpr int WN = BN_T / 2;
     constexpr int NT_ = WN / 16;
     constexpr int MT_ = 4;
-    constexpr int WROWS = BN_T / 32;             // weight rows per thread
-    constexpr int A_BYTES = BM_T * 128;
-    constexpr int W_BYTES = BN_T * 128;
+    constexpr int AROWS = 2;                     // A-tile DMA instructions per thread (128 rows)
+    constexpr int WROWS = BN_T / 64;             // weight-tile DMA instructions per thread
+    constexpr int LPT = AROWS + WROWS;           // loads per thread per K tile
+    constexpr int NSTAGE = 4;
+    constexpr int A_BYTES = BM_T * 64;
+    constexpr int W_BYTES = BN_T * 64;
     constexpr int STAGE = A_BYTES + W_BYTES;
     constexpr uint32_t OOB = 0xfffffff0u;   // 16-byte aligned, beyond any operand (host checks sizes)
 
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base)
     const int wm = wave & 1;
     const int wn = wave >> 1;
 
@@ -118,14 +133,15 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     const __amdgpu_buffer_rsrc_t wgt_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
 
-    // ---- per-thread gather state: chunk column cc, rows rb + 32*i
-    const int cc = tid & 7;
-    const int rb = tid >> 3;
-    int rowc[4], a0[4], b0[4];          // rowc = (image base + A0*W + B0) * C  [elements]
+    // ---- per-thread DMA state.  Wave w, instruction i, lane l fills LDS bytes
+    // [(i*4 + w)*1024 + l*16, +16) of the A region: row (i*4+w)*16 + (l>>2), slot l&3, i.e. the
+    // logical chunk (l&3) ^ f((row>>2)&3) = (l&3) ^ f((l>>4)&3) -- one K-chunk column per thread.
+    const int cc = (lane & 3) ^ lds_swz((lane >> 4) & 3);
+    int rowc[AROWS], a0[AROWS], b0[AROWS];   // rowc = (image base + A0*W + B0) * C  [elements]
     const int ohw = Hc * Wc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = tile_m * BM_T + rb + 32 * i;
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = tile_m * BM_T + (i * 4 + wave) * 16 + (lane >> 2);
         if (m < Mc) {
             int img, oh, ow;
             if (cs == 1) {
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     int wrow[WROWS];                    // weight row base [elements], or -1
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
-        const int n = tile_n * BN_T + rb + 32 * j;
+        const int n = tile_n * BN_T + (j * 4 + wave) * 16 + (lane >> 2);
         wrow[j] = n < p.Nn ? n * p.Kd : -1;
     }
 
@@ -170,12 +186,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         tts = tap - ttr * Sc;
     }
 
-    u32x4 ra[4], rw[WROWS];
-
-    auto load_tile = [&]() {
+    typedef __attribute__((address_space(3))) void lds_void;
+    // issue the DMA of the next K tile (walker position) into ring slot `stage`
+    auto issue_tile = [&](int stage) {
+        char* base = smem + stage * STAGE + wave * 1024;
         const bool kvalid = kpos < Kc;
         int tapoff, kw;
-        if (MODE == 0) {
+        if (PLAIN) {
+            tapoff = kpos;
+            kw = kpos;
+        } else if (MODE == 0) {
             tapoff = (ttr * p.W + tts) * p.C + tc0;
             kw = kpos;
         } else {
@@ -183,22 +203,24 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
             kw = ((r0 + ttr * cs) * p.S + (s0 + tts * cs)) * p.C + tc0;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ih = (MODE == 0) ? a0[i] + ttr : a0[i] - ttr;
-            const int iw = (MODE == 0) ? b0[i] + tts : b0[i] - tts;
+        for (int i = 0; i < AROWS; ++i) {
+            const int ih = PLAIN ? a0[i] : (MODE == 0) ? a0[i] + ttr : a0[i] - ttr;
+            const int iw = PLAIN ? b0[i] : (MODE == 0) ? b0[i] + tts : b0[i] - tts;
             // bitwise (not short-circuit) logic keeps this branch-free
-            const bool ok = kvalid & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+            const bool ok = PLAIN ? (kvalid & (a0[i] >= 0))
+                                  : (kvalid & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W));
             const uint32_t off = ok ? (uint32_t)(rowc[i] + tapoff) * (uint32_t)sizeof(T) : OOB;
-            ra[i] = buf_ld(src_rs, off);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + i * 4096), 16, (int)off, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < WROWS; ++j) {
             const bool ok = kvalid & (wrow[j] >= 0);
             const uint32_t off = ok ? (uint32_t)(wrow[j] + kw) * (uint32_t)sizeof(T) : OOB;
-            rw[j] = buf_ld(wgt_rs, off);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rs, (lds_void*)(base + A_BYTES + j * 4096), 16, (int)off, 0, 0, 0);
         }
         // advance to the next K tile
         kpos += BK;
+        if (PLAIN) return;
         tc0 += BK;
         if (p.C >= BK) {                 // at most one tap boundary per tile (uniform branch)
             const bool wrap = tc0 >= p.C;
@@ -215,20 +237,6 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         }
     };
 
-    int st_a[4], st_w[WROWS];           // LDS store offsets (stage 0)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) st_a[i] = lds_off(rb + 32 * i, cc);
-#pragma unroll
-    for (int j = 0; j < WROWS; ++j) st_w[j] = A_BYTES + lds_off(rb + 32 * j, cc);
-
-    auto store_tile = [&](int stage) {
-        char* base = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) st_chunk(base + st_a[i], ra[i]);
-#pragma unroll
-        for (int j = 0; j < WROWS; ++j) st_chunk(base + st_w[j], rw[j]);
-    };
-
     f32x4 acc[NT_][MT_];
 #pragma unroll
     for (int ni = 0; ni < NT_; ++ni)
@@ -237,45 +245,47 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
 
     const int l15 = lane & 15;
     const int lg = lane >> 4;
-    int fa[2][MT_], fw[2][NT_];         // LDS fragment offsets (stage 0), hoisted out of the K loop
+    int fa[MT_], fw[NT_];               // LDS fragment offsets within a stage, hoisted out of the K loop
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int mi = 0; mi < MT_; ++mi) fa[mi] = lds_off(wm * 64 + mi * 16 + l15, lg);
 #pragma unroll
-        for (int mi = 0; mi < MT_; ++mi) fa[ks][mi] = lds_off(wm * 64 + mi * 16 + l15, ks * 4 + lg);
-#pragma unroll
-        for (int ni = 0; ni < NT_; ++ni) fw[ks][ni] = A_BYTES + lds_off(wn * WN + ni * 16 + l15, ks * 4 + lg);
-    }
+    for (int ni = 0; ni < NT_; ++ni) fw[ni] = A_BYTES + lds_off(wn * WN + ni * 16 + l15, lg);
 
     auto compute = [&](int stage) {
         const char* base = smem + stage * STAGE;
+        u32x4 af[MT_], wf[NT_];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 af[MT_], wf[NT_];
+        for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(base + fa[mi]);
 #pragma unroll
-            for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(base + fa[ks][mi]);
+        for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(base + fw[ni]);
 #pragma unroll
-            for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(base + fw[ks][ni]);
+        for (int ni = 0; ni < NT_; ++ni)
 #pragma unroll
-            for (int ni = 0; ni < NT_; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
-        }
+            for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
     };
 
     const int nkt = (Kc + BK - 1) / BK;        // 0 for a class without taps: the output is zero
-    if (nkt > 0) {
-        load_tile();
-        store_tile(0);
-    }
-    __syncthreads();
+    // prologue: NSTAGE-1 tiles in flight
+    int issued = 0;
+    for (; issued < NSTAGE - 1 && issued < nkt; ++issued) issue_tile(issued);
+    int st_c = 0;                              // ring slot of the tile being consumed
+    int st_i = issued % NSTAGE;                // ring slot the next DMA fills
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1) < nkt;
-        if (more) load_tile();
-        compute(cur);
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
+        // retire tile kt only: the tiles issued after it stay in flight across the barrier
+        const int ahead = issued - kt - 1;     // wave-uniform
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everyone's part of tile kt landed; tile kt-1 fully consumed
+        if (issued < nkt) {                    // refill the slot tile kt-1 just vacated
+            issue_tile(st_i);
+            ++issued;
+            st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+        }
+        compute(st_c);
+        st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
     }
+    __syncthreads();                           // LDS is reused by the epilogue
 
     // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*16 + lg*4 + r ; m = m_base + mi*16 + l15
     // BN statistics come straight from the accumulators; the output tile is staged through LDS
@@ -683,26 +693,29 @@ void allow_lds(K k, size_t smem) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
+template <typename T, int BN_T, int MODE, bool OUT_F32, bool PLAIN>
+void launch_nt_inst(const NTParams& p, size_t smem, hipStream_t st) {
+    auto k = igemm_nt_kernel<T, BN_T, MODE, OUT_F32, PLAIN>;
+    static bool once = (allow_lds(k, 72 * 1024), true);
+    (void)once;
+    dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(256);
+    hipLaunchKernelGGL(k, grid, block, smem, st, p);
+}
+
 template <typename T, int BN_T, int MODE>
 int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
-    constexpr size_t smem_full = 2 * (128 * 128 + BN_T * 128);
-    constexpr int BK = 8 * ElemTraits<T>::EPC;
-    // a single K tile never touches the second LDS stage: ask for half the LDS so that more
-    // workgroups are resident per CU (the K=64 1x1 convolutions are latency/HBM bound)
+    constexpr size_t smem_full = 4 * (128 * 64 + BN_T * 64);      // 4-stage ring
     const size_t epi = 128 * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16);
-    size_t smem = (p.Kd <= BK) ? smem_full / 2 : smem_full;
+    size_t smem = smem_full;
     if (smem < epi) smem = epi;
-    dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(256);
+    // pointwise taps without padding: the source pixel of a row never leaves the image
+    const bool plain = p.R == 1 && p.S == 1 && p.pad == 0 && (MODE == 0 || p.stride == 1);
     if (out_f32) {
-        auto k = igemm_nt_kernel<T, BN_T, MODE, true>;
-        static bool once = (allow_lds(k, smem_full + 4096), true);
-        (void)once;
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+        if (plain) launch_nt_inst<T, BN_T, MODE, true, true>(p, smem, st);
+        else launch_nt_inst<T, BN_T, MODE, true, false>(p, smem, st);
     } else {
-        auto k = igemm_nt_kernel<T, BN_T, MODE, false>;
-        static bool once = (allow_lds(k, smem_full + 4096), true);
-        (void)once;
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+        if (plain) launch_nt_inst<T, BN_T, MODE, false, true>(p, smem, st);
+        else launch_nt_inst<T, BN_T, MODE, false, false>(p, smem, st);
     }
     return saicv::check_launch("igemm_nt");
 }
