@@ -75,16 +75,21 @@ DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
 //  * LDS fragment addresses (with the XOR swizzle) are computed once.
 // PLAIN: 1x1 taps without padding (pointwise conv, nn.Linear and their data-gradients): the K
 // index IS the channel offset, no tap walker and no halo tests in the loop.
-template <typename T, int BN_T, int MODE, bool OUT_F32, bool PLAIN>
-__global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
+// Tile geometry (BM_T x BN_T output tile, WM_ x WN_ wavefronts, each owning a
+// (BM_T/WM_) x (BN_T/WN_) sub-tile): 256x256 / 2x4, 256x128 / 4x2, 128x128 / 2x2, 128x64 / 2x2.
+// Wider tiles raise flop per LDS-fill byte and the MFMAs issued per barrier and per DMA.
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
+__global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = 4 * EPC;                  // one 64-byte row per K tile
-    constexpr int BM_T = 128;
-    constexpr int WN = BN_T / 2;
+    constexpr int NWAVES = WM_ * WN_;
+    constexpr int NTHREADS = 64 * NWAVES;
+    constexpr int WMR = BM_T / WM_;              // rows of the output tile owned by one wavefront
+    constexpr int WN = BN_T / WN_;
     constexpr int NT_ = WN / 16;
-    constexpr int MT_ = 4;
-    constexpr int AROWS = 2;                     // A-tile DMA instructions per thread (128 rows)
-    constexpr int WROWS = BN_T / 64;             // weight-tile DMA instructions per thread
+    constexpr int MT_ = WMR / 16;
+    constexpr int AROWS = BM_T / 16 / NWAVES;    // A-tile DMA instructions per thread
+    constexpr int WROWS = BN_T / 16 / NWAVES;    // weight-tile DMA instructions per thread
     constexpr int LPT = AROWS + WROWS;           // loads per thread per K tile
     constexpr int NSTAGE = 4;
     constexpr int A_BYTES = BM_T * 64;
@@ -97,8 +102,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base)
-    const int wm = wave & 1;
-    const int wn = wave >> 1;
+    const int wm = wave % WM_;
+    const int wn = wave / WM_;
 
     // ---- data-gradient with stride s > 1: the input pixels split into s*s parity classes
     // (h % s, w % s); a class only ever meets the taps r == (h + pad) mod s, so each class is a
@@ -134,14 +139,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
 
     // ---- per-thread DMA state.  Wave w, instruction i, lane l fills LDS bytes
-    // [(i*4 + w)*1024 + l*16, +16) of the A region: row (i*4+w)*16 + (l>>2), slot l&3, i.e. the
+    // [(i*NWAVES + w)*1024 + l*16, +16) of the A region: row (i*NWAVES+w)*16 + (l>>2), slot l&3, i.e. the
     // logical chunk (l&3) ^ f((row>>2)&3) = (l&3) ^ f((l>>4)&3) -- one K-chunk column per thread.
     const int cc = (lane & 3) ^ lds_swz((lane >> 4) & 3);
     int rowc[AROWS], a0[AROWS], b0[AROWS];   // rowc = (image base + A0*W + B0) * C  [elements]
     const int ohw = Hc * Wc;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-        const int m = tile_m * BM_T + (i * 4 + wave) * 16 + (lane >> 2);
+        const int m = tile_m * BM_T + (i * NWAVES + wave) * 16 + (lane >> 2);
         if (m < Mc) {
             int img, oh, ow;
             if (cs == 1) {
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     int wrow[WROWS];                    // weight row base [elements], or -1
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
-        const int n = tile_n * BN_T + (j * 4 + wave) * 16 + (lane >> 2);
+        const int n = tile_n * BN_T + (j * NWAVES + wave) * 16 + (lane >> 2);
         wrow[j] = n < p.Nn ? n * p.Kd : -1;
     }
 
@@ -210,13 +215,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
             const bool ok = PLAIN ? (kvalid & (a0[i] >= 0))
                                   : (kvalid & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W));
             const uint32_t off = ok ? (uint32_t)(rowc[i] + tapoff) * (uint32_t)sizeof(T) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + i * 4096), 16, (int)off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + i * NWAVES * 1024), 16, (int)off, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < WROWS; ++j) {
             const bool ok = kvalid & (wrow[j] >= 0);
             const uint32_t off = ok ? (uint32_t)(wrow[j] + kw) * (uint32_t)sizeof(T) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rs, (lds_void*)(base + A_BYTES + j * 4096), 16, (int)off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rs, (lds_void*)(base + A_BYTES + j * NWAVES * 1024), 16, (int)off, 0, 0, 0);
         }
         // advance to the next K tile
         kpos += BK;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     const int lg = lane >> 4;
     int fa[MT_], fw[NT_];               // LDS fragment offsets within a stage, hoisted out of the K loop
 #pragma unroll
-    for (int mi = 0; mi < MT_; ++mi) fa[mi] = lds_off(wm * 64 + mi * 16 + l15, lg);
+    for (int mi = 0; mi < MT_; ++mi) fa[mi] = lds_off(wm * WMR + mi * 16 + l15, lg);
 #pragma unroll
     for (int ni = 0; ni < NT_; ++ni) fw[ni] = A_BYTES + lds_off(wn * WN + ni * 16 + l15, lg);
 
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
     constexpr int OPITCH = BN_T * (int)sizeof(TO) + 16;         // bytes; +16 staggers banks
     constexpr int OCPR = BN_T * (int)sizeof(TO) / 16;           // 16-byte chunks per tile row
     constexpr int OEPC = 16 / (int)sizeof(TO);
-    const int m_base = tile_m * BM_T + wm * 64;
+    const int m_base = tile_m * BM_T + wm * WMR;
     const int n_base = tile_n * BN_T + wn * WN;
     const bool do_stats = p.stat_sum != nullptr;
     const bool staged = ((p.ldo * (int)sizeof(TO)) & 15) == 0;
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
                 }
             }
             if (staged) {
-                char* q = smem + (wm * 64 + mi * 16 + l15) * OPITCH + (wn * WN + ni * 16 + lg * 4) * (int)sizeof(TO);
+                char* q = smem + (wm * WMR + mi * 16 + l15) * OPITCH + (wn * WN + ni * 16 + lg * 4) * (int)sizeof(TO);
                 if (sizeof(TO) == 2) {
                     bf16x4 pk;
 #pragma unroll
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
                 }
             }
             if (l15 == 0) {
-                const size_t prow = (size_t)(tile_m * 2 + wm) * (size_t)p.Nn;
+                const size_t prow = (size_t)(tile_m * WM_ + wm) * (size_t)p.Nn;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (n0 + r < p.Nn) {
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NTParams p) {
         __syncthreads();
         const int oc = tid % OCPR;               // chunk within the tile row
         const int orow0 = tid / OCPR;
-        constexpr int RPP = 256 / OCPR;          // tile rows per pass
+        constexpr int RPP = NTHREADS / OCPR;     // tile rows per pass
         const int ncol = tile_n * BN_T + oc * OEPC;
         if (ncol < p.Nn) {
             const bool whole = ncol + OEPC <= p.Nn;
@@ -693,31 +698,54 @@ void allow_lds(K k, size_t smem) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
-template <typename T, int BN_T, int MODE, bool OUT_F32, bool PLAIN>
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
 void launch_nt_inst(const NTParams& p, size_t smem, hipStream_t st) {
-    auto k = igemm_nt_kernel<T, BN_T, MODE, OUT_F32, PLAIN>;
-    static bool once = (allow_lds(k, 72 * 1024), true);
+    auto k = igemm_nt_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN>;
+    static bool once = (allow_lds(k, 160 * 1024), true);
     (void)once;
-    dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(256);
+    dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
 }
 
-template <typename T, int BN_T, int MODE>
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE>
 int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
-    constexpr size_t smem_full = 4 * (128 * 64 + BN_T * 64);      // 4-stage ring
-    const size_t epi = 128 * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16);
+    constexpr size_t smem_full = 4 * (size_t)(BM_T * 64 + BN_T * 64);      // 4-stage ring
+    const size_t epi = BM_T * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16);
     size_t smem = smem_full;
     if (smem < epi) smem = epi;
     // pointwise taps without padding: the source pixel of a row never leaves the image
     const bool plain = p.R == 1 && p.S == 1 && p.pad == 0 && (MODE == 0 || p.stride == 1);
     if (out_f32) {
-        if (plain) launch_nt_inst<T, BN_T, MODE, true, true>(p, smem, st);
-        else launch_nt_inst<T, BN_T, MODE, true, false>(p, smem, st);
+        if (plain) launch_nt_inst<T, BM_T, BN_T, WM_, WN_, MODE, true, true>(p, smem, st);
+        else launch_nt_inst<T, BM_T, BN_T, WM_, WN_, MODE, true, false>(p, smem, st);
     } else {
-        if (plain) launch_nt_inst<T, BN_T, MODE, false, true>(p, smem, st);
-        else launch_nt_inst<T, BN_T, MODE, false, false>(p, smem, st);
+        if (plain) launch_nt_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, true>(p, smem, st);
+        else launch_nt_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, false>(p, smem, st);
     }
     return saicv::check_launch("igemm_nt");
+}
+
+// Tile choice shared by the kernel launch and conv_stat_rows(): relative per-flop speed of each
+// geometry x wave-quantisation efficiency on 256 CUs x useful fraction of the N tile.
+struct NTTile { int bm, bn, wm, blocks_per_cu; float speed; };
+const NTTile kTiles[4] = {{256, 256, 2, 1, 1.00f}, {256, 128, 4, 1, 0.85f}, {128, 128, 2, 2, 0.70f}, {128, 64, 2, 3, 0.50f}};
+
+int pick_tile(int M, int Nn, bool f32_out_big) {
+    int best = 2;
+    float best_score = -1.f;
+    for (int t = 0; t < 4; ++t) {
+        if (f32_out_big && kTiles[t].bm * kTiles[t].bn * 4 > 150 * 1024) continue;   // fp32 epilogue tile must fit LDS
+        const NTTile& g = kTiles[t];
+        const long tm = (M + g.bm - 1) / g.bm, tn = (Nn + g.bn - 1) / g.bn;
+        const float blocks = (float)(tm * tn);
+        const float slots = 256.f * g.blocks_per_cu;
+        const float rounds = blocks / slots;
+        const float quant = rounds / (float)(long)(rounds + 0.999999f);
+        const float useful = ((float)M / (tm * g.bm)) * ((float)Nn / (tn * g.bn));
+        const float score = g.speed * quant * useful;
+        if (score > best_score) { best_score = score; best = t; }
+    }
+    return best;
 }
 
 template <typename T, int BA, int BB>
@@ -738,7 +766,10 @@ int launch_tn(const TNParams& p, int splits, hipStream_t st) {
 namespace saicv {
 
 // rows of per-wave BN partial statistics written by the forward kernel
-int conv_stat_rows(int M) { return ((M + 127) / 128) * 2; }
+int conv_stat_rows(int M, int Nn, int dtype) {
+    const NTTile& g = kTiles[pick_tile(M, Nn, dtype == SAICV_DTYPE_F32)];
+    return ((M + g.bm - 1) / g.bm) * g.wm;
+}
 
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
@@ -770,24 +801,29 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.wgt_bytes = (uint32_t)wgt_bytes;
     p.fd_ohw = make_fastdiv((uint32_t)(OH * OW));
     p.fd_ow = make_fastdiv((uint32_t)OW);
-    const bool narrow = Nn <= 64;
-    const int bn = narrow ? 64 : 128;
-    p.tiles_n = (Nn + bn - 1) / bn;
-    p.nblk = p.tiles_n * ((M + 127) / 128);
+    const bool f32o = out_f32 != 0 || dtype == SAICV_DTYPE_F32;
+    int M_tile = M;
     if (mode == 1 && stride > 1) {
-        // grid.x must cover the largest parity class (class (0,0))
         const int nimg = M / (OH * OW);
-        const int mc = nimg * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);
-        p.nblk = p.tiles_n * ((mc + 127) / 128);
+        M_tile = nimg * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);   // largest parity class
     }
-    const bool f32o = out_f32 != 0;
+    const int t = (stat_sum != nullptr) ? pick_tile(M, Nn, f32o) : pick_tile(M_tile, Nn, f32o);
+    const NTTile& g = kTiles[t];
+    p.tiles_n = (Nn + g.bn - 1) / g.bn;
+    p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
+#define NT_DISPATCH(TT, MODE_)                                                              \
+    switch (t) {                                                                            \
+        case 0: return launch_nt<TT, 256, 256, 2, 4, MODE_>(p, f32o, st);                   \
+        case 1: return launch_nt<TT, 256, 128, 4, 2, MODE_>(p, f32o, st);                   \
+        case 2: return launch_nt<TT, 128, 128, 2, 2, MODE_>(p, f32o, st);                   \
+        default: return launch_nt<TT, 128, 64, 2, 2, MODE_>(p, f32o, st);                   \
+    }
     if (dtype == SAICV_DTYPE_BF16) {
-        if (mode == 0) return narrow ? launch_nt<bf16_t, 64, 0>(p, f32o, st) : launch_nt<bf16_t, 128, 0>(p, f32o, st);
-        return narrow ? launch_nt<bf16_t, 64, 1>(p, f32o, st) : launch_nt<bf16_t, 128, 1>(p, f32o, st);
+        if (mode == 0) { NT_DISPATCH(bf16_t, 0) } else { NT_DISPATCH(bf16_t, 1) }
     } else {
-        if (mode == 0) return narrow ? launch_nt<float, 64, 0>(p, true, st) : launch_nt<float, 128, 0>(p, true, st);
-        return narrow ? launch_nt<float, 64, 1>(p, true, st) : launch_nt<float, 128, 1>(p, true, st);
+        if (mode == 0) { NT_DISPATCH(float, 0) } else { NT_DISPATCH(float, 1) }
     }
+#undef NT_DISPATCH
 }
 
 int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W, int C, int OH,
