@@ -170,6 +170,33 @@ int saicv_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B
 int saicv_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         void* dqkv, int B, int N, int H, int D, double scale, void* stream);
 
+/* Streaming attention (any Nq / Nk, head dim 32 or 64, separate q / k / v with strides).
+ * Replaces SAM Attention.forward + add_decomposed_rel_pos (reference interactive_segmentation/models/
+ * segment_anything/image_encoder.py:116-184) and DETR's nn.MultiheadAttention calls with a float
+ * key_padding_mask = additive bias (reference detection/models/detr.py:252-260, 309-327).
+ * logits[q, k] = scale * <q, k> + key_bias[b, k] + rel_h[bh, q, k / Sw] + rel_w[bh, q, k % Sw]
+ * (each bias term optional).  All strides in ELEMENTS and multiples of 16 bytes; head h of a row
+ * starts at element h * D.  lse / dsum are [B*H, Nq] fp32; d_rel_h / d_rel_w are overwritten. */
+typedef struct saicv_attn_desc {
+    const void* q; const void* k; const void* v;
+    long q_rs, k_rs, v_rs;          /* row strides */
+    long q_bs, k_bs, v_bs;          /* batch strides */
+    void* out; long o_rs, o_bs;     /* [B, Nq, H*D]-like, also the layout of dout */
+    const void* dout;
+    void* dq; void* dk; void* dv;   /* layouts of q / k / v */
+    float* lse;
+    float* dsum;
+    const float* key_bias;          /* [B, Nk] or NULL */
+    const float* rel_h; const float* rel_w;   /* [B*H, Nq, Sh] / [B*H, Nq, Sw] or NULL */
+    float* d_rel_h; float* d_rel_w;
+    int Sh, Sw;
+    int B, H, Nq, Nk;
+    float scale;
+} saicv_attn_desc;
+int saicv_attention_stream_fwd(int dtype, int D, const saicv_attn_desc* desc, void* stream);
+/* backward = dQ pass (also writes dsum and d_rel_*) followed by the dK/dV pass */
+int saicv_attention_stream_bwd(int dtype, int D, const saicv_attn_desc* desc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

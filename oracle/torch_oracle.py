@@ -167,3 +167,77 @@ def loss_and_grads(forward_fn, sd, param_names, *inputs, loss_fn=ce_loss, label=
     loss.backward()
     grads = {k: leaves[k].grad for k in param_names}
     return logits.detach(), loss.detach(), grads
+
+
+# ------------------------------------------------------------------------------ SAM image encoder
+def sam_randomize_zero_init(named_parameters, seed):
+    """The reference initialises pos_embed / rel_pos_h / rel_pos_w to ZEROS (image_encoder.py:157-160,
+    287-289), which would leave the relative-position path untested: fixtures and tests overwrite
+    every all-zero parameter with N(0, 0.2) draws from this seeded generator, in registration order."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for _, p in named_parameters:
+            if float(p.detach().abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+
+
+def _rel_pos_gather(size, table):
+    """get_rel_pos for q_size == k_size (reference image_encoder.py:82-113): row q - k + size - 1."""
+    r = torch.arange(size)
+    return table[(r[:, None] - r[None, :]) + (size - 1)]
+
+
+def sam_attention(x, sd, p, heads):
+    """Attention.forward + add_decomposed_rel_pos (reference image_encoder.py:116-184): the relative
+    terms use the UNSCALED q; logits = (q * scale) k^T + rel_h[..., None] + rel_w[..., None, :]."""
+    b, h, w, c = x.shape
+    hd = c // heads
+    qkv = F.linear(x, sd[p + 'qkv.weight'], sd[p + 'qkv.bias']).reshape(b, h * w, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.reshape(3, b * heads, h * w, hd).unbind(0)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    rh = _rel_pos_gather(h, sd[p + 'rel_pos_h'])
+    rw = _rel_pos_gather(w, sd[p + 'rel_pos_w'])
+    rq = q.reshape(b * heads, h, w, hd)
+    rel_h = torch.einsum('bhwc,hkc->bhwk', rq, rh)
+    rel_w = torch.einsum('bhwc,wkc->bhwk', rq, rw)
+    attn = (attn.view(b * heads, h, w, h, w) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(
+        b * heads, h * w, h * w)
+    attn = attn.softmax(dim=-1)
+    o = (attn @ v).view(b, heads, h, w, hd).permute(0, 2, 3, 1, 4).reshape(b, h, w, c)
+    return F.linear(o, sd[p + 'proj.weight'], sd[p + 'proj.bias'])
+
+
+def sam_layernorm2d(x, weight, bias, eps=1e-6):
+    """LayerNorm2d.forward (reference image_encoder.py:250-256)."""
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    x = (x - u) / torch.sqrt(s + eps)
+    return weight[:, None, None] * x + bias[:, None, None]
+
+
+def sam_encoder_forward(sd, x, patch=16, heads=12, blocks=12, window=14, global_idx=(2, 5, 8, 11), eps=1e-6):
+    """ViTImageEncoder.forward (reference image_encoder.py:318-335) with Block.forward (:222-239),
+    window_partition / window_unpartition (:32-79: zero pad AFTER norm1 to a multiple of the window)."""
+    t = F.conv2d(x, sd['patch_embed.proj.weight'], sd['patch_embed.proj.bias'], stride=patch).permute(0, 2, 3, 1)
+    t = t + sd['pos_embed']
+    b, hh, ww, c = t.shape
+    for i in range(blocks):
+        p = f'blocks.{i}.'
+        ws = 0 if i in global_idx else window
+        h = F.layer_norm(t, (c,), sd[p + 'norm1.weight'], sd[p + 'norm1.bias'], eps)
+        if ws > 0:
+            ph, pw = (ws - hh % ws) % ws, (ws - ww % ws) % ws
+            h = F.pad(h, (0, 0, 0, pw, 0, ph))
+            hp, wp = hh + ph, ww + pw
+            h = h.view(b, hp // ws, ws, wp // ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, c)
+        h = sam_attention(h, sd, p + 'attn.', heads)
+        if ws > 0:
+            h = h.view(b, hp // ws, wp // ws, ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(b, hp, wp, c)[:, :hh, :ww, :]
+        t = t + h
+        h = F.layer_norm(t, (c,), sd[p + 'norm2.weight'], sd[p + 'norm2.bias'], eps)
+        h = F.gelu(F.linear(h, sd[p + 'mlp.lin1.weight'], sd[p + 'mlp.lin1.bias']))
+        t = t + F.linear(h, sd[p + 'mlp.lin2.weight'], sd[p + 'mlp.lin2.bias'])
+    t = t.permute(0, 3, 1, 2)
+    t = sam_layernorm2d(F.conv2d(t, sd['neck.0.weight']), sd['neck.1.weight'], sd['neck.1.bias'])
+    t = sam_layernorm2d(F.conv2d(t, sd['neck.2.weight'], padding=1), sd['neck.3.weight'], sd['neck.3.bias'])
+    return t

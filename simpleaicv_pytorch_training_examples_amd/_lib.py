@@ -24,6 +24,22 @@ class ConvDesc(Structure):
 _P = c_void_p
 _PD = POINTER(ConvDesc)
 
+
+class AttnDesc(Structure):
+    """saicv_attn_desc (include/saicv_hip.h): streaming attention problem descriptor."""
+    _fields_ = [('q', _P), ('k', _P), ('v', _P),
+                ('q_rs', c_long), ('k_rs', c_long), ('v_rs', c_long),
+                ('q_bs', c_long), ('k_bs', c_long), ('v_bs', c_long),
+                ('out', _P), ('o_rs', c_long), ('o_bs', c_long),
+                ('dout', _P), ('dq', _P), ('dk', _P), ('dv', _P),
+                ('lse', _P), ('dsum', _P), ('key_bias', _P), ('rel_h', _P), ('rel_w', _P),
+                ('d_rel_h', _P), ('d_rel_w', _P),
+                ('Sh', c_int), ('Sw', c_int), ('B', c_int), ('H', c_int), ('Nq', c_int), ('Nk', c_int),
+                ('scale', c_float)]
+
+
+_PA = POINTER(AttnDesc)
+
 # name -> (restype, argtypes); mirrors include/saicv_hip.h one to one
 SIGNATURES = {
     'saicv_version': (c_int, []),
@@ -66,6 +82,8 @@ SIGNATURES = {
     'saicv_gelu_bwd': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
     'saicv_attention_fwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
     'saicv_attention_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
+    'saicv_attention_stream_fwd': (c_int, [c_int, c_int, _PA, _P]),
+    'saicv_attention_stream_bwd': (c_int, [c_int, c_int, _PA, _P]),
 }
 
 _lib = None

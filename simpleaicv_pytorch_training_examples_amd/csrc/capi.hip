@@ -266,5 +266,22 @@ int saicv_attention_bwd(int dtype, const void* qkv, const void* out, const void*
                         void* dqkv, int B, int N, int H, int D, double scale, void* stream) {
     return attention_bwd(dtype, qkv, out, dout, lse, dqkv, B, N, H, D, scale, S(stream));
 }
+int saicv_attention_stream_fwd(int dtype, int D, const saicv_attn_desc* desc, void* stream) {
+    if (!desc) { set_error("attention_stream: null descriptor"); return -1; }
+    return attention_stream(dtype, D, 0, desc, S(stream));
+}
+int saicv_attention_stream_bwd(int dtype, int D, const saicv_attn_desc* desc, void* stream) {
+    if (!desc) { set_error("attention_stream: null descriptor"); return -1; }
+    if (!desc->dout || !desc->dq || !desc->dk || !desc->dv || !desc->dsum) {
+        set_error("attention_stream_bwd: dout / dq / dk / dv / dsum are required");
+        return -1;
+    }
+    if (desc->rel_h && (!desc->d_rel_h || !desc->d_rel_w)) {
+        set_error("attention_stream_bwd: d_rel_h / d_rel_w are required with rel_h / rel_w");
+        return -1;
+    }
+    const int rc = attention_stream(dtype, D, 1, desc, S(stream));
+    return rc ? rc : attention_stream(dtype, D, 2, desc, S(stream));
+}
 
 }  // extern "C"

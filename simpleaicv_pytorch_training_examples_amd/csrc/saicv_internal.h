@@ -23,4 +23,7 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
              int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st,
              float* dbias = nullptr);
 
+// attn_stream.hip: which = 0 forward, 1 dQ pass, 2 dK/dV pass; desc = const saicv_attn_desc*
+int attention_stream(int dtype, int D, int which, const void* desc, hipStream_t st);
+
 }  // namespace saicv

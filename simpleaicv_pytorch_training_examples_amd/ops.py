@@ -312,6 +312,79 @@ def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None):
 
 
 # ------------------------------------------------------------------------------ plain conv / linear
+class ConvFn(torch.autograd.Function):
+    """nn.Conv2d (optional bias, no normalisation) on NHWC data: SAM neck convs (reference
+    interactive_segmentation/models/segment_anything/image_encoder.py:303-316), DETR input
+    projection (reference detection/models/detr.py:301)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        require_gpu(x, weight)
+        x = _nhwc(x)
+        dt = x.dtype
+        n, c, h, w = x.shape
+        k, ci, r, s = weight.shape
+        if c != ci:
+            raise ValueError(f'input has {c} channels, weight expects {ci}')
+        need_dx = ctx.needs_input_grad[0]
+        wf, wd = packed_weight(weight, dt, c, need_dx)
+        d = _desc(n, h, w, c, k, r, s, stride, pad, dt)
+        y = _empty_nhwc(n, k, d.OH, d.OW, dt, x.device)
+        t0 = KernelTimer.begin()
+        check(lib().saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), ptr(bias), ptr(y), 0, 0, 0, stream()),
+              'conv2d_fwd')
+        KernelTimer.end(t0, 'igemm_nt', 2.0 * n * d.OH * d.OW * k * r * s * c, 0)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.cfg = (d, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        d, wd = ctx.cfg
+        L, st = lib(), stream()
+        dt = x.dtype
+        dy = _nhwc(dy)
+        if dy.dtype != dt:
+            dy = dy.to(dt)
+        n, c, h, w = x.shape
+        k = weight.shape[0]
+        M = n * d.OH * d.OW
+        flops = 2.0 * M * k * d.R * d.S * c
+        dx = dwt = db = None
+        if ctx.needs_input_grad[0]:
+            if wd is None:
+                _, wd = packed_weight(weight, dt, c, True)
+            dx = _empty_nhwc(n, c, h, w, dt, x.device)
+            t0 = KernelTimer.begin()
+            check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
+            KernelTimer.end(t0, 'igemm_nt', flops, 0)
+        if ctx.needs_input_grad[1]:
+            gw = _arena_grad(weight)
+            direct = gw is not None and weight.is_contiguous(memory_format=torch.channels_last)
+            dw = gw if direct else torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=x.device)
+            t0 = KernelTimer.begin()
+            check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
+            KernelTimer.end(t0, 'igemm_tn', flops, 0)
+            if direct:
+                _grad_ready(weight)
+            else:
+                dwt = _weight_grad(dw, weight, c)
+        if bias is not None and ctx.needs_input_grad[2]:
+            gb = _arena_grad(bias)
+            tb = gb if gb is not None else torch.zeros(k, dtype=torch.float32, device=x.device)
+            check(L.saicv_colsum(dtype_code(dt), ptr(dy), M, k, ptr(tb), st), 'colsum')
+            if gb is not None:
+                _grad_ready(bias)
+            else:
+                db = tb
+        return dx, dwt, db, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0):
+    return ConvFn.apply(x, weight, bias, stride, pad)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b on the implicit-GEMM kernel (1x1 geometry).  nn.Linear of resnet.py:204."""
 

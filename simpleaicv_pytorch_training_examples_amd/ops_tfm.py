@@ -146,6 +146,63 @@ def attn_bwd(qkv, out, dout, lse, b, n, heads, scale):
     return dqkv
 
 
+def _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w):
+    """q [B, Nq, H*D], k / v [B, Nk, H*D]: any batch / row strides, unit stride on the last axis."""
+    b, nq, c = q.shape
+    nk = k.shape[1]
+    for t in (q, k, v):
+        if t.stride(-1) != 1 or t.dtype != q.dtype:
+            raise ValueError('attention operands need a contiguous last axis and one dtype')
+    d = _lib.AttnDesc()
+    d.q, d.k, d.v = ptr(q), ptr(k), ptr(v)
+    d.q_bs, d.q_rs = q.stride(0), q.stride(1)
+    d.k_bs, d.k_rs = k.stride(0), k.stride(1)
+    d.v_bs, d.v_rs = v.stride(0), v.stride(1)
+    d.B, d.H, d.Nq, d.Nk = b, heads, nq, nk
+    d.scale = float(scale)
+    if key_bias is not None:
+        if key_bias.dtype != torch.float32 or tuple(key_bias.shape) != (b, nk) or not key_bias.is_contiguous():
+            raise ValueError('key_bias must be a contiguous fp32 [B, Nk] tensor')
+        d.key_bias = ptr(key_bias)
+    if rel_h is not None:
+        for t in (rel_h, rel_w):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape[0] != b * heads or t.shape[1] != nq:
+                raise ValueError('rel_h / rel_w must be contiguous fp32 [B*H, Nq, S]')
+        d.rel_h, d.rel_w = ptr(rel_h), ptr(rel_w)
+        d.Sh, d.Sw = rel_h.shape[2], rel_w.shape[2]
+    return d, c // heads
+
+
+def sattn_fwd(q, k, v, heads, scale, key_bias=None, rel_h=None, rel_w=None):
+    """Streaming attention forward -> (out [B, Nq, C], lse [B*H, Nq])."""
+    d, hd = _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w)
+    out = torch.empty((d.B, d.Nq, q.shape[2]), dtype=q.dtype, device=q.device)
+    lse = torch.empty((d.B * heads, d.Nq), dtype=torch.float32, device=q.device)
+    d.out, d.o_bs, d.o_rs, d.lse = ptr(out), out.stride(0), out.stride(1), ptr(lse)
+    check(lib().saicv_attention_stream_fwd(dtype_code(q.dtype), hd, d, stream()), 'attention_stream_fwd')
+    return out, lse
+
+
+def sattn_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv, key_bias=None, rel_h=None, rel_w=None):
+    """Streaming attention backward into dq / dk / dv (tensors or views with the strides of q / k / v).
+    -> (d_rel_h, d_rel_w) or (None, None)."""
+    d, hd = _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w)
+    for g, t in ((dq, q), (dk, k), (dv, v)):
+        if g.stride() != t.stride() or g.dtype != t.dtype:
+            raise ValueError('gradient views must share strides and dtype with their operands')
+    if not (out.is_contiguous() and dout.is_contiguous() and dout.dtype == q.dtype):
+        raise ValueError('out / dout must be contiguous [B, Nq, C] of the compute dtype')
+    dsum = torch.empty_like(lse)
+    d.out, d.o_bs, d.o_rs, d.lse = ptr(out), out.stride(0), out.stride(1), ptr(lse)
+    d.dout, d.dq, d.dk, d.dv, d.dsum = ptr(dout), ptr(dq), ptr(dk), ptr(dv), ptr(dsum)
+    drh = drw = None
+    if rel_h is not None:
+        drh, drw = torch.empty_like(rel_h), torch.empty_like(rel_w)
+        d.d_rel_h, d.d_rel_w = ptr(drh), ptr(drw)
+    check(lib().saicv_attention_stream_bwd(dtype_code(q.dtype), hd, d, stream()), 'attention_stream_bwd')
+    return drh, drw
+
+
 def row_scale(x2, scale, rows_per_scale):
     out = torch.empty_like(x2)
     check(lib().saicv_row_scale(dtype_code(x2.dtype), ptr(x2), ptr(scale), ptr(out), x2.shape[0], x2.shape[1],
@@ -251,6 +308,37 @@ def attention(qkv, heads, scale):
     return AttentionFn.apply(qkv, heads, scale)
 
 
+class StreamAttentionFn(torch.autograd.Function):
+    """softmax(scale * q k^T + key_bias) v for separate q [B, Nq, C], k / v [B, Nk, C] (views allowed),
+    any sequence lengths, head dim 32 or 64 -- the [Nq, Nk] matrix never reaches HBM.
+    key_bias [B, Nk] fp32 is ADDED to the logits (DETR's float key_padding_mask, detr.py:252-260)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, key_bias):
+        require_gpu(q, k, v)
+        out, lse = sattn_fwd(q, k, v, heads, scale, key_bias)
+        ctx.save_for_backward(q, k, v, out, lse, key_bias)
+        ctx.cfg = (heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, key_bias = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        dout = dout.contiguous()
+        if dout.dtype != q.dtype:
+            dout = dout.to(q.dtype)
+        dq, dk, dv = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device), \
+            torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device), \
+            torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
+        sattn_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv, key_bias)
+        return dq, dk, dv, None, None, None
+
+
+def stream_attention(q, k, v, heads, scale, key_bias=None):
+    return StreamAttentionFn.apply(q, k, v, heads, scale, key_bias)
+
+
 # ------------------------------------------------------------------------------ fused ViT sub-layers
 class AttnSubLayerFn(torch.autograd.Function):
     """out = x + s * proj(attention(qkv(LN(x))))   -- one node (reference vit.py:160)."""
@@ -323,6 +411,142 @@ def attn_sublayer(x, norm, attn, drop_scale):
 def mlp_sublayer(x, norm, mlp, drop_scale):
     return MlpSubLayerFn.apply(x, norm.weight, norm.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias,
                                drop_scale, norm.eps)
+
+
+# ------------------------------------------------------------------------------ SAM encoder block (windows + rel-pos)
+def window_partition(x4, ws):
+    """[B, H, W, C] -> ([B*nW, ws*ws, C], (Hp, Wp)); zero pad to a multiple of ws
+    (reference segment_anything/image_encoder.py:32-55).  Layout glue: one copy."""
+    b, h, w, c = x4.shape
+    ph, pw = (ws - h % ws) % ws, (ws - w % ws) % ws
+    if ph or pw:
+        x4 = torch.nn.functional.pad(x4, (0, 0, 0, pw, 0, ph))
+    hp, wp = h + ph, w + pw
+    x = x4.view(b, hp // ws, ws, wp // ws, ws, c).permute(0, 1, 3, 2, 4, 5).contiguous()
+    return x.view(-1, ws * ws, c), (hp, wp)
+
+
+def window_unpartition(win, ws, pad_hw, hw):
+    """inverse of window_partition, dropping the padding (reference image_encoder.py:58-79)."""
+    hp, wp = pad_hw
+    h, w = hw
+    b = win.shape[0] // ((hp // ws) * (wp // ws))
+    x = win.view(b, hp // ws, wp // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5)
+    if hp > h or wp > w:
+        return x.reshape(b, hp, wp, -1)[:, :h, :w, :].contiguous()
+    return x.contiguous().view(b, h, w, -1)
+
+
+_rel_index_cache = {}
+
+
+def _rel_index(size, table_len, device):
+    """index [q, k] -> q - k + size - 1 into a [2*size-1, D] table (get_rel_pos with q_size == k_size,
+    reference image_encoder.py:82-113; the interpolating branch is not needed at native sizes)."""
+    if table_len != 2 * size - 1:
+        raise NotImplementedError(f'relative-position table of length {table_len} for size {size}: '
+                                  'interpolated tables are not supported')
+    key = (size, str(device))
+    idx = _rel_index_cache.get(key)
+    if idx is None:
+        r = torch.arange(size, device=device)
+        idx = (r[:, None] - r[None, :] + (size - 1)).contiguous()
+        _rel_index_cache[key] = idx
+    return idx
+
+
+def _rel_bias(q, heads, sh, sw, rel_pos_h, rel_pos_w):
+    """Decomposed relative-position logits (add_decomposed_rel_pos, reference image_encoder.py:116-144):
+    rel_h[b*heads + n, (h, w), k] = <q[b, (h, w), n, :], rel_pos_h[h - k + S - 1, :]>, same for w.
+    q is the UNSCALED query view [Bw, N, C].  Small fp32 batched GEMMs (0.8 % of the attention flops)."""
+    bw, n, c = q.shape
+    d = c // heads
+    idx_h = _rel_index(sh, rel_pos_h.shape[0], q.device)
+    idx_w = _rel_index(sw, rel_pos_w.shape[0], q.device)
+    rh = rel_pos_h.detach().float()[idx_h]                  # [sh, sh, d]
+    rw = rel_pos_w.detach().float()[idx_w]
+    rq = q.reshape(bw, sh, sw, heads, d).float()
+    with torch.autocast('cuda', enabled=False):             # fp32 logits whatever the autocast state
+        rel_h = torch.einsum('bhwnc,hkc->bnhwk', rq, rh).contiguous().view(bw * heads, n, sh)
+        rel_w = torch.einsum('bhwnc,wkc->bnhwk', rq, rw).contiguous().view(bw * heads, n, sw)
+    return rel_h, rel_w, rh, rw, rq, idx_h, idx_w
+
+
+class SamAttnSubLayerFn(torch.autograd.Function):
+    """out = x + unpartition(proj(rel_pos_attention(qkv(partition(LN(x))))))  -- the attention half of a
+    SAM encoder Block as ONE autograd node (reference segment_anything/image_encoder.py:147-184, 222-236).
+    x [B, H, W, C]; window = 0 -> global attention over H*W tokens.  The [N, N] logits never reach HBM."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, rel_pos_h, rel_pos_w, heads, eps, window):
+        require_gpu(x, qkv_w)
+        b, hh, ww, c = x.shape
+        x2 = _as2d(x)
+        h, mean, rstd = ln_fwd(x2, ln_w, ln_b, eps)
+        if window > 0:
+            hw, pad_hw = window_partition(h.view(b, hh, ww, c), window)
+            sh = sw = window
+        else:
+            hw, pad_hw = h.view(b, hh * ww, c), (hh, ww)
+            sh, sw = hh, ww
+        bw, n, _ = hw.shape
+        hw2 = hw.view(-1, c)
+        qkv = lin_fwd(hw2, qkv_w, qkv_b).view(bw, n, 3 * c)
+        q, k, v = qkv[:, :, :c], qkv[:, :, c:2 * c], qkv[:, :, 2 * c:]
+        scale = (c // heads) ** -0.5
+        rel_h, rel_w = _rel_bias(q, heads, sh, sw, rel_pos_h, rel_pos_w)[:2]
+        a, lse = sattn_fwd(q, k, v, heads, scale, None, rel_h, rel_w)
+        a2 = a.view(-1, c)
+        if window > 0:
+            p = lin_fwd(a2, proj_w, proj_b)
+            out = x + window_unpartition(p.view(bw, n, c), window, pad_hw, (hh, ww))
+        else:
+            out = lin_fwd(a2, proj_w, proj_b, addend=x2).view(b, hh, ww, c)
+        ctx.save_for_backward(x2, ln_w, ln_b, mean, rstd, hw2, qkv_w, qkv_b, qkv, a, lse, rel_h, rel_w, proj_w,
+                              proj_b, rel_pos_h, rel_pos_w)
+        ctx.cfg = (b, hh, ww, c, heads, scale, window, pad_hw, sh, sw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, ln_w, ln_b, mean, rstd, hw2, qkv_w, qkv_b, qkv, a, lse, rel_h, rel_w, proj_w, proj_b, rel_pos_h,
+         rel_pos_w) = ctx.saved_tensors
+        b, hh, ww, c, heads, scale, window, pad_hw, sh, sw = ctx.cfg
+        dt = x2.dtype
+        dy = dout.contiguous()
+        if dy.dtype != dt:
+            dy = dy.to(dt)
+        bw, n, _ = qkv.shape
+        dp = window_partition(dy.view(b, hh, ww, c), window)[0].view(-1, c) if window > 0 else dy.view(-1, c)
+        da, dpw, dpb = lin_bwd(a.view(-1, c), proj_w, proj_b, dp)
+        q, k, v = qkv[:, :, :c], qkv[:, :, c:2 * c], qkv[:, :, 2 * c:]
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[:, :, :c], dqkv[:, :, c:2 * c], dqkv[:, :, 2 * c:]
+        drh, drw = sattn_bwd(q, k, v, a, da.view(bw, n, c), lse, heads, scale, dq, dk, dv, None, rel_h, rel_w)
+        # relative-position tables and the extra query gradient (fp32 batched GEMMs)
+        _, _, rh, rw, rq, idx_h, idx_w = _rel_bias(q, heads, sh, sw, rel_pos_h, rel_pos_w)
+        d = c // heads
+        drh5 = drh.view(bw, heads, sh, sw, sh)
+        drw5 = drw.view(bw, heads, sh, sw, sw)
+        g_rh = g_rw = None
+        with torch.autocast('cuda', enabled=False):
+            dq_extra = torch.einsum('bnhwk,hkc->bhwnc', drh5, rh) + torch.einsum('bnhwk,wkc->bhwnc', drw5, rw)
+            dq.add_(dq_extra.reshape(bw, n, c).to(dt))
+            if ctx.needs_input_grad[7]:
+                g = torch.einsum('bnhwk,bhwnc->hkc', drh5, rq)
+                g_rh = torch.zeros_like(rel_pos_h, dtype=torch.float32).index_add_(0, idx_h.view(-1), g.reshape(-1, d))
+            if ctx.needs_input_grad[8]:
+                g = torch.einsum('bnhwk,bhwnc->wkc', drw5, rq)
+                g_rw = torch.zeros_like(rel_pos_w, dtype=torch.float32).index_add_(0, idx_w.view(-1), g.reshape(-1, d))
+        dhw, dqw, dqb = lin_bwd(hw2, qkv_w, qkv_b, dqkv.view(-1, 3 * c))
+        dh = window_unpartition(dhw.view(bw, n, c), window, pad_hw, (hh, ww)) if window > 0 else dhw
+        dx, dlw, dlb = ln_bwd(dh.reshape(-1, c), x2, ln_w, ln_b, mean, rstd, addend=dy.view(-1, c))
+        return dx.view(b, hh, ww, c), dlw, dlb, dqw, dqb, dpw, dpb, g_rh, g_rw, None, None, None
+
+
+def sam_attn_sublayer(x, norm, attn, window):
+    return SamAttnSubLayerFn.apply(x, norm.weight, norm.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight,
+                                   attn.proj.bias, attn.rel_pos_h, attn.rel_pos_w, attn.head_nums, norm.eps, window)
 
 
 # ------------------------------------------------------------------------------ patch embedding

@@ -1,0 +1,170 @@
+"""Streaming attention kernels and the SAM image encoder on a real MI355X.
+
+Kernel level : saicv_attention_stream_{fwd,bwd} (through the C-ABI) against a plain fp32 PyTorch
+               restatement of softmax(scale q k^T + bias) v.  fp32 parity mode: outputs and all
+               gradients within 2e-4 of the tensor scale (exact-f32 MFMA, only summation order
+               differs); bf16: within 3e-2 (operands and probabilities rounded to bf16).
+Model level  : ViTImageEncoder against the fixture produced by the reference's own module
+               (tests/golden/sam_encoder_tiny.pt): fp32 output within 1e-3 (north_star), gradient
+               norms within 1e-2, samples within 2e-2; bf16 autocast measured against the
+               reference's own bf16-vs-fp32 deviation stored in the fixture.
+"""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_attention(q, k, v, heads, scale, key_bias=None, rel_h=None, rel_w=None):
+    b, nq, c = q.shape
+    nk = k.shape[1]
+    d = c // heads
+    qh = q.view(b, nq, heads, d).transpose(1, 2)
+    kh = k.view(b, nk, heads, d).transpose(1, 2)
+    vh = v.view(b, nk, heads, d).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale                       # [b, h, nq, nk]
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    if rel_h is not None:
+        sh, sw = rel_h.shape[-1], rel_w.shape[-1]
+        s = (s.view(b, heads, nq, sh, sw) + rel_h.view(b, heads, nq, sh, 1) + rel_w.view(b, heads, nq, 1, sw)).view(
+            b, heads, nq, nk)
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(b, nq, c)
+
+
+CASES = [
+    # b, heads, d, nq, nk, key_bias, rel (sh, sw)
+    (2, 3, 64, 196, 196, False, (14, 14)),     # SAM window
+    (1, 2, 64, 256, 256, False, (16, 16)),     # global block, several key chunks
+    (2, 2, 64, 200, 200, False, None),         # ragged tails, no bias
+    (2, 8, 32, 100, 330, True, None),          # DETR cross-attention: head dim 32, additive key bias
+    (2, 8, 32, 330, 330, True, None),          # DETR encoder self-attention
+    (1, 1, 64, 1, 70, False, None),            # single query
+    (1, 2, 32, 130, 5, True, None),            # fewer keys than one tile
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CASES)
+def test_stream_attention_matches_fp32_reference(case, dtype):
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    b, heads, d, nq, nk, use_kb, rel = case
+    c = heads * d
+    g = torch.Generator().manual_seed(nq * 131 + nk)
+    packed = nq == nk
+    if packed:      # q / k / v are views of one packed projection, as in the encoder blocks
+        qkv = torch.randn(b, nq, 3 * c, generator=g).cuda().to(dtype)
+        q, k, v = qkv[:, :, :c], qkv[:, :, c:2 * c], qkv[:, :, 2 * c:]
+    else:
+        q = torch.randn(b, nq, c, generator=g).cuda().to(dtype)
+        k = torch.randn(b, nk, c, generator=g).cuda().to(dtype)
+        v = torch.randn(b, nk, c, generator=g).cuda().to(dtype)
+    kb = (torch.rand(b, nk, generator=g) > 0.7).float().cuda() * 1.0 if use_kb else None
+    rel_h = rel_w = None
+    if rel:
+        rel_h = torch.randn(b * heads, nq, rel[0], generator=g).cuda()
+        rel_w = torch.randn(b * heads, nq, rel[1], generator=g).cuda()
+    scale = d ** -0.5
+    out, lse = ops_tfm.sattn_fwd(q, k, v, heads, scale, kb, rel_h, rel_w)
+    dout = torch.randn(b, nq, c, generator=g).cuda().to(dtype)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    if packed:
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[:, :, :c], dqkv[:, :, c:2 * c], dqkv[:, :, 2 * c:]
+    drh, drw = ops_tfm.sattn_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv, kb, rel_h, rel_w)
+    torch.cuda.synchronize()
+
+    leaves = [t.detach().float().clone().requires_grad_(True) for t in (q, k, v)]
+    rl = [t.detach().clone().requires_grad_(True) for t in (rel_h, rel_w)] if rel else [None, None]
+    ref = _ref_attention(leaves[0], leaves[1], leaves[2], heads, scale, kb, rl[0], rl[1])
+    ref.backward(dout.float())
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(out, ref) < tol
+    assert rel_err(dq, leaves[0].grad) < tol
+    assert rel_err(dk, leaves[1].grad) < tol
+    assert rel_err(dv, leaves[2].grad) < tol
+    if rel:
+        assert rel_err(drh, rl[0].grad) < tol
+        assert rel_err(drw, rl[1].grad) < tol
+
+
+def test_stream_attention_rejects_bad_arguments():
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    q = torch.randn(1, 16, 48, device='cuda')
+    with pytest.raises(RuntimeError, match='head dim'):
+        ops_tfm.sattn_fwd(q, q, q, 1, 1.0)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops_tfm.stream_attention(q.cpu(), q.cpu(), q.cpu(), 1, 1.0)
+
+
+def _sam_model(fx):
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.models.segment_anything.image_encoder import ViTImageEncoder
+    torch.manual_seed(fx['model_seed'])
+    m = ViTImageEncoder(**fx['kwargs'])
+    O.sam_randomize_zero_init(m.named_parameters(), fx['model_seed'] + 100)
+    return m.cuda().train()
+
+
+def _sam_inputs(fx):
+    g = torch.Generator().manual_seed(fx['data_seed'])
+    s = fx['kwargs']['image_size']
+    x = torch.randn(fx['batch'], 3, s, s, generator=g)
+    probe = torch.randn(fx['output'].shape, generator=g)
+    assert abs(float(x.double().sum()) - fx['input_checksum']) < 1e-6
+    return x.cuda(), probe.cuda()
+
+
+def test_sam_encoder_fp32_matches_reference():
+    fx = load_golden('sam_encoder_tiny')
+    m = _sam_model(fx)
+    x, probe = _sam_inputs(fx)
+    out = m(x)
+    assert out.shape == fx['output'].shape and out.dtype == torch.float32
+    (out * probe).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_err(out, fx['output']) < 1e-3
+    worst = 0.0
+    for n, p in m.named_parameters():
+        assert p.grad is not None, n
+        ref_n = fx['grad_norm'][n]
+        assert abs(float(p.grad.norm()) - ref_n) <= 1e-2 * max(ref_n, 1e-6), (n, float(p.grad.norm()), ref_n)
+        e = rel_err(p.grad.flatten()[:64], fx['grad_sample'][n])
+        worst = max(worst, e)
+        assert e < 2e-2, (n, e)
+        if n in fx['grad_full']:
+            assert rel_err(p.grad, fx['grad_full'][n]) < 2e-2, n
+    print(f'sam_encoder_tiny fp32: worst gradient-sample error {worst:.2e}')
+
+
+def test_sam_encoder_bf16_tracks_reference_autocast():
+    fx = load_golden('sam_encoder_tiny')
+    m = _sam_model(fx)
+    x, probe = _sam_inputs(fx)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = m(x)
+    (out.float() * probe).sum().backward()
+    torch.cuda.synchronize()
+    noise = fx['reference_noise']
+    assert rel_err(out.float(), fx['output']) < 1.5 * noise['bf16_output'] + 2e-2
+    a = torch.cat([p.grad.flatten()[:64].double().cpu() for _, p in m.named_parameters()])
+    b = torch.cat([fx['grad_sample'][n].double() for n, _ in m.named_parameters()])
+    cos = float(a @ b / (a.norm() * b.norm()))
+    assert cos > noise['bf16_grad_sample_cos'] - 0.1, cos
+
+
+def test_sam_encoder_gradient_checkpoint_equals_plain():
+    fx = load_golden('sam_encoder_tiny')
+    kw = dict(fx['kwargs'])
+    x, probe = _sam_inputs(fx)
+    grads = []
+    for ck in (False, True):
+        fx2 = dict(fx)
+        fx2['kwargs'] = dict(kw, use_gradient_checkpoint=ck)
+        m = _sam_model(fx2)
+        (m(x) * probe).sum().backward()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    for n in grads[0]:
+        assert rel_err(grads[1][n], grads[0][n]) < 1e-4, n
