@@ -26,7 +26,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
-TRAIN_GFLOP_PER_IMG = {'resnet50': 24.54, 'vit_base_patch16': 105.38}
+TRAIN_GFLOP_PER_IMG = {'resnet50': 24.54, 'vit_base_patch16': 105.38, 'sam_b_encoder': 3 * 972.1}
+IMAGE_SIZE = {'sam_b_encoder': 1024}
 
 
 def pmc_traffic(kernel):
@@ -65,6 +66,17 @@ def build(model_name, device):
                                            num_classes=1000).to(device)
         crit = losses.OneHotLabelCELoss()
         soft = True
+    elif model_name == 'sam_b_encoder':
+        # BASELINE.json configs[4]: SAM ViT-B image encoder, 3x1024x1024.  Trained as in the reference's
+        # encoder-distillation setup (13.0.encoder_distill_training): MSE against a fixed embedding.
+        # 288 GB of HBM hold every block's activations at per-GPU batch 20, so the reference's
+        # use_gradient_checkpoint=True recompute (train_config.py:21) is not needed.
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.models.segment_anything.image_encoder import ViTImageEncoder
+        model = ViTImageEncoder(image_size=1024, patch_size=16, inplanes=3, embedding_planes=768, block_nums=12,
+                                head_nums=12, mlp_ratio=4, out_planes=256, window_size=14,
+                                global_attn_indexes=[2, 5, 8, 11], use_gradient_checkpoint=False).to(device)
+        crit = lambda out, tgt: torch.nn.functional.mse_loss(out.float(), tgt)
+        soft = 'embedding'
     else:
         raise SystemExit(f'unknown model {model_name}')
     return model, crit, soft, engine
@@ -76,6 +88,9 @@ def make_optimizer(model_name, model, engine):
     ViT-B AdamW lr 5e-4 wd 0.05 (vit_base_patch16.../train_config.py:93-124)."""
     decay = [p for p in model.parameters() if p.ndim > 1]
     no_decay = [p for p in model.parameters() if p.ndim <= 1]
+    if model_name == 'sam_b_encoder':     # sam_b_training/train_config.py: AdamW lr 1e-5, no weight decay
+        return engine.AdamW(model, [{'params': list(model.parameters()), 'weight_decay': 0.0}], lr=1e-5,
+                            betas=(0.9, 0.999), eps=1e-8)
     if model_name == 'resnet50':
         return engine.SGD(model, [{'params': decay, 'weight_decay': 1e-4}, {'params': no_decay, 'weight_decay': 0.0}],
                           lr=0.1, momentum=0.9)
@@ -140,8 +155,15 @@ def main():
 
     g = torch.Generator(device='cpu').manual_seed(1 + rank)
     # NCHW-shaped, NHWC-strided fp32 batch, as the reference collater delivers it
-    images = torch.randn(args.batch, 224, 224, 3, generator=g).to(device).permute(0, 3, 1, 2)
-    if soft:
+    size = IMAGE_SIZE.get(args.model, 224)
+    if soft == 'embedding':       # SAMBatchCollater stacks per-sample CHW tensors: true NCHW input
+        images = torch.randn(args.batch, 3, size, size, generator=g).to(device)
+        labels = torch.randn(args.batch, 256, size // 16, size // 16, generator=g).to(device)
+    else:
+        images = torch.randn(args.batch, size, size, 3, generator=g).to(device).permute(0, 3, 1, 2)
+    if soft == 'embedding':
+        pass
+    elif soft:
         labels = torch.softmax(torch.randn(args.batch, 1000, generator=g) * 4, -1).to(device)
     else:
         labels = torch.randint(0, 1000, (args.batch,), generator=g).to(device)
@@ -189,7 +211,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
             'data': 'synthetic',
-            'config': {'workload': f'{args.model} ImageNet-1K-shape 3x224x224 training step '
+            'config': {'workload': f'{args.model} 3x{size}x{size} synthetic training step '
                                    f'(fwd+loss+bwd+all-reduce+optimizer), per-GPU batch {args.batch}',
                        'model': args.model, 'global_batch': args.batch * world, 'per_gpu_batch': args.batch,
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),

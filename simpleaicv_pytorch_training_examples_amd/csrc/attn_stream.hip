@@ -10,23 +10,37 @@
 //   * DETR nn.MultiheadAttention self / cross attention with a FLOAT key_padding_mask, which
 //          PyTorch applies as an ADDITIVE bias (+1.0 on padded keys, reference detection/models/
 //          detr.py:252-260) -> `key_bias`, head dim 32.
-// Structure: a workgroup = 8 wavefronts = 128 queries (forward / dQ) or 128 keys (dK,dV); the
-// other side streams through LDS in 64-row chunks; scores live in the S^T accumulator layout
-// (query on the lane, keys on lane-group/register) so softmax row reductions are two shuffles;
-// P.V and dS.K go through transposing LDS reads.  Online softmax with running max / sum.
+//
+// Structure.  A workgroup is 4 wavefronts; each wavefront owns 32 rows (queries in the forward
+// and dQ kernels, keys in the dK/dV kernel) as two 16-row MFMA tiles that share every LDS
+// fragment read; the other operand streams through LDS in 64-row chunks, the next chunk being
+// fetched into registers while the current one is consumed.  Scores live in the S^T accumulator
+// layout (query on the lane, keys on lane-group / register), so softmax row reductions are two
+// shuffles; P.V and dS.K use transposing LDS reads.  Softmax runs in the log2 domain (v_exp_f32).
+// Relative-position modes (template REL):
+//   0 none;
+//   1 small tables (Sh + Sw <= 32, Nk <= 256: SAM windows): rows of rel_h / rel_w in LDS, gradients
+//     as one more MFMA against a 0/1 key -> (kh, kw) indicator matrix;
+//   2 Sw == 64 (SAM global blocks): a 64-key chunk is exactly one kh row, so rel_w lives in 16
+//     registers per tile and rel_h is one value per chunk; gradients accumulate in registers;
+//   3 anything else: LDS tables + LDS atomics (slow, kept for generality).
 #include "common.h"
 #include "saicv_internal.h"
 #include "../../include/saicv_hip.h"
 
 namespace {
 
-constexpr int SA_THREADS = 512;
-constexpr int SA_WAVES = 8;
+constexpr int SA_THREADS = 256;
+constexpr int SA_WAVES = 4;
 constexpr int SA_CHUNK = 64;            // rows of the streamed operand per LDS chunk
+constexpr int SA_WROWS = 32;            // rows owned by one wavefront (two MFMA tiles)
+constexpr int SA_BROWS = SA_WAVES * SA_WROWS;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
 
 typedef saicv_attn_desc SAParams;   // public descriptor (include/saicv_hip.h) is the kernel argument
 
-// ---------------------------------------------------------------- LDS image of a [rows][D] operand
+// ---------------------------------------------------------------- LDS image of a [rows][cols] operand
 template <int ROWB> DEVINL int sa_off(int row, int chunk);
 template <> DEVINL int sa_off<64>(int row, int chunk) {
     const int q = (row >> 2) & 3;
@@ -34,6 +48,53 @@ template <> DEVINL int sa_off<64>(int row, int chunk) {
 }
 template <> DEVINL int sa_off<128>(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
 template <> DEVINL int sa_off<256>(int row, int chunk) { return row * 256 + (((chunk ^ row) & 15) << 4); }
+
+DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// acc[s][dt] += A_s(16 x 32) * M(32 x 16*DT): A_s given as two C-layout tiles t0[s], t1[s] (lane: A row l15,
+// k = kbase + {0,16} + lg*4 + r), M an LDS image with ROWB-byte rows = k.  The B fragments are read once
+// and shared by the NS row sets.
+template <typename T, int ROWB, int DT, int NS>
+DEVINL void pvN(f32x4 (&acc)[NS][DT], const f32x4 (&t0)[NS], const f32x4 (&t1)[NS], const char* lds, int kbase,
+                int l15, int lg) {
+    if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        u32x4 pa[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float f[8] = {t0[s][0], t0[s][1], t0[s][2], t0[s][3], t1[s][0], t1[s][1], t1[s][2], t1[s][3]};
+            pa[s] = Chunk<bf16_t>::pack(f);
+        }
+        const int r0 = kbase + lg * 4 + (l15 >> 2), r1 = r0 + 16;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int col = dt * 16 + (l15 & 3) * 4;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + sa_off<ROWB>(r0, col >> 3) + ((col & 4) << 1)));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + sa_off<ROWB>(r1, col >> 3) + ((col & 4) << 1)));
+            const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+            const u32x4 vb = {a[0], a[1], b[0], b[1]};
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                acc[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa[s]),
+                                                                    __builtin_bit_cast(bf16x8, vb), acc[s][dt], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kbase + half * 16 + lg * 4 + r;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int d = dt * 16 + l15;
+                    const float b = *reinterpret_cast<const float*>(lds + sa_off<ROWB>(row, d >> 2) + (d & 3) * 4);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        acc[s][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(half == 0 ? t0[s][r] : t1[s][r], b, acc[s][dt], 0, 0, 0);
+                }
+            }
+    }
+}
 
 template <typename T, int D>
 struct SA {
@@ -43,15 +104,28 @@ struct SA {
     static constexpr int STEPS = DCH / 4;              // MFMA k-steps over d
     static constexpr int DT = D / 16;                  // 16-wide output tiles over d
     static constexpr int CHUNK_BYTES = SA_CHUNK * ROWB;
+    static constexpr int NLD = SA_CHUNK * DCH / SA_THREADS;   // 16-byte loads per thread per chunk
 
-    // stage `rows` (<= SA_CHUNK) rows starting at global row r0; rows >= nvalid are zero
-    static DEVINL void stage(char* lds, const T* __restrict__ g, long rs, int r0, int nvalid) {
-        for (int i = threadIdx.x; i < SA_CHUNK * DCH; i += SA_THREADS) {
-            const int r = i / DCH, c = i - r * DCH;
-            const u32x4 v = (r0 + r) < nvalid ? ld_chunk(g + (size_t)(r0 + r) * rs + c * EPC) : zero_chunk();
-            st_chunk(lds + sa_off<ROWB>(r, c), v);
+    // one 64-row chunk in flight: global -> registers (load), registers -> LDS image (store)
+    struct Stager {
+        u32x4 r[NLD];
+        DEVINL void load(const T* __restrict__ g, long rs, int r0, int nvalid) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int i = threadIdx.x + j * SA_THREADS;
+                const int row = i / DCH, c = i - row * DCH;
+                r[j] = (r0 + row) < nvalid ? ld_chunk(g + (size_t)(r0 + row) * rs + c * EPC) : zero_chunk();
+            }
         }
-    }
+        DEVINL void store(char* lds) const {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int i = threadIdx.x + j * SA_THREADS;
+                const int row = i / DCH, c = i - row * DCH;
+                st_chunk(lds + sa_off<ROWB>(row, c), r[j]);
+            }
+        }
+    };
     static DEVINL void lds_frags(u32x4 (&f)[STEPS], const char* lds, int row0, int l15, int lg) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) f[s] = ld_chunk(lds + sa_off<ROWB>(row0 + l15, s * 4 + lg));
@@ -68,252 +142,391 @@ struct SA {
         for (int s = 0; s < STEPS; ++s) Mma<T>::run(acc, a[s], b[s]);
         return acc;
     }
-    // o(16 x D) += P(16 x 32) * M(32 x D), P as two C-layout tiles (rows kbase + {0,16} + lg*4 + r of M)
-    static DEVINL void pv(f32x4 (&o)[DT], const f32x4& t0, const f32x4& t1, const char* lds, int kbase, int l15, int lg) {
-        if constexpr (sizeof(T) == 2) {
-            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-            float f[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-            const u32x4 pa = Chunk<bf16_t>::pack(f);
-            const int r0 = kbase + lg * 4 + (l15 >> 2), r1 = r0 + 16;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int col = dt * 16 + (l15 & 3) * 4;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + sa_off<ROWB>(r0, col >> 3) + ((col & 4) << 1)));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + sa_off<ROWB>(r1, col >> 3) + ((col & 4) << 1)));
-                const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
-                const u32x4 vb = {a[0], a[1], b[0], b[1]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, vb), o[dt], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = kbase + half * 16 + lg * 4 + r;
-                    const float a = half == 0 ? t0[r] : t1[r];
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        const int d = dt * 16 + l15;
-                        const float b = *reinterpret_cast<const float*>(lds + sa_off<ROWB>(row, d >> 2) + (d & 3) * 4);
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, o[dt], 0, 0, 0);
-                    }
-                }
-        }
-    }
 };
 
-// additive bias of (query q, key) in the S^T layout: the lane owns one query (its rel rows are
-// staged in LDS as rh[SA_Q16][Sh+1], rw[..][Sw+1]), keys vary
-DEVINL float sa_bias(const float* rh, const float* rw, int Sh, int Sw, int l15, int key, const float* kb) {
-    float b = kb ? kb[key] : 0.f;
-    if (rh) {
-        const int kh = key / Sw, kw = key - kh * Sw;
-        b += rh[l15 * (Sh + 1) + kh] + rw[l15 * (Sw + 1) + kw];
+// per-wavefront LDS tables of the rows of rel_h / rel_w it owns, pre-multiplied by log2(e)
+DEVINL void sa_load_tables(float* rh, float* rw, const SAParams& p, int bh, int q0, int lane) {
+    for (int i = lane; i < SA_WROWS * p.Sh; i += 64) {
+        const int r = i / p.Sh, c = i - r * p.Sh;
+        rh[r * (p.Sh + 1) + c] = (q0 + r) < p.Nq ? p.rel_h[((size_t)bh * p.Nq + q0 + r) * p.Sh + c] * LOG2E : 0.f;
     }
-    return b;
+    for (int i = lane; i < SA_WROWS * p.Sw; i += 64) {
+        const int r = i / p.Sw, c = i - r * p.Sw;
+        rw[r * (p.Sw + 1) + c] = (q0 + r) < p.Nq ? p.rel_w[((size_t)bh * p.Nq + q0 + r) * p.Sw + c] * LOG2E : 0.f;
+    }
+}
+
+// key -> (kh, kw) without an integer division: (key + 0.5) / Sw is never within 0.5 / Sw of an integer,
+// far outside the fp32 error for any key count this kernel can meet
+DEVINL void sa_split_key(int key, float inv_sw, int Sw, int& kh, int& kw) {
+    kh = (int)(((float)key + 0.5f) * inv_sw);
+    kw = key - kh * Sw;
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <typename T, int D>
+template <typename T, int D, int REL>
 __global__ __launch_bounds__(SA_THREADS) void sa_fwd_kernel(const SAParams p) {
     using S = SA<T, D>;
+    constexpr bool TAB = REL == 1 || REL == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
     char* Ks = smem;
     char* Vs = smem + S::CHUNK_BYTES;
-    float* relbuf = reinterpret_cast<float*>(smem + 2 * S::CHUNK_BYTES) + wave * 16 * (p.Sh + p.Sw + 2);
+    float* rh = reinterpret_cast<float*>(smem + 2 * S::CHUNK_BYTES) + wave * SA_WROWS * (p.Sh + p.Sw + 2);
+    float* rw = rh + SA_WROWS * (p.Sh + 1);
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
     const float* kb = p.key_bias ? p.key_bias + (size_t)b * p.Nk : nullptr;
-    const int q0 = blockIdx.x * 128 + wave * 16;
-    const bool has_rel = p.rel_h != nullptr;
-    float* rh = has_rel ? relbuf : nullptr;
-    float* rw = has_rel ? relbuf + 16 * (p.Sh + 1) : nullptr;
-    if (has_rel) {      // this wave's 16 query rows of rel_h / rel_w -> LDS (pitch S+1)
-        for (int i = lane; i < 16 * p.Sh; i += 64) {
-            const int r = i / p.Sh, c = i - r * p.Sh;
-            rh[r * (p.Sh + 1) + c] = (q0 + r) < p.Nq ? p.rel_h[((size_t)bh * p.Nq + q0 + r) * p.Sh + c] : 0.f;
-        }
-        for (int i = lane; i < 16 * p.Sw; i += 64) {
-            const int r = i / p.Sw, c = i - r * p.Sw;
-            rw[r * (p.Sw + 1) + c] = (q0 + r) < p.Nq ? p.rel_w[((size_t)bh * p.Nq + q0 + r) * p.Sw + c] : 0.f;
+    const int q0 = blockIdx.x * SA_BROWS + wave * SA_WROWS;
+    if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
+    float rwreg[2][16];
+    if constexpr (REL == 2) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = q0 + qt * 16 + l15;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (q < p.Nq) v = *reinterpret_cast<const f32x4*>(p.rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rwreg[qt][kt * 4 + r] = v[r] * LOG2E;
+            }
         }
     }
-    u32x4 qf[S::STEPS];
-    S::gmem_frags(qf, qg, p.q_rs, q0, p.Nq, l15, lg);
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4 o[S::DT];
+    u32x4 qf[2][S::STEPS];
+    S::gmem_frags(qf[0], qg, p.q_rs, q0, p.Nq, l15, lg);
+    S::gmem_frags(qf[1], qg, p.q_rs, q0 + 16, p.Nq, l15, lg);
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    f32x4 o[2][S::DT];
 #pragma unroll
-    for (int dt = 0; dt < S::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < S::DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float c2 = p.scale * LOG2E;
+    const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
+    typename S::Stager sk, sv;
+    sk.load(kg, p.k_rs, 0, p.Nk);
+    sv.load(vg, p.v_rs, 0, p.Nk);
 
     for (int k0 = 0; k0 < p.Nk; k0 += SA_CHUNK) {
         __syncthreads();                                  // previous chunk fully consumed
-        S::stage(Ks, kg, p.k_rs, k0, p.Nk);
-        S::stage(Vs, vg, p.v_rs, k0, p.Nk);
+        sk.store(Ks);
+        sv.store(Vs);
         __syncthreads();
-        f32x4 st[4];
-        float mx = -INFINITY;
+        if (k0 + SA_CHUNK < p.Nk) {                       // next chunk rides under this one's math
+            sk.load(kg, p.k_rs, k0 + SA_CHUNK, p.Nk);
+            sv.load(vg, p.v_rs, k0 + SA_CHUNK, p.Nk);
+        }
+        float rhc[2] = {0.f, 0.f};
+        if constexpr (REL == 2) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int q = q0 + qt * 16 + l15;
+                if (q < p.Nq) rhc[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6)] * LOG2E;
+            }
+        }
+        f32x4 st[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             u32x4 kf[S::STEPS];
             S::lds_frags(kf, Ks, kt * 16, l15, lg);
-            st[kt] = S::tile(kf, qf);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + kt * 16 + lg * 4 + r;
-                st[kt][r] = key < p.Nk ? st[kt][r] * p.scale + sa_bias(rh, rw, p.Sh, p.Sw, l15, key, kb) : -INFINITY;
-                mx = fmaxf(mx, st[kt][r]);
-            }
+            st[0][kt] = S::tile(kf, qf[0]);
+            st[1][kt] = S::tile(kf, qf[1]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = expf(m_run - m_new);          // first chunk: exp(-inf) = 0
-        m_run = m_new;
-        float psum = 0.f;
+        const bool tail = k0 + SA_CHUNK > p.Nk;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                st[kt][r] = expf(st[kt][r] - m_new);
-                psum += st[kt][r];
+                const int key = k0 + kt * 16 + lg * 4 + r;
+                float kbv = 0.f;
+                if (kb) kbv = key < p.Nk ? kb[key] * LOG2E : 0.f;
+                int kh = 0, kw = 0;
+                if constexpr (TAB) sa_split_key(key, inv_sw, p.Sw, kh, kw);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    float bias = kbv;
+                    if constexpr (REL == 2) bias += rhc[qt] + rwreg[qt][kt * 4 + r];
+                    if constexpr (TAB) bias += rh[(qt * 16 + l15) * (p.Sh + 1) + kh] + rw[(qt * 16 + l15) * (p.Sw + 1) + kw];
+                    float s = st[qt][kt][r] * c2 + bias;
+                    if (tail && key >= p.Nk) s = -INFINITY;
+                    st[qt][kt][r] = s;
+                }
             }
-        l_run = l_run * alpha + psum;                      // per-lane partial sum (same alpha on all lane groups)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float aq = __shfl(alpha, lg * 4 + r, 64);   // O rows are queries lg*4 + r
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
 #pragma unroll
-            for (int dt = 0; dt < S::DT; ++dt) o[dt][r] *= aq;
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = fast_exp2(m_run[qt] - m_new);       // first chunk: exp2(-inf) = 0
+            m_run[qt] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[qt][kt][r] = fast_exp2(st[qt][kt][r] - m_new);
+                    psum += st[qt][kt][r];
+                }
+            l_run[qt] = l_run[qt] * alpha + psum;         // per-lane partial (alpha is equal on all lane groups)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float aq = __shfl(alpha, lg * 4 + r, 64);     // O rows are queries lg*4 + r
+#pragma unroll
+                for (int dt = 0; dt < S::DT; ++dt) o[qt][dt][r] *= aq;
+            }
         }
-        S::pv(o, st[0], st[1], Vs, 0, l15, lg);
-        S::pv(o, st[2], st[3], Vs, 32, l15, lg);
+        {
+            const f32x4 a0[2] = {st[0][0], st[1][0]}, a1[2] = {st[0][1], st[1][1]};
+            pvN<T, S::ROWB, S::DT, 2>(o, a0, a1, Vs, 0, l15, lg);
+            const f32x4 b0[2] = {st[0][2], st[1][2]}, b1[2] = {st[0][3], st[1][3]};
+            pvN<T, S::ROWB, S::DT, 2>(o, b0, b1, Vs, 32, l15, lg);
+        }
     }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    if (lg == 0 && q0 + l15 < p.Nq) p.lse[(size_t)bh * p.Nq + q0 + l15] = m_run + logf(l_run);
-    const float inv = 1.f / l_run;
     T* og = (T*)p.out + (size_t)b * p.o_bs + h * D;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float iq = __shfl(inv, lg * 4 + r, 64);
-        const int q = q0 + lg * 4 + r;
-        if (q < p.Nq) {
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int qrow = q0 + qt * 16 + l15;
+        if (lg == 0 && qrow < p.Nq) p.lse[(size_t)bh * p.Nq + qrow] = (m_run[qt] + log2f(l)) * LN2;
+        const float inv = 1.f / l;
 #pragma unroll
-            for (int dt = 0; dt < S::DT; ++dt) og[(size_t)q * p.o_rs + dt * 16 + l15] = from_f32<T>(o[dt][r] * iq);
+        for (int r = 0; r < 4; ++r) {
+            const float iq = __shfl(inv, lg * 4 + r, 64);
+            const int q = q0 + qt * 16 + lg * 4 + r;
+            if (q < p.Nq) {
+#pragma unroll
+                for (int dt = 0; dt < S::DT; ++dt) og[(size_t)q * p.o_rs + dt * 16 + l15] = from_f32<T>(o[qt][dt][r] * iq);
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------ backward: dQ (+ D, d rel-pos)
-template <typename T, int D>
+// LDS: K chunk | V chunk | REL 1: indicator [256][32] | REL 1/3: per-wave tables | REL 3: per-wave gradient tables
+template <typename T, int D, int REL>
 __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p) {
     using S = SA<T, D>;
+    constexpr bool TAB = REL == 1 || REL == 3;
+    constexpr int EROWB = 32 * (int)sizeof(T);            // indicator rows: 32 columns
+    constexpr int EBYTES = REL == 1 ? 256 * EROWB : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
     char* Ks = smem;
     char* Vs = smem + S::CHUNK_BYTES;
-    const int relpitch = 16 * (p.Sh + p.Sw + 2);
-    float* relbuf = reinterpret_cast<float*>(smem + 2 * S::CHUNK_BYTES) + wave * 2 * relpitch;
+    char* Es = smem + 2 * S::CHUNK_BYTES;
+    const int tabw = SA_WROWS * (p.Sh + p.Sw + 2);
+    float* tabs = reinterpret_cast<float*>(smem + 2 * S::CHUNK_BYTES + EBYTES);
+    float* rh = tabs + wave * tabw * (REL == 3 ? 2 : 1);
+    float* rw = rh + SA_WROWS * (p.Sh + 1);
+    float* gh = rh + tabw;                                // REL 3 only
+    float* gw = gh + SA_WROWS * (p.Sh + 1);
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
     const T* og = (const T*)p.out + (size_t)b * p.o_bs + h * D;
     const T* dog = (const T*)p.dout + (size_t)b * p.o_bs + h * D;
     const float* kb = p.key_bias ? p.key_bias + (size_t)b * p.Nk : nullptr;
-    const int q0 = blockIdx.x * 128 + wave * 16;
-    const bool has_rel = p.rel_h != nullptr;
-    float* rh = has_rel ? relbuf : nullptr;
-    float* rw = has_rel ? relbuf + 16 * (p.Sh + 1) : nullptr;
-    float* gh = has_rel ? relbuf + relpitch : nullptr;         // gradient accumulators, same shape
-    float* gw = has_rel ? gh + 16 * (p.Sh + 1) : nullptr;
-    if (has_rel) {
-        for (int i = lane; i < 16 * p.Sh; i += 64) {
-            const int r = i / p.Sh, c = i - r * p.Sh;
-            rh[r * (p.Sh + 1) + c] = (q0 + r) < p.Nq ? p.rel_h[((size_t)bh * p.Nq + q0 + r) * p.Sh + c] : 0.f;
-            gh[r * (p.Sh + 1) + c] = 0.f;
-        }
-        for (int i = lane; i < 16 * p.Sw; i += 64) {
-            const int r = i / p.Sw, c = i - r * p.Sw;
-            rw[r * (p.Sw + 1) + c] = (q0 + r) < p.Nq ? p.rel_w[((size_t)bh * p.Nq + q0 + r) * p.Sw + c] : 0.f;
-            gw[r * (p.Sw + 1) + c] = 0.f;
+    const int q0 = blockIdx.x * SA_BROWS + wave * SA_WROWS;
+    const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
+    if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
+    if constexpr (REL == 3) {
+        for (int i = lane; i < tabw; i += 64) gh[i] = 0.f;
+    }
+    if constexpr (REL == 1) {        // E[key][kh] = E[key][Sh + kw] = 1
+        for (int i = threadIdx.x; i < 256 * 4 * (int)sizeof(T) / 2; i += SA_THREADS) {
+            constexpr int CPR = EROWB / 16;               // 16-byte chunks per row
+            const int row = i / CPR, ch = i - row * CPR;
+            int kh, kw;
+            sa_split_key(row, inv_sw, p.Sw, kh, kw);
+            float f[Chunk<T>::N];
+#pragma unroll
+            for (int j = 0; j < Chunk<T>::N; ++j) {
+                const int col = ch * Chunk<T>::N + j;
+                f[j] = (row < p.Nk && (col == kh || col == p.Sh + kw)) ? 1.f : 0.f;
+            }
+            st_chunk(Es + sa_off<EROWB>(row, ch), Chunk<T>::pack(f));
         }
     }
-    u32x4 qf[S::STEPS], dof[S::STEPS];
-    S::gmem_frags(qf, qg, p.q_rs, q0, p.Nq, l15, lg);
-    S::gmem_frags(dof, dog, p.o_rs, q0, p.Nq, l15, lg);
-    const int q = q0 + l15;
-    const bool qok = q < p.Nq;
-    // D[q] = sum_d dO*O: this lane covers chunks s*4+lg of its query row
-    float dsum = 0.f;
-    if (qok) {
+    float rwreg[2][16], gwreg[2][16];
+    if constexpr (REL == 2) {
 #pragma unroll
-        for (int s = 0; s < S::STEPS; ++s) {
-            float a[Chunk<T>::N], c[Chunk<T>::N];
-            Chunk<T>::unpack(dof[s], a);
-            Chunk<T>::unpack(ld_chunk(og + (size_t)q * p.o_rs + (s * 4 + lg) * S::EPC), c);
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = q0 + qt * 16 + l15;
 #pragma unroll
-            for (int k = 0; k < Chunk<T>::N; ++k) dsum += a[k] * c[k];
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (q < p.Nq) v = *reinterpret_cast<const f32x4*>(p.rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rwreg[qt][kt * 4 + r] = v[r] * LOG2E; gwreg[qt][kt * 4 + r] = 0.f; }
+            }
         }
     }
-    dsum += __shfl_xor(dsum, 16, 64);
-    dsum += __shfl_xor(dsum, 32, 64);
-    if (lg == 0 && qok) p.dsum[(size_t)bh * p.Nq + q] = dsum;
-    const float lq = qok ? p.lse[(size_t)bh * p.Nq + q] : 0.f;
-    f32x4 o[S::DT];
+    u32x4 qf[2][S::STEPS], dof[2][S::STEPS];
+    float dsum[2], lq2[2];
+    bool qok[2];
 #pragma unroll
-    for (int dt = 0; dt < S::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < 2; ++qt) {
+        S::gmem_frags(qf[qt], qg, p.q_rs, q0 + qt * 16, p.Nq, l15, lg);
+        S::gmem_frags(dof[qt], dog, p.o_rs, q0 + qt * 16, p.Nq, l15, lg);
+        const int q = q0 + qt * 16 + l15;
+        qok[qt] = q < p.Nq;
+        float ds = 0.f;                                    // D[q] = sum_d dO * O
+        if (qok[qt]) {
+#pragma unroll
+            for (int s = 0; s < S::STEPS; ++s) {
+                float a[Chunk<T>::N], c[Chunk<T>::N];
+                Chunk<T>::unpack(dof[qt][s], a);
+                Chunk<T>::unpack(ld_chunk(og + (size_t)q * p.o_rs + (s * 4 + lg) * S::EPC), c);
+#pragma unroll
+                for (int k = 0; k < Chunk<T>::N; ++k) ds += a[k] * c[k];
+            }
+        }
+        ds += __shfl_xor(ds, 16, 64);
+        ds += __shfl_xor(ds, 32, 64);
+        dsum[qt] = ds;
+        if (lg == 0 && qok[qt]) p.dsum[(size_t)bh * p.Nq + q] = ds;
+        lq2[qt] = qok[qt] ? p.lse[(size_t)bh * p.Nq + q] * LOG2E : 0.f;
+    }
+    f32x4 o[2][S::DT];
+    f32x4 ge[2][2];                                        // REL 1: d rel tables, 32 columns
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int dt = 0; dt < S::DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ge[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ge[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c2 = p.scale * LOG2E;
+    typename S::Stager sk, sv;
+    sk.load(kg, p.k_rs, 0, p.Nk);
+    sv.load(vg, p.v_rs, 0, p.Nk);
 
     for (int k0 = 0; k0 < p.Nk; k0 += SA_CHUNK) {
         __syncthreads();
-        S::stage(Ks, kg, p.k_rs, k0, p.Nk);
-        S::stage(Vs, vg, p.v_rs, k0, p.Nk);
+        sk.store(Ks);
+        sv.store(Vs);
         __syncthreads();
-        f32x4 ds[4];
+        if (k0 + SA_CHUNK < p.Nk) {
+            sk.load(kg, p.k_rs, k0 + SA_CHUNK, p.Nk);
+            sv.load(vg, p.v_rs, k0 + SA_CHUNK, p.Nk);
+        }
+        float rhc[2] = {0.f, 0.f}, ghc[2] = {0.f, 0.f};
+        if constexpr (REL == 2) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int q = q0 + qt * 16 + l15;
+                if (q < p.Nq) rhc[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6)] * LOG2E;
+            }
+        }
+        f32x4 g[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             u32x4 kf[S::STEPS], vf[S::STEPS];
             S::lds_frags(kf, Ks, kt * 16, l15, lg);
             S::lds_frags(vf, Vs, kt * 16, l15, lg);
-            const f32x4 sv = S::tile(kf, qf);
-            const f32x4 dp = S::tile(vf, dof);
+            f32x4 sv2[2], dp[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                sv2[qt] = S::tile(kf, qf[qt]);
+                dp[qt] = S::tile(vf, dof[qt]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + kt * 16 + lg * 4 + r;
-                float g = 0.f;
-                if (key < p.Nk && qok) {
-                    const float pr = expf(sv[r] * p.scale + sa_bias(rh, rw, p.Sh, p.Sw, l15, key, kb) - lq);
-                    g = pr * (dp[r] - dsum);               // d logits
-                    if (has_rel) {
-                        const int kh = key / p.Sw, kw = key - kh * p.Sw;
-                        atomicAdd(&gh[l15 * (p.Sh + 1) + kh], g);
-                        atomicAdd(&gw[l15 * (p.Sw + 1) + kw], g);
+                const bool kok = key < p.Nk;
+                float kbv = 0.f;
+                if (kb) kbv = kok ? kb[key] * LOG2E : 0.f;
+                int kh = 0, kw = 0;
+                if constexpr (TAB) sa_split_key(key, inv_sw, p.Sw, kh, kw);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    float bias = kbv;
+                    if constexpr (REL == 2) bias += rhc[qt] + rwreg[qt][kt * 4 + r];
+                    if constexpr (TAB) bias += rh[(qt * 16 + l15) * (p.Sh + 1) + kh] + rw[(qt * 16 + l15) * (p.Sw + 1) + kw];
+                    const float pr = fast_exp2(sv2[qt][r] * c2 + bias - lq2[qt]);
+                    const float gv = (kok && qok[qt]) ? pr * (dp[qt][r] - dsum[qt]) : 0.f;      // d logits
+                    g[qt][kt][r] = gv;
+                    if constexpr (REL == 2) { gwreg[qt][kt * 4 + r] += gv; ghc[qt] += gv; }
+                    if constexpr (REL == 3) {
+                        if (kok && qok[qt]) {
+                            atomicAdd(&gh[(qt * 16 + l15) * (p.Sh + 1) + kh], gv);
+                            atomicAdd(&gw[(qt * 16 + l15) * (p.Sw + 1) + kw], gv);
+                        }
                     }
                 }
-                ds[kt][r] = g * p.scale;
             }
         }
-        S::pv(o, ds[0], ds[1], Ks, 0, l15, lg);            // dQ += dS K
-        S::pv(o, ds[2], ds[3], Ks, 32, l15, lg);
+        if constexpr (REL == 2) {       // the whole chunk is one kh row
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float v = ghc[qt];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int q = q0 + qt * 16 + l15;
+                if (lg == 0 && q < p.Nq) p.d_rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6)] = v;
+            }
+        }
+        {
+            const f32x4 a0[2] = {g[0][0], g[1][0]}, a1[2] = {g[0][1], g[1][1]};
+            const f32x4 b0[2] = {g[0][2], g[1][2]}, b1[2] = {g[0][3], g[1][3]};
+            pvN<T, S::ROWB, S::DT, 2>(o, a0, a1, Ks, 0, l15, lg);          // dQ += dS K   (scale applied at the end)
+            pvN<T, S::ROWB, S::DT, 2>(o, b0, b1, Ks, 32, l15, lg);
+            if constexpr (REL == 1) {
+                pvN<T, EROWB, 2, 2>(ge, a0, a1, Es, k0, l15, lg);          // d rel += dS E
+                pvN<T, EROWB, 2, 2>(ge, b0, b1, Es, k0 + 32, l15, lg);
+            }
+        }
     }
     T* dqg = (T*)p.dq + (size_t)b * p.q_bs + h * D;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qq = q0 + lg * 4 + r;
-        if (qq < p.Nq) {
+    for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int dt = 0; dt < S::DT; ++dt) dqg[(size_t)qq * p.q_rs + dt * 16 + l15] = from_f32<T>(o[dt][r]);
+        for (int r = 0; r < 4; ++r) {
+            const int qq = q0 + qt * 16 + lg * 4 + r;
+            if (qq < p.Nq) {
+#pragma unroll
+                for (int dt = 0; dt < S::DT; ++dt) dqg[(size_t)qq * p.q_rs + dt * 16 + l15] = from_f32<T>(o[qt][dt][r] * p.scale);
+                if constexpr (REL == 1) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int col = t * 16 + l15;
+                        if (col < p.Sh) p.d_rel_h[((size_t)bh * p.Nq + qq) * p.Sh + col] = ge[qt][t][r];
+                        else if (col < p.Sh + p.Sw) p.d_rel_w[((size_t)bh * p.Nq + qq) * p.Sw + col - p.Sh] = ge[qt][t][r];
+                    }
+                }
+            }
+        }
+    if constexpr (REL == 2) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = q0 + qt * 16 + l15;
+            if (q < p.Nq) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const f32x4 v = {gwreg[qt][kt * 4], gwreg[qt][kt * 4 + 1], gwreg[qt][kt * 4 + 2], gwreg[qt][kt * 4 + 3]};
+                    *reinterpret_cast<f32x4*>(p.d_rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4) = v;
+                }
+            }
         }
     }
-    if (has_rel) {      // LDS atomics of this wave are visible to the wave after its own waits
+    if constexpr (REL == 3) {       // this wavefront's LDS atomics are complete once its own counters drain
         __builtin_amdgcn_s_waitcnt(0);
-        for (int i = lane; i < 16 * p.Sh; i += 64) {
+        for (int i = lane; i < SA_WROWS * p.Sh; i += 64) {
             const int r = i / p.Sh, c = i - r * p.Sh;
             if (q0 + r < p.Nq) p.d_rel_h[((size_t)bh * p.Nq + q0 + r) * p.Sh + c] = gh[r * (p.Sh + 1) + c];
         }
-        for (int i = lane; i < 16 * p.Sw; i += 64) {
+        for (int i = lane; i < SA_WROWS * p.Sw; i += 64) {
             const int r = i / p.Sw, c = i - r * p.Sw;
             if (q0 + r < p.Nq) p.d_rel_w[((size_t)bh * p.Nq + q0 + r) * p.Sw + c] = gw[r * (p.Sw + 1) + c];
         }
@@ -321,84 +534,155 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
 }
 
 // ------------------------------------------------------------------------------------ backward: dK, dV
-// P / dS tiles in the un-swapped layout (col = key l15, rows = queries lg*4 + r)
-template <typename T, int D>
+// A wavefront owns 32 keys; queries stream in 64-row chunks (Q, dO, D, lse and, with a relative-position
+// bias, the chunk's rows of rel_h / rel_w).  P / dS tiles: rows = queries lg*4 + r, column = key l15.
+// REL 2 (Sw == 64): the block's 128 keys are two kh rows, so only two columns of rel_h are needed per
+// chunk; rel_w rows go through LDS as float4 with an XOR swizzle on (row >> 2) that keeps the four lane
+// groups (rows lg*4 + r) on disjoint banks.  Everything for chunk i+1 is fetched into registers during chunk i.
+DEVINL int sa_rw_off(int row, int kw) { return row * 64 + ((((kw >> 2) ^ (((row >> 2) & 3) << 2))) << 2) + (kw & 3); }
+
+template <typename T, int D, int REL>
 __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dkv_kernel(const SAParams p) {
     using S = SA<T, D>;
+    constexpr bool TAB = REL == 1 || REL == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     char* Qs = smem;
     char* Os = smem + S::CHUNK_BYTES;                      // dO chunk
     float* Dq = reinterpret_cast<float*>(smem + 2 * S::CHUNK_BYTES);
     float* Ls = Dq + SA_CHUNK;
+    float* rhs = Ls + SA_CHUNK;                            // TAB: [64][Sh + 1]      REL 2: [2][64]
+    float* rws = TAB ? rhs + SA_CHUNK * (p.Sh + 1) : rhs + 2 * SA_CHUNK;   // TAB: [64][Sw + 1]   REL 2: [64][64] swizzled
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
     const T* dog = (const T*)p.dout + (size_t)b * p.o_bs + h * D;
-    const int key0 = blockIdx.x * 128 + wave * 16;
-    const int key = key0 + l15;
-    const bool kok = key < p.Nk;
-    const float kbias = (p.key_bias && kok) ? p.key_bias[(size_t)b * p.Nk + key] : 0.f;
-    const int kh = (p.rel_h && kok) ? key / p.Sw : 0;
-    const int kw = (p.rel_h && kok) ? key - kh * p.Sw : 0;
-    u32x4 kf[S::STEPS], vf[S::STEPS];
-    S::gmem_frags(kf, kg, p.k_rs, key0, p.Nk, l15, lg);
-    S::gmem_frags(vf, vg, p.v_rs, key0, p.Nk, l15, lg);
-    f32x4 dv[S::DT], dk[S::DT];
+    const float* dsg = p.dsum + (size_t)bh * p.Nq;
+    const float* lsg = p.lse + (size_t)bh * p.Nq;
+    const int key0 = blockIdx.x * SA_BROWS + wave * SA_WROWS;
+    u32x4 kf[2][S::STEPS], vf[2][S::STEPS];
+    float kbias[2];
+    int khl[2], kwl[2];
+    bool kok[2];
 #pragma unroll
-    for (int dt = 0; dt < S::DT; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < 2; ++t) {
+        const int key = key0 + t * 16 + l15;
+        kok[t] = key < p.Nk;
+        kbias[t] = (p.key_bias && kok[t]) ? p.key_bias[(size_t)b * p.Nk + key] * LOG2E : 0.f;
+        khl[t] = kwl[t] = 0;
+        if constexpr (TAB) {
+            if (kok[t]) sa_split_key(key, 1.f / (float)p.Sw, p.Sw, khl[t], kwl[t]);
+        }
+        if constexpr (REL == 2) kwl[t] = key & 63;
+        S::gmem_frags(kf[t], kg, p.k_rs, key0 + t * 16, p.Nk, l15, lg);
+        S::gmem_frags(vf[t], vg, p.v_rs, key0 + t * 16, p.Nk, l15, lg);
+    }
+    f32x4 dv[2][S::DT], dk[2][S::DT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < S::DT; ++dt) { dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float c2 = p.scale * LOG2E;
+    typename S::Stager sq, so;
+    float pf_stat = 0.f, pf_rh = 0.f;                      // D / lse (tid < 128), rel_h column (tid < 128)
+    f32x4 pf_rw[4];
+    const float* rwg = REL == 2 ? p.rel_w + (size_t)bh * p.Nq * 64 : nullptr;
+    const float* rhg = REL == 2 ? p.rel_h + (size_t)bh * p.Nq * p.Sh + 2 * blockIdx.x : nullptr;
+    auto prefetch = [&](int q0) {
+        sq.load(qg, p.q_rs, q0, p.Nq);
+        so.load(dog, p.o_rs, q0, p.Nq);
+        if (tid < 2 * SA_CHUNK) {
+            const int r = q0 + (tid & 63);
+            pf_stat = r < p.Nq ? (tid < SA_CHUNK ? dsg[r] : lsg[r] * LOG2E) : 0.f;
+            if constexpr (REL == 2) pf_rh = r < p.Nq ? rhg[(size_t)r * p.Sh + (tid >> 6)] * LOG2E : 0.f;
+        }
+        if constexpr (REL == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = tid + j * SA_THREADS, row = i >> 4, c4 = i & 15;
+                pf_rw[j] = (q0 + row) < p.Nq ? *reinterpret_cast<const f32x4*>(rwg + (size_t)(q0 + row) * 64 + c4 * 4)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    prefetch(0);
 
     for (int q0 = 0; q0 < p.Nq; q0 += SA_CHUNK) {
         __syncthreads();
-        S::stage(Qs, qg, p.q_rs, q0, p.Nq);
-        S::stage(Os, dog, p.o_rs, q0, p.Nq);
-        for (int i = threadIdx.x; i < SA_CHUNK; i += SA_THREADS) {
-            const bool ok = q0 + i < p.Nq;
-            Dq[i] = ok ? p.dsum[(size_t)bh * p.Nq + q0 + i] : 0.f;
-            Ls[i] = ok ? p.lse[(size_t)bh * p.Nq + q0 + i] : 0.f;
+        sq.store(Qs);
+        so.store(Os);
+        if (tid < 2 * SA_CHUNK) {
+            Dq[tid] = pf_stat;                             // Dq[0..63] then Ls[0..63] (contiguous)
+            if constexpr (REL == 2) rhs[tid] = pf_rh;
         }
-        __syncthreads();
-        f32x4 pt[4], dst[4];
+        if constexpr (REL == 2) {
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            u32x4 qf[S::STEPS], dof[S::STEPS];
-            S::lds_frags(qf, Qs, qt * 16, l15, lg);
-            S::lds_frags(dof, Os, qt * 16, l15, lg);
-            const f32x4 sv = S::tile(qf, kf);              // rows queries, col key
-            const f32x4 dp = S::tile(dof, vf);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = qt * 16 + lg * 4 + r, qq = q0 + ql;
-                float pr = 0.f;
-                if (qq < p.Nq && kok) {
-                    float bias = kbias;
-                    if (p.rel_h)
-                        bias += p.rel_h[((size_t)bh * p.Nq + qq) * p.Sh + kh] + p.rel_w[((size_t)bh * p.Nq + qq) * p.Sw + kw];
-                    pr = expf(sv[r] * p.scale + bias - Ls[ql]);
-                }
-                pt[qt][r] = pr;
-                dst[qt][r] = pr * (dp[r] - Dq[ql]) * p.scale;
+            for (int j = 0; j < 4; ++j) {
+                const int i = tid + j * SA_THREADS, row = i >> 4, c4 = i & 15;
+                *reinterpret_cast<f32x4*>(rws + row * 64 + ((c4 ^ (((row >> 2) & 3) << 2)) << 2)) = pf_rw[j] * LOG2E;
             }
         }
-        S::pv(dv, pt[0], pt[1], Os, 0, l15, lg);           // dV += P^T dO
-        S::pv(dv, pt[2], pt[3], Os, 32, l15, lg);
-        S::pv(dk, dst[0], dst[1], Qs, 0, l15, lg);         // dK += dS^T Q
-        S::pv(dk, dst[2], dst[3], Qs, 32, l15, lg);
+        if constexpr (TAB) {
+            for (int i = tid; i < SA_CHUNK * p.Sh; i += SA_THREADS) {
+                const int r = i / p.Sh, c = i - r * p.Sh;
+                rhs[r * (p.Sh + 1) + c] = (q0 + r) < p.Nq ? p.rel_h[((size_t)bh * p.Nq + q0 + r) * p.Sh + c] * LOG2E : 0.f;
+            }
+            for (int i = tid; i < SA_CHUNK * p.Sw; i += SA_THREADS) {
+                const int r = i / p.Sw, c = i - r * p.Sw;
+                rws[r * (p.Sw + 1) + c] = (q0 + r) < p.Nq ? p.rel_w[((size_t)bh * p.Nq + q0 + r) * p.Sw + c] * LOG2E : 0.f;
+            }
+        }
+        __syncthreads();
+        if (q0 + SA_CHUNK < p.Nq) prefetch(q0 + SA_CHUNK);
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {             // 32 queries at a time
+            f32x4 pt[2][2], dst[2][2];                     // [key tile][query tile of the pair]
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int qt = pair * 2 + qq;
+                u32x4 qf[S::STEPS], dof[S::STEPS];
+                S::lds_frags(qf, Qs, qt * 16, l15, lg);
+                S::lds_frags(dof, Os, qt * 16, l15, lg);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 sv2 = S::tile(qf, kf[t]);  // rows queries, col key
+                    const f32x4 dp = S::tile(dof, vf[t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ql = qt * 16 + lg * 4 + r;
+                        float bias = kbias[t];
+                        if constexpr (TAB) bias += rhs[ql * (p.Sh + 1) + khl[t]] + rws[ql * (p.Sw + 1) + kwl[t]];
+                        if constexpr (REL == 2) bias += rhs[(wave >> 1) * SA_CHUNK + ql] + rws[sa_rw_off(ql, kwl[t])];
+                        float pr = fast_exp2(sv2[r] * c2 + bias - Ls[ql]);
+                        if (!(kok[t] && q0 + ql < p.Nq)) pr = 0.f;
+                        pt[t][qq][r] = pr;
+                        dst[t][qq][r] = pr * (dp[r] - Dq[ql]);
+                    }
+                }
+            }
+            const f32x4 p0[2] = {pt[0][0], pt[1][0]}, p1[2] = {pt[0][1], pt[1][1]};
+            const f32x4 d0[2] = {dst[0][0], dst[1][0]}, d1[2] = {dst[0][1], dst[1][1]};
+            pvN<T, S::ROWB, S::DT, 2>(dv, p0, p1, Os, pair * 32, l15, lg);      // dV += P^T dO
+            pvN<T, S::ROWB, S::DT, 2>(dk, d0, d1, Qs, pair * 32, l15, lg);      // dK += dS^T Q  (scale at the end)
+        }
     }
     T* dkg = (T*)p.dk + (size_t)b * p.k_bs + h * D;
     T* dvg = (T*)p.dv + (size_t)b * p.v_bs + h * D;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int kk = key0 + lg * 4 + r;
-        if (kk < p.Nk) {
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int dt = 0; dt < S::DT; ++dt) {
-                dkg[(size_t)kk * p.k_rs + dt * 16 + l15] = from_f32<T>(dk[dt][r]);
-                dvg[(size_t)kk * p.v_rs + dt * 16 + l15] = from_f32<T>(dv[dt][r]);
+        for (int r = 0; r < 4; ++r) {
+            const int kk = key0 + t * 16 + lg * 4 + r;
+            if (kk < p.Nk) {
+#pragma unroll
+                for (int dt = 0; dt < S::DT; ++dt) {
+                    dkg[(size_t)kk * p.k_rs + dt * 16 + l15] = from_f32<T>(dk[t][dt][r] * p.scale);
+                    dvg[(size_t)kk * p.v_rs + dt * 16 + l15] = from_f32<T>(dv[t][dt][r]);
+                }
             }
         }
-    }
 }
 
 template <typename K>
@@ -406,27 +690,41 @@ void sa_allow_lds(K k) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <typename T, int D>
+template <typename T, int D, int REL>
 int sa_launch(const SAParams& p, int which, hipStream_t st) {
     const size_t chunk = (size_t)SA_CHUNK * D * sizeof(T);
-    const size_t rel = p.rel_h ? (size_t)SA_WAVES * 16 * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
+    const size_t tab = (REL == 1 || REL == 3) ? (size_t)SA_WAVES * SA_WROWS * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
     if (which == 0) {
-        auto k = sa_fwd_kernel<T, D>;
+        auto k = sa_fwd_kernel<T, D, REL>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3((p.Nq + 127) / 128, p.B * p.H), dim3(SA_THREADS), 2 * chunk + rel, st, p);
+        hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS), 2 * chunk + tab, st, p);
     } else if (which == 1) {
-        auto k = sa_bwd_dq_kernel<T, D>;
+        auto k = sa_bwd_dq_kernel<T, D, REL>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3((p.Nq + 127) / 128, p.B * p.H), dim3(SA_THREADS), 2 * chunk + 2 * rel, st, p);
+        const size_t e = REL == 1 ? (size_t)256 * 32 * sizeof(T) : 0;
+        hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
+                           2 * chunk + e + tab * (REL == 3 ? 2 : 1), st, p);
     } else {
-        auto k = sa_bwd_dkv_kernel<T, D>;
+        auto k = sa_bwd_dkv_kernel<T, D, REL>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3((p.Nk + 127) / 128, p.B * p.H), dim3(SA_THREADS), 2 * chunk + 2 * SA_CHUNK * sizeof(float), st, p);
+        const size_t rel = REL == 2 ? (size_t)(2 * SA_CHUNK + SA_CHUNK * 64) * sizeof(float)
+                                    : REL ? (size_t)SA_CHUNK * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
+        hipLaunchKernelGGL(k, dim3((p.Nk + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
+                           2 * chunk + 2 * SA_CHUNK * sizeof(float) + rel, st, p);
     }
     return saicv::check_launch("attention_stream");
+}
+
+template <typename T>
+int sa_dispatch(int D, const SAParams& p, int which, hipStream_t st) {
+    if (D == 32) return sa_launch<T, 32, 0>(p, which, st);
+    if (!p.rel_h) return sa_launch<T, 64, 0>(p, which, st);
+    if (p.Sw == 64) return sa_launch<T, 64, 2>(p, which, st);
+    if (p.Sh + p.Sw <= 32 && p.Nk <= 256) return sa_launch<T, 64, 1>(p, which, st);
+    return sa_launch<T, 64, 3>(p, which, st);
 }
 
 }  // namespace
@@ -443,11 +741,12 @@ int attention_stream(int dtype, int D, int which, const void* desc_ptr, hipStrea
                   "attention_stream: strides must be multiples of %d elements (16-byte rows)", e);
     SAICV_REQUIRE((p.rel_h == nullptr) == (p.rel_w == nullptr), "attention_stream: rel_h and rel_w come together");
     if (p.rel_h) {
+        SAICV_REQUIRE(D == 64, "attention_stream: the relative-position bias is instantiated for head dim 64");
         SAICV_REQUIRE(p.Sh >= 1 && p.Sw >= 1 && p.Sh * p.Sw == p.Nk, "attention_stream: Sh*Sw must equal Nk");
-        SAICV_REQUIRE(p.Sh + p.Sw <= 160, "attention_stream: relative-position tables too wide for LDS");
+        SAICV_REQUIRE(p.Sh + p.Sw <= 128, "attention_stream: relative-position tables too wide for LDS");
     }
-    if (dtype == SAICV_DTYPE_BF16) return D == 64 ? sa_launch<bf16_t, 64>(p, which, st) : sa_launch<bf16_t, 32>(p, which, st);
-    return D == 64 ? sa_launch<float, 64>(p, which, st) : sa_launch<float, 32>(p, which, st);
+    if (dtype == SAICV_DTYPE_BF16) return sa_dispatch<bf16_t>(D, p, which, st);
+    return sa_dispatch<float>(D, p, which, st);
 }
 
 }  // namespace saicv

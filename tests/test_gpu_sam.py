@@ -39,6 +39,9 @@ CASES = [
     # b, heads, d, nq, nk, key_bias, rel (sh, sw)
     (2, 3, 64, 196, 196, False, (14, 14)),     # SAM window
     (1, 2, 64, 256, 256, False, (16, 16)),     # global block, several key chunks
+    (1, 2, 64, 192, 192, False, (3, 64)),      # Sw = 64: the register path of the 64x64 global blocks
+    (2, 1, 64, 320, 320, True, (5, 64)),       # same, more chunks, plus a key bias
+    (1, 1, 64, 400, 400, False, (20, 20)),     # generic table path (LDS atomics)
     (2, 2, 64, 200, 200, False, None),         # ragged tails, no bias
     (2, 8, 32, 100, 330, True, None),          # DETR cross-attention: head dim 32, additive key bias
     (2, 8, 32, 330, 330, True, None),          # DETR encoder self-attention
