@@ -170,6 +170,16 @@ int saicv_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B
 int saicv_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         void* dqkv, int B, int N, int H, int D, double scale, void* stream);
 
+/* SAM mask-loss statistics of logits [B, M, HW] against targets [B, HW] (fp32) in one pass:
+ * stats[b, m, 0..5] = { sum focal, sum sigmoid*t, sum sigmoid, sum t, #(x>thr & t>thr), #(x>thr | t>thr) }.
+ * Replaces SAMLoss.focal_loss / dice_loss / iou_predict_loss reductions
+ * (reference interactive_segmentation/losses.py:136-198).  stats is zeroed by the call. */
+int saicv_mask_loss_stats(int dtype, const void* logits, const float* targets, float* stats, int B, int M, size_t HW,
+                          double alpha, double gamma, double thr, void* stream);
+/* dlogits = coef[b,m,0] * dfocal/dx + (coef[b,m,1] * t + coef[b,m,2]) * sigmoid'(x) */
+int saicv_mask_loss_grad(int dtype, const void* logits, const float* targets, const float* coef, void* dlogits, int B,
+                         int M, size_t HW, double alpha, double gamma, void* stream);
+
 /* Streaming attention (any Nq / Nk, head dim 32 or 64, separate q / k / v with strides).
  * Replaces SAM Attention.forward + add_decomposed_rel_pos (reference interactive_segmentation/models/
  * segment_anything/image_encoder.py:116-184) and DETR's nn.MultiheadAttention calls with a float

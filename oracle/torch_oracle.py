@@ -241,3 +241,24 @@ def sam_encoder_forward(sd, x, patch=16, heads=12, blocks=12, window=14, global_
     t = sam_layernorm2d(F.conv2d(t, sd['neck.0.weight']), sd['neck.1.weight'], sd['neck.1.bias'])
     t = sam_layernorm2d(F.conv2d(t, sd['neck.2.weight'], padding=1), sd['neck.3.weight'], sd['neck.3.bias'])
     return t
+
+
+# ------------------------------------------------------------------------------ SAM losses
+def sam_per_mask_losses(inputs, targets, pred_ious, alpha=0.25, gamma=2, mask_threshold=0.0):
+    """SAMLoss.focal_loss / dice_loss / iou_predict_loss (reference interactive_segmentation/losses.py:136-198)
+    -> three [B, M] tensors, each already divided by the batch size."""
+    b = inputs.shape[0]
+    x = inputs.float()
+    t = targets.expand_as(inputs).float()
+    bce = F.binary_cross_entropy_with_logits(x, t, reduction='none')
+    p = torch.sigmoid(x)
+    pt = p * t + (1 - p) * (1 - t)
+    focal = ((alpha * t + (1 - alpha) * (1 - t)) * torch.pow(1. - pt, gamma) * bce).flatten(2).mean(dim=-1) / b
+    pf, tf = p.flatten(2), t.flatten(2)
+    dice = (1. - (2. * (pf * tf).sum(-1) + 1) / (pf.sum(-1) + tf.sum(-1) + 1)) / b
+    xi, ti = (x > mask_threshold).flatten(2), (t > mask_threshold).flatten(2)
+    inter = torch.sum(xi & ti, dim=-1).float()
+    union = torch.sum(xi | ti, dim=-1).float()
+    gt = torch.clamp(inter / torch.clamp(union, min=1e-6), min=0.0, max=1.0)
+    iou = F.mse_loss(pred_ious.float(), gt, reduction='none') / b
+    return focal, dice, iou

@@ -266,6 +266,14 @@ int saicv_attention_bwd(int dtype, const void* qkv, const void* out, const void*
                         void* dqkv, int B, int N, int H, int D, double scale, void* stream) {
     return attention_bwd(dtype, qkv, out, dout, lse, dqkv, B, N, H, D, scale, S(stream));
 }
+int saicv_mask_loss_stats(int dtype, const void* logits, const float* targets, float* stats, int B, int M, size_t HW,
+                          double alpha, double gamma, double thr, void* stream) {
+    return mask_loss_stats(dtype, logits, targets, stats, B, M, HW, alpha, gamma, thr, S(stream));
+}
+int saicv_mask_loss_grad(int dtype, const void* logits, const float* targets, const float* coef, void* dlogits, int B,
+                         int M, size_t HW, double alpha, double gamma, void* stream) {
+    return mask_loss_grad(dtype, logits, targets, coef, dlogits, B, M, HW, alpha, gamma, S(stream));
+}
 int saicv_attention_stream_fwd(int dtype, int D, const saicv_attn_desc* desc, void* stream) {
     if (!desc) { set_error("attention_stream: null descriptor"); return -1; }
     return attention_stream(dtype, D, 0, desc, S(stream));

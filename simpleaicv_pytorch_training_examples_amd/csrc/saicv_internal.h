@@ -23,6 +23,11 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
              int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st,
              float* dbias = nullptr);
 
+// maskloss.hip
+int mask_loss_stats(int dtype, const void* logits, const float* targets, float* stats, int B, int M, size_t HW,
+                    double alpha, double gamma, double thr, hipStream_t st);
+int mask_loss_grad(int dtype, const void* logits, const float* targets, const float* coef, void* dlogits, int B, int M,
+                   size_t HW, double alpha, double gamma, hipStream_t st);
 // attn_stream.hip: which = 0 forward, 1 dQ pass, 2 dK/dV pass; desc = const saicv_attn_desc*
 int attention_stream(int dtype, int D, int which, const void* desc, hipStream_t st);
 

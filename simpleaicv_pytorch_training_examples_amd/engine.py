@@ -70,7 +70,10 @@ class FlatArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad.as_strided(p.shape, p.stride(), o)
-                p._saicv_direct = True      # kernels may accumulate into p.grad in place (ops._arena_grad)
+                # kernels may accumulate into p.grad in place (ops._arena_grad) -- except for parameters a
+                # model marks as used several times per step (SAM decoder: 1 + decoder_iters passes),
+                # whose gradient is only complete when autograd's own accumulation node has run
+                p._saicv_direct = not getattr(p, '_saicv_multi_use', False)
         ops.bump_weights_epoch()
 
     def zero_grad(self):

@@ -171,3 +171,89 @@ def test_sam_encoder_gradient_checkpoint_equals_plain():
         grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
     for n in grads[0]:
         assert rel_err(grads[1][n], grads[0][n]) < 1e-4, n
+
+
+# ------------------------------------------------------------------------------------------ mask loss kernel
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_mask_loss_stats_kernel_matches_reference_formulas(dtype):
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.losses import SAMLoss
+    g = torch.Generator().manual_seed(5)
+    b, m, h, w = 3, 4, 64, 96
+    x = (torch.randn(b, m, h, w, generator=g) * 3).cuda().to(dtype)
+    t = (torch.rand(b, 1, h, w, generator=g) > 0.6).float().cuda()
+    ious = torch.rand(b, m, generator=g).cuda()
+    crit = SAMLoss()
+    xl = x.detach().clone().requires_grad_(True)
+    f, d, i = crit.per_mask_losses(xl, ious, t)
+    (f.sum() * 20 + d.sum() + i.sum()).backward()
+    xr = x.detach().float().clone().requires_grad_(True)
+    rf, rd, ri = O.sam_per_mask_losses(xr, t, ious)
+    (rf.sum() * 20 + rd.sum() + ri.sum()).backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-5      # the kernel computes in fp32 from the stored logits
+    assert rel_err(f, rf) < tol and rel_err(d, rd) < tol and rel_err(i, ri) < 1e-5
+    gtol = 1e-4 if dtype == torch.float32 else 1e-2     # bf16: the gradient is rounded to bf16 on store
+    assert rel_err(xl.grad, xr.grad) < gtol
+
+
+def test_sam_full_model_two_pass_matches_reference():
+    """SAM (encoder + prompt encoder + mask decoder) + SAMLoss, two decoder passes, against the fixture
+    produced by the reference modules (oracle/make_golden_sam.py: sam_case)."""
+    from oracle.make_golden_sam import sam_inputs, sam_two_pass_loss
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.models.segment_anything import sam
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation import losses
+    fx = load_golden('sam_tiny_two_pass')
+    torch.manual_seed(fx['model_seed'])
+    model = sam.SAM(**fx['kwargs'])
+    O.sam_randomize_zero_init(model.named_parameters(), fx['model_seed'] + 100)
+    model = model.cuda().train()
+    crit = losses.SAMLoss(alpha=0.25, gamma=2, focal_loss_weight=20, dice_loss_weight=1, iou_predict_loss_weight=1,
+                          supervise_all_iou=True, mask_threshold=0.0)
+    images, masks, points, boxes = sam_inputs(fx['kwargs'], fx['batch'], fx['data_seed'])
+    assert abs(float(images.double().sum() + masks.double().sum() + points.double().sum()) - fx['input_checksum']) < 1e-6
+    ld, total, mps, ips = sam_two_pass_loss(model, crit, images.cuda(), masks.cuda(), points.cuda(), boxes.cuda(),
+                                            fx['kwargs']['image_size'])
+    total.backward()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert rel_err(mps[k][:, :, ::16, ::16], fx['mask_preds_sample'][k]) < 1e-3
+        assert rel_err(torch.nn.functional.avg_pool2d(mps[k].float(), 4), fx['mask_preds_lowres'][k]) < 1e-3
+        assert rel_err(ips[k], fx['iou_preds'][k]) < 1e-3
+    for k, v in fx['loss'].items():
+        assert abs(float(ld[k]) - v) < 1e-3 * max(abs(v), 1e-3), (k, float(ld[k]), v)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if n in fx['no_grad_params']:
+            continue
+        assert p.grad is not None, n
+        ref_n = fx['grad_norm'][n]
+        assert abs(float(p.grad.norm()) - ref_n) <= 1e-2 * max(ref_n, 1e-6), (n, float(p.grad.norm()), ref_n)
+        if ref_n > 1e-7:
+            e = rel_err(p.grad.flatten()[:64], fx['grad_sample'][n])
+            worst = max(worst, e)
+            assert e < 2e-2, (n, e)
+    print(f'sam_tiny_two_pass fp32: worst gradient-sample error {worst:.2e}')
+
+
+def test_sam_full_model_bf16_tracks_reference_autocast():
+    from oracle.make_golden_sam import sam_inputs, sam_two_pass_loss
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.models.segment_anything import sam
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation import losses
+    fx = load_golden('sam_tiny_two_pass')
+    torch.manual_seed(fx['model_seed'])
+    model = sam.SAM(**fx['kwargs'])
+    O.sam_randomize_zero_init(model.named_parameters(), fx['model_seed'] + 100)
+    model = model.cuda().train()
+    crit = losses.SAMLoss()
+    images, masks, points, boxes = sam_inputs(fx['kwargs'], fx['batch'], fx['data_seed'])
+    ld, total, mps, ips = sam_two_pass_loss(model, crit, images.cuda(), masks.cuda(), points.cuda(), boxes.cuda(),
+                                            fx['kwargs']['image_size'], autocast_dtype=torch.bfloat16, device_type='cuda')
+    total.backward()
+    torch.cuda.synchronize()
+    noise = fx['reference_noise']
+    assert rel_err(mps[0][:, :, ::16, ::16].float(), fx['mask_preds_sample'][0]) < 1.5 * noise['bf16_masks'] + 2e-2
+    assert abs(float(total) - fx['total']) < (1.5 * noise['bf16_loss'] + 1e-2) * abs(fx['total'])
+    names = [n for n, p in model.named_parameters() if p.grad is not None and n in fx['grad_sample']]
+    a = torch.cat([dict(model.named_parameters())[n].grad.flatten()[:64].double().cpu() for n in names])
+    b = torch.cat([fx['grad_sample'][n].double() for n in names])
+    cos = float(a @ b / (a.norm() * b.norm()))
+    assert cos > noise['bf16_grad_sample_cos'] - 0.1, cos
