@@ -202,6 +202,8 @@ typedef struct saicv_attn_desc {
     int Sh, Sw;
     int B, H, Nq, Nk;
     float scale;
+    float dropout_p;                /* attention-probability dropout (0 = off); same seed in fwd and bwd */
+    unsigned int seed;
 } saicv_attn_desc;
 int saicv_attention_stream_fwd(int dtype, int D, const saicv_attn_desc* desc, void* stream);
 /* backward = dQ pass (also writes dsum and d_rel_*) followed by the dK/dV pass */

@@ -1,0 +1,149 @@
+"""DETR set-prediction loss -- drop-in for the reference DETRLoss (SimpleAICV/detection/losses.py:843-1095).
+
+Same constructor arguments and output keys (`layer_{i}_cls_loss`, `layer_{i}_box_l1_loss`, `layer_{i}_box_iou_loss`
+for the 6 decoder layers).  Semantics kept: boxes clamped to [1e-4, 1 - 1e-4]; ONE Hungarian matching per image on
+the LAST layer's outputs (cost = 1 * (-p[class]) + 5 * L1 + 2 * (-GIoU), probabilities clamped like the boxes) reused
+by every layer; weighted cross-entropy with the no-object class at 0.1; L1 and (1 - GIoU) summed over matched pairs
+and divided by the number of ground-truth boxes in the batch.  The assignment itself runs on the host with scipy,
+as in the reference (one [100, n_i] matrix per image); everything else is [B, 100, *] tensor arithmetic in fp32.
+"""
+import numpy as np
+import scipy.optimize
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = [
+    'DETRLoss',
+]
+
+
+def _cxcywh_to_xyxy(boxes):
+    cx, cy, w, h = boxes.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+
+def _giou(b1, b2):
+    """Generalised IoU of broadcastable [..., 4] xyxy boxes, with the reference's clamps (areas >= 0,
+    union and enclosing area >= 1e-4)."""
+    area1 = ((b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])).clamp(min=0)
+    area2 = ((b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])).clamp(min=0)
+    wh = (torch.min(b1[..., 2:], b2[..., 2:]) - torch.max(b1[..., :2], b2[..., :2])).clamp(min=0)
+    inter = (wh[..., 0] * wh[..., 1]).clamp(min=0)
+    union = (area1 + area2 - inter).clamp(min=1e-4)
+    ewh = (torch.max(b1[..., 2:], b2[..., 2:]) - torch.min(b1[..., :2], b2[..., :2])).clamp(min=0)
+    enclose = (ewh[..., 0] * ewh[..., 1]).clamp(min=1e-4)
+    return inter / union - (enclose - union) / enclose
+
+
+class DETRLoss(nn.Module):
+
+    def __init__(self, cls_match_cost=1.0, box_match_cost=5.0, giou_match_cost=2.0, cls_loss_weight=1.0,
+                 box_l1_loss_weight=5.0, iou_loss_weight=2.0, no_object_cls_weight=0.1, num_classes=80):
+        super(DETRLoss, self).__init__()
+        self.cls_match_cost = cls_match_cost
+        self.box_match_cost = box_match_cost
+        self.giou_match_cost = giou_match_cost
+        self.cls_loss_weight = cls_loss_weight
+        self.box_l1_loss_weight = box_l1_loss_weight
+        self.iou_loss_weight = iou_loss_weight
+        self.no_object_cls_weight = no_object_cls_weight
+        self.num_classes = num_classes
+        assert self.cls_match_cost != 0 or self.box_match_cost != 0 or self.giou_match_cost != 0, "all costs cant be 0"
+
+    def forward(self, preds, annotations):
+        cls_preds, reg_preds = preds
+        reg_preds = torch.clamp(reg_preds, min=1e-4, max=1. - 1e-4).float()
+        cls_preds = cls_preds.float()
+        annotations = annotations.float()
+        indices = self.get_matched_pred_target_idxs(cls_preds[-1], reg_preds[-1], annotations)
+        # flat (image, query) <-> ground-truth correspondence, shared by all layers
+        valid = [a[a[:, 4] >= 0] for a in annotations]
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)]).to(cls_preds.device)
+        src_idx = torch.cat([src for src, _ in indices]).to(cls_preds.device)
+        matched = torch.cat([v[j.to(v.device)] for v, (_, j) in zip(valid, indices)], dim=0)     # [n, 5]
+        target_num = sum(v.shape[0] for v in valid)
+        loss_dict = {}
+        for idx, (layer_cls, layer_reg) in enumerate(zip(cls_preds, reg_preds)):
+            cls_loss = self._cls_loss(layer_cls, batch_idx, src_idx, matched[:, 4])
+            l1_loss, iou_loss = self._box_losses(layer_reg[batch_idx, src_idx], matched[:, 0:4], target_num)
+            loss_dict[f'layer_{idx}_cls_loss'] = self.cls_loss_weight * cls_loss
+            loss_dict[f'layer_{idx}_box_l1_loss'] = self.box_l1_loss_weight * l1_loss
+            loss_dict[f'layer_{idx}_box_iou_loss'] = self.iou_loss_weight * iou_loss
+        return loss_dict
+
+    def _cls_loss(self, cls_preds, batch_idx, src_idx, target_classes):
+        b, q = cls_preds.shape[0], cls_preds.shape[1]
+        gt = torch.full((b, q), self.num_classes, dtype=torch.long, device=cls_preds.device)
+        gt[batch_idx, src_idx] = target_classes.long()
+        weight = torch.ones(self.num_classes + 1, device=cls_preds.device)
+        weight[-1] = self.no_object_cls_weight
+        return F.cross_entropy(cls_preds.transpose(1, 2), gt, weight)
+
+    def _box_losses(self, matched_preds, target_boxes, target_num):
+        l1 = F.l1_loss(matched_preds, target_boxes, reduction='none').sum() / target_num
+        giou = _giou(_cxcywh_to_xyxy(matched_preds), _cxcywh_to_xyxy(target_boxes))
+        return l1, (1 - giou).sum() / target_num
+
+    # reference-named views of the same computations (used by its tests / tools)
+    def compute_batch_cls_loss(self, cls_preds, annotations, indices):
+        valid = [a[a[:, 4] >= 0] for a in annotations]
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)]).to(cls_preds.device)
+        src_idx = torch.cat([src for src, _ in indices]).to(cls_preds.device)
+        classes = torch.cat([v[j.to(v.device), 4] for v, (_, j) in zip(valid, indices)])
+        return self._cls_loss(cls_preds, batch_idx, src_idx, classes)
+
+    def compute_batch_l1_iou_loss(self, reg_preds, annotations, indices):
+        valid = [a[a[:, 4] >= 0] for a in annotations]
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)]).to(reg_preds.device)
+        src_idx = torch.cat([src for src, _ in indices]).to(reg_preds.device)
+        boxes = torch.cat([v[j.to(v.device), 0:4] for v, (_, j) in zip(valid, indices)], dim=0)
+        return self._box_losses(reg_preds[batch_idx, src_idx], boxes, sum(v.shape[0] for v in valid))
+
+    def transform_cxcywh_box_to_xyxy_box(self, boxes):
+        return _cxcywh_to_xyxy(boxes)
+
+    def compute_box_giou(self, boxes1, boxes2):
+        """[N, 4] x [M, 4] xyxy -> [N, M] pairwise GIoU."""
+        return _giou(boxes1[:, None, :], boxes2[None, :, :])
+
+    @torch.no_grad()
+    def get_matched_pred_target_idxs(self, cls_preds, reg_preds, annotations):
+        b, q = cls_preds.shape[0], cls_preds.shape[1]
+        prob = torch.clamp(F.softmax(cls_preds.flatten(0, 1), dim=-1), min=1e-4, max=1. - 1e-4)
+        boxes = reg_preds.flatten(0, 1)
+        valid = [a[a[:, 4] >= 0] for a in annotations]
+        counts = [v.shape[0] for v in valid]
+        gt = torch.cat(valid, dim=0)
+        cls_cost = -prob[:, gt[:, 4].long()]
+        box_cost = torch.cdist(boxes, gt[:, 0:4], p=1)
+        giou_cost = -self.compute_box_giou(_cxcywh_to_xyxy(boxes), _cxcywh_to_xyxy(gt[:, 0:4]))
+        total = (self.cls_match_cost * cls_cost + self.box_match_cost * box_cost +
+                 self.giou_match_cost * giou_cost).view(b, q, -1).cpu()      # ONE device->host copy per step
+        indices = []
+        for i, block in enumerate(total.split(counts, -1)):
+            rows, cols = self.linear_sum_assignment_with_inf(block[i].numpy())
+            indices.append((torch.as_tensor(rows, dtype=torch.int64), torch.as_tensor(cols, dtype=torch.int64)))
+        return indices
+
+    def linear_sum_assignment_with_inf(self, cost_matrix):
+        """scipy's assignment, tolerating nan (-> 1e5) and one-signed infinities (-> a finite value beyond any
+        achievable total), as the reference does."""
+        cost_matrix = np.array(cost_matrix, copy=True)
+        if np.isnan(cost_matrix).any():
+            cost_matrix[np.isnan(cost_matrix)] = 1e5
+        min_inf = np.isneginf(cost_matrix).any()
+        max_inf = np.isposinf(cost_matrix).any()
+        if min_inf and max_inf:
+            raise ValueError("matrix contains both inf and -inf")
+        if min_inf or max_inf:
+            values = cost_matrix[~np.isinf(cost_matrix)]
+            lo, hi = values.min(), values.max()
+            m = min(cost_matrix.shape)
+            positive = m * (hi - lo + np.abs(hi) + np.abs(lo) + 1)
+            if max_inf:
+                place_holder = (hi + (m - 1) * (hi - lo)) + positive
+            else:
+                place_holder = (lo + (m - 1) * (lo - hi)) - positive
+            cost_matrix[np.isinf(cost_matrix)] = place_holder
+        return scipy.optimize.linear_sum_assignment(cost_matrix)

@@ -35,7 +35,7 @@ class AttnDesc(Structure):
                 ('lse', _P), ('dsum', _P), ('key_bias', _P), ('rel_h', _P), ('rel_w', _P),
                 ('d_rel_h', _P), ('d_rel_w', _P),
                 ('Sh', c_int), ('Sw', c_int), ('B', c_int), ('H', c_int), ('Nq', c_int), ('Nk', c_int),
-                ('scale', c_float)]
+                ('scale', c_float), ('dropout_p', c_float), ('seed', ctypes.c_uint32)]
 
 
 _PA = POINTER(AttnDesc)

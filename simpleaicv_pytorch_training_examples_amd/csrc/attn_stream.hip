@@ -51,6 +51,19 @@ template <> DEVINL int sa_off<256>(int row, int chunk) { return row * 256 + (((c
 
 DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// attention-probability dropout (nn.MultiheadAttention(dropout=p) in DETR): a counter-based hash of
+// (seed, batch*head, query, key) decides, identically in the forward and both backward kernels,
+// whether P[q, key] survives; survivors are scaled by 1 / (1 - p).  The softmax normaliser and the
+// saved log-sum-exp are those of the undropped probabilities.
+DEVINL bool sa_keep(unsigned seed, int bh, int q, int key, int Nk, unsigned thresh) {
+    unsigned h = (unsigned)q * (unsigned)Nk + (unsigned)key;
+    h ^= seed;
+    h += (unsigned)bh * 0x9E3779B9u;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h >= thresh;
+}
+DEVINL unsigned sa_thresh(float p) { return (unsigned)fminf(p * 4294967296.f, 4294967040.f); }
+
 // acc[s][dt] += A_s(16 x 32) * M(32 x 16*DT): A_s given as two C-layout tiles t0[s], t1[s] (lane: A row l15,
 // k = kbase + {0,16} + lg*4 + r), M an LDS image with ROWB-byte rows = k.  The B fragments are read once
 // and shared by the NS row sets.
@@ -205,6 +218,9 @@ __global__ __launch_bounds__(SA_THREADS) void sa_fwd_kernel(const SAParams p) {
 #pragma unroll
         for (int dt = 0; dt < S::DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c2 = p.scale * LOG2E;
+    const bool drop = p.dropout_p > 0.f;
+    const unsigned dthresh = sa_thresh(p.dropout_p);
+    const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
     typename S::Stager sk, sv;
     sk.load(kg, p.k_rs, 0, p.Nk);
@@ -282,6 +298,16 @@ __global__ __launch_bounds__(SA_THREADS) void sa_fwd_kernel(const SAParams p) {
 #pragma unroll
                 for (int dt = 0; dt < S::DT; ++dt) o[qt][dt][r] *= aq;
             }
+        }
+        if (drop) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        st[qt][kt][r] = sa_keep(p.seed, bh, q0 + qt * 16 + l15, k0 + kt * 16 + lg * 4 + r, p.Nk, dthresh)
+                                            ? st[qt][kt][r] * inv_keep : 0.f;
         }
         {
             const f32x4 a0[2] = {st[0][0], st[1][0]}, a1[2] = {st[0][1], st[1][1]};
@@ -408,6 +434,9 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
         ge[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float c2 = p.scale * LOG2E;
+    const bool drop = p.dropout_p > 0.f;
+    const unsigned dthresh = sa_thresh(p.dropout_p);
+    const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     typename S::Stager sk, sv;
     sk.load(kg, p.k_rs, 0, p.Nk);
     sv.load(vg, p.v_rs, 0, p.Nk);
@@ -455,7 +484,9 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
                     if constexpr (REL == 2) bias += rhc[qt] + rwreg[qt][kt * 4 + r];
                     if constexpr (TAB) bias += rh[(qt * 16 + l15) * (p.Sh + 1) + kh] + rw[(qt * 16 + l15) * (p.Sw + 1) + kw];
                     const float pr = fast_exp2(sv2[qt][r] * c2 + bias - lq2[qt]);
-                    const float gv = (kok && qok[qt]) ? pr * (dp[qt][r] - dsum[qt]) : 0.f;      // d logits
+                    float dpe = dp[qt][r];
+                    if (drop) dpe = sa_keep(p.seed, bh, q0 + qt * 16 + l15, key, p.Nk, dthresh) ? dpe * inv_keep : 0.f;
+                    const float gv = (kok && qok[qt]) ? pr * (dpe - dsum[qt]) : 0.f;      // d logits
                     g[qt][kt][r] = gv;
                     if constexpr (REL == 2) { gwreg[qt][kt * 4 + r] += gv; ghc[qt] += gv; }
                     if constexpr (REL == 3) {
@@ -585,6 +616,9 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dkv_kernel(const SAParams p
 #pragma unroll
         for (int dt = 0; dt < S::DT; ++dt) { dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float c2 = p.scale * LOG2E;
+    const bool drop = p.dropout_p > 0.f;
+    const unsigned dthresh = sa_thresh(p.dropout_p);
+    const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     typename S::Stager sq, so;
     float pf_stat = 0.f, pf_rh = 0.f;                      // D / lse (tid < 128), rel_h column (tid < 128)
     f32x4 pf_rw[4];
@@ -657,8 +691,10 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dkv_kernel(const SAParams p
                         if constexpr (REL == 2) bias += rhs[(wave >> 1) * SA_CHUNK + ql] + rws[sa_rw_off(ql, kwl[t])];
                         float pr = fast_exp2(sv2[r] * c2 + bias - Ls[ql]);
                         if (!(kok[t] && q0 + ql < p.Nq)) pr = 0.f;
-                        pt[t][qq][r] = pr;
-                        dst[t][qq][r] = pr * (dp[r] - Dq[ql]);
+                        float keepf = 1.f;
+                        if (drop) keepf = sa_keep(p.seed, bh, q0 + ql, key0 + t * 16 + l15, p.Nk, dthresh) ? inv_keep : 0.f;
+                        pt[t][qq][r] = pr * keepf;
+                        dst[t][qq][r] = pr * (dp[r] * keepf - Dq[ql]);
                     }
                 }
             }
@@ -739,6 +775,7 @@ int attention_stream(int dtype, int D, int which, const void* desc_ptr, hipStrea
     SAICV_REQUIRE(p.q_rs % e == 0 && p.k_rs % e == 0 && p.v_rs % e == 0 && p.o_rs % e == 0 &&
                       p.q_bs % e == 0 && p.k_bs % e == 0 && p.v_bs % e == 0 && p.o_bs % e == 0,
                   "attention_stream: strides must be multiples of %d elements (16-byte rows)", e);
+    SAICV_REQUIRE(p.dropout_p >= 0.f && p.dropout_p < 1.f, "attention_stream: dropout_p=%f outside [0, 1)", (double)p.dropout_p);
     SAICV_REQUIRE((p.rel_h == nullptr) == (p.rel_w == nullptr), "attention_stream: rel_h and rel_w come together");
     if (p.rel_h) {
         SAICV_REQUIRE(D == 64, "attention_stream: the relative-position bias is instantiated for head dim 64");

@@ -146,7 +146,7 @@ def attn_bwd(qkv, out, dout, lse, b, n, heads, scale):
     return dqkv
 
 
-def _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w):
+def _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w, dropout_p=0.0, seed=0):
     """q [B, Nq, H*D], k / v [B, Nk, H*D]: any batch / row strides, unit stride on the last axis."""
     b, nq, c = q.shape
     nk = k.shape[1]
@@ -160,6 +160,7 @@ def _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w):
     d.v_bs, d.v_rs = v.stride(0), v.stride(1)
     d.B, d.H, d.Nq, d.Nk = b, heads, nq, nk
     d.scale = float(scale)
+    d.dropout_p, d.seed = float(dropout_p), int(seed) & 0xffffffff
     if key_bias is not None:
         if key_bias.dtype != torch.float32 or tuple(key_bias.shape) != (b, nk) or not key_bias.is_contiguous():
             raise ValueError('key_bias must be a contiguous fp32 [B, Nk] tensor')
@@ -173,9 +174,9 @@ def _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w):
     return d, c // heads
 
 
-def sattn_fwd(q, k, v, heads, scale, key_bias=None, rel_h=None, rel_w=None):
+def sattn_fwd(q, k, v, heads, scale, key_bias=None, rel_h=None, rel_w=None, dropout_p=0.0, seed=0):
     """Streaming attention forward -> (out [B, Nq, C], lse [B*H, Nq])."""
-    d, hd = _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w)
+    d, hd = _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w, dropout_p, seed)
     out = torch.empty((d.B, d.Nq, q.shape[2]), dtype=q.dtype, device=q.device)
     lse = torch.empty((d.B * heads, d.Nq), dtype=torch.float32, device=q.device)
     d.out, d.o_bs, d.o_rs, d.lse = ptr(out), out.stride(0), out.stride(1), ptr(lse)
@@ -183,10 +184,11 @@ def sattn_fwd(q, k, v, heads, scale, key_bias=None, rel_h=None, rel_w=None):
     return out, lse
 
 
-def sattn_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv, key_bias=None, rel_h=None, rel_w=None):
+def sattn_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv, key_bias=None, rel_h=None, rel_w=None,
+              dropout_p=0.0, seed=0):
     """Streaming attention backward into dq / dk / dv (tensors or views with the strides of q / k / v).
     -> (d_rel_h, d_rel_w) or (None, None)."""
-    d, hd = _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w)
+    d, hd = _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w, dropout_p, seed)
     for g, t in ((dq, q), (dk, k), (dv, v)):
         if g.stride() != t.stride() or g.dtype != t.dtype:
             raise ValueError('gradient views must share strides and dtype with their operands')
@@ -314,29 +316,32 @@ class StreamAttentionFn(torch.autograd.Function):
     key_bias [B, Nk] fp32 is ADDED to the logits (DETR's float key_padding_mask, detr.py:252-260)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale, key_bias):
+    def forward(ctx, q, k, v, heads, scale, key_bias, dropout_p):
         require_gpu(q, k, v)
-        out, lse = sattn_fwd(q, k, v, heads, scale, key_bias)
+        # the mask is a pure function of (seed, head, query, key): drawing the seed on the host generator
+        # costs no device sync and lets backward (and checkpoint re-forward) regenerate the same mask
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if dropout_p > 0 else 0
+        out, lse = sattn_fwd(q, k, v, heads, scale, key_bias, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(q, k, v, out, lse, key_bias)
-        ctx.cfg = (heads, scale)
+        ctx.cfg = (heads, scale, dropout_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse, key_bias = ctx.saved_tensors
-        heads, scale = ctx.cfg
+        heads, scale, dropout_p, seed = ctx.cfg
         dout = dout.contiguous()
         if dout.dtype != q.dtype:
             dout = dout.to(q.dtype)
         dq, dk, dv = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device), \
             torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device), \
             torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
-        sattn_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv, key_bias)
-        return dq, dk, dv, None, None, None
+        sattn_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv, key_bias, dropout_p=dropout_p, seed=seed)
+        return dq, dk, dv, None, None, None, None
 
 
-def stream_attention(q, k, v, heads, scale, key_bias=None):
-    return StreamAttentionFn.apply(q, k, v, heads, scale, key_bias)
+def stream_attention(q, k, v, heads, scale, key_bias=None, dropout_p=0.0):
+    return StreamAttentionFn.apply(q, k, v, heads, scale, key_bias, float(dropout_p))
 
 
 # ------------------------------------------------------------------------------ fused ViT sub-layers

@@ -181,3 +181,115 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
         iter_index += 1
     drain(0)
     return losses.avg * acc_steps
+
+
+def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, total_name, iter_width):
+    """Shared iteration engine of the dict-loss loops (detection here; the SAM loop in
+    interactive_segmentation_scripts.py follows the same scheme): `step_fn(data)` runs forward + loss and
+    returns (bad flag tensor, {name: loss tensor}, batch size).  Everything else -- accumulation, the single
+    packed all-reduce of [skip, total, terms...], device-side skip, clipping, scaler, EMA, scheduler, lagged
+    host reads and the reference log line -- is common."""
+    losses = AverageMeter()
+    local_rank = config.local_rank
+    main = local_rank == 0 and getattr(config, 'total_rank', 0) == 0
+    iters = len(train_loader.dataset) // config.batch_size
+    iter_index = 1
+    acc_steps = config.accumulation_steps
+    assert acc_steps >= 1, 'illegal accumulation_steps!'
+    lag = getattr(config, 'host_sync_lag', 2)
+    scaler = getattr(config, 'scaler', None) if config.use_amp else None
+    clip_norm = getattr(config, 'clip_max_norm', 0) or 0
+    if (getattr(config, 'clip_grad_value', 0) or 0) > 0:
+        raise NotImplementedError('clip_grad_value is not used by the hot-path configs')
+    pending = collections.deque()
+    carried_bad = None
+    keys = None
+
+    def drain(keep):
+        nonlocal iter_index
+        while len(pending) > keep:
+            packed, n, log_fmt = pending.popleft()
+            vals = packed.tolist()
+            if vals[0]:
+                if main:
+                    logger.info('skip this batch!')
+                iter_index -= 1
+                continue
+            loss = vals[1] / float(config.gpus_num)
+            losses.update(loss, n)
+            if log_fmt is not None and main:
+                terms = ''.join(f'{k}: {v / float(config.gpus_num) * acc_steps:.4f}, ' for k, v in zip(keys, vals[2:]))
+                logger.info(log_fmt.format(loss=loss * acc_steps) + terms)
+
+    for data in train_loader:
+        bad, loss_value, n = step_fn(data)
+        if keys is None:
+            keys = list(loss_value.keys())
+        loss = sum(loss_value.values())
+        terms = torch.stack([loss_value[k].detach().float() for k in keys]) / acc_steps
+        bad = bad | (loss == 0.) | ~torch.isfinite(loss) | ~torch.isfinite(terms).all()
+        loss = loss / acc_steps
+        boundary = iter_index % acc_steps == 0
+        scaled = scaler.scale(loss) if scaler is not None else loss
+        if boundary:
+            scaled.backward()
+        else:
+            with model.no_sync():
+                scaled.backward()
+        packed = torch.cat([torch.stack([bad.float(), loss.detach().float()]), terms])
+        if _dist_on(config.group):
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=config.group)
+        if carried_bad is not None:
+            packed = torch.cat([torch.maximum(packed[0:1], carried_bad), packed[1:]])
+        carried_bad = None if boundary else packed[0:1]
+        if boundary:
+            if hasattr(model, 'finish_gradient_sync'):
+                model.finish_gradient_sync()
+            skip_flag = packed[0:1]
+            if getattr(config, 'skip_inf_nan_grad', False) or scaler is not None:
+                optimizer.check_finite()
+                skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
+            inv_scale = scaler.state[2:3] if scaler is not None else None
+            if clip_norm > 0:
+                optimizer.clip_grad_norm_(clip_norm, inv_scale)
+                inv_scale = None
+            optimizer.step(inv_scale, skip_flag)
+            if scaler is not None:
+                scaler._found_inf = optimizer.found_inf
+                scaler.update()
+            optimizer.zero_grad()
+            if getattr(config, 'use_ema_model', False):
+                config.ema_model.update(model)
+            scheduler.step(optimizer, iter_index / iters + (epoch - 1))
+            log_fmt = None
+            if iter_index % int(config.print_interval * acc_steps) == 0:
+                log_fmt = (f'train: epoch {epoch:0>4d}, iter [{int(iter_index // acc_steps):0>{iter_width}d}, '
+                           f'{int(iters // acc_steps):0>{iter_width}d}], lr: {scheduler.current_lr:.6f}, ' +
+                           total_name + ': {loss:.4f}, ')
+            pending.append((packed, n, log_fmt))
+        drain(lag)
+        iter_index += 1
+    drain(0)
+    return losses.avg * acc_steps
+
+
+def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch, logger, config):
+    '''train detection model for one epoch (reference tools/scripts.py:900-1092).  DETR-family networks
+    ('detr' in config.network) take the padding mask and the normalised cxcywh annotations.'''
+    model.train()
+    device = _device_of(model)
+    amp_type = get_amp_type(model)
+    if config.local_rank == 0 and getattr(config, 'total_rank', 0) == 0:
+        logger.info(f'use_amp: {config.use_amp}, amp_type: {amp_type}!')
+    is_detr = 'detr' in config.network
+
+    def step_fn(data):
+        images = data['image'].to(device, non_blocking=True)
+        targets = (data['scaled_annots'] if is_detr else data['annots']).to(device, non_blocking=True)
+        bad = ~torch.isfinite(images).all() | ~torch.isfinite(targets).all()
+        with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
+            outs = model(images, data['mask'].to(device, non_blocking=True)) if is_detr else model(images)
+            loss_value = criterion(outs, targets)
+        return bad, loss_value, images.size(0)
+
+    return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5)
