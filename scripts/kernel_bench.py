@@ -61,7 +61,7 @@ def main():
         flops = 2.0 * batch * d.OH * d.OW * co * k * k * ci
         t_f = timeit(lambda: check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, ptr(stats[0]), ptr(stats[1]), st)))
         t_d = timeit(lambda: check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st))) if ci != 8 else 0.0
-        t_w = timeit(lambda: check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st)))
+        t_w = timeit(lambda: check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st))) if not os.environ.get('KB_SKIP_WGRAD') else 1.0
         rec = {'conv': f'{ci}->{co} k{k} s{s} {h}->{d.OH}', 'gflop': round(flops / 1e9, 2),
                'fwd_us': round(t_f * 1e6, 1), 'fwd_tflops': round(flops / t_f / 1e12, 1),
                'dgrad_us': round(t_d * 1e6, 1), 'dgrad_tflops': round(flops / t_d / 1e12, 1) if t_d else None,
@@ -74,6 +74,8 @@ def main():
         del x, wf, wd, y, dy, dx, dw
     print(json.dumps({'distinct_shape_totals_ms': {k: round(v * 1e3, 3) for k, v in tot.items() if k != 'flops'}}))
 
+    if os.environ.get('KB_CONV_ONLY'):
+        return
     # streaming kernels on the largest activation (layer1 output: [B,56,56,256])
     M, C = batch * 56 * 56, 256
     yb = torch.randn(M, C, device='cuda').to(dt)

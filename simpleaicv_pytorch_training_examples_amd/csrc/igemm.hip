@@ -16,6 +16,7 @@
 // buffered LDS with an XOR swizzle that makes ds_read_b128 fragment reads conflict free.
 #include <type_traits>
 
+#include <stdlib.h>
 #include "common.h"
 #include "saicv_internal.h"
 
@@ -441,8 +442,9 @@ struct TNParams {
     FastDiv fd_ohw, fd_ow;
 };
 
-template <typename T, int BA, int BB>
-__global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
+template <typename T, int BA, int BB, int NWA, int NWB>
+__global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_kernel(const TNParams p) {
+    constexpr int THREADS = 64 * NWA * NWB;
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BR = 8 * EPC;                  // reduction rows per tile (64 bf16 / 32 f32)
     constexpr int PITCH_A = (BA + 16) * (int)sizeof(T);
@@ -451,9 +453,9 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
     constexpr int B_BYTES = BR * PITCH_B;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int CPR_A = BA / EPC, CPR_B = BB / EPC;     // chunks per row
-    constexpr int RPP_A = 256 / CPR_A, RPP_B = 256 / CPR_B;
+    constexpr int RPP_A = THREADS / CPR_A, RPP_B = THREADS / CPR_B;
     constexpr int NA = BR / RPP_A, NB = BR / RPP_B;       // chunks per thread
-    constexpr int WA = BA / 2, WB = BB / 2;
+    constexpr int WA = BA / NWA, WB = BB / NWB;
     constexpr int AT = WA / 16, BT = WB / 16;
     constexpr uint32_t OOB = 0xfffffff0u;
 
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TNParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wa = wave & 1, wb = wave >> 1;
+    const int wa = wave % NWA, wb = wave / NWA;
     const int l15 = lane & 15, lg = lane >> 4;
 
     const int tile = blockIdx.x;
@@ -731,6 +733,10 @@ struct NTTile { int bm, bn, wm, blocks_per_cu; float speed; };
 const NTTile kTiles[4] = {{256, 256, 2, 1, 1.00f}, {256, 128, 4, 1, 0.85f}, {128, 128, 2, 2, 0.70f}, {128, 64, 2, 3, 0.50f}};
 
 int pick_tile(int M, int Nn, bool f32_out_big) {
+    if (const char* force = getenv("SAICV_NT_TILE")) {      // tuning aid: force a geometry
+        const int t = atoi(force);
+        if (t >= 0 && t < 4 && !(f32_out_big && kTiles[t].bm * kTiles[t].bn * 4 > 150 * 1024)) return t;
+    }
     int best = 2;
     float best_score = -1.f;
     for (int t = 0; t < 4; ++t) {
@@ -748,13 +754,13 @@ int pick_tile(int M, int Nn, bool f32_out_big) {
     return best;
 }
 
-template <typename T, int BA, int BB>
+template <typename T, int BA, int BB, int NWA = 2, int NWB = 2>
 int launch_tn(const TNParams& p, int splits, hipStream_t st) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BR = 8 * EPC;
     constexpr size_t smem = 2 * (size_t)BR * ((BA + 16) + (BB + 16)) * sizeof(T);
-    dim3 grid(p.tiles_a * p.tiles_b, splits), block(256);
-    auto k = igemm_tn_kernel<T, BA, BB>;
+    dim3 grid(p.tiles_a * p.tiles_b, splits), block(64 * NWA * NWB);
+    auto k = igemm_tn_kernel<T, BA, BB, NWA, NWB>;
     static bool once = (allow_lds(k, smem), true);
     (void)once;
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
@@ -844,14 +850,25 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     p.fd_ohw = make_fastdiv((uint32_t)(OH * OW));
     p.fd_ow = make_fastdiv((uint32_t)OW);
     const int BR = 8 * epc;
-    const int ba = Cout <= 64 ? 64 : 128;
-    const int bb = Kd <= 64 ? 64 : 128;
+    // 256 x 256 tiles (8 wavefronts of 128 x 64) halve both the HBM/L2 traffic and the LDS fragment reads per
+    // MFMA of the 128 x 128 geometry; used when both output dimensions fill them
+    // ... when both output dimensions fill them and every workgroup keeps >= 48 reduction steps (below that the
+    // 256 KiB of fp32 atomics per workgroup outweigh the gain: the small-M ResNet stages stay on 128 x 128)
+    static const int force_big = getenv("SAICV_TN_BIG") ? atoi(getenv("SAICV_TN_BIG")) : -1;
+    const int big_tiles = ((Cout + 255) / 256) * ((Kd + 255) / 256);
+    const int big_steps = ((M + BR - 1) / BR) / (256 / big_tiles > 0 ? 256 / big_tiles : 1);
+    const bool big = force_big >= 0 ? (force_big != 0 && Cout >= 128 && Kd >= 128)
+                                    : (Cout % 256 == 0 && Kd >= 256 && (Kd % 256 == 0 || Kd >= 1024) && big_steps >= 48);
+    const int ba = big ? 256 : Cout <= 64 ? 64 : 128;
+    const int bb = big ? 256 : Kd <= 64 ? 64 : 128;
     p.tiles_a = (Cout + ba - 1) / ba;
     p.tiles_b = (Kd + bb - 1) / bb;
     const int tiles = p.tiles_a * p.tiles_b;
     // split the pixel reduction so that ~4 workgroups per CU are in flight
     const int total_rt = (M + BR - 1) / BR;
-    int splits = (512 + tiles - 1) / tiles;     // 2 workgroups per CU are resident (73 KiB LDS each)
+    // 128-wide tiles: 2 workgroups per CU are resident (73 KiB LDS each); 256-wide: one (139 KiB)
+    // rounded DOWN: one full round of resident workgroups beats a second, nearly empty one
+    int splits = (big ? 256 : 512) / tiles;
     if (splits > total_rt) splits = total_rt;
     if (splits < 1) splits = 1;
     int rt_per = (total_rt + splits - 1) / splits;
@@ -862,6 +879,10 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     const int rem = BR - p.d_img * ohw;
     p.d_oh = rem / OW;
     p.d_ow = rem - p.d_oh * OW;
+    if (big) {
+        if (dtype == SAICV_DTYPE_BF16) return launch_tn<bf16_t, 256, 256, 2, 4>(p, splits, st);
+        return launch_tn<float, 256, 256, 2, 4>(p, splits, st);
+    }
     if (dtype == SAICV_DTYPE_BF16) {
         if (ba == 64 && bb == 64) return launch_tn<bf16_t, 64, 64>(p, splits, st);
         if (ba == 64) return launch_tn<bf16_t, 64, 128>(p, splits, st);
