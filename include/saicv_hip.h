@@ -80,6 +80,14 @@ int saicv_linear_fwd(int dtype, const void* x, const void* wf, const float* bias
                      int out_f32, const void* addend, const float* row_scale, int rows_per_scale, void* stream);
 int saicv_linear_dgrad(int dtype, const void* dy, const void* wd, void* dx, int M, int K, int N, const void* addend,
                        void* stream);
+/* MLP fusions (reference vit.py:91-99, segment_anything/image_encoder.py:187-198):
+ * y_pre = x W^T + b and y_act = gelu(y_pre) from ONE GEMM (exact-erf GELU applied to the stored, rounded y_pre);
+ * dx = (dy W) * gelu'(pre): the backward of the activation folded into the epilogue of the next layer's dgrad.
+ * N (fwd) / K (dgrad) must keep rows 16-byte aligned. */
+int saicv_linear_gelu_fwd(int dtype, const void* x, const void* wf, const float* bias, void* y_pre, void* y_act, int M,
+                          int K, int N, void* stream);
+int saicv_linear_dgrad_gelu(int dtype, const void* dy, const void* wd, const void* pre, void* dx, int M, int K, int N,
+                            void* stream);
 int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int M, int K, int N,
                        void* stream);
 /* conv data-gradient that adds an existing gradient (residual branch) in its epilogue */

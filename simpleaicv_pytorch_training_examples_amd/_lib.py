@@ -82,6 +82,8 @@ SIGNATURES = {
     'saicv_gelu_bwd': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
     'saicv_attention_fwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
     'saicv_attention_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
+    'saicv_linear_gelu_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_linear_dgrad_gelu': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_mask_loss_stats': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_size_t, c_double, c_double, c_double, _P]),
     'saicv_mask_loss_grad': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_size_t, c_double, c_double, _P]),
     'saicv_attention_stream_fwd': (c_int, [c_int, c_int, _PA, _P]),

@@ -115,6 +115,29 @@ template <> struct Mma<float> {
     }
 };
 
+// ---------------------------------------------------------------- exact-erf GELU pieces
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) and phi(x) = exp(-x^2 / 2) / sqrt(2 pi) from ONE v_exp_f32 and ONE v_rcp_f32:
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 and below the 1e-3 fp32 parity bound);
+// ~14 VALU operations against ~60 for erff + expf, which matters inside GEMM epilogues.
+DEVINL void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);      // exp(-x^2 / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-poly, e, 1.f);
+    cdf = 0.5f + copysignf(0.5f * erf_abs, x);
+    pdf = 0.39894228040143268f * e;
+}
+DEVINL float gelu_fwd_f(float x) {
+    float c, d;
+    gelu_cdf_pdf(x, c, d);
+    return x * c;
+}
+DEVINL float gelu_grad_f(float x) {
+    float c, d;
+    gelu_cdf_pdf(x, c, d);
+    return fmaf(x, d, c);
+}
+
 // ---------------------------------------------------------------- reductions
 DEVINL float wave_sum(float v) {
 #pragma unroll

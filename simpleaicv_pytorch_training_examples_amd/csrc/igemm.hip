@@ -37,7 +37,9 @@ struct NTParams {
     const float* bias;
     float* stat_sum;
     float* stat_sq;
-    const void* addend;         // epilogue: out = addend + row_scale * (acc + bias)
+    const void* addend;         // epilogue: out = addend + row_scale * (acc + bias)   (act_mode 2: the GELU pre-activation)
+    void* out2;                 // act_mode 1: second output, gelu(out)
+    int act_mode;               // 0 none | 1 out2 = gelu(out) | 2 out = (acc + bias) * gelu'(addend)
     const float* row_scale;
     int rows_per_scale;
     uint32_t src_bytes, wgt_bytes;
@@ -398,7 +400,20 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 }
                 u32x4 v = ld_chunk(smem + rr * OPITCH + oc * 16);
                 TO* o = reinterpret_cast<TO*>(p.out) + (size_t)m * p.ldo + ncol;
-                if (p.addend != nullptr || p.row_scale != nullptr) {
+                if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
+                    float f[OEPC];
+                    Chunk<TO>::unpack(v, f);
+#pragma unroll
+                    for (int j = 0; j < OEPC; ++j) f[j] = gelu_fwd_f(f[j]);
+                    st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(f));
+                } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)
+                    float f[OEPC], a[OEPC];
+                    Chunk<TO>::unpack(v, f);
+                    Chunk<TO>::unpack(ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol), a);
+#pragma unroll
+                    for (int j = 0; j < OEPC; ++j) f[j] *= gelu_grad_f(a[j]);
+                    v = Chunk<TO>::pack(f);
+                } else if (p.addend != nullptr || p.row_scale != nullptr) {
                     float f[OEPC], a[OEPC];
                     Chunk<TO>::unpack(v, f);
                     const float sc = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.f;
@@ -791,6 +806,15 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.addend = ex ? ex->addend : nullptr;
     p.row_scale = ex ? ex->row_scale : nullptr;
     p.rows_per_scale = ex ? ex->rows_per_scale : 1;
+    p.out2 = ex ? ex->out2 : nullptr;
+    p.act_mode = ex ? ex->act_mode : 0;
+    if (p.act_mode) {
+        const int osz0 = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
+        SAICV_REQUIRE((ldo * osz0) % 16 == 0 && Nn % (16 / osz0) == 0,
+                      "igemm_nt: the fused GELU epilogues need 16-byte aligned rows (N=%d)", Nn);
+        SAICV_REQUIRE(p.act_mode == 1 ? p.out2 != nullptr : p.addend != nullptr, "igemm_nt: fused GELU operand missing");
+        SAICV_REQUIRE(stat_sum == nullptr && p.row_scale == nullptr, "igemm_nt: fused GELU excludes BN statistics / row scale");
+    }
     if (p.addend || p.row_scale) {
         const int osz = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
         SAICV_REQUIRE((ldo * osz) % 16 == 0, "igemm_nt: fused residual needs a 16-byte aligned leading dimension");

@@ -14,6 +14,8 @@ struct EpiExtra {
     const void* addend = nullptr;      // same dtype / layout as out
     const float* row_scale = nullptr;  // one factor per group of rows_per_scale rows (drop-path)
     int rows_per_scale = 1;
+    int act_mode = 0;                  // 1: out2 = gelu(out) ; 2: out = (acc + bias) * gelu'(addend)
+    void* out2 = nullptr;
 };
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,

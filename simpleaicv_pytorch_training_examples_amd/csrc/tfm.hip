@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, 
         float v[N];
         Chunk<T>::unpack(ld_chunk(x + i * N), v);
 #pragma unroll
-        for (int k = 0; k < N; ++k) v[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+        for (int k = 0; k < N; ++k) v[k] = gelu_fwd_f(v[k]);
         st_chunk(y + i * N, Chunk<T>::pack(v));
     }
 }
@@ -197,11 +197,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy,
         Chunk<T>::unpack(ld_chunk(x + i * N), v);
         Chunk<T>::unpack(ld_chunk(dy + i * N), g);
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const float cdf = 0.5f * (1.f + erff(v[k] * 0.70710678118654752f));
-            const float pdf = 0.39894228040143268f * expf(-0.5f * v[k] * v[k]);
-            g[k] *= cdf + v[k] * pdf;
-        }
+        for (int k = 0; k < N; ++k) g[k] *= gelu_grad_f(v[k]);
         st_chunk(dx + i * N, Chunk<T>::pack(g));
     }
 }

@@ -41,9 +41,28 @@ def lin_fwd(x2, weight, bias, out_f32=False, addend=None, row_scale=None, rows_p
     return y if op == o else y[:, :o]
 
 
-def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None):
+def lin_gelu_fwd(x2, weight, bias):
+    """(pre, act) = (x2 W^T + b, gelu(pre)) from one GEMM; falls back to two kernels when the output
+    width is not a whole number of 16-byte chunks."""
+    dt = x2.dtype
+    m, k = x2.shape
+    o = weight.shape[0]
+    e = _lib.epc(dt)
+    if o % e or k % e:
+        pre = lin_fwd(x2, weight, bias)
+        return pre, gelu_fwd(pre)
+    wf, _ = packed_weight(weight, dt, k, True, o)
+    pre = torch.empty((m, o), dtype=dt, device=x2.device)
+    act = torch.empty((m, o), dtype=dt, device=x2.device)
+    check(lib().saicv_linear_gelu_fwd(dtype_code(dt), ptr(x2), ptr(wf), ptr(bias), ptr(pre), ptr(act), m, k, o, stream()),
+          'linear_gelu_fwd')
+    return pre, act
+
+
+def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None):
     """-> (dx or None, dw or None, db or None); a None dw/db means it was accumulated in place
-    into the parameter's arena gradient."""
+    into the parameter's arena gradient.  gelu_pre: x2 = gelu(gelu_pre) and the caller wants the gradient
+    with respect to gelu_pre -- the activation's backward is applied in the dgrad epilogue."""
     dt = x2.dtype
     m, k = x2.shape
     o = weight.shape[0]
@@ -62,7 +81,13 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None):
     if need_dx:
         _, wd = packed_weight(weight, dt, k, True, op)
         dx = torch.empty((m, k), dtype=dt, device=x2.device)
-        check(L.saicv_linear_dgrad(dtype_code(dt), ptr(dy), ptr(wd), ptr(dx), m, k, op, ptr(addend), st), 'linear_dgrad')
+        if gelu_pre is not None:
+            if addend is not None or k % e:
+                raise ValueError('fused GELU backward: no addend, 16-byte aligned rows')
+            check(L.saicv_linear_dgrad_gelu(dtype_code(dt), ptr(dy), ptr(wd), ptr(gelu_pre), ptr(dx), m, k, op, st),
+                  'linear_dgrad_gelu')
+        else:
+            check(L.saicv_linear_dgrad(dtype_code(dt), ptr(dy), ptr(wd), ptr(dx), m, k, op, ptr(addend), st), 'linear_dgrad')
     want_b = bias is not None and bias.requires_grad
     gb = _arena_grad(bias) if (want_b and op == o) else None
     tb = (gb if gb is not None else torch.zeros(op, dtype=torch.float32, device=x2.device)) if want_b else None
@@ -386,8 +411,7 @@ class MlpSubLayerFn(torch.autograd.Function):
         b, n, c = x.shape
         x2 = _as2d(x)
         h, mean, rstd = ln_fwd(x2, ln_w, ln_b, eps)
-        f1 = lin_fwd(h, fc1_w, fc1_b)
-        g = gelu_fwd(f1)
+        f1, g = lin_gelu_fwd(h, fc1_w, fc1_b)
         out = lin_fwd(g, fc2_w, fc2_b, addend=x2, row_scale=drop_scale, rows_per_scale=n)
         ctx.save_for_backward(x2, ln_w, ln_b, mean, rstd, h, fc1_w, fc1_b, f1, g, fc2_w, fc2_b, drop_scale)
         ctx.cfg = (b, n, c)
@@ -401,8 +425,7 @@ class MlpSubLayerFn(torch.autograd.Function):
         if dy.dtype != x2.dtype:
             dy = dy.to(x2.dtype)
         dys = row_scale(dy, drop_scale, n) if drop_scale is not None else dy
-        dg, d2w, d2b = lin_bwd(g, fc2_w, fc2_b, dys)
-        df1 = gelu_bwd(dg, f1)
+        df1, d2w, d2b = lin_bwd(g, fc2_w, fc2_b, dys, gelu_pre=f1)      # dgrad epilogue applies gelu'(f1)
         dh, d1w, d1b = lin_bwd(h, fc1_w, fc1_b, df1)
         dx, dlw, dlb = ln_bwd(dh, x2, ln_w, ln_b, mean, rstd, addend=dy)
         return dx.view(b, n, c), dlw, dlb, d1w, d1b, d2w, d2b, None, None

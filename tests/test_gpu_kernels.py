@@ -362,3 +362,26 @@ def test_vit_sublayers_match_composition(dt, use_drop):
     assert rel_err(xd.grad.float(), xr.grad) < tol * 3
     for k, p in blk.named_parameters():
         assert rel_err(p.grad, params[k].grad) < tol * 4, k
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_gelu_linear_epilogues_equal_the_unfused_kernels(dtype):
+    """saicv_linear_gelu_fwd / saicv_linear_dgrad_gelu against linear + gelu kernels run separately: the fused
+    epilogues apply the activation to the same rounded values, so the results are bit-identical."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    g = torch.Generator().manual_seed(11)
+    m, k, o = 300, 96, 256
+    x = torch.randn(m, k, generator=g).cuda().to(dtype)
+    w = (torch.randn(o, k, generator=g) * 0.2).cuda().requires_grad_(True)
+    b = torch.randn(o, generator=g).cuda().requires_grad_(True)
+    pre, act = ops_tfm.lin_gelu_fwd(x, w, b)
+    pre_ref = ops_tfm.lin_fwd(x, w, b)
+    assert torch.equal(pre, pre_ref) and torch.equal(act, ops_tfm.gelu_fwd(pre_ref))
+    ref = torch.nn.functional.gelu(torch.nn.functional.linear(x.float(), w.detach(), b.detach()))
+    assert rel_err(act, ref) < (2e-5 if dtype == torch.float32 else 2e-2)
+    # backward of  y = act W2^T : d pre = (dy W2) * gelu'(pre)
+    w2 = (torch.randn(64, o, generator=g) * 0.2).cuda().requires_grad_(True)
+    dy = torch.randn(m, 64, generator=g).cuda().to(dtype)
+    dpre, _, _ = ops_tfm.lin_bwd(act, w2, None, dy, gelu_pre=pre)
+    dact, _, _ = ops_tfm.lin_bwd(act, w2, None, dy)
+    assert torch.equal(dpre, ops_tfm.gelu_bwd(dact, pre))
