@@ -11,6 +11,7 @@
 // qkv GEMM output [B*N, 3*C] and writes the head-merged [B*N, C] layout, so none of the
 // reference's permute / contiguous copies exist.  Sequence length N <= 256 (ViT-B: 197; SAM
 // windows: 196); the 4096-token global attention of SAM needs the streaming variant (next).
+#include <stdlib.h>
 #include "common.h"
 #include "saicv_internal.h"
 
@@ -67,8 +68,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // backward: dx per row; per-block partial dgamma / dbeta (a wavefront walks rows_per rows)
+constexpr int LNB_WAVES = 8;       // wavefronts per block of the backward kernel
+
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -89,11 +92,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             ab[j][k] = 0.f;
         }
     }
-    const int r0 = blockIdx.x * rows_per * 4;
+    const int r0 = blockIdx.x * rows_per * LNB_WAVES;
+    // software pipeline: the 16-byte chunks of row i+1 are in flight while row i is reduced and written
+    u32x4 nd[NCH], nx[NCH], na[NCH];
+    float nmu = 0.f, nrs = 0.f;
+    auto fetch = [&](int row) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cpr) {
+                nd[j] = ld_chunk(dy + (size_t)row * C + c * N);
+                nx[j] = ld_chunk(x + (size_t)row * C + c * N);
+                if (addend != nullptr) na[j] = ld_chunk(addend + (size_t)row * C + c * N);
+            }
+        }
+        nmu = mean[row];
+        nrs = rstd[row];
+    };
+    if (r0 + wave < M) fetch(r0 + wave);
     for (int i = 0; i < rows_per; ++i) {
-        const int row = r0 + i * 4 + wave;
+        const int row = r0 + i * LNB_WAVES + wave;
         if (row >= M) break;
-        const float mu = mean[row], rs = rstd[row];
+        const float mu = nmu, rs = nrs;
+        u32x4 cd[NCH], cx[NCH], ca[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { cd[j] = nd[j]; cx[j] = nx[j]; ca[j] = na[j]; }
+        if (i + 1 < rows_per && row + LNB_WAVES < M) fetch(row + LNB_WAVES);
         float g[NCH][N], xh[NCH][N];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -101,8 +125,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             const int c = lane + 64 * j;
             if (c < cpr) {
                 float d[N], xv[N];
-                Chunk<T>::unpack(ld_chunk(dy + (size_t)row * C + c * N), d);
-                Chunk<T>::unpack(ld_chunk(x + (size_t)row * C + c * N), xv);
+                Chunk<T>::unpack(cd[j], d);
+                Chunk<T>::unpack(cx[j], xv);
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     xh[j][k] = (xv[k] - mu) * rs;
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 for (int k = 0; k < N; ++k) o[k] = rs * (g[j][k] - s1 - xh[j][k] * s2);
                 if (addend != nullptr) {        // residual-stream gradient joins here (pre-LN blocks)
                     float a[N];
-                    Chunk<T>::unpack(ld_chunk(addend + (size_t)row * C + c * N), a);
+                    Chunk<T>::unpack(ca[j], a);
 #pragma unroll
                     for (int k = 0; k < N; ++k) o[k] += a[k];
                 }
@@ -133,8 +157,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
-    // combine the four wavefronts of the block: one column at a time through LDS
-    __shared__ float red[4][64 * 8];
+    // combine the wavefronts of the block through LDS, one accumulator set at a time
+    __shared__ float red[LNB_WAVES][64 * 8];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = lane + 64 * j;
@@ -145,8 +169,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             if (wave == 0 && c < cpr) {
                 float* dst = (pass == 0 ? part_g : part_b) + (size_t)blockIdx.x * C + c * N;
 #pragma unroll
-                for (int k = 0; k < N; ++k)
-                    dst[k] = red[0][lane * N + k] + red[1][lane * N + k] + red[2][lane * N + k] + red[3][lane * N + k];
+                for (int k = 0; k < N; ++k) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < LNB_WAVES; ++w) v += red[w][lane * N + k];
+                    dst[k] = v;
+                }
             }
             __syncthreads();
         }
@@ -582,10 +610,13 @@ int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* bet
 }
 
 static int ln_bwd_blocks(int M, int* rows_per) {
-    int rp = (M + 4 * 256 - 1) / (4 * 256);        // <= 256 blocks (one per CU)
+    // one block of 8 wavefronts per CU, each wavefront streaming its rows with a one-row prefetch: more, smaller
+    // blocks were measured slower (start-up latency and dgamma / dbeta partial rows per block)
+    static const int target = getenv("SAICV_LN_BWD_BLOCKS") ? atoi(getenv("SAICV_LN_BWD_BLOCKS")) : 256;
+    int rp = (M + LNB_WAVES * target - 1) / (LNB_WAVES * target);
     if (rp < 1) rp = 1;
     *rows_per = rp;
-    return (M + 4 * rp - 1) / (4 * rp);
+    return (M + LNB_WAVES * rp - 1) / (LNB_WAVES * rp);
 }
 
 size_t layernorm_bwd_ws_floats(int M, int C) {
@@ -603,7 +634,7 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
     const int nb = ln_bwd_blocks(M, &rp);
     float* pg = ws;
     float* pb = ws + (size_t)nb * C;
-    dim3 grid(nb), block(256);
+    dim3 grid(nb), block(64 * LNB_WAVES);
 #define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)addend, (T*)dx, pg, pb, M, C, rp)
     if (nch <= 1) LN_LAUNCH(1);
     else if (nch <= 2) LN_LAUNCH(2);
