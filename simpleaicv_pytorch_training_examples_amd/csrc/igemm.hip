@@ -30,6 +30,10 @@ DEVINL uint32_t fdiv(uint32_t n, FastDiv d) {
     return (t + ((n - t) >> d.s1)) >> d.s2;
 }
 
+// LDS-DMA ring depth per geometry: 4 stages, except 256 x 128 where 3 stages (72 KiB) let TWO workgroups share
+// a CU so that one's epilogue overlaps the other's main loop
+constexpr int nt_stages(int bm, int bn) { return (bm == 256 && bn == 128) ? 3 : 4; }
+
 struct NTParams {
     const void* src;
     const void* wgt;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
     constexpr int AROWS = BM_T / 16 / NWAVES;    // A-tile DMA instructions per thread
     constexpr int WROWS = BN_T / 16 / NWAVES;    // weight-tile DMA instructions per thread
     constexpr int LPT = AROWS + WROWS;           // loads per thread per K tile
-    constexpr int NSTAGE = 4;
+    constexpr int NSTAGE = nt_stages(BM_T, BN_T);
     constexpr int A_BYTES = BM_T * 64;
     constexpr int W_BYTES = BN_T * 64;
     constexpr int STAGE = A_BYTES + W_BYTES;
@@ -726,7 +730,7 @@ void launch_nt_inst(const NTParams& p, size_t smem, hipStream_t st) {
 
 template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE>
 int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
-    constexpr size_t smem_full = 4 * (size_t)(BM_T * 64 + BN_T * 64);      // 4-stage ring
+    constexpr size_t smem_full = nt_stages(BM_T, BN_T) * (size_t)(BM_T * 64 + BN_T * 64);      // DMA ring
     const size_t epi = BM_T * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16);
     size_t smem = smem_full;
     if (smem < epi) smem = epi;
@@ -745,7 +749,7 @@ int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
 // Tile choice shared by the kernel launch and conv_stat_rows(): relative per-flop speed of each
 // geometry x wave-quantisation efficiency on 256 CUs x useful fraction of the N tile.
 struct NTTile { int bm, bn, wm, blocks_per_cu; float speed; };
-const NTTile kTiles[4] = {{256, 256, 2, 1, 1.00f}, {256, 128, 4, 1, 0.85f}, {128, 128, 2, 2, 0.70f}, {128, 64, 2, 3, 0.50f}};
+const NTTile kTiles[4] = {{256, 256, 2, 1, 1.00f}, {256, 128, 4, 2, 0.85f}, {128, 128, 2, 2, 0.70f}, {128, 64, 2, 3, 0.50f}};
 
 int pick_tile(int M, int Nn, bool f32_out_big) {
     if (const char* force = getenv("SAICV_NT_TILE")) {      // tuning aid: force a geometry
