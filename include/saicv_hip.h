@@ -101,24 +101,28 @@ int saicv_colsum(int dtype, const void* dy, int M, int N, float* dbias, void* st
 
 /* ---- BatchNorm2d + ReLU + residual ---------------------------------------------------- */
 size_t saicv_bn_ws_floats(int C);
-/* partial sums -> mean/invstd/scale/shift, running-stat update (momentum, unbiased var).
- * `native_batch_norm` (training) under resnet.py:41. */
+/* partial sums -> mean/invstd/scale/shift, running-stat update (momentum, unbiased var) and, when
+ * num_batches_tracked (device int64) is given, its += 1.  `native_batch_norm` (training) under resnet.py:41. */
 int saicv_bn_finalize_fwd(const float* sum, const float* sq, int rows, int C, double count,
                           const float* gamma, const float* beta, float* running_mean,
                           float* running_var, double momentum, double eps, float* mean,
-                          float* invstd, float* scale, float* shift, float* ws, void* stream);
+                          float* invstd, float* scale, float* shift, float* ws, long long* num_batches_tracked,
+                          void* stream);
 /* eval mode: scale/shift from running statistics */
 int saicv_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, double eps, float* scale, float* shift,
                          void* stream);
-/* z = [relu](y*scale + shift [+ res])   (resnet.py:41-42, :94-95, :152-153) */
+/* z = [relu](y*scale + shift [+ res])   (resnet.py:41-42, :94-95, :152-153).
+ * relu_mask (optional, M*C/8 bytes in bf16, M*C/4 in fp32): one byte per 16-byte chunk of z holding the
+ * sign bits [pre-ReLU value > 0] -- everything the backward pass needs from z at 1/16 of its size. */
 int saicv_bn_act_fwd(int dtype, const void* y, const void* res, void* z, const float* scale,
-                     const float* shift, size_t M, int C, int relu, void* stream);
+                     const float* shift, size_t M, int C, int relu, void* relu_mask, void* stream);
 size_t saicv_bn_bwd_ws_floats(size_t M, int C, int dtype);
 /* backward of the fused block: g = dz*[z>0]; dy, dres(=g, optional), dgamma, dbeta
  * (accumulate != 0: dgamma/dbeta are added to, e.g. straight into the gradient arena).
+ * The ReLU gate comes from relu_mask when given (z may then be NULL), else from z.
  * `threshold_backward` + `native_batch_norm_backward` (+ residual `add` backward). */
-int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
+int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* relu_mask, const void* y, const float* gamma,
                      const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
                      float* dbeta, size_t M, int C, int relu, int accumulate, float* ws,
                      void* stream);

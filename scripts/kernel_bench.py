@@ -91,11 +91,12 @@ def main():
     dg = torch.empty(C, device='cuda')
     db = torch.empty(C, device='cuda')
     ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, C, 0), device='cuda')
-    t = timeit(lambda: check(L.saicv_bn_act_fwd(0, ptr(yb), ptr(rb), ptr(zb), ptr(sc), ptr(sh), M, C, 1, st)))
+    mk = torch.empty(M * C // 8, dtype=torch.uint8, device='cuda')
+    t = timeit(lambda: check(L.saicv_bn_act_fwd(0, ptr(yb), ptr(rb), ptr(zb), ptr(sc), ptr(sh), M, C, 1, ptr(mk), st)))
     by = M * C * 2 * 3
     print(json.dumps({'kernel': 'bn_act_fwd(+res,relu)', 'us': round(t * 1e6, 1), 'GBps': round(by / t / 1e9, 1), 'frac_8TBps': round(by / t / 8e12, 3)}))
-    t = timeit(lambda: check(L.saicv_bn_act_bwd(0, ptr(dzb), ptr(zb), ptr(yb), ptr(sc), ptr(mean), ptr(invstd), ptr(dyb), ptr(drb), ptr(dg), ptr(db), M, C, 1, 0, ptr(ws), st)))
-    by = M * C * 2 * (3 + 3 + 2)
+    t = timeit(lambda: check(L.saicv_bn_act_bwd(0, ptr(dzb), 0, ptr(mk), ptr(yb), ptr(sc), ptr(mean), ptr(invstd), ptr(dyb), ptr(drb), ptr(dg), ptr(db), M, C, 1, 0, ptr(ws), st)))
+    by = M * C * 2 * (2 + 2 + 2) + 2 * M * C // 8
     print(json.dumps({'kernel': 'bn_act_bwd(+res,relu)', 'us': round(t * 1e6, 1), 'GBps': round(by / t / 1e9, 1), 'frac_8TBps': round(by / t / 8e12, 3)}))
 
 

@@ -58,11 +58,11 @@ SIGNATURES = {
     'saicv_conv2d_dgrad_add': (c_int, [_PD, _P, _P, _P, _P, _P]),
     'saicv_row_scale': (c_int, [c_int, _P, _P, _P, c_size_t, c_int, c_int, _P]),
     'saicv_bn_ws_floats': (c_size_t, [c_int]),
-    'saicv_bn_finalize_fwd': (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P, _P, c_double, c_double, _P, _P, _P, _P, _P, _P]),
+    'saicv_bn_finalize_fwd': (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P, _P, c_double, c_double, _P, _P, _P, _P, _P, _P, _P]),
     'saicv_bn_eval_coeffs': (c_int, [c_int, _P, _P, _P, _P, c_double, _P, _P, _P]),
-    'saicv_bn_act_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
+    'saicv_bn_act_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P, _P]),
     'saicv_bn_bwd_ws_floats': (c_size_t, [c_size_t, c_int, c_int]),
-    'saicv_bn_act_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, _P, _P]),
+    'saicv_bn_act_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, _P, _P]),
     'saicv_maxpool_fwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_maxpool_bwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_avgpool_fwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),

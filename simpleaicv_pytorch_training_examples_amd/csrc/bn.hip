@@ -55,8 +55,10 @@ __global__ void bn_finalize_fwd_kernel(const float* __restrict__ sum, const floa
                                        const float* __restrict__ beta, float* running_mean,
                                        float* running_var, float momentum, float eps,
                                        float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                       float* __restrict__ scale, float* __restrict__ shift) {
+                                       float* __restrict__ scale, float* __restrict__ shift,
+                                       long long* __restrict__ num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;     // BatchNorm2d bookkeeping, no extra launch
     if (c >= C) return;
     float s = 0.f, q = 0.f;
     for (int p = 0; p < P; ++p) {
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
                                                          const T* __restrict__ res, T* __restrict__ z,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
-                                                         size_t nchunks, int C) {
+                                                         size_t nchunks, int C, uint8_t* __restrict__ mask) {
     constexpr int N = Chunk<T>::N;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,14 +126,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         Chunk<T>::unpack(ld_chunk(y + i * N), v);
         float rr[N];
         if (RES) Chunk<T>::unpack(ld_chunk(res + i * N), rr);
+        unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float o = fmaf(v[j], sc[j], sh[j]);
             if (RES) o += rr[j];
-            if (RELU) o = fmaxf(o, 0.f);
+            if (RELU) {
+                bits |= (o > 0.f ? 1u : 0u) << j;
+                o = fmaxf(o, 0.f);
+            }
             v[j] = o;
         }
         st_chunk(z + i * N, Chunk<T>::pack(v));
+        if (RELU && mask != nullptr) mask[i] = (uint8_t)bits;     // one bit per element: all backward needs of z
     }
 }
 
@@ -141,6 +148,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 template <typename T, bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz,
                                                             const T* __restrict__ z,
+                                                            const uint8_t* __restrict__ mask,
                                                             const T* __restrict__ y,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int M,
@@ -169,10 +177,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 float g[N], yy[N], zz[N];
                 Chunk<T>::unpack(ld_chunk(dz + e), g);
                 Chunk<T>::unpack(ld_chunk(y + e), yy);
-                if (RELU) Chunk<T>::unpack(ld_chunk(z + e), zz);
+                unsigned bits = 0xffu;
+                if (RELU) {
+                    if (mask != nullptr) {
+                        bits = mask[e / N];
+                    } else {
+                        Chunk<T>::unpack(ld_chunk(z + e), zz);
+                        bits = 0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) bits |= (zz[j] > 0.f ? 1u : 0u) << j;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const float gj = (RELU && !(zz[j] > 0.f)) ? 0.f : g[j];
+                    const float gj = ((bits >> j) & 1u) ? g[j] : 0.f;
                     ag[j] += gj;
                     ax[j] += gj * (yy[j] - mu[j]) * is[j];
                 }
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ cb,
                                                            const float* __restrict__ cc,
                                                            T* __restrict__ dy, T* __restrict__ dres,
-                                                           size_t nchunks, int C) {
+                                                           size_t nchunks, int C, const uint8_t* __restrict__ mask) {
     constexpr int N = Chunk<T>::N;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,10 +273,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         float g[N], yy[N], zz[N], o[N];
         Chunk<T>::unpack(ld_chunk(dz + i * N), g);
         Chunk<T>::unpack(ld_chunk(y + i * N), yy);
-        if (RELU) Chunk<T>::unpack(ld_chunk(z + i * N), zz);
+        unsigned bits = 0xffu;
+        if (RELU) {
+            if (mask != nullptr) {
+                bits = mask[i];
+            } else {
+                Chunk<T>::unpack(ld_chunk(z + i * N), zz);
+                bits = 0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) bits |= (zz[j] > 0.f ? 1u : 0u) << j;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const float gj = (RELU && !(zz[j] > 0.f)) ? 0.f : g[j];
+            const float gj = ((bits >> j) & 1u) ? g[j] : 0.f;
             g[j] = gj;
             o[j] = fmaf(ka[j], gj, fmaf(kb[j], yy[j], kc[j]));
         }
@@ -299,11 +327,11 @@ size_t bn_ws_floats(int C) { return (size_t)64 * C; }
 int bn_finalize_fwd(const float* sum, const float* sq, int P, int C, double count, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, double momentum,
                     double eps, float* mean, float* invstd, float* scale, float* shift, float* ws,
-                    hipStream_t st) {
+                    long long* num_batches_tracked, hipStream_t st) {
     P = reduce_partials(sum, sq, P, C, ws, st);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sum, sq, P, C,
                        (float)count, gamma, beta, running_mean, running_var, (float)momentum, (float)eps,
-                       mean, invstd, scale, shift);
+                       mean, invstd, scale, shift, num_batches_tracked);
     return check_launch("bn_finalize_fwd");
 }
 
@@ -316,14 +344,14 @@ int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* ru
 
 template <typename T>
 static int bn_act_fwd_t(const void* y, const void* res, void* z, const float* scale,
-                        const float* shift, size_t M, int C, int relu, hipStream_t st) {
+                        const float* shift, size_t M, int C, int relu, uint8_t* mask, hipStream_t st) {
     constexpr int N = Chunk<T>::N;
     const size_t nchunks = M * (size_t)C / N;
     const int grid = stream_grid(nchunks);
     const T* yy = (const T*)y; const T* rr = (const T*)res; T* zz = (T*)z;
     const bool hoist = ((size_t)grid * 256) % (size_t)(C / N) == 0;
-#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, true>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C); \
-                          else hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, false>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C); } while (0)
+#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, true>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C, mask); \
+                          else hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, false>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C, mask); } while (0)
     if (relu) { if (res) LAUNCH(true, true); else LAUNCH(true, false); }
     else      { if (res) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -331,11 +359,12 @@ static int bn_act_fwd_t(const void* y, const void* res, void* z, const float* sc
 }
 
 int bn_act_fwd(int dtype, const void* y, const void* res, void* z, const float* scale,
-               const float* shift, size_t M, int C, int relu, hipStream_t st) {
+               const float* shift, size_t M, int C, int relu, void* relu_mask, hipStream_t st) {
+    uint8_t* mask = (uint8_t*)relu_mask;
     const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     SAICV_REQUIRE(C % n == 0, "bn_act_fwd: C=%d must be a multiple of %d", C, n);
-    if (dtype == SAICV_DTYPE_BF16) return bn_act_fwd_t<bf16_t>(y, res, z, scale, shift, M, C, relu, st);
-    return bn_act_fwd_t<float>(y, res, z, scale, shift, M, C, relu, st);
+    if (dtype == SAICV_DTYPE_BF16) return bn_act_fwd_t<bf16_t>(y, res, z, scale, shift, M, C, relu, mask, st);
+    return bn_act_fwd_t<float>(y, res, z, scale, shift, M, C, relu, mask, st);
 }
 
 // rows of partials produced by bn_bwd (so the caller can size the workspace)
@@ -355,7 +384,7 @@ size_t bn_bwd_ws_floats(size_t M, int C, int dtype) {
 }
 
 template <typename T>
-static int bn_bwd_t(const void* dz, const void* z, const void* y, const float* gamma,
+static int bn_bwd_t(const void* dz, const void* z, const uint8_t* mask, const void* y, const float* gamma,
                     const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
                     float* dbeta, size_t M, int C, int relu, int accumulate, float* ws, hipStream_t st) {
     constexpr int N = Chunk<T>::N;
@@ -368,9 +397,9 @@ static int bn_bwd_t(const void* dz, const void* z, const void* y, const float* g
     float* coef = ws2 + (size_t)64 * C;
     const T* dzz = (const T*)dz; const T* zz = (const T*)z; const T* yy = (const T*)y;
     if (relu)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(used), dim3(256), 0, st, dzz, zz, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(used), dim3(256), 0, st, dzz, zz, mask, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
     else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(used), dim3(256), 0, st, dzz, zz, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(used), dim3(256), 0, st, dzz, zz, mask, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
     const float* a = pg; const float* b = pgx;
     const int P = reduce_partials(a, b, used, C, ws2, st);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, a, b, P, C,
@@ -379,23 +408,24 @@ static int bn_bwd_t(const void* dz, const void* z, const void* y, const float* g
     const int grid = stream_grid(nchunks);
     T* dyy = (T*)dy; T* drr = (T*)dres;
     const bool hoist = ((size_t)grid * 256) % (size_t)(C / N) == 0;
-#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, true>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C); \
-                          else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, false>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C); } while (0)
+#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, true>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C, mask); \
+                          else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, false>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C, mask); } while (0)
     if (relu) { if (dres) LAUNCH(true, true); else LAUNCH(true, false); }
     else      { if (dres) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
     return check_launch("bn_bwd");
 }
 
-int bn_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
+int bn_bwd(int dtype, const void* dz, const void* z, const void* relu_mask, const void* y, const float* gamma,
            const float* mean, const float* invstd, void* dy, void* dres, float* dgamma, float* dbeta,
            size_t M, int C, int relu, int accumulate, float* ws, hipStream_t st) {
+    const uint8_t* mask = (const uint8_t*)relu_mask;
     const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     SAICV_REQUIRE(C % n == 0, "bn_bwd: C=%d must be a multiple of %d", C, n);
-    SAICV_REQUIRE(!relu || z != nullptr, "bn_bwd: relu needs the forward output z");
+    SAICV_REQUIRE(!relu || z != nullptr || mask != nullptr, "bn_bwd: relu needs the forward output z or its sign mask");
     if (dtype == SAICV_DTYPE_BF16)
-        return bn_bwd_t<bf16_t>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, st);
-    return bn_bwd_t<float>(dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, st);
+        return bn_bwd_t<bf16_t>(dz, z, mask, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, st);
+    return bn_bwd_t<float>(dz, z, mask, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, st);
 }
 
 }  // namespace saicv

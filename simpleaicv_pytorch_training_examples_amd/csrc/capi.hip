@@ -30,13 +30,13 @@ int check_launch(const char* what) {
 // declared in the other translation units
 size_t bn_ws_floats(int C);
 int bn_finalize_fwd(const float*, const float*, int, int, double, const float*, const float*, float*,
-                    float*, double, double, float*, float*, float*, float*, float*, hipStream_t);
+                    float*, double, double, float*, float*, float*, float*, float*, long long*, hipStream_t);
 int bn_eval_coeffs(int, const float*, const float*, const float*, const float*, double, float*, float*,
                    hipStream_t);
-int bn_act_fwd(int, const void*, const void*, void*, const float*, const float*, size_t, int, int,
+int bn_act_fwd(int, const void*, const void*, void*, const float*, const float*, size_t, int, int, void*,
                hipStream_t);
 size_t bn_bwd_ws_floats(size_t, int, int);
-int bn_bwd(int, const void*, const void*, const void*, const float*, const float*, const float*, void*,
+int bn_bwd(int, const void*, const void*, const void*, const void*, const float*, const float*, const float*, void*,
            void*, float*, float*, size_t, int, int, int, float*, hipStream_t);
 int maxpool_fwd(int, const void*, void*, uint8_t*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int maxpool_bwd(int, const void*, const uint8_t*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -188,9 +188,10 @@ size_t saicv_bn_ws_floats(int C) { return bn_ws_floats(C); }
 int saicv_bn_finalize_fwd(const float* sum, const float* sq, int rows, int C, double count,
                           const float* gamma, const float* beta, float* running_mean,
                           float* running_var, double momentum, double eps, float* mean,
-                          float* invstd, float* scale, float* shift, float* ws, void* stream) {
+                          float* invstd, float* scale, float* shift, float* ws, long long* num_batches_tracked,
+                          void* stream) {
     return bn_finalize_fwd(sum, sq, rows, C, count, gamma, beta, running_mean, running_var, momentum,
-                           eps, mean, invstd, scale, shift, ws, S(stream));
+                           eps, mean, invstd, scale, shift, ws, num_batches_tracked, S(stream));
 }
 int saicv_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, double eps, float* scale, float* shift,
@@ -198,14 +199,15 @@ int saicv_bn_eval_coeffs(int C, const float* gamma, const float* beta, const flo
     return bn_eval_coeffs(C, gamma, beta, running_mean, running_var, eps, scale, shift, S(stream));
 }
 int saicv_bn_act_fwd(int dtype, const void* y, const void* res, void* z, const float* scale,
-                     const float* shift, size_t M, int C, int relu, void* stream) {
-    return bn_act_fwd(dtype, y, res, z, scale, shift, M, C, relu, S(stream));
+                     const float* shift, size_t M, int C, int relu, void* relu_mask, void* stream) {
+    return bn_act_fwd(dtype, y, res, z, scale, shift, M, C, relu, relu_mask, S(stream));
 }
 size_t saicv_bn_bwd_ws_floats(size_t M, int C, int dtype) { return bn_bwd_ws_floats(M, C, dtype); }
-int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* y, const float* gamma,
+int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* relu_mask, const void* y, const float* gamma,
                      const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
                      float* dbeta, size_t M, int C, int relu, int accumulate, float* ws, void* stream) {
-    return bn_bwd(dtype, dz, z, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, S(stream));
+    return bn_bwd(dtype, dz, z, relu_mask, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws,
+                  S(stream));
 }
 
 int saicv_maxpool_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C,

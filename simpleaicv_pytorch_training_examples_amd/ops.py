@@ -212,13 +212,12 @@ class ConvBnActFn(torch.autograd.Function):
             if bn.momentum is None:
                 raise NotImplementedError('BatchNorm2d(momentum=None) is not supported')
             track = bn.track_running_stats and bn.running_mean is not None
+            nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
             check(L.saicv_bn_finalize_fwd(ptr(stats[0]), ptr(stats[1]), rows, k, float(M), ptr(gamma),
                                           ptr(beta), ptr(bn.running_mean) if track else 0,
                                           ptr(bn.running_var) if track else 0, float(bn.momentum),
                                           float(bn.eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                          ptr(ws), st), 'bn_finalize_fwd')
-            if track and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+                                          ptr(ws), ptr(nbt), st), 'bn_finalize_fwd')      # also num_batches_tracked += 1
         else:
             check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, 0, 0, st), 'conv2d_fwd')
             check(L.saicv_bn_eval_coeffs(k, ptr(gamma), ptr(beta), ptr(bn.running_mean),
@@ -229,22 +228,25 @@ class ConvBnActFn(torch.autograd.Function):
             if residual.dtype != dt:
                 residual = residual.to(dt)
         z = _empty_nhwc(n, k, d.OH, d.OW, dt, dev)
+        # backward needs only the sign of z: one byte per 16-byte chunk instead of re-reading z twice
+        mask = (torch.empty(M * k // _lib.epc(dt), dtype=torch.uint8, device=dev)
+                if (relu and training and any(ctx.needs_input_grad)) else None)
         t0 = KernelTimer.begin()
         check(L.saicv_bn_act_fwd(dtype_code(dt), ptr(y), ptr(residual), ptr(z), ptr(scale), ptr(shift), M,
-                                 k, int(relu), st), 'bn_act_fwd')
+                                 k, int(relu), ptr(mask), st), 'bn_act_fwd')
         KernelTimer.end(t0, 'bn_act_fwd', 0, float(M) * k * y.element_size() * (3 if residual is not None else 2))
         if training:
-            ctx.save_for_backward(x, weight, gamma, y, z if relu else None, mean, invstd)
+            ctx.save_for_backward(x, weight, gamma, y, mask, mean, invstd)
         else:
             # eval-mode backward (frozen statistics) is linear: dy = scale * g
-            ctx.save_for_backward(x, weight, gamma, y, z if relu else None, None, scale)
+            ctx.save_for_backward(x, weight, gamma, y, None, None, scale)
         ctx.cfg = (stride, pad, bool(relu), residual is not None, training, d, wd)
         ctx.beta_ref = beta
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, weight, gamma, y, z, mean, invstd = ctx.saved_tensors
+        x, weight, gamma, y, mask, mean, invstd = ctx.saved_tensors
         stride, pad, relu, has_res, training, d, wd = ctx.cfg
         if not training:
             raise NotImplementedError('backward through eval-mode BatchNorm is not implemented')
@@ -269,16 +271,16 @@ class ConvBnActFn(torch.autograd.Function):
             dbeta = torch.empty(k, dtype=torch.float32, device=dev)
         ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, k, dtype_code(dt)), dtype=torch.float32, device=dev)
         t0 = KernelTimer.begin()
-        check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), ptr(z), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
+        check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), 0, ptr(mask), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
                                  ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), M, k, int(relu), int(direct_bn),
                                  ptr(ws), st), 'bn_act_bwd')
         if direct_bn:
             _grad_ready(gamma)
             _grad_ready(beta)
             dgamma = dbeta = None
-        # two streaming passes: (dz, y[, z]) read twice, dy (and dres) written once
+        # two streaming passes: (dz, y) read twice (+ the 1-bit ReLU mask), dy (and dres) written once
         KernelTimer.end(t0, 'bn_act_bwd', 0, float(M) * k * y.element_size() *
-                        (2 * (3 if relu else 2) + (2 if dres is not None else 1)))
+                        (2 * (2 + (1.0 / 16 if relu else 0)) + (2 if dres is not None else 1)))
         c = x.shape[1]
         flops = 2.0 * M * k * d.R * d.S * min(c, weight.shape[1])
         dx = None
