@@ -48,11 +48,13 @@ class ConvBnActBlock(nn.Module):
         self.padding = padding
         self.has_act = has_act
 
-    def forward(self, x, residual=None, act=None):
-        """`residual` / `act` let the enclosing residual block fuse its add + ReLU in here."""
+    def forward(self, x, residual=None, act=None, want_skip=False):
+        """`residual` / `act` let the enclosing residual block fuse its add + ReLU in here; `want_skip` also
+        returns the input as an alias the block uses for its shortcut, so that the shortcut's gradient is
+        added inside this conv's dgrad epilogue (no separate gradient-sum kernel)."""
         conv, bn = self.layer[0], self.layer[1]
         relu = self.has_act if act is None else act
-        return ops.conv_bn_act(x, conv.weight, bn, self.stride, self.padding, relu, residual)
+        return ops.conv_bn_act(x, conv.weight, bn, self.stride, self.padding, relu, residual, want_skip)
 
 
 class BasicBlock(nn.Module):
@@ -70,8 +72,8 @@ class BasicBlock(nn.Module):
                                                   groups=1, has_bn=True, has_act=False)
 
     def forward(self, x):
-        identity = self.downsample_conv(x) if self.downsample else x
-        out = self.conv1(x)
+        out, skip = self.conv1(x, want_skip=True)
+        identity = self.downsample_conv(skip) if self.downsample else skip
         # relu(bn2(conv2(out)) + identity), fused into conv2's BN-apply kernel
         return self.conv2(out, residual=identity, act=True)
 
@@ -93,8 +95,8 @@ class Bottleneck(nn.Module):
                                                   groups=1, has_bn=True, has_act=False)
 
     def forward(self, x):
-        identity = self.downsample_conv(x) if self.downsample else x
-        out = self.conv1(x)
+        out, skip = self.conv1(x, want_skip=True)
+        identity = self.downsample_conv(skip) if self.downsample else skip
         out = self.conv2(out)
         return self.conv3(out, residual=identity, act=True)
 

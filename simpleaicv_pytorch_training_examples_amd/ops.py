@@ -179,7 +179,10 @@ class ConvBnActFn(torch.autograd.Function):
     residual tail of BasicBlock / Bottleneck (:94-95, :152-153)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, pad, relu):
+    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, pad, relu, want_skip=False):
+        """want_skip: also return the (NHWC) input as a second output.  A residual block routes its shortcut
+        through that alias, so the shortcut's gradient reaches THIS node's backward and is added in the
+        dgrad kernel's epilogue instead of by a separate elementwise add."""
         require_gpu(x, weight)
         x = _nhwc(x)
         dt = x.dtype
@@ -242,10 +245,12 @@ class ConvBnActFn(torch.autograd.Function):
             ctx.save_for_backward(x, weight, gamma, y, None, None, scale)
         ctx.cfg = (stride, pad, bool(relu), residual is not None, training, d, wd)
         ctx.beta_ref = beta
+        if want_skip:
+            return z, x
         return z
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, dskip=None):
         x, weight, gamma, y, mask, mean, invstd = ctx.saved_tensors
         stride, pad, relu, has_res, training, d, wd = ctx.cfg
         if not training:
@@ -289,7 +294,14 @@ class ConvBnActFn(torch.autograd.Function):
                 _, wd = packed_weight(weight, dt, c, True)
             dx = _empty_nhwc(n, c, x.shape[2], x.shape[3], dt, dev)
             t0 = KernelTimer.begin()
-            check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
+            if dskip is not None:           # gradient of the shortcut alias joins in the dgrad epilogue
+                dskip = _nhwc(dskip)
+                if dskip.dtype != dt:
+                    dskip = dskip.to(dt)
+                check(L.saicv_conv2d_dgrad_add(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dskip), ptr(dx), st),
+                      'conv2d_dgrad_add')
+            else:
+                check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
             KernelTimer.end(t0, 'igemm_nt', flops, 0)
         dwt = None
         if ctx.needs_input_grad[1]:
@@ -306,11 +318,11 @@ class ConvBnActFn(torch.autograd.Function):
             else:
                 dwt = _weight_grad(dw, weight, c)
         return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
-                dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None)
+                dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None, None)
 
 
-def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None):
-    return ConvBnActFn.apply(x, weight, bn.weight, bn.bias, residual, bn, stride, pad, relu)
+def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None, want_skip=False):
+    return ConvBnActFn.apply(x, weight, bn.weight, bn.bias, residual, bn, stride, pad, relu, want_skip)
 
 
 # ------------------------------------------------------------------------------ plain conv / linear
