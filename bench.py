@@ -34,7 +34,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes); None when the
     summary is absent.  Counters cannot be collected inside the timed run itself."""
-    path = os.path.join(ROOT, 'profiles', 'r01c_pmc_hbm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r01d_pmc_hbm_traffic.json')
     try:
         return json.load(open(path))['kernels'][kernel]['bytes_per_launch']
     except (OSError, KeyError, ValueError):
@@ -222,9 +222,10 @@ def main():
         if 'igemm_nt' in summ:
             k = summ['igemm_nt']
             achieved = k['flops'] / (k['ms'] * 1e-3) / 1e12
-            out['roofline'] = {'kernel': 'igemm_nt_kernel (implicit-GEMM conv fwd + dgrad)', 'bound': 'mfma',
+            out['roofline'] = {'kernel': 'igemm_nt_kernel (implicit-GEMM conv / linear, fwd + dgrad)', 'bound': 'mfma',
                                'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic('igemm_nt'),
+                               'frac': round(achieved / PEAK_BF16_TFLOPS, 4),
+                               'traffic': pmc_traffic('igemm_nt') if args.model == 'resnet50' else None,
                                'launches': k['calls'], 'avg_launch_us': round(k['ms'] * 1e3 / k['calls'], 2)}
             out['kernel_breakdown_ms_per_step'] = {t: round(v['ms'] / args.steps, 3) for t, v in summ.items()}
             for t, v in summ.items():
