@@ -26,8 +26,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
-TRAIN_GFLOP_PER_IMG = {'resnet50': 24.54, 'vit_base_patch16': 105.38, 'sam_b_encoder': 3 * 972.1}
-IMAGE_SIZE = {'sam_b_encoder': 1024}
+# SURVEY.md section 8(d); DETR: 189.1 GFLOP fwd at 800x1344, scaled to the 1333x1333 canvas the collater pads to
+TRAIN_GFLOP_PER_IMG = {'resnet50': 24.54, 'vit_base_patch16': 105.38, 'sam_b_encoder': 3 * 972.1,
+                       'resnet50_detr': 3 * 189.1 * (1333 * 1333) / (800 * 1344)}
+IMAGE_SIZE = {'sam_b_encoder': 1024, 'resnet50_detr': 1333}
 
 
 def pmc_traffic(kernel):
@@ -77,6 +79,15 @@ def build(model_name, device):
                                 global_attn_indexes=[2, 5, 8, 11], use_gradient_checkpoint=False).to(device)
         crit = lambda out, tgt: torch.nn.functional.mse_loss(out.float(), tgt)
         soft = 'embedding'
+    elif model_name == 'resnet50_detr':
+        # BASELINE.json configs[3]: DETR-ResNet50, COCO-shape 3x800x1333 images on the square canvas
+        # DETRDetectionCollater(resize_type='retina_style') pads to (1333 x 1333), padding mask included
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import detr
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
+        model = detr.resnet50_detr(num_classes=80).to(device)
+        loss_mod = DETRLoss(num_classes=80)
+        crit = lambda outs, tgt: sum(loss_mod(outs, tgt).values())
+        soft = 'detr'
     else:
         raise SystemExit(f'unknown model {model_name}')
     return model, crit, soft, engine
@@ -88,6 +99,11 @@ def make_optimizer(model_name, model, engine):
     ViT-B AdamW lr 5e-4 wd 0.05 (vit_base_patch16.../train_config.py:93-124)."""
     decay = [p for p in model.parameters() if p.ndim > 1]
     no_decay = [p for p in model.parameters() if p.ndim <= 1]
+    if model_name == 'resnet50_detr':     # res50_detr_yoloresize1024/train_config.py: AdamW lr 1e-4, wd 1e-3, backbone lr 1e-5
+        bb = [p for n, p in model.named_parameters() if n.startswith('backbone.')]
+        rest = [p for n, p in model.named_parameters() if not n.startswith('backbone.')]
+        return engine.AdamW(model, [{'params': bb, 'weight_decay': 1e-3, 'lr': 1e-5}, {'params': rest, 'weight_decay': 1e-3}],
+                            lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
     if model_name == 'sam_b_encoder':     # sam_b_training/train_config.py: AdamW lr 1e-5, no weight decay
         return engine.AdamW(model, [{'params': list(model.parameters()), 'weight_decay': 0.0}], lr=1e-5,
                             betas=(0.9, 0.999), eps=1e-8)
@@ -156,26 +172,47 @@ def main():
     g = torch.Generator(device='cpu').manual_seed(1 + rank)
     # NCHW-shaped, NHWC-strided fp32 batch, as the reference collater delivers it
     size = IMAGE_SIZE.get(args.model, 224)
+    masks = None
     if soft == 'embedding':       # SAMBatchCollater stacks per-sample CHW tensors: true NCHW input
         images = torch.randn(args.batch, 3, size, size, generator=g).to(device)
         labels = torch.randn(args.batch, 256, size // 16, size // 16, generator=g).to(device)
+    elif soft == 'detr':          # 800 x 1333 image at the top-left of the canvas, 10 boxes per image
+        canvas = torch.zeros(args.batch, size, size, 3)
+        canvas[:, :800, :, :] = torch.randn(args.batch, 800, size, 3, generator=g)
+        images = canvas.to(device).permute(0, 3, 1, 2)
+        masks = torch.ones(args.batch, size, size, dtype=torch.bool)
+        masks[:, :800, :] = False
+        masks = masks.to(device)
+        labels = -torch.ones(args.batch, 100, 5)
+        labels[:, :10, 0:2] = torch.rand(args.batch, 10, 2, generator=g) * 0.5 + 0.25
+        labels[:, :10, 2:4] = torch.rand(args.batch, 10, 2, generator=g) * 0.3 + 0.05
+        labels[:, :10, 4] = torch.randint(0, 80, (args.batch, 10), generator=g).float()
+        labels = labels.to(device)
     else:
         images = torch.randn(args.batch, size, size, 3, generator=g).to(device).permute(0, 3, 1, 2)
-    if soft == 'embedding':
+    if soft in ('embedding', 'detr'):
         pass
     elif soft:
         labels = torch.softmax(torch.randn(args.batch, 1000, generator=g) * 4, -1).to(device)
     else:
         labels = torch.randint(0, 1000, (args.batch,), generator=g).to(device)
 
+    clip = {'resnet50_detr': 0.1, 'sam_b_encoder': 1.0}.get(args.model, 0.0)     # clip_max_norm of the reference configs
+
     def step():
         opt.zero_grad()
         with torch.autocast('cuda', dtype=torch.bfloat16):
-            out = ddp(images)
+            out = ddp(images, masks) if masks is not None else ddp(images)
             loss = crit(out, labels)
         scaler.scale(loss).backward()
         ddp.finish_gradient_sync()
-        scaler.step(opt)
+        if clip > 0:        # the reference loop: unscale, clip the global norm, step (tools/scripts.py:1029-1049)
+            opt.check_finite()
+            opt.clip_grad_norm_(clip, scaler.state[2:3])
+            opt.step(None, opt.found_inf)
+            scaler._found_inf = opt.found_inf
+        else:
+            scaler.step(opt)
         scaler.update()
         return loss
 
