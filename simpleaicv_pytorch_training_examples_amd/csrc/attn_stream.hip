@@ -177,8 +177,9 @@ DEVINL void sa_split_key(int key, float inv_sw, int Sw, int& kh, int& kw) {
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <typename T, int D, int REL>
-__global__ __launch_bounds__(SA_THREADS) void sa_fwd_kernel(const SAParams p) {
+template <typename T, int D, int REL, bool DROP>
+// (256, 2): two workgroups per CU; the backward kernels spill under that bound and are faster at one
+__global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_fwd_kernel(const SAParams p) {
 #pragma unroll
         for (int dt = 0; dt < S::DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c2 = p.scale * LOG2E;
-    const bool drop = p.dropout_p > 0.f;
+    constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_fwd_kernel(const SAParams p) {
 
 // ------------------------------------------------------------------------------------ backward: dQ (+ D, d rel-pos)
 // LDS: K chunk | V chunk | REL 1: indicator [256][32] | REL 1/3: per-wave tables | REL 3: per-wave gradient tables
-template <typename T, int D, int REL>
+template <typename T, int D, int REL, bool DROP>
 __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
         ge[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float c2 = p.scale * LOG2E;
-    const bool drop = p.dropout_p > 0.f;
+    constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     typename S::Stager sk, sv;
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
 // groups (rows lg*4 + r) on disjoint banks.  Everything for chunk i+1 is fetched into registers during chunk i.
 DEVINL int sa_rw_off(int row, int kw) { return row * 64 + ((((kw >> 2) ^ (((row >> 2) & 3) << 2))) << 2) + (kw & 3); }
 
-template <typename T, int D, int REL>
+template <typename T, int D, int REL, bool DROP>
 __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dkv_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dkv_kernel(const SAParams p
 #pragma unroll
         for (int dt = 0; dt < S::DT; ++dt) { dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float c2 = p.scale * LOG2E;
-    const bool drop = p.dropout_p > 0.f;
+    constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     typename S::Stager sq, so;
@@ -726,24 +727,24 @@ void sa_allow_lds(K k) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <typename T, int D, int REL>
+template <typename T, int D, int REL, bool DROP = false>
 int sa_launch(const SAParams& p, int which, hipStream_t st) {
     const size_t chunk = (size_t)SA_CHUNK * D * sizeof(T);
     const size_t tab = (REL == 1 || REL == 3) ? (size_t)SA_WAVES * SA_WROWS * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
     if (which == 0) {
-        auto k = sa_fwd_kernel<T, D, REL>;
+        auto k = sa_fwd_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
         hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS), 2 * chunk + tab, st, p);
     } else if (which == 1) {
-        auto k = sa_bwd_dq_kernel<T, D, REL>;
+        auto k = sa_bwd_dq_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
         const size_t e = REL == 1 ? (size_t)256 * 32 * sizeof(T) : 0;
         hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
                            2 * chunk + e + tab * (REL == 3 ? 2 : 1), st, p);
     } else {
-        auto k = sa_bwd_dkv_kernel<T, D, REL>;
+        auto k = sa_bwd_dkv_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
         const size_t rel = REL == 2 ? (size_t)(2 * SA_CHUNK + SA_CHUNK * 64) * sizeof(float)
@@ -756,6 +757,10 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
 
 template <typename T>
 int sa_dispatch(int D, const SAParams& p, int which, hipStream_t st) {
+    if (p.dropout_p > 0.f) {
+        if (D == 32) return sa_launch<T, 32, 0, true>(p, which, st);
+        return sa_launch<T, 64, 0, true>(p, which, st);
+    }
     if (D == 32) return sa_launch<T, 32, 0>(p, which, st);
     if (!p.rel_h) return sa_launch<T, 64, 0>(p, which, st);
     if (p.Sw == 64) return sa_launch<T, 64, 2>(p, which, st);
@@ -778,6 +783,7 @@ int attention_stream(int dtype, int D, int which, const void* desc_ptr, hipStrea
     SAICV_REQUIRE(p.dropout_p >= 0.f && p.dropout_p < 1.f, "attention_stream: dropout_p=%f outside [0, 1)", (double)p.dropout_p);
     SAICV_REQUIRE((p.rel_h == nullptr) == (p.rel_w == nullptr), "attention_stream: rel_h and rel_w come together");
     if (p.rel_h) {
+        SAICV_REQUIRE(p.dropout_p == 0.f, "attention_stream: dropout is not instantiated together with a relative-position bias");
         SAICV_REQUIRE(D == 64, "attention_stream: the relative-position bias is instantiated for head dim 64");
         SAICV_REQUIRE(p.Sh >= 1 && p.Sw >= 1 && p.Sh * p.Sw == p.Nk, "attention_stream: Sh*Sw must equal Nk");
         SAICV_REQUIRE(p.Sh + p.Sw <= 128, "attention_stream: relative-position tables too wide for LDS");
