@@ -182,6 +182,24 @@ int saicv_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B
 int saicv_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                         void* dqkv, int B, int N, int H, int D, double scale, void* stream);
 
+/* ---- SAM image-encoder layout / relative position (reference segment_anything/image_encoder.py) -------- */
+/* window_partition (:32-55): x [B, H, W, C] -> out [B*nW, ws*ws, C], zero padded to multiples of ws */
+int saicv_window_partition(int dtype, const void* x, void* out, int B, int H, int W, int C, int ws, void* stream);
+/* window_unpartition (:58-79) fused with the residual add of Block.forward (:236): out = addend + unpartition(win) */
+int saicv_window_unpartition(int dtype, const void* win, const void* addend, void* out, int B, int H, int W, int C, int ws,
+                             void* stream);
+/* get_rel_pos + the einsums of add_decomposed_rel_pos (:82-144) for q_size == k_size, head dim 64:
+ * rel_h[b*heads + n, q, kh] = <q[b, q, n, :], tab_h[qh - kh + Sh - 1, :]>, rel_w likewise; q is addressed as
+ * q + b*q_bs + qi*q_rs + n*64 (elements); tab_* are the fp32 parameters [2S-1][64]. */
+int saicv_relpos_fwd(int dtype, const void* q, long q_rs, long q_bs, const float* tab_h, const float* tab_w, float* rel_h,
+                     float* rel_w, int B, int heads, int Sh, int Sw, void* stream);
+/* backward: dq (layout of q) += d_rel_* . tab_* ; dtab_* (fp32, both or neither) += d_rel_* . q, accumulated
+ * through privatised copies in `ws` (saicv_relpos_bwd_ws_floats floats, contents irrelevant) */
+size_t saicv_relpos_bwd_ws_floats(int Sh, int Sw);
+int saicv_relpos_bwd(int dtype, const void* q, void* dq, long q_rs, long q_bs, const float* tab_h, const float* tab_w,
+                     const float* d_rel_h, const float* d_rel_w, float* dtab_h, float* dtab_w, float* ws, int B, int heads,
+                     int Sh, int Sw, void* stream);
+
 /* SAM mask-loss statistics of logits [B, M, HW] against targets [B, HW] (fp32) in one pass:
  * stats[b, m, 0..5] = { sum focal, sum sigmoid*t, sum sigmoid, sum t, #(x>thr & t>thr), #(x>thr | t>thr) }.
  * Replaces SAMLoss.focal_loss / dice_loss / iou_predict_loss reductions

@@ -84,6 +84,11 @@ SIGNATURES = {
     'saicv_attention_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
     'saicv_linear_gelu_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_linear_dgrad_gelu': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_window_partition': (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_window_unpartition': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_relpos_fwd': (c_int, [c_int, _P, c_long, c_long, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'saicv_relpos_bwd': (c_int, [c_int, _P, _P, c_long, c_long, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'saicv_relpos_bwd_ws_floats': (c_size_t, [c_int, c_int]),
     'saicv_mask_loss_stats': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_size_t, c_double, c_double, c_double, _P]),
     'saicv_mask_loss_grad': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_size_t, c_double, c_double, _P]),
     'saicv_attention_stream_fwd': (c_int, [c_int, c_int, _PA, _P]),

@@ -280,6 +280,23 @@ int saicv_attention_bwd(int dtype, const void* qkv, const void* out, const void*
                         void* dqkv, int B, int N, int H, int D, double scale, void* stream) {
     return attention_bwd(dtype, qkv, out, dout, lse, dqkv, B, N, H, D, scale, S(stream));
 }
+int saicv_window_partition(int dtype, const void* x, void* out, int B, int H, int W, int C, int ws, void* stream) {
+    return window_partition(dtype, x, out, B, H, W, C, ws, S(stream));
+}
+int saicv_window_unpartition(int dtype, const void* win, const void* addend, void* out, int B, int H, int W, int C, int ws,
+                             void* stream) {
+    return window_unpartition(dtype, win, addend, out, B, H, W, C, ws, S(stream));
+}
+int saicv_relpos_fwd(int dtype, const void* q, long q_rs, long q_bs, const float* tab_h, const float* tab_w, float* rel_h,
+                     float* rel_w, int B, int heads, int Sh, int Sw, void* stream) {
+    return relpos_fwd(dtype, q, q_rs, q_bs, tab_h, tab_w, rel_h, rel_w, B, heads, Sh, Sw, S(stream));
+}
+int saicv_relpos_bwd(int dtype, const void* q, void* dq, long q_rs, long q_bs, const float* tab_h, const float* tab_w,
+                     const float* d_rel_h, const float* d_rel_w, float* dtab_h, float* dtab_w, float* ws, int B, int heads,
+                     int Sh, int Sw, void* stream) {
+    return relpos_bwd(dtype, q, dq, q_rs, q_bs, tab_h, tab_w, d_rel_h, d_rel_w, dtab_h, dtab_w, ws, B, heads, Sh, Sw, S(stream));
+}
+size_t saicv_relpos_bwd_ws_floats(int Sh, int Sw) { return relpos_bwd_ws_floats(Sh, Sw); }
 int saicv_mask_loss_stats(int dtype, const void* logits, const float* targets, float* stats, int B, int M, size_t HW,
                           double alpha, double gamma, double thr, void* stream) {
     return mask_loss_stats(dtype, logits, targets, stats, B, M, HW, alpha, gamma, thr, S(stream));

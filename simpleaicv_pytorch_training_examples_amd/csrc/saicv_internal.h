@@ -25,6 +25,16 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
              int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st,
              float* dbias = nullptr);
 
+// sam.hip
+int window_partition(int dtype, const void* x, void* out, int B, int H, int W, int C, int ws, hipStream_t st);
+int window_unpartition(int dtype, const void* win, const void* addend, void* out, int B, int H, int W, int C, int ws,
+                       hipStream_t st);
+int relpos_fwd(int dtype, const void* q, long q_rs, long q_bs, const float* tab_h, const float* tab_w, float* rel_h,
+               float* rel_w, int B, int heads, int Sh, int Sw, hipStream_t st);
+int relpos_bwd(int dtype, const void* q, void* dq, long q_rs, long q_bs, const float* tab_h, const float* tab_w,
+               const float* d_rel_h, const float* d_rel_w, float* dtab_h, float* dtab_w, float* ws, int B, int heads, int Sh,
+               int Sw, hipStream_t st);
+size_t relpos_bwd_ws_floats(int Sh, int Sw);
 // maskloss.hip
 int mask_loss_stats(int dtype, const void* logits, const float* targets, float* stats, int B, int M, size_t HW,
                     double alpha, double gamma, double thr, hipStream_t st);

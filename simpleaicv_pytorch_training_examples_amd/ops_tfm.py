@@ -452,60 +452,71 @@ def mlp_sublayer(x, norm, mlp, drop_scale):
 # ------------------------------------------------------------------------------ SAM encoder block (windows + rel-pos)
 def window_partition(x4, ws):
     """[B, H, W, C] -> ([B*nW, ws*ws, C], (Hp, Wp)); zero pad to a multiple of ws
-    (reference segment_anything/image_encoder.py:32-55).  Layout glue: one copy."""
+    (reference segment_anything/image_encoder.py:32-55) in one streaming kernel."""
     b, h, w, c = x4.shape
-    ph, pw = (ws - h % ws) % ws, (ws - w % ws) % ws
-    if ph or pw:
-        x4 = torch.nn.functional.pad(x4, (0, 0, 0, pw, 0, ph))
-    hp, wp = h + ph, w + pw
-    x = x4.view(b, hp // ws, ws, wp // ws, ws, c).permute(0, 1, 3, 2, 4, 5).contiguous()
-    return x.view(-1, ws * ws, c), (hp, wp)
+    x4 = x4.contiguous()
+    nwh, nww = (h + ws - 1) // ws, (w + ws - 1) // ws
+    out = torch.empty((b * nwh * nww, ws * ws, c), dtype=x4.dtype, device=x4.device)
+    check(lib().saicv_window_partition(dtype_code(x4.dtype), ptr(x4), ptr(out), b, h, w, c, ws, stream()), 'window_partition')
+    return out, (nwh * ws, nww * ws)
 
 
-def window_unpartition(win, ws, pad_hw, hw):
-    """inverse of window_partition, dropping the padding (reference image_encoder.py:58-79)."""
+def window_unpartition(win, ws, pad_hw, hw, addend=None):
+    """inverse of window_partition, dropping the padding (reference image_encoder.py:58-79); with `addend`
+    ([B, H, W, C]) the residual add of Block.forward (:236) happens in the same pass."""
     hp, wp = pad_hw
     h, w = hw
+    c = win.shape[-1]
     b = win.shape[0] // ((hp // ws) * (wp // ws))
-    x = win.view(b, hp // ws, wp // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5)
-    if hp > h or wp > w:
-        return x.reshape(b, hp, wp, -1)[:, :h, :w, :].contiguous()
-    return x.contiguous().view(b, h, w, -1)
+    win = win.contiguous()
+    out = torch.empty((b, h, w, c), dtype=win.dtype, device=win.device)
+    check(lib().saicv_window_unpartition(dtype_code(win.dtype), ptr(win), ptr(addend), ptr(out), b, h, w, c, ws, stream()),
+          'window_unpartition')
+    return out
 
 
-_rel_index_cache = {}
+def _rel_tables_ok(sh, sw, rel_pos_h, rel_pos_w):
+    if rel_pos_h.shape[0] != 2 * sh - 1 or rel_pos_w.shape[0] != 2 * sw - 1:
+        raise NotImplementedError(f'relative-position tables of length {rel_pos_h.shape[0]} / {rel_pos_w.shape[0]} for a '
+                                  f'{sh} x {sw} grid: interpolated tables (get_rel_pos, image_encoder.py:96-103) are not supported')
+    if rel_pos_h.shape[1] != 64 or not (rel_pos_h.is_contiguous() and rel_pos_w.is_contiguous()):
+        raise NotImplementedError('relative-position tables must be contiguous [2S-1, 64] fp32')
 
 
-def _rel_index(size, table_len, device):
-    """index [q, k] -> q - k + size - 1 into a [2*size-1, D] table (get_rel_pos with q_size == k_size,
-    reference image_encoder.py:82-113; the interpolating branch is not needed at native sizes)."""
-    if table_len != 2 * size - 1:
-        raise NotImplementedError(f'relative-position table of length {table_len} for size {size}: '
-                                  'interpolated tables are not supported')
-    key = (size, str(device))
-    idx = _rel_index_cache.get(key)
-    if idx is None:
-        r = torch.arange(size, device=device)
-        idx = (r[:, None] - r[None, :] + (size - 1)).contiguous()
-        _rel_index_cache[key] = idx
-    return idx
-
-
-def _rel_bias(q, heads, sh, sw, rel_pos_h, rel_pos_w):
-    """Decomposed relative-position logits (add_decomposed_rel_pos, reference image_encoder.py:116-144):
-    rel_h[b*heads + n, (h, w), k] = <q[b, (h, w), n, :], rel_pos_h[h - k + S - 1, :]>, same for w.
-    q is the UNSCALED query view [Bw, N, C].  Small fp32 batched GEMMs (0.8 % of the attention flops)."""
+def relpos_fwd(q, heads, sh, sw, rel_pos_h, rel_pos_w):
+    """Decomposed relative-position logits (add_decomposed_rel_pos, reference image_encoder.py:116-144) from the
+    UNSCALED query view q [Bw, N, C]: -> rel_h [Bw*heads, N, sh], rel_w [Bw*heads, N, sw] (fp32)."""
     bw, n, c = q.shape
-    d = c // heads
-    idx_h = _rel_index(sh, rel_pos_h.shape[0], q.device)
-    idx_w = _rel_index(sw, rel_pos_w.shape[0], q.device)
-    rh = rel_pos_h.detach().float()[idx_h]                  # [sh, sh, d]
-    rw = rel_pos_w.detach().float()[idx_w]
-    rq = q.reshape(bw, sh, sw, heads, d).float()
-    with torch.autocast('cuda', enabled=False):             # fp32 logits whatever the autocast state
-        rel_h = torch.einsum('bhwnc,hkc->bnhwk', rq, rh).contiguous().view(bw * heads, n, sh)
-        rel_w = torch.einsum('bhwnc,wkc->bnhwk', rq, rw).contiguous().view(bw * heads, n, sw)
-    return rel_h, rel_w, rh, rw, rq, idx_h, idx_w
+    _rel_tables_ok(sh, sw, rel_pos_h, rel_pos_w)
+    rel_h = torch.empty((bw * heads, n, sh), dtype=torch.float32, device=q.device)
+    rel_w = torch.empty((bw * heads, n, sw), dtype=torch.float32, device=q.device)
+    check(lib().saicv_relpos_fwd(dtype_code(q.dtype), ptr(q), q.stride(1), q.stride(0), ptr(rel_pos_h.detach()),
+                                 ptr(rel_pos_w.detach()), ptr(rel_h), ptr(rel_w), bw, heads, sh, sw, stream()), 'relpos_fwd')
+    return rel_h, rel_w
+
+
+def relpos_bwd(q, dq, heads, sh, sw, rel_pos_h, rel_pos_w, drh, drw, want_tables):
+    """dq += d_rel . tables (in place, layout of q); -> (d rel_pos_h, d rel_pos_w): tensors, or None when the
+    gradient was accumulated straight into the parameter's arena gradient / not wanted."""
+    bw = q.shape[0]
+    gh = gw = th = tw = ws = None
+    if want_tables:
+        ws = torch.empty(lib().saicv_relpos_bwd_ws_floats(sh, sw), dtype=torch.float32, device=q.device)
+        th, tw = _arena_grad(rel_pos_h), _arena_grad(rel_pos_w)
+        direct = th is not None and tw is not None
+        if not direct:
+            th = torch.zeros_like(rel_pos_h, dtype=torch.float32)
+            tw = torch.zeros_like(rel_pos_w, dtype=torch.float32)
+    check(lib().saicv_relpos_bwd(dtype_code(q.dtype), ptr(q), ptr(dq), q.stride(1), q.stride(0), ptr(rel_pos_h.detach()),
+                                 ptr(rel_pos_w.detach()), ptr(drh), ptr(drw), ptr(th), ptr(tw), ptr(ws), bw, heads, sh, sw, stream()),
+          'relpos_bwd')
+    if want_tables:
+        if direct:
+            _grad_ready(rel_pos_h)
+            _grad_ready(rel_pos_w)
+        else:
+            gh, gw = th, tw
+    return gh, gw
 
 
 class SamAttnSubLayerFn(torch.autograd.Function):
@@ -530,12 +541,12 @@ class SamAttnSubLayerFn(torch.autograd.Function):
         qkv = lin_fwd(hw2, qkv_w, qkv_b).view(bw, n, 3 * c)
         q, k, v = qkv[:, :, :c], qkv[:, :, c:2 * c], qkv[:, :, 2 * c:]
         scale = (c // heads) ** -0.5
-        rel_h, rel_w = _rel_bias(q, heads, sh, sw, rel_pos_h, rel_pos_w)[:2]
+        rel_h, rel_w = relpos_fwd(q, heads, sh, sw, rel_pos_h, rel_pos_w)
         a, lse = sattn_fwd(q, k, v, heads, scale, None, rel_h, rel_w)
         a2 = a.view(-1, c)
         if window > 0:
             p = lin_fwd(a2, proj_w, proj_b)
-            out = x + window_unpartition(p.view(bw, n, c), window, pad_hw, (hh, ww))
+            out = window_unpartition(p.view(bw, n, c), window, pad_hw, (hh, ww), addend=x2)     # x + unpartition(p)
         else:
             out = lin_fwd(a2, proj_w, proj_b, addend=x2).view(b, hh, ww, c)
         ctx.save_for_backward(x2, ln_w, ln_b, mean, rstd, hw2, qkv_w, qkv_b, qkv, a, lse, rel_h, rel_w, proj_w,
@@ -559,21 +570,9 @@ class SamAttnSubLayerFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = dqkv[:, :, :c], dqkv[:, :, c:2 * c], dqkv[:, :, 2 * c:]
         drh, drw = sattn_bwd(q, k, v, a, da.view(bw, n, c), lse, heads, scale, dq, dk, dv, None, rel_h, rel_w)
-        # relative-position tables and the extra query gradient (fp32 batched GEMMs)
-        _, _, rh, rw, rq, idx_h, idx_w = _rel_bias(q, heads, sh, sw, rel_pos_h, rel_pos_w)
-        d = c // heads
-        drh5 = drh.view(bw, heads, sh, sw, sh)
-        drw5 = drw.view(bw, heads, sh, sw, sw)
-        g_rh = g_rw = None
-        with torch.autocast('cuda', enabled=False):
-            dq_extra = torch.einsum('bnhwk,hkc->bhwnc', drh5, rh) + torch.einsum('bnhwk,wkc->bhwnc', drw5, rw)
-            dq.add_(dq_extra.reshape(bw, n, c).to(dt))
-            if ctx.needs_input_grad[7]:
-                g = torch.einsum('bnhwk,bhwnc->hkc', drh5, rq)
-                g_rh = torch.zeros_like(rel_pos_h, dtype=torch.float32).index_add_(0, idx_h.view(-1), g.reshape(-1, d))
-            if ctx.needs_input_grad[8]:
-                g = torch.einsum('bnhwk,bhwnc->wkc', drw5, rq)
-                g_rw = torch.zeros_like(rel_pos_w, dtype=torch.float32).index_add_(0, idx_w.view(-1), g.reshape(-1, d))
+        # extra query gradient and the table gradients of the relative-position logits
+        g_rh, g_rw = relpos_bwd(q, dq, heads, sh, sw, rel_pos_h, rel_pos_w, drh, drw,
+                                ctx.needs_input_grad[7] or ctx.needs_input_grad[8])
         dhw, dqw, dqb = lin_bwd(hw2, qkv_w, qkv_b, dqkv.view(-1, 3 * c))
         dh = window_unpartition(dhw.view(bw, n, c), window, pad_hw, (hh, ww)) if window > 0 else dhw
         dx, dlw, dlb = ln_bwd(dh.reshape(-1, c), x2, ln_w, ln_b, mean, rstd, addend=dy.view(-1, c))

@@ -257,3 +257,60 @@ def test_sam_full_model_bf16_tracks_reference_autocast():
     b = torch.cat([fx['grad_sample'][n].double() for n in names])
     cos = float(a @ b / (a.norm() * b.norm()))
     assert cos > noise['bf16_grad_sample_cos'] - 0.1, cos
+
+
+# ------------------------------------------------------------------------------------------ SAM layout / rel-pos kernels
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64, 7), (1, 64, 64, 128, 14), (3, 14, 28, 32, 14)])
+def test_window_kernels_match_reference_layout(shape, dtype):
+    """saicv_window_partition / _unpartition against the reference's pad + view + permute (image_encoder.py:32-79)."""
+    import torch.nn.functional as F
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    b, h, w, c, ws = shape
+    g = torch.Generator().manual_seed(h * 7 + ws)
+    x = torch.randn(b, h, w, c, generator=g).cuda().to(dtype)
+    ph, pw = (ws - h % ws) % ws, (ws - w % ws) % ws
+    xp = F.pad(x, (0, 0, 0, pw, 0, ph))
+    hp, wp = h + ph, w + pw
+    ref = xp.view(b, hp // ws, ws, wp // ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, c)
+    win, pad_hw = ops_tfm.window_partition(x, ws)
+    assert pad_hw == (hp, wp) and torch.equal(win, ref)
+    back = ops_tfm.window_unpartition(win, ws, pad_hw, (h, w))
+    assert torch.equal(back, x)
+    add = torch.randn(b, h, w, c, generator=g).cuda().to(dtype)
+    fused = ops_tfm.window_unpartition(win, ws, pad_hw, (h, w), addend=add)
+    assert rel_err(fused, (x.float() + add.float())) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('grid', [(14, 14), (64, 64), (16, 16), (5, 64)])
+def test_relpos_kernels_match_einsum(grid, dtype):
+    """saicv_relpos_fwd / _bwd against get_rel_pos + the einsums of add_decomposed_rel_pos (image_encoder.py:82-144)."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    sh, sw = grid
+    bw, heads, d = 2, 3, 64
+    n, c = sh * sw, heads * d
+    g = torch.Generator().manual_seed(sh * 100 + sw)
+    qkv = torch.randn(bw, n, 3 * c, generator=g).cuda().to(dtype)
+    q = qkv[:, :, :c]
+    th = (torch.randn(2 * sh - 1, d, generator=g) * 0.5).cuda().requires_grad_(True)
+    tw = (torch.randn(2 * sw - 1, d, generator=g) * 0.5).cuda().requires_grad_(True)
+    rel_h, rel_w = ops_tfm.relpos_fwd(q, heads, sh, sw, th, tw)
+    ql = q.detach().float().clone().requires_grad_(True)
+    rq = ql.view(bw, sh, sw, heads, d)
+    rh = th[(torch.arange(sh)[:, None] - torch.arange(sh)[None, :] + sh - 1).cuda()]
+    rw = tw[(torch.arange(sw)[:, None] - torch.arange(sw)[None, :] + sw - 1).cuda()]
+    ref_h = torch.einsum('bhwnc,hkc->bnhwk', rq, rh).reshape(bw * heads, n, sh)
+    ref_w = torch.einsum('bhwnc,wkc->bnhwk', rq, rw).reshape(bw * heads, n, sw)
+    assert rel_err(rel_h, ref_h) < 1e-5 and rel_err(rel_w, ref_w) < 1e-5
+    drh = torch.randn(bw * heads, n, sh, generator=g).cuda()
+    drw = torch.randn(bw * heads, n, sw, generator=g).cuda()
+    (ref_h * drh).sum().backward(retain_graph=True)
+    (ref_w * drw).sum().backward()
+    dqkv = torch.zeros_like(qkv)
+    dq = dqkv[:, :, :c]
+    gh, gw = ops_tfm.relpos_bwd(q, dq, heads, sh, sw, th, tw, drh, drw, True)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2        # bf16: dq is rounded on store
+    assert rel_err(dq, ql.grad) < tol
+    assert rel_err(gh, th.grad) < 1e-4 and rel_err(gw, tw.grad) < 1e-4
+    assert float(dqkv[:, :, c:].abs().sum()) == 0.0       # only the q slice is touched
