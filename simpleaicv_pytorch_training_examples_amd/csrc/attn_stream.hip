@@ -358,6 +358,10 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
     float* rw = rh + SA_WROWS * (p.Sh + 1);
     float* gh = rh + tabw;                                // REL 3 only
     float* gw = gh + SA_WROWS * (p.Sh + 1);
+    // REL 2: d rel_w accumulates in LDS ([32 queries][64 kw], pitch 68 floats) -- every lane owns its own
+    // 16-byte slots, so plain ds_read_b128 / ds_write_b128 pairs do (LDS float atomics are far slower); keeping
+    // the 32 accumulators in registers held the kernel at one wavefront per SIMD
+    float* gws = tabs + wave * SA_WROWS * 68;
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
@@ -385,7 +389,10 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
             st_chunk(Es + sa_off<EROWB>(row, ch), Chunk<T>::pack(f));
         }
     }
-    float rwreg[2][16], gwreg[2][16];
+    float rwreg[2][16];
+    if constexpr (REL == 2) {
+        for (int i = lane; i < SA_WROWS * 68; i += 64) gws[i] = 0.f;
+    }
     if constexpr (REL == 2) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (q < p.Nq) v = *reinterpret_cast<const f32x4*>(p.rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { rwreg[qt][kt * 4 + r] = v[r] * LOG2E; gwreg[qt][kt * 4 + r] = 0.f; }
+                for (int r = 0; r < 4; ++r) rwreg[qt][kt * 4 + r] = v[r] * LOG2E;
             }
         }
     }
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
                     if (drop) dpe = sa_keep(p.seed, bh, q0 + qt * 16 + l15, key, p.Nk, dthresh) ? dpe * inv_keep : 0.f;
                     const float gv = (kok && qok[qt]) ? pr * (dpe - dsum[qt]) : 0.f;      // d logits
                     g[qt][kt][r] = gv;
-                    if constexpr (REL == 2) { gwreg[qt][kt * 4 + r] += gv; ghc[qt] += gv; }
+                    if constexpr (REL == 2) ghc[qt] += gv;
                     if constexpr (REL == 3) {
                         if (kok && qok[qt]) {
                             atomicAdd(&gh[(qt * 16 + l15) * (p.Sh + 1) + kh], gv);
@@ -498,6 +505,15 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
                     }
                 }
             }
+        }
+        if constexpr (REL == 2) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    f32x4* slot = reinterpret_cast<f32x4*>(gws + (qt * 16 + l15) * 68 + kt * 16 + lg * 4);
+                    *slot += g[qt][kt];
+                }
         }
         if constexpr (REL == 2) {       // the whole chunk is one kh row
 #pragma unroll
@@ -539,17 +555,12 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
                 }
             }
         }
-    if constexpr (REL == 2) {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int q = q0 + qt * 16 + l15;
-            if (q < p.Nq) {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    const f32x4 v = {gwreg[qt][kt * 4], gwreg[qt][kt * 4 + 1], gwreg[qt][kt * 4 + 2], gwreg[qt][kt * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(p.d_rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4) = v;
-                }
-            }
+    if constexpr (REL == 2) {       // each lane only ever touched its own slots; the wave reads them all back here
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < SA_WROWS * 64; i += 64) {
+            const int r = i >> 6, c = i & 63;
+            if (q0 + r < p.Nq) p.d_rel_w[((size_t)bh * p.Nq + q0 + r) * 64 + c] = gws[r * 68 + c];
         }
     }
     if constexpr (REL == 3) {       // this wavefront's LDS atomics are complete once its own counters drain
@@ -741,8 +752,9 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
         static bool once = (sa_allow_lds(k), true);
         (void)once;
         const size_t e = REL == 1 ? (size_t)256 * 32 * sizeof(T) : 0;
+        const size_t g2 = REL == 2 ? (size_t)SA_WAVES * SA_WROWS * 68 * sizeof(float) : 0;
         hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
-                           2 * chunk + e + tab * (REL == 3 ? 2 : 1), st, p);
+                           2 * chunk + e + g2 + tab * (REL == 3 ? 2 : 1), st, p);
     } else {
         auto k = sa_bwd_dkv_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
