@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--kernel-breakdown', action='store_true',
+                    help='bracket every kernel family with HIP events (adds host overhead; default: only the dominant kernel)')
     return ap.parse_args()
 
 
@@ -224,10 +226,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ops.KernelTimer.enabled = not args.no_kernel_timer
+    ops.KernelTimer.only = None if args.kernel_breakdown else {'igemm_nt'}
     ops.KernelTimer.records = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host enqueue time per step (launch-bound if ~ ms_per_step)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -252,7 +256,7 @@ def main():
                                    f'(fwd+loss+bwd+all-reduce+optimizer), per-GPU batch {args.batch}',
                        'model': args.model, 'global_batch': args.batch * world, 'per_gpu_batch': args.batch,
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
-                       'loss_scale': scaler.get_scale()},
+                       'loss_scale': scaler.get_scale(), 'host_enqueue_ms_per_step': round(host_ms, 3)},
             'model_mfma_frac': round(TRAIN_GFLOP_PER_IMG.get(args.model, 0) * value / world / 1e3 / PEAK_BF16_TFLOPS, 4),
         }
         summ = ops.KernelTimer.summary() if not args.no_kernel_timer else {}

@@ -20,11 +20,13 @@ class KernelTimer:
     saicv kernel is launched on).  bench.py enables it to price the dominant kernel against
     its roofline from live measurements; it is off by default (zero overhead)."""
     enabled = False
+    only = None           # optional set of tags to bracket (every event pair costs host time: ~1400 per ResNet-50 step
+                          # with all tags made the bench host-bound and 7 % slower; bench.py brackets the dominant kernel)
     records = []          # (tag, start_event, end_event, algorithmic_flops, algorithmic_bytes)
 
     @classmethod
-    def begin(cls):
-        if not cls.enabled:
+    def begin(cls, tag=None):
+        if not cls.enabled or (cls.only is not None and tag not in cls.only):
             return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
@@ -205,7 +207,7 @@ class ConvBnActFn(torch.autograd.Function):
         if training:
             rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
             stats = torch.empty((2, rows, k), dtype=torch.float32, device=dev)
-            t0 = KernelTimer.begin()
+            t0 = KernelTimer.begin('igemm_nt')
             check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, ptr(stats[0]),
                                      ptr(stats[1]), st), 'conv2d_fwd')
             KernelTimer.end(t0, 'igemm_nt', 2.0 * M * k * r * s * min(c, ci), 0)
@@ -234,7 +236,7 @@ class ConvBnActFn(torch.autograd.Function):
         # backward needs only the sign of z: one byte per 16-byte chunk instead of re-reading z twice
         mask = (torch.empty(M * k // _lib.epc(dt), dtype=torch.uint8, device=dev)
                 if (relu and training and any(ctx.needs_input_grad)) else None)
-        t0 = KernelTimer.begin()
+        t0 = KernelTimer.begin('bn_act_fwd')
         check(L.saicv_bn_act_fwd(dtype_code(dt), ptr(y), ptr(residual), ptr(z), ptr(scale), ptr(shift), M,
                                  k, int(relu), ptr(mask), st), 'bn_act_fwd')
         KernelTimer.end(t0, 'bn_act_fwd', 0, float(M) * k * y.element_size() * (3 if residual is not None else 2))
@@ -275,7 +277,7 @@ class ConvBnActFn(torch.autograd.Function):
             dgamma = torch.empty(k, dtype=torch.float32, device=dev)
             dbeta = torch.empty(k, dtype=torch.float32, device=dev)
         ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, k, dtype_code(dt)), dtype=torch.float32, device=dev)
-        t0 = KernelTimer.begin()
+        t0 = KernelTimer.begin('bn_act_bwd')
         check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), 0, ptr(mask), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
                                  ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), M, k, int(relu), int(direct_bn),
                                  ptr(ws), st), 'bn_act_bwd')
@@ -293,7 +295,7 @@ class ConvBnActFn(torch.autograd.Function):
             if wd is None:
                 _, wd = packed_weight(weight, dt, c, True)
             dx = _empty_nhwc(n, c, x.shape[2], x.shape[3], dt, dev)
-            t0 = KernelTimer.begin()
+            t0 = KernelTimer.begin('igemm_nt')
             if dskip is not None:           # gradient of the shortcut alias joins in the dgrad epilogue
                 dskip = _nhwc(dskip)
                 if dskip.dtype != dt:
@@ -310,7 +312,7 @@ class ConvBnActFn(torch.autograd.Function):
                       weight.is_contiguous(memory_format=torch.channels_last))
             # KRSC fp32 gradient: straight into the arena (atomics accumulate), else a temporary
             dw = gw if direct else torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=dev)
-            t0 = KernelTimer.begin()
+            t0 = KernelTimer.begin('igemm_tn')
             check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
             KernelTimer.end(t0, 'igemm_tn', flops, 0)
             if direct:
@@ -344,7 +346,7 @@ class ConvFn(torch.autograd.Function):
         wf, wd = packed_weight(weight, dt, c, need_dx)
         d = _desc(n, h, w, c, k, r, s, stride, pad, dt)
         y = _empty_nhwc(n, k, d.OH, d.OW, dt, x.device)
-        t0 = KernelTimer.begin()
+        t0 = KernelTimer.begin('igemm_nt')
         check(lib().saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), ptr(bias), ptr(y), 0, 0, 0, stream()),
               'conv2d_fwd')
         KernelTimer.end(t0, 'igemm_nt', 2.0 * n * d.OH * d.OW * k * r * s * c, 0)
@@ -370,14 +372,14 @@ class ConvFn(torch.autograd.Function):
             if wd is None:
                 _, wd = packed_weight(weight, dt, c, True)
             dx = _empty_nhwc(n, c, h, w, dt, x.device)
-            t0 = KernelTimer.begin()
+            t0 = KernelTimer.begin('igemm_nt')
             check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
             KernelTimer.end(t0, 'igemm_nt', flops, 0)
         if ctx.needs_input_grad[1]:
             gw = _arena_grad(weight)
             direct = gw is not None and weight.is_contiguous(memory_format=torch.channels_last)
             dw = gw if direct else torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=x.device)
-            t0 = KernelTimer.begin()
+            t0 = KernelTimer.begin('igemm_tn')
             check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
             KernelTimer.end(t0, 'igemm_tn', flops, 0)
             if direct:

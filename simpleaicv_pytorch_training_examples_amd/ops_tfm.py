@@ -36,7 +36,7 @@ def lin_fwd(x2, weight, bias, out_f32=False, addend=None, row_scale=None, rows_p
         bp[:o] = bias.detach()
     if (addend is not None or row_scale is not None) and op != o:
         raise ValueError('fused residual needs out_features to be a multiple of the chunk width')
-    t0 = KernelTimer.begin()
+    t0 = KernelTimer.begin('igemm_nt')
     check(lib().saicv_linear_fwd(dtype_code(dt), ptr(x2), ptr(wf), ptr(bp), ptr(y), m, k, op, int(odt == torch.float32),
                                  ptr(addend), ptr(row_scale), rows_per_scale, stream()), 'linear_fwd')
     KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, 0)
@@ -56,7 +56,7 @@ def lin_gelu_fwd(x2, weight, bias):
     wf, _ = packed_weight(weight, dt, k, True, o)
     pre = torch.empty((m, o), dtype=dt, device=x2.device)
     act = torch.empty((m, o), dtype=dt, device=x2.device)
-    t0 = KernelTimer.begin()
+    t0 = KernelTimer.begin('igemm_nt')
     check(lib().saicv_linear_gelu_fwd(dtype_code(dt), ptr(x2), ptr(wf), ptr(bias), ptr(pre), ptr(act), m, k, o, stream()),
           'linear_gelu_fwd')
     KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, 0)
@@ -85,7 +85,7 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None):
     if need_dx:
         _, wd = packed_weight(weight, dt, k, True, op)
         dx = torch.empty((m, k), dtype=dt, device=x2.device)
-        t0 = KernelTimer.begin()
+        t0 = KernelTimer.begin('igemm_nt')
         if gelu_pre is not None:
             if addend is not None or k % e:
                 raise ValueError('fused GELU backward: no addend, 16-byte aligned rows')
@@ -101,7 +101,7 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None):
         gw = _arena_grad(weight) if (op == o and weight.is_contiguous()) else None
         tgt = gw if gw is not None else torch.zeros((op, k), dtype=torch.float32, device=x2.device)
         # the weight-gradient kernel also emits the bias gradient from the dY tiles it streams
-        t0 = KernelTimer.begin()
+        t0 = KernelTimer.begin('igemm_tn')
         check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), ptr(tb), m, k, op, st), 'linear_wgrad')
         KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, 0)
         if gw is not None:
