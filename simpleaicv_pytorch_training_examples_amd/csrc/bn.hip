@@ -172,28 +172,47 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
         for (int j = 0; j < N; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; ag[j] = 0.f; ax[j] = 0.f; }
         if (active) {
-            for (int r = r0 + ty; r < r1; r += rpp) {
-                const size_t e = (size_t)r * C + c0;
-                float g[N], yy[N], zz[N];
-                Chunk<T>::unpack(ld_chunk(dz + e), g);
-                Chunk<T>::unpack(ld_chunk(y + e), yy);
-                unsigned bits = 0xffu;
-                if (RELU) {
-                    if (mask != nullptr) {
-                        bits = mask[e / N];
-                    } else {
-                        Chunk<T>::unpack(ld_chunk(z + e), zz);
-                        bits = 0;
+            // rows are taken four at a time: all loads of the group are issued before the first use, which keeps
+            // ~12 16-byte requests per thread in flight (the one-row loop ran at 3.3 TB/s)
+            auto row_bits = [&](size_t e) -> unsigned {
+                if (!RELU) return 0xffu;
+                if (mask != nullptr) return mask[e / N];
+                float zz[N];
+                Chunk<T>::unpack(ld_chunk(z + e), zz);
+                unsigned b = 0;
 #pragma unroll
-                        for (int j = 0; j < N; ++j) bits |= (zz[j] > 0.f ? 1u : 0u) << j;
-                    }
-                }
+                for (int j = 0; j < N; ++j) b |= (zz[j] > 0.f ? 1u : 0u) << j;
+                return b;
+            };
+            auto accumulate = [&](const u32x4& cg, const u32x4& cy, unsigned bits) {
+                float g[N], yy[N];
+                Chunk<T>::unpack(cg, g);
+                Chunk<T>::unpack(cy, yy);
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const float gj = ((bits >> j) & 1u) ? g[j] : 0.f;
                     ag[j] += gj;
                     ax[j] += gj * (yy[j] - mu[j]) * is[j];
                 }
+            };
+            int r = r0 + ty;
+            for (; r + 3 * rpp < r1; r += 4 * rpp) {
+                u32x4 cg[4], cy[4];
+                unsigned bits[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t e = (size_t)(r + u * rpp) * C + c0;
+                    cg[u] = ld_chunk(dz + e);
+                    cy[u] = ld_chunk(y + e);
+                    bits[u] = row_bits(e);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) accumulate(cg[u], cy[u], bits[u]);
+            }
+            for (; r < r1; r += rpp) {
+                const size_t e = (size_t)r * C + c0;
+                const u32x4 cg = ld_chunk(dz + e), cy = ld_chunk(y + e);
+                accumulate(cg, cy, row_bits(e));
             }
         }
         // combine the rpp row-lanes of this column through LDS
