@@ -59,7 +59,8 @@ def main():
         rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
         stats = torch.empty(2, rows, co, device='cuda')
         flops = 2.0 * batch * d.OH * d.OW * co * k * k * ci
-        t_f = timeit(lambda: check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, ptr(stats[0]), ptr(stats[1]), st)))
+        nostat = bool(os.environ.get('KB_NO_STATS'))
+        t_f = timeit(lambda: check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, 0 if nostat else ptr(stats[0]), 0 if nostat else ptr(stats[1]), st)))
         t_d = timeit(lambda: check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st))) if ci != 8 else 0.0
         t_w = timeit(lambda: check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st))) if not os.environ.get('KB_SKIP_WGRAD') else 1.0
         rec = {'conv': f'{ci}->{co} k{k} s{s} {h}->{d.OH}', 'gflop': round(flops / 1e9, 2),

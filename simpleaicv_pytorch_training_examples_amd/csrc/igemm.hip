@@ -365,12 +365,9 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
         if (do_stats) {
             // rows m >= M were gathered as zeros (no bias when stats are requested) -> add 0.
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    ssum[r] += __shfl_xor(ssum[r], o, 64);
-                    ssq[r] += __shfl_xor(ssq[r], o, 64);
-                }
+            for (int r = 0; r < 4; ++r) {        // over the 16 pixel lanes: four DPP adds each
+                ssum[r] = row16_sum(ssum[r]);
+                ssq[r] = row16_sum(ssq[r]);
             }
             if (l15 == 0) {
                 const size_t prow = (size_t)(tile_m * WM_ + wm) * (size_t)p.Nn;
