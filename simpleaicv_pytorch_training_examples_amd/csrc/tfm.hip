@@ -379,7 +379,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(const T* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + lg * 4 + r;
-                    st[kt][r] = key < N ? st[kt][r] * scale : -INFINITY;
+                    st[kt][r] = key < N ? st[kt][r] * (scale * 1.4426950408889634f) : -INFINITY;        // log2 domain: v_exp_f32 below
                     mx = fmaxf(mx, st[kt][r]);
                 }
             }
@@ -395,8 +395,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(const T* __r
             if (blk * 2 < nkt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    st[2 * blk][r] = expf(st[2 * blk][r] - mx);
-                    st[2 * blk + 1][r] = expf(st[2 * blk + 1][r] - mx);
+                    st[2 * blk][r] = __builtin_amdgcn_exp2f(st[2 * blk][r] - mx);
+                    st[2 * blk + 1][r] = __builtin_amdgcn_exp2f(st[2 * blk + 1][r] - mx);
                     sum += st[2 * blk][r] + st[2 * blk + 1][r];
                 }
                 pv_pair<T>(o, st[2 * blk], st[2 * blk + 1], Vs, blk * 32, l15, lg);
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(const T* __r
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        if (lg == 0 && qt * 16 + l15 < N) lse[((size_t)b * H + h) * N + qt * 16 + l15] = mx + logf(sum);
+        if (lg == 0 && qt * 16 + l15 < N) lse[((size_t)b * H + h) * N + qt * 16 + l15] = (mx + log2f(sum)) * 0.6931471805599453f;
         // O tile: col d = dt*16 + l15, rows = queries lg*4 + r; 1/sum lives on lanes with l15 == query
         const float inv = 1.f / sum;
 #pragma unroll
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(const T* __r
         d += __shfl_xor(d, 1, 64);
         if (hf == 0) {
             Dq[q] = d;
-            Ls[q] = q < N ? lse[((size_t)b * H + h) * N + q] : 0.f;
+            Ls[q] = q < N ? lse[((size_t)b * H + h) * N + q] * 1.4426950408889634f : 0.f;      // log2 units
         }
     }
     attn_stage<T>(M0, qb + C, RS, N, Np);          // K
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(const T* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + lg * 4 + r;
-                    const float p = (key < N && qok) ? expf(sv[r] * scale - lq) : 0.f;
+                    const float p = (key < N && qok) ? __builtin_amdgcn_exp2f(sv[r] * (scale * 1.4426950408889634f) - lq) : 0.f;
                     ds[t][r] = p * (dp[r] - dq_) * scale;
                 }
             }
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(const T* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = qt * 16 + lg * 4 + r;
-                    const float p = (qq < N && kok) ? expf(sv[r] * scale - Ls[qq]) : 0.f;
+                    const float p = (qq < N && kok) ? __builtin_amdgcn_exp2f(sv[r] * (scale * 1.4426950408889634f) - Ls[qq]) : 0.f;
                     pt[t][r] = p;
                     dst_[t][r] = p * (dp[r] - Dq[qq]) * scale;
                 }
