@@ -314,3 +314,21 @@ def test_relpos_kernels_match_einsum(grid, dtype):
     assert rel_err(dq, ql.grad) < tol
     assert rel_err(gh, th.grad) < 1e-4 and rel_err(gw, tw.grad) < 1e-4
     assert float(dqkv[:, :, c:].abs().sum()) == 0.0       # only the q slice is touched
+
+
+def test_sam_encoder_arena_direct_gradients_equal_autograd_gradients():
+    """With the flat gradient arena attached, linear / LayerNorm / relative-position-table gradients are written in
+    place by the kernels; they must equal the plain autograd path (and the rel-pos tables go through the privatised
+    atomic copies either way)."""
+    from simpleaicv_pytorch_training_examples_amd import engine
+    fx = load_golden('sam_encoder_tiny')
+    a = _sam_model(fx)
+    b = _sam_model(fx)
+    arena = engine.FlatArena(list(b.named_parameters()), torch.device('cuda'))
+    x, probe = _sam_inputs(fx)
+    (a(x) * probe).sum().backward()
+    arena.zero_grad()
+    (b(x) * probe).sum().backward()
+    torch.cuda.synchronize()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_err(pb.grad, pa.grad) < 1e-4, n
