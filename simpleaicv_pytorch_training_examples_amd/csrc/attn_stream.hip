@@ -341,7 +341,9 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
 // ------------------------------------------------------------------------------------ backward: dQ (+ D, d rel-pos)
 // LDS: K chunk | V chunk | REL 1: indicator [256][32] | REL 1/3: per-wave tables | REL 3: per-wave gradient tables
 template <typename T, int D, int REL, bool DROP>
-__global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p) {
+// without a relative-position bias the kernel fits 256 VGPRs: two workgroups per CU and VGPR-form MFMAs (no
+// AGPR <-> VGPR copies around the short-lived S / dP tiles); the rel-pos variants spill under that bound
+__global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dq_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
     constexpr int EROWB = 32 * (int)sizeof(T);            // indicator rows: 32 columns
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_bwd_dq_kernel(const SAParams p)
 DEVINL int sa_rw_off(int row, int kw) { return row * 64 + ((((kw >> 2) ^ (((row >> 2) & 3) << 2))) << 2) + (kw & 3); }
 
 template <typename T, int D, int REL, bool DROP>
-__global__ __launch_bounds__(SA_THREADS) void sa_bwd_dkv_kernel(const SAParams p) {
+__global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dkv_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
