@@ -294,6 +294,7 @@ class DistributedDataParallel(torch.nn.Module):
         self.arena = _arena_of(module)
         self._sync = True
         self._works = []
+        self._arrived = set()
         self._build_buckets(int(bucket_cap_mb * 2 ** 20 // 4), int(last_bucket_cap_mb * 2 ** 20 // 4))
         self._flatten_buffers()
         if self.world > 1:
@@ -341,6 +342,11 @@ class DistributedDataParallel(torch.nn.Module):
         def hook(param):
             if not self._sync or self.world == 1:
                 return
+            # a parameter counts once per step: for gradients the kernels write in place BOTH the kernel-side
+            # call and autograd's post-accumulate hook (invoked even though backward returned None) arrive
+            if i in self._arrived:
+                return
+            self._arrived.add(i)
             b = self.buckets[self.bucket_of[i]]
             b['count'] += 1
             if b['count'] == len(b['params']):
@@ -370,6 +376,7 @@ class DistributedDataParallel(torch.nn.Module):
             if view is not None:
                 view.div_(self.world)
         self._works = []
+        self._arrived.clear()
         for b in self.buckets:
             b['count'] = 0
 

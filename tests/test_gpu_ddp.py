@@ -1,0 +1,93 @@
+"""The data-parallel engine with the real HIP kernels and world_size 2 on ONE GPU (both ranks on cuda:0, gloo
+transport -- RCCL refuses two ranks per device).  What this covers that the CPU gloo tests cannot: gradients that the
+kernels write straight into the flat arena and announce through `_saicv_grad_ready` (no autograd AccumulateGrad),
+bucket completion counting over such parameters, BatchNorm buffer broadcast, the fused optimizer after the sync.
+Each rank trains on its half of a batch; the synchronised gradient must equal the mean of the two local gradients
+(obtained under no_sync) and both ranks must end with bit-identical parameters."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q, kind):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from simpleaicv_pytorch_training_examples_amd import engine
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones, losses
+    torch.manual_seed(rank)                       # ranks start different; the ctor broadcast must fix that
+    if kind == 'resnet':
+        model = backbones.resnet18cifar(num_classes=10).cuda()
+        shape, crit, soft = (8, 3, 32, 32), losses.CELoss(), False
+    else:
+        model = backbones.vit._vit(16, 192, 2, 3, 4, image_size=64, drop_path_prob=0.0, global_pool=True, num_classes=10).cuda()
+        shape, crit, soft = (8, 3, 64, 64), losses.CELoss(), False
+    opt = engine.SGD(model, [{'params': list(model.parameters()), 'weight_decay': 0.0}], lr=0.05, momentum=0.9)
+    ddp = engine.DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=0.5, last_bucket_cap_mb=0.05)
+    assert len(ddp.buckets) >= 3
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(shape, generator=g)
+    y = torch.randint(0, 10, (shape[0],), generator=g)
+    h = shape[0] // 2
+    xs, ys = x[rank * h:(rank + 1) * h].cuda(), y[rank * h:(rank + 1) * h].cuda()
+    ddp.train()
+    for m in model.modules():                     # same BN behaviour on both passes below
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.0
+
+    def run(sync):
+        opt.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss = crit(ddp(xs), ys)
+        if sync:
+            loss.backward()
+            ddp.finish_gradient_sync()
+        else:
+            with ddp.no_sync():
+                loss.backward()
+        torch.cuda.synchronize()
+        return ddp.arena.flat_grad.clone()
+
+    local = run(False)
+    synced = run(True)
+    opt.step()
+    torch.cuda.synchronize()
+    q.put((rank, local.cpu().numpy(), synced.cpu().numpy(), ddp.arena.flat_param.detach().cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('kind', ['resnet', 'vit'])
+def test_world2_on_one_gpu_kernel_side_gradient_hooks(kind):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, l0, s0, p0), (_, l1, s1, p1) = [(r,) + tuple(torch.from_numpy(a) for a in rest) for r, *rest in res]
+    assert not torch.allclose(l0, l1)                                 # different halves, local gradients differ
+    assert torch.equal(s0, s1)                                        # one all-reduced gradient on both ranks
+    mean = (l0.double() + l1.double()) / 2
+    err = float((s0.double() - mean).abs().max() / mean.abs().max())
+    assert err < 2e-3, err                                            # fp32 atomics order only
+    assert torch.equal(p0, p1)                                        # identical parameters after the fused step
