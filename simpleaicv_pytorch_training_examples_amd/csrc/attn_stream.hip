@@ -587,7 +587,7 @@ __global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dq_kernel
 DEVINL int sa_rw_off(int row, int kw) { return row * 64 + ((((kw >> 2) ^ (((row >> 2) & 3) << 2))) << 2) + (kw & 3); }
 
 template <typename T, int D, int REL, bool DROP>
-__global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dkv_kernel(const SAParams p) {
+__global__ __launch_bounds__(SA_THREADS, (REL == 0 || REL == 2) ? 2 : 1) void sa_bwd_dkv_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -635,8 +635,22 @@ __global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dkv_kerne
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     typename S::Stager sq, so;
     float pf_stat = 0.f, pf_rh = 0.f;                      // D / lse (tid < 128), rel_h column (tid < 128)
-    f32x4 pf_rw[4];
+    // REL 2: the [64 queries][64 kw] fp32 tile of rel_w goes global -> LDS by DMA (no registers, double buffered);
+    // the DMA writes wave-linear 16-byte slots, so the XOR swizzle is applied to the SOURCE address
+    typedef __attribute__((address_space(3))) void lds_void;
     const float* rwg = REL == 2 ? p.rel_w + (size_t)bh * p.Nq * 64 : nullptr;
+    const __amdgpu_buffer_rsrc_t rw_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(REL == 2 ? rwg : p.lse), 0, REL == 2 ? (int)((size_t)p.Nq * 64 * sizeof(float)) : 0, 0x00020000);
+    auto dma_rw = [&](int q0, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int slot = (j * SA_WAVES + wave) * 64 + lane, row = slot >> 4, pos = slot & 15;
+            const int c4 = pos ^ (((row >> 2) & 3) << 2);
+            const unsigned off = (q0 + row) < p.Nq ? (unsigned)(((q0 + row) * 64 + c4 * 4) * (int)sizeof(float)) : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_rs, (lds_void*)((char*)(rws + buf * SA_CHUNK * 64) + (j * SA_WAVES + wave) * 1024),
+                                                     16, (int)off, 0, 0, 0);
+        }
+    };
     const float* rhg = REL == 2 ? p.rel_h + (size_t)bh * p.Nq * p.Sh + 2 * blockIdx.x : nullptr;
     auto prefetch = [&](int q0) {
         sq.load(qg, p.q_rs, q0, p.Nq);
@@ -646,31 +660,18 @@ __global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dkv_kerne
             pf_stat = r < p.Nq ? (tid < SA_CHUNK ? dsg[r] : lsg[r] * LOG2E) : 0.f;
             if constexpr (REL == 2) pf_rh = r < p.Nq ? rhg[(size_t)r * p.Sh + (tid >> 6)] * LOG2E : 0.f;
         }
-        if constexpr (REL == 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = tid + j * SA_THREADS, row = i >> 4, c4 = i & 15;
-                pf_rw[j] = (q0 + row) < p.Nq ? *reinterpret_cast<const f32x4*>(rwg + (size_t)(q0 + row) * 64 + c4 * 4)
-                                             : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
     };
     prefetch(0);
+    if constexpr (REL == 2) dma_rw(0, 0);
 
     for (int q0 = 0; q0 < p.Nq; q0 += SA_CHUNK) {
+        if constexpr (REL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk's rel_w tile has landed
         __syncthreads();
         sq.store(Qs);
         so.store(Os);
         if (tid < 2 * SA_CHUNK) {
             Dq[tid] = pf_stat;                             // Dq[0..63] then Ls[0..63] (contiguous)
             if constexpr (REL == 2) rhs[tid] = pf_rh;
-        }
-        if constexpr (REL == 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = tid + j * SA_THREADS, row = i >> 4, c4 = i & 15;
-                *reinterpret_cast<f32x4*>(rws + row * 64 + ((c4 ^ (((row >> 2) & 3) << 2)) << 2)) = pf_rw[j] * LOG2E;
-            }
         }
         if constexpr (TAB) {
             for (int i = tid; i < SA_CHUNK * p.Sh; i += SA_THREADS) {
@@ -683,7 +684,11 @@ __global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dkv_kerne
             }
         }
         __syncthreads();
-        if (q0 + SA_CHUNK < p.Nq) prefetch(q0 + SA_CHUNK);
+        if (q0 + SA_CHUNK < p.Nq) {
+            prefetch(q0 + SA_CHUNK);
+            if constexpr (REL == 2) dma_rw(q0 + SA_CHUNK, ((q0 >> 6) + 1) & 1);
+        }
+        const float* rwc = rws + ((q0 >> 6) & 1) * SA_CHUNK * 64;      // REL 2: this chunk's tile
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair) {             // 32 queries at a time
             f32x4 pt[2][2], dst[2][2];                     // [key tile][query tile of the pair]
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dkv_kerne
                         const int ql = qt * 16 + lg * 4 + r;
                         float bias = kbias[t];
                         if constexpr (TAB) bias += rhs[ql * (p.Sh + 1) + khl[t]] + rws[ql * (p.Sw + 1) + kwl[t]];
-                        if constexpr (REL == 2) bias += rhs[(wave >> 1) * SA_CHUNK + ql] + rws[sa_rw_off(ql, kwl[t])];
+                        if constexpr (REL == 2) bias += rhs[(wave >> 1) * SA_CHUNK + ql] + rwc[sa_rw_off(ql, kwl[t])] * LOG2E;
                         float pr = fast_exp2(sv2[r] * c2 + bias - Ls[ql]);
                         if (!(kok[t] && q0 + ql < p.Nq)) pr = 0.f;
                         float keepf = 1.f;
@@ -761,7 +766,7 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
         auto k = sa_bwd_dkv_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
-        const size_t rel = REL == 2 ? (size_t)(2 * SA_CHUNK + SA_CHUNK * 64) * sizeof(float)
+        const size_t rel = REL == 2 ? (size_t)(2 * SA_CHUNK + 2 * SA_CHUNK * 64) * sizeof(float)
                                     : REL ? (size_t)SA_CHUNK * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
         hipLaunchKernelGGL(k, dim3((p.Nk + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
                            2 * chunk + 2 * SA_CHUNK * sizeof(float) + rel, st, p);
