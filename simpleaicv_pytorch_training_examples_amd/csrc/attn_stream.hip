@@ -109,6 +109,12 @@ DEVINL void pvN(f32x4 (&acc)[NS][DT], const f32x4 (&t0)[NS], const f32x4 (&t1)[N
     }
 }
 
+// XOR term of sa_off: the chunk stored at 16-byte position `pos` of row `row` is chunk pos ^ sa_swz(row)
+template <int ROWB> DEVINL int sa_swz(int row);
+template <> DEVINL int sa_swz<64>(int row) { const int q = (row >> 2) & 3; return ((q & 1) << 1) ^ ((q >> 1) * 3); }
+template <> DEVINL int sa_swz<128>(int row) { return (row >> 1) & 7; }
+template <> DEVINL int sa_swz<256>(int row) { return row & 15; }
+
 template <typename T, int D>
 struct SA {
     static constexpr int EPC = ElemTraits<T>::EPC;
@@ -139,6 +145,22 @@ struct SA {
             }
         }
     };
+    // the same chunk global -> LDS by DMA (no staging registers): the DMA fills wave-linear 16-byte slots, so the
+    // image's XOR swizzle is applied to the SOURCE address; rows >= nvalid come back as zeros (buffer bounds)
+    static DEVINL __amdgpu_buffer_rsrc_t rsrc(const T* g, long rs, int nvalid) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g), 0, (int)(((size_t)(nvalid - 1) * rs + D) * sizeof(T)), 0x00020000);
+    }
+    static DEVINL void dma(const __amdgpu_buffer_rsrc_t& r, char* lds, long rs, int r0, int nvalid, int wave, int lane) {
+        typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int slot = (j * SA_WAVES + wave) * 64 + lane;
+            const int row = slot / DCH, pos = slot - row * DCH;
+            const int c = pos ^ sa_swz<ROWB>(row);
+            const unsigned off = (r0 + row) < nvalid ? (unsigned)(((size_t)(r0 + row) * rs + c * EPC) * sizeof(T)) : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(lds + (j * SA_WAVES + wave) * 1024), 16, (int)off, 0, 0, 0);
+        }
+    }
     static DEVINL void lds_frags(u32x4 (&f)[STEPS], const char* lds, int row0, int l15, int lg) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) f[s] = ld_chunk(lds + sa_off<ROWB>(row0 + l15, s * 4 + lg));
@@ -343,7 +365,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
 template <typename T, int D, int REL, bool DROP>
 // without a relative-position bias the kernel fits 256 VGPRs: two workgroups per CU and VGPR-form MFMAs (no
 // AGPR <-> VGPR copies around the short-lived S / dP tiles); the rel-pos variants spill under that bound
-__global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dq_kernel(const SAParams p) {
+__global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
     constexpr int EROWB = 32 * (int)sizeof(T);            // indicator rows: 32 columns
@@ -351,11 +373,10 @@ __global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dq_kernel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
-    char* Ks = smem;
-    char* Vs = smem + S::CHUNK_BYTES;
-    char* Es = smem + 2 * S::CHUNK_BYTES;
+    char* KV = smem;                                      // [2 buffers][K chunk | V chunk], filled by DMA
+    char* Es = smem + 4 * S::CHUNK_BYTES;
     const int tabw = SA_WROWS * (p.Sh + p.Sw + 2);
-    float* tabs = reinterpret_cast<float*>(smem + 2 * S::CHUNK_BYTES + EBYTES);
+    float* tabs = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES + EBYTES);
     float* rh = tabs + wave * tabw * (REL == 3 ? 2 : 1);
     float* rw = rh + SA_WROWS * (p.Sh + 1);
     float* gh = rh + tabw;                                // REL 3 only
@@ -447,18 +468,20 @@ __global__ __launch_bounds__(SA_THREADS, REL == 0 ? 2 : 1) void sa_bwd_dq_kernel
     constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
-    typename S::Stager sk, sv;
-    sk.load(kg, p.k_rs, 0, p.Nk);
-    sv.load(vg, p.v_rs, 0, p.Nk);
+    const __amdgpu_buffer_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
+    S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.v_rs, 0, p.Nk, wave, lane);
 
     for (int k0 = 0; k0 < p.Nk; k0 += SA_CHUNK) {
-        __syncthreads();
-        sk.store(Ks);
-        sv.store(Vs);
-        __syncthreads();
-        if (k0 + SA_CHUNK < p.Nk) {
-            sk.load(kg, p.k_rs, k0 + SA_CHUNK, p.Nk);
-            sv.load(vg, p.v_rs, k0 + SA_CHUNK, p.Nk);
+        const int buf = (k0 / SA_CHUNK) & 1;
+        const char* Ks = KV + buf * 2 * S::CHUNK_BYTES;
+        const char* Vs = Ks + S::CHUNK_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk has landed (own DMA) ...
+        __syncthreads();                                      // ... for every wavefront; the other buffer is free again
+        if (k0 + SA_CHUNK < p.Nk) {                           // next chunk streams in under this one's math
+            char* nxt = KV + (buf ^ 1) * 2 * S::CHUNK_BYTES;
+            S::dma(k_rsrc, nxt, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.v_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
         }
         float rhc[2] = {0.f, 0.f}, ghc[2] = {0.f, 0.f};
         if constexpr (REL == 2) {
@@ -761,7 +784,7 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
         const size_t e = REL == 1 ? (size_t)256 * 32 * sizeof(T) : 0;
         const size_t g2 = REL == 2 ? (size_t)SA_WAVES * SA_WROWS * 68 * sizeof(float) : 0;
         hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
-                           2 * chunk + e + g2 + tab * (REL == 3 ? 2 : 1), st, p);
+                           4 * chunk + e + g2 + tab * (REL == 3 ? 2 : 1), st, p);
     } else {
         auto k = sa_bwd_dkv_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
