@@ -207,9 +207,8 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
-    char* Ks = smem;
-    char* Vs = smem + S::CHUNK_BYTES;
-    float* rh = reinterpret_cast<float*>(smem + 2 * S::CHUNK_BYTES) + wave * SA_WROWS * (p.Sh + p.Sw + 2);
+    char* KV = smem;                                      // [2 buffers][K chunk | V chunk], filled by DMA
+    float* rh = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES) + wave * SA_WROWS * (p.Sh + p.Sw + 2);
     float* rw = rh + SA_WROWS * (p.Sh + 1);
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
@@ -245,18 +244,20 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
-    typename S::Stager sk, sv;
-    sk.load(kg, p.k_rs, 0, p.Nk);
-    sv.load(vg, p.v_rs, 0, p.Nk);
+    const __amdgpu_buffer_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
+    S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.v_rs, 0, p.Nk, wave, lane);
 
     for (int k0 = 0; k0 < p.Nk; k0 += SA_CHUNK) {
-        __syncthreads();                                  // previous chunk fully consumed
-        sk.store(Ks);
-        sv.store(Vs);
-        __syncthreads();
-        if (k0 + SA_CHUNK < p.Nk) {                       // next chunk rides under this one's math
-            sk.load(kg, p.k_rs, k0 + SA_CHUNK, p.Nk);
-            sv.load(vg, p.v_rs, k0 + SA_CHUNK, p.Nk);
+        const int buf = (k0 / SA_CHUNK) & 1;
+        const char* Ks = KV + buf * 2 * S::CHUNK_BYTES;
+        const char* Vs = Ks + S::CHUNK_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk has landed (own DMA) ...
+        __syncthreads();                                      // ... for every wavefront; the other buffer is free again
+        if (k0 + SA_CHUNK < p.Nk) {                           // next chunk streams in under this one's math
+            char* nxt = KV + (buf ^ 1) * 2 * S::CHUNK_BYTES;
+            S::dma(k_rsrc, nxt, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.v_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
         }
         float rhc[2] = {0.f, 0.f};
         if constexpr (REL == 2) {
@@ -776,7 +777,7 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
         auto k = sa_fwd_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS), 2 * chunk + tab, st, p);
+        hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS), 4 * chunk + tab, st, p);
     } else if (which == 1) {
         auto k = sa_bwd_dq_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
