@@ -618,9 +618,8 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 || REL == 2) ? 2 : 1) void sa
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-    char* Qs = smem;
-    char* Os = smem + S::CHUNK_BYTES;                      // dO chunk
-    float* Dq = reinterpret_cast<float*>(smem + 2 * S::CHUNK_BYTES);
+    char* QO = smem;                                       // [2 buffers][Q chunk | dO chunk], filled by DMA
+    float* Dq = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
     float* Ls = Dq + SA_CHUNK;
     float* rhs = Ls + SA_CHUNK;                            // TAB: [64][Sh + 1]      REL 2: [2][64]
     float* rws = TAB ? rhs + SA_CHUNK * (p.Sh + 1) : rhs + 2 * SA_CHUNK;   // TAB: [64][Sw + 1]   REL 2: [64][64] swizzled
@@ -657,7 +656,7 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 || REL == 2) ? 2 : 1) void sa
     constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
-    typename S::Stager sq, so;
+    const __amdgpu_buffer_rsrc_t q_rsrc = S::rsrc(qg, p.q_rs, p.Nq), o_rsrc = S::rsrc(dog, p.o_rs, p.Nq);
     float pf_stat = 0.f, pf_rh = 0.f;                      // D / lse (tid < 128), rel_h column (tid < 128)
     // REL 2: the [64 queries][64 kw] fp32 tile of rel_w goes global -> LDS by DMA (no registers, double buffered);
     // the DMA writes wave-linear 16-byte slots, so the XOR swizzle is applied to the SOURCE address
@@ -677,8 +676,9 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 || REL == 2) ? 2 : 1) void sa
     };
     const float* rhg = REL == 2 ? p.rel_h + (size_t)bh * p.Nq * p.Sh + 2 * blockIdx.x : nullptr;
     auto prefetch = [&](int q0) {
-        sq.load(qg, p.q_rs, q0, p.Nq);
-        so.load(dog, p.o_rs, q0, p.Nq);
+        char* nxt = QO + ((q0 / SA_CHUNK) & 1) * 2 * S::CHUNK_BYTES;
+        S::dma(q_rsrc, nxt, p.q_rs, q0, p.Nq, wave, lane);
+        S::dma(o_rsrc, nxt + S::CHUNK_BYTES, p.o_rs, q0, p.Nq, wave, lane);
         if (tid < 2 * SA_CHUNK) {
             const int r = q0 + (tid & 63);
             pf_stat = r < p.Nq ? (tid < SA_CHUNK ? dsg[r] : lsg[r] * LOG2E) : 0.f;
@@ -689,10 +689,10 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 || REL == 2) ? 2 : 1) void sa
     if constexpr (REL == 2) dma_rw(0, 0);
 
     for (int q0 = 0; q0 < p.Nq; q0 += SA_CHUNK) {
-        if constexpr (REL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk's rel_w tile has landed
+        const char* Qs = QO + ((q0 / SA_CHUNK) & 1) * 2 * S::CHUNK_BYTES;
+        const char* Os = Qs + S::CHUNK_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk's Q / dO (and rel_w) tiles have landed
         __syncthreads();
-        sq.store(Qs);
-        so.store(Os);
         if (tid < 2 * SA_CHUNK) {
             Dq[tid] = pf_stat;                             // Dq[0..63] then Ls[0..63] (contiguous)
             if constexpr (REL == 2) rhs[tid] = pf_rh;
@@ -793,7 +793,7 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
         const size_t rel = REL == 2 ? (size_t)(2 * SA_CHUNK + 2 * SA_CHUNK * 64) * sizeof(float)
                                     : REL ? (size_t)SA_CHUNK * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
         hipLaunchKernelGGL(k, dim3((p.Nk + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
-                           2 * chunk + 2 * SA_CHUNK * sizeof(float) + rel, st, p);
+                           4 * chunk + 2 * SA_CHUNK * sizeof(float) + rel, st, p);
     }
     return saicv::check_launch("attention_stream");
 }
