@@ -611,7 +611,7 @@ __global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel
 DEVINL int sa_rw_off(int row, int kw) { return row * 64 + ((((kw >> 2) ^ (((row >> 2) & 3) << 2))) << 2) + (kw & 3); }
 
 template <typename T, int D, int REL, bool DROP>
-__global__ __launch_bounds__(SA_THREADS, (REL == 0 || REL == 2) ? 2 : 1) void sa_bwd_dkv_kernel(const SAParams p) {
+__global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
