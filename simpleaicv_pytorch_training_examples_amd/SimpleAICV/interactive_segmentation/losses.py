@@ -14,7 +14,6 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import _lib
 from ..._lib import check, dtype_code, lib, ptr, require_gpu, stream
 
 __all__ = [

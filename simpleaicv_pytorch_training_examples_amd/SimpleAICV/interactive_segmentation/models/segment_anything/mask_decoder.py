@@ -12,7 +12,6 @@ The 4 hyper-network MLPs and the IoU head act on <= 5 tokens per sample.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..... import ops_tfm
 from .transformer import TwoWayTransformer

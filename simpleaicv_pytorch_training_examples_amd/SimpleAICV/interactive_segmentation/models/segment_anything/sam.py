@@ -5,7 +5,6 @@ with forward / forward_image_encoder (:119) / forward_prompt_encoder_mask_decode
 sam_l / sam_h (:181-215); identical constructor arguments and state_dict keys.  sam_h (head dim 80) is
 declared but its encoder raises: the streaming attention kernel is instantiated for head dims 32 and 64.
 """
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 

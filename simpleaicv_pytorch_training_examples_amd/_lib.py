@@ -5,7 +5,7 @@ HIP device, the call raises.  PyTorch is used only for device memory and streams
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_uint8, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 import torch
 

@@ -23,7 +23,6 @@ Design (MI355X-first, one process per GPU):
   * `no_sync()` only suppresses the enqueue; gradients keep accumulating in the arena.
 """
 import contextlib
-import math
 
 import torch
 import torch.distributed as dist
