@@ -247,6 +247,14 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     const __amdgpu_buffer_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
     S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.v_rs, 0, p.Nk, wave, lane);
+    float rhn[2] = {0.f, 0.f};
+    if constexpr (REL == 2) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = q0 + qt * 16 + l15;
+            if (q < p.Nq) rhn[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh];
+        }
+    }
 
     for (int k0 = 0; k0 < p.Nk; k0 += SA_CHUNK) {
         const int buf = (k0 / SA_CHUNK) & 1;
@@ -259,12 +267,16 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
             S::dma(k_rsrc, nxt, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
             S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.v_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
         }
-        float rhc[2] = {0.f, 0.f};
+        // REL 2: this chunk's rel_h value was fetched during the previous chunk (a load issued here and used
+        // right away would also wait for the DMA of the NEXT chunk: vmcnt retires in order)
+        float rhc[2] = {rhn[0] * LOG2E, rhn[1] * LOG2E};
         if constexpr (REL == 2) {
+            if (k0 + SA_CHUNK < p.Nk) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const int q = q0 + qt * 16 + l15;
-                if (q < p.Nq) rhc[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6)] * LOG2E;
+                for (int qt = 0; qt < 2; ++qt) {
+                    const int q = q0 + qt * 16 + l15;
+                    if (q < p.Nq) rhn[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6) + 1];
+                }
             }
         }
         f32x4 st[2][4];
@@ -472,6 +484,14 @@ __global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel
     const __amdgpu_buffer_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
     S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.v_rs, 0, p.Nk, wave, lane);
+    float rhn[2] = {0.f, 0.f};
+    if constexpr (REL == 2) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = q0 + qt * 16 + l15;
+            if (q < p.Nq) rhn[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh];
+        }
+    }
 
     for (int k0 = 0; k0 < p.Nk; k0 += SA_CHUNK) {
         const int buf = (k0 / SA_CHUNK) & 1;
@@ -484,12 +504,14 @@ __global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel
             S::dma(k_rsrc, nxt, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
             S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.v_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
         }
-        float rhc[2] = {0.f, 0.f}, ghc[2] = {0.f, 0.f};
+        float rhc[2] = {rhn[0] * LOG2E, rhn[1] * LOG2E}, ghc[2] = {0.f, 0.f};     // fetched one chunk ahead (see forward)
         if constexpr (REL == 2) {
+            if (k0 + SA_CHUNK < p.Nk) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const int q = q0 + qt * 16 + l15;
-                if (q < p.Nq) rhc[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6)] * LOG2E;
+                for (int qt = 0; qt < 2; ++qt) {
+                    const int q = q0 + qt * 16 + l15;
+                    if (q < p.Nq) rhn[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6) + 1];
+                }
             }
         }
         f32x4 g[2][4];
