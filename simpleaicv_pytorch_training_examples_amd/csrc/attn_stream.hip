@@ -37,6 +37,7 @@ constexpr int SA_WROWS = 32;            // rows owned by one wavefront (two MFMA
 constexpr int SA_BROWS = SA_WAVES * SA_WROWS;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+constexpr int SA_KB_LDS = 8192;         // longest key-bias row staged in LDS (32 KB)
 
 typedef saicv_attn_desc SAParams;   // public descriptor (include/saicv_hip.h) is the kernel argument
 
@@ -214,6 +215,13 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
     const float* kb = p.key_bias ? p.key_bias + (size_t)b * p.Nk : nullptr;
+    if constexpr (REL == 0) {        // DETR: the key-bias row goes to LDS once; a global load inside the chunk loop
+        if (kb != nullptr && p.Nk <= SA_KB_LDS) {       // would wait behind the next chunk's DMA (vmcnt is in order)
+            float* kbs = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
+            for (int i = threadIdx.x; i < p.Nk; i += SA_THREADS) kbs[i] = kb[i];
+            kb = kbs;                                   // published by the first barrier of the loop
+        }
+    }
     const int q0 = blockIdx.x * SA_BROWS + wave * SA_WROWS;
     if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
     float rwreg[2][16];
@@ -404,6 +412,13 @@ __global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel
     const T* og = (const T*)p.out + (size_t)b * p.o_bs + h * D;
     const T* dog = (const T*)p.dout + (size_t)b * p.o_bs + h * D;
     const float* kb = p.key_bias ? p.key_bias + (size_t)b * p.Nk : nullptr;
+    if constexpr (REL == 0) {        // key-bias row in LDS (see the forward kernel)
+        if (kb != nullptr && p.Nk <= SA_KB_LDS) {
+            float* kbs = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
+            for (int i = threadIdx.x; i < p.Nk; i += SA_THREADS) kbs[i] = kb[i];
+            kb = kbs;
+        }
+    }
     const int q0 = blockIdx.x * SA_BROWS + wave * SA_WROWS;
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
     if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
@@ -795,11 +810,12 @@ template <typename T, int D, int REL, bool DROP = false>
 int sa_launch(const SAParams& p, int which, hipStream_t st) {
     const size_t chunk = (size_t)SA_CHUNK * D * sizeof(T);
     const size_t tab = (REL == 1 || REL == 3) ? (size_t)SA_WAVES * SA_WROWS * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
+    const size_t kbl = (REL == 0 && p.key_bias && p.Nk <= SA_KB_LDS) ? (size_t)p.Nk * sizeof(float) : 0;
     if (which == 0) {
         auto k = sa_fwd_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS), 4 * chunk + tab, st, p);
+        hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS), 4 * chunk + tab + kbl, st, p);
     } else if (which == 1) {
         auto k = sa_bwd_dq_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
@@ -807,7 +823,7 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
         const size_t e = REL == 1 ? (size_t)256 * 32 * sizeof(T) : 0;
         const size_t g2 = REL == 2 ? (size_t)SA_WAVES * SA_WROWS * 68 * sizeof(float) : 0;
         hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
-                           4 * chunk + e + g2 + tab * (REL == 3 ? 2 : 1), st, p);
+                           4 * chunk + e + g2 + kbl + tab * (REL == 3 ? 2 : 1), st, p);
     } else {
         auto k = sa_bwd_dkv_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
