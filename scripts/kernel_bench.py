@@ -46,7 +46,10 @@ def main():
     L = lib()
     st = _lib.stream()
     tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0, 'flops': 0.0}
-    for (ci, co, k, s, h) in R50:
+    only = [int(i) for i in os.environ['KB_ONLY'].split(',')] if os.environ.get('KB_ONLY') else None
+    for idx, (ci, co, k, s, h) in enumerate(R50):
+        if only is not None and idx not in only:
+            continue
         pad = k // 2
         d = ops._desc(batch, h, h, ci, co, k, k, s, pad, dt)
         x = torch.randn(batch, h, h, ci, device='cuda').to(dt)

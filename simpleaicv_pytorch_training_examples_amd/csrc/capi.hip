@@ -106,7 +106,7 @@ int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int Sx, int Ip, flo
 
 int saicv_conv2d_stat_rows(const saicv_conv_desc* d) {
     if (!d) return -1;
-    return conv_stat_rows(d->N * d->OH * d->OW, d->K, d->dtype);
+    return conv_stat_rows(d->N * d->OH * d->OW, d->K, d->R * d->S * d->C, d->dtype);
 }
 
 int saicv_conv2d_fwd(const saicv_conv_desc* d, const void* x, const void* wf, const float* bias,

@@ -302,7 +302,12 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
     // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*16 + lg*4 + r ; m = m_base + mi*16 + l15
     // BN statistics come straight from the accumulators; the output tile is staged through LDS
     // so that HBM sees whole rows written 16 bytes per lane (a lane's fragment is only 4 values
-    // of one row: storing it directly gives 32-byte row segments and half the write bandwidth).
+    // of one row: storing it directly gives 32- or 64-byte row segments and half the write bandwidth -- measured).
+    // CODE SIZE is what this section is tuned for: with one workgroup per CU nothing overlaps the epilogue, and a
+    // fully unrolled epilogue that carries every fused mode in every unrolled copy (6 k instructions, 48 KiB)
+    // spent most of its 6 us per tile waiting for instruction fetch.  So: the unrolled part (accumulator -> LDS)
+    // carries no alternatives, the common copy-out is 16 loads + 16 stores, and everything with a fused operand,
+    // a row remap, an N tail or an unaligned leading dimension runs in ROLLED loops (one copy of the mode code).
     typedef typename std::conditional<OUT_F32, float, T>::type TO;
     constexpr int OPITCH = BN_T * (int)sizeof(TO) + 16;         // bytes; +16 staggers banks
     constexpr int OCPR = BN_T * (int)sizeof(TO) / 16;           // 16-byte chunks per tile row
@@ -310,7 +315,6 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
     const int m_base = tile_m * BM_T + wm * WMR;
     const int n_base = tile_n * BN_T + wn * WN;
     const bool do_stats = p.stat_sum != nullptr;
-    const bool staged = ((p.ldo * (int)sizeof(TO)) & 15) == 0;
 #pragma unroll
     for (int ni = 0; ni < NT_; ++ni) {
         const int n0 = n_base + ni * 16 + lg * 4;
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 if (n0 + r < p.Nn) bs[r] = p.bias[n0 + r];
         }
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+        char* q0 = smem + (wm * WMR + l15) * OPITCH + (wn * WN + ni * 16 + lg * 4) * (int)sizeof(TO);
 #pragma unroll
         for (int mi = 0; mi < MT_; ++mi) {
             float v[4];
@@ -334,32 +339,14 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                     ssq[r] += vr * vr;
                 }
             }
-            if (staged) {
-                char* q = smem + (wm * WMR + mi * 16 + l15) * OPITCH + (wn * WN + ni * 16 + lg * 4) * (int)sizeof(TO);
-                if (sizeof(TO) == 2) {
-                    bf16x4 pk;
+            char* q = q0 + mi * 16 * OPITCH;
+            if (sizeof(TO) == 2) {
+                bf16x4 pk;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                    *reinterpret_cast<bf16x4*>(q) = pk;
-                } else {
-                    *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
-                }
+                for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(q) = pk;
             } else {
-                // unaligned leading dimension: scalar stores straight from the fragment
-                const int mrow = m_base + mi * 16 + l15;
-                if (mrow < Mc) {
-                    int m = mrow;
-                    if (MODE == 1 && cs > 1) {
-                        const int img = mrow / ohw;
-                        const int rem = mrow - img * ohw;
-                        const int hc = rem / Wc;
-                        m = (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
-                    }
-                    TO* o = reinterpret_cast<TO*>(p.out) + (size_t)m * p.ldo + n0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n0 + r < p.Nn) o[r] = from_f32<TO>(v[r]);
-                }
+                *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
             }
         }
         if (do_stats) {
@@ -380,62 +367,87 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
             }
         }
     }
-    if (staged) {
-        __syncthreads();
-        const int oc = tid % OCPR;               // chunk within the tile row
-        const int orow0 = tid / OCPR;
-        constexpr int RPP = NTHREADS / OCPR;     // tile rows per pass
-        const int ncol = tile_n * BN_T + oc * OEPC;
-        if (ncol < p.Nn) {
-            const bool whole = ncol + OEPC <= p.Nn;
-#pragma unroll 4
-            for (int rr = orow0; rr < BM_T; rr += RPP) {
-                const int mrow = tile_m * BM_T + rr;
-                if (mrow >= Mc) break;
-                int m = mrow;
-                if (MODE == 1 && cs > 1) {
-                    const int img = mrow / ohw;
-                    const int rem = mrow - img * ohw;
-                    const int hc = rem / Wc;
-                    m = (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
-                }
-                u32x4 v = ld_chunk(smem + rr * OPITCH + oc * 16);
-                TO* o = reinterpret_cast<TO*>(p.out) + (size_t)m * p.ldo + ncol;
-                if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
-                    float f[OEPC];
-                    Chunk<TO>::unpack(v, f);
+    __syncthreads();
+    const int oc = tid % OCPR;               // chunk within the tile row
+    const int orow0 = tid / OCPR;
+    constexpr int RPP = NTHREADS / OCPR;     // tile rows per pass
+    constexpr int NIT = BM_T / RPP;
+    const int ncol = tile_n * BN_T + oc * OEPC;
+    TO* const outp = reinterpret_cast<TO*>(p.out);
+    const bool aligned = ((p.ldo * (int)sizeof(TO)) & 15) == 0;
+    const bool remap = MODE == 1 && cs > 1;
+    const bool plain = aligned && !remap && p.act_mode == 0 && p.addend == nullptr && p.row_scale == nullptr;   // uniform
+    if (plain && ncol + OEPC <= p.Nn) {
+        // the common case: a branch-free copy, the LDS reads of eight rows in flight before the first store
+        constexpr int GRP = NIT < 8 ? NIT : 8;
+        const int mrow0 = tile_m * BM_T + orow0;
+        const char* ls = smem + orow0 * OPITCH + oc * 16;
+        TO* o = outp + (size_t)mrow0 * p.ldo + ncol;
+        const size_t ostep = (size_t)RPP * p.ldo;
+        const bool full = (tile_m + 1) * BM_T <= Mc;                                         // uniform
 #pragma unroll
-                    for (int j = 0; j < OEPC; ++j) f[j] = gelu_fwd_f(f[j]);
-                    st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(f));
-                } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)
-                    float f[OEPC], a[OEPC];
-                    Chunk<TO>::unpack(v, f);
+        for (int g = 0; g < NIT; g += GRP) {
+            u32x4 v[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) v[j] = ld_chunk(ls + (g + j) * RPP * OPITCH);
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) st_chunk(o + (g + j) * ostep, v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j)
+                    if (mrow0 + (g + j) * RPP < Mc) st_chunk(o + (g + j) * ostep, v[j]);
+            }
+        }
+    } else if (ncol < p.Nn) {
+        const bool whole = aligned && ncol + OEPC <= p.Nn;
+#pragma unroll 1
+        for (int rr = orow0; rr < BM_T; rr += RPP) {
+            const int mrow = tile_m * BM_T + rr;
+            if (mrow >= Mc) break;
+            int m = mrow;
+            if (remap) {
+                const int img = mrow / ohw;
+                const int rem = mrow - img * ohw;
+                const int hc = rem / Wc;
+                m = (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
+            }
+            u32x4 v = ld_chunk(smem + rr * OPITCH + oc * 16);
+            TO* o = outp + (size_t)m * p.ldo + ncol;
+            if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
+                float f[OEPC];
+                Chunk<TO>::unpack(v, f);
+#pragma unroll
+                for (int j = 0; j < OEPC; ++j) f[j] = gelu_fwd_f(f[j]);
+                st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(f));
+            } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)
+                float f[OEPC], a[OEPC];
+                Chunk<TO>::unpack(v, f);
+                Chunk<TO>::unpack(ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol), a);
+#pragma unroll
+                for (int j = 0; j < OEPC; ++j) f[j] *= gelu_grad_f(a[j]);
+                v = Chunk<TO>::pack(f);
+            } else if (p.addend != nullptr || p.row_scale != nullptr) {
+                float f[OEPC], a[OEPC];
+                Chunk<TO>::unpack(v, f);
+                const float sc = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.f;
+                if (p.addend != nullptr && whole) {
                     Chunk<TO>::unpack(ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol), a);
-#pragma unroll
-                    for (int j = 0; j < OEPC; ++j) f[j] *= gelu_grad_f(a[j]);
-                    v = Chunk<TO>::pack(f);
-                } else if (p.addend != nullptr || p.row_scale != nullptr) {
-                    float f[OEPC], a[OEPC];
-                    Chunk<TO>::unpack(v, f);
-                    const float sc = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.f;
-                    if (p.addend != nullptr && whole) {
-                        Chunk<TO>::unpack(ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol), a);
-                    } else {
-                        for (int j = 0; j < OEPC; ++j)
-                            a[j] = (p.addend != nullptr && ncol + j < p.Nn)
-                                       ? to_f32(reinterpret_cast<const TO*>(p.addend)[(size_t)m * p.ldo + ncol + j]) : 0.f;
-                    }
-#pragma unroll
-                    for (int j = 0; j < OEPC; ++j) f[j] = fmaf(sc, f[j], a[j]);
-                    v = Chunk<TO>::pack(f);
-                }
-                if (whole) {
-                    st_chunk(o, v);
                 } else {
-                    const TO* e = reinterpret_cast<const TO*>(&v);
                     for (int j = 0; j < OEPC; ++j)
-                        if (ncol + j < p.Nn) o[j] = e[j];
+                        a[j] = (p.addend != nullptr && ncol + j < p.Nn)
+                                   ? to_f32(reinterpret_cast<const TO*>(p.addend)[(size_t)m * p.ldo + ncol + j]) : 0.f;
                 }
+#pragma unroll
+                for (int j = 0; j < OEPC; ++j) f[j] = fmaf(sc, f[j], a[j]);
+                v = Chunk<TO>::pack(f);
+            }
+            if (whole) {
+                st_chunk(o, v);
+            } else {                          // N tail, or a leading dimension without 16-byte alignment
+                const TO* e = reinterpret_cast<const TO*>(&v);
+                for (int j = 0; j < OEPC; ++j)
+                    if (ncol + j < p.Nn) o[j] = e[j];
             }
         }
     }
@@ -743,12 +755,16 @@ int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
     return saicv::check_launch("igemm_nt");
 }
 
-// Tile choice shared by the kernel launch and conv_stat_rows(): relative per-flop speed of each
-// geometry x wave-quantisation efficiency on 256 CUs x useful fraction of the N tile.
+// Tile choice shared by the kernel launch and conv_stat_rows(): relative per-flop speed of each geometry x
+// wave-quantisation efficiency on 256 CUs x useful fraction of the tile.  The speeds are fitted to a sweep of
+// every geometry over the 23 ResNet-50 shapes and the ViT / SAM linear shapes (scripts/gpu_tiles.sh, r01e): two
+// co-resident 256 x 128 workgroups hide each other's epilogue (launch, prologue latency, store drain: ~11 us per
+// 64 K outputs per CU whatever the geometry), which beats one 256 x 256 workgroup until the K loop is long enough
+// (~100 K tiles) for its lower LDS traffic per flop to matter.
 struct NTTile { int bm, bn, wm, blocks_per_cu; float speed; };
-const NTTile kTiles[4] = {{256, 256, 2, 1, 1.00f}, {256, 128, 4, 2, 0.85f}, {128, 128, 2, 2, 0.70f}, {128, 64, 2, 3, 0.50f}};
+const NTTile kTiles[4] = {{256, 256, 2, 1, 0.80f}, {256, 128, 4, 2, 1.00f}, {128, 128, 2, 2, 0.60f}, {128, 64, 2, 3, 0.50f}};
 
-int pick_tile(int M, int Nn, bool f32_out_big) {
+int pick_tile(int M, int Nn, int nkt, bool f32_out_big) {
     if (const char* force = getenv("SAICV_NT_TILE")) {      // tuning aid: force a geometry
         const int t = atoi(force);
         if (t >= 0 && t < 4 && !(f32_out_big && kTiles[t].bm * kTiles[t].bn * 4 > 150 * 1024)) return t;
@@ -764,7 +780,9 @@ int pick_tile(int M, int Nn, bool f32_out_big) {
         const float rounds = blocks / slots;
         const float quant = rounds / (float)(long)(rounds + 0.999999f);
         const float useful = ((float)M / (tm * g.bm)) * ((float)Nn / (tn * g.bn));
-        const float score = g.speed * quant * useful;
+        float speed = g.speed;
+        if (t == 0) speed = nkt >= 100 ? 1.10f : nkt >= 48 ? 0.90f : 0.80f;
+        const float score = speed * quant * useful;
         if (score > best_score) { best_score = score; best = t; }
     }
     return best;
@@ -788,8 +806,9 @@ int launch_tn(const TNParams& p, int splits, hipStream_t st) {
 namespace saicv {
 
 // rows of per-wave BN partial statistics written by the forward kernel
-int conv_stat_rows(int M, int Nn, int dtype) {
-    const NTTile& g = kTiles[pick_tile(M, Nn, dtype == SAICV_DTYPE_F32)];
+int conv_stat_rows(int M, int Nn, int Kd, int dtype) {
+    const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
+    const NTTile& g = kTiles[pick_tile(M, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32)];
     return ((M + g.bm - 1) / g.bm) * g.wm;
 }
 
@@ -838,7 +857,8 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
         const int nimg = M / (OH * OW);
         M_tile = nimg * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);   // largest parity class
     }
-    const int t = (stat_sum != nullptr) ? pick_tile(M, Nn, f32o) : pick_tile(M_tile, Nn, f32o);
+    const int nkt_host = (Kd + 4 * epc - 1) / (4 * epc);      // K tiles (stride > 1 data-gradient classes run fewer)
+    const int t = (stat_sum != nullptr) ? pick_tile(M, Nn, nkt_host, f32o) : pick_tile(M_tile, Nn, nkt_host, f32o);
     const NTTile& g = kTiles[t];
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);

@@ -8,7 +8,7 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // igemm.hip
-int conv_stat_rows(int M, int Nn, int dtype);
+int conv_stat_rows(int M, int Nn, int Kd, int dtype);
 // optional epilogue extras: out = addend + row_scale[m / rows_per_scale] * (acc + bias)
 struct EpiExtra {
     const void* addend = nullptr;      // same dtype / layout as out
