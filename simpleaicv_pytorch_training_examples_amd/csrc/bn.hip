@@ -31,10 +31,22 @@ __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __
     const int p1 = min(P, p0 + rows_per);
     float sa = 0.f, sb = 0.f;
     if (c < C) {
-        for (int p = p0 + ty; p < p1; p += 4) {
-            sa += a[(size_t)p * C + c];
-            sb += b[(size_t)p * C + c];
+        // latency-bound without it: four rows (eight loads) in flight per thread
+        float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+        int p = p0 + ty;
+        for (; p + 12 < p1; p += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a4[u] += a[(size_t)(p + 4 * u) * C + c];
+                b4[u] += b[(size_t)(p + 4 * u) * C + c];
+            }
         }
+        for (; p < p1; p += 4) {
+            a4[0] += a[(size_t)p * C + c];
+            b4[0] += b[(size_t)p * C + c];
+        }
+        sa = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        sb = (b4[0] + b4[1]) + (b4[2] + b4[3]);
     }
     __shared__ float la[4][64], lb[4][64];
     la[ty][threadIdx.x & 63] = sa;
@@ -47,24 +59,46 @@ __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __
     }
 }
 
+// column sums of P <= 32 partial rows by a 256-thread block: wave ty takes rows ty, ty+4, ... with all of its (at
+// most eight) loads in flight, LDS combines the four waves.  A one-wave serial loop over 32 rows costs ~10 us of pure
+// load latency per BatchNorm, twice per step.
+DEVINL void finalize_colsum(const float* __restrict__ a, const float* __restrict__ b, int P, int C, int c, int ty,
+                            float& sa, float& sb) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int p = ty + 4 * u;
+        const bool ok = c < C && p < P;
+        va[u] = ok ? a[(size_t)p * C + c] : 0.f;
+        vb[u] = ok ? b[(size_t)p * C + c] : 0.f;
+    }
+    sa = ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
+    sb = ((vb[0] + vb[1]) + (vb[2] + vb[3])) + ((vb[4] + vb[5]) + (vb[6] + vb[7]));
+    __shared__ float la[4][64], lb[4][64];
+    la[ty][threadIdx.x & 63] = sa;
+    lb[ty][threadIdx.x & 63] = sb;
+    __syncthreads();
+    const int x = threadIdx.x & 63;
+    sa = (la[0][x] + la[1][x]) + (la[2][x] + la[3][x]);
+    sb = (lb[0][x] + lb[1][x]) + (lb[2][x] + lb[3][x]);
+}
+
 // ---------------------------------------------------------------- forward finalize
 // Follows torch.nn.BatchNorm2d training semantics (biased var for normalisation, unbiased
 // var into running_var, momentum 0.1) as used by reference resnet.py:41.
-__global__ void bn_finalize_fwd_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
                                        int P, int C, float count, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* running_mean,
                                        float* running_var, float momentum, float eps,
                                        float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                        float* __restrict__ scale, float* __restrict__ shift,
                                        long long* __restrict__ num_batches_tracked) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;     // BatchNorm2d bookkeeping, no extra launch
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int p = 0; p < P; ++p) {
-        s += sum[(size_t)p * C + c];
-        q += sq[(size_t)p * C + c];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;     // BatchNorm2d bookkeeping, no extra launch
+    float s, q;
+    finalize_colsum(sum, sq, P, C, c, ty, s, q);
+    if (c >= C || ty != 0) return;
     const float mean = s / count;
     float var = q / count - mean * mean;
     var = fmaxf(var, 0.f);
@@ -238,19 +272,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // ---------------------------------------------------------------- backward finalize
 // dy = A*(g - mg) - A*xhat*mgx  with A = gamma*invstd, mg = sum(g)/M, mgx = sum(g*xhat)/M
 // written as dy = ca*g + cb*y + cc per channel.
-__global__ void bn_finalize_bwd_kernel(const float* __restrict__ pg, const float* __restrict__ pgx,
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ pg, const float* __restrict__ pgx,
                                        int P, int C, float count, const float* __restrict__ gamma,
                                        const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ ca,
                                        float* __restrict__ cb, float* __restrict__ cc, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float sg = 0.f, sx = 0.f;
-    for (int p = 0; p < P; ++p) {
-        sg += pg[(size_t)p * C + c];
-        sx += pgx[(size_t)p * C + c];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = threadIdx.x >> 6;
+    float sg, sx;
+    finalize_colsum(pg, pgx, P, C, c, ty, sg, sx);
+    if (c >= C || ty != 0) return;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sx : sx;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sg : sg;
     const float g = gamma ? gamma[c] : 1.f;
@@ -348,7 +380,7 @@ int bn_finalize_fwd(const float* sum, const float* sq, int P, int C, double coun
                     double eps, float* mean, float* invstd, float* scale, float* shift, float* ws,
                     long long* num_batches_tracked, hipStream_t st) {
     P = reduce_partials(sum, sq, P, C, ws, st);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sum, sq, P, C,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, sum, sq, P, C,
                        (float)count, gamma, beta, running_mean, running_var, (float)momentum, (float)eps,
                        mean, invstd, scale, shift, num_batches_tracked);
     return check_launch("bn_finalize_fwd");
@@ -421,7 +453,7 @@ static int bn_bwd_t(const void* dz, const void* z, const uint8_t* mask, const vo
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(used), dim3(256), 0, st, dzz, zz, mask, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
     const float* a = pg; const float* b = pgx;
     const int P = reduce_partials(a, b, used, C, ws2, st);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, a, b, P, C,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, a, b, P, C,
                        (float)M, gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, accumulate);
     const size_t nchunks = M * (size_t)C / N;
     const int grid = stream_grid(nchunks);

@@ -356,18 +356,27 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 ssum[r] = row16_sum(ssum[r]);
                 ssq[r] = row16_sum(ssq[r]);
             }
-            if (l15 == 0) {
-                const size_t prow = (size_t)(tile_m * WM_ + wm) * (size_t)p.Nn;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n0 + r < p.Nn) {
-                        p.stat_sum[prow + n0 + r] = ssum[r];
-                        p.stat_sq[prow + n0 + r] = ssq[r];
-                    }
+            if (l15 == 0) {                      // per-wavefront column sums -> LDS [2][WM_][BN_T] behind the staged tile
+                float* ws = reinterpret_cast<float*>(smem + BM_T * OPITCH) + wm * BN_T + wn * WN + ni * 16 + lg * 4;
+                *reinterpret_cast<f32x4*>(ws) = f32x4{ssum[0], ssum[1], ssum[2], ssum[3]};
+                *reinterpret_cast<f32x4*>(ws + WM_ * BN_T) = f32x4{ssq[0], ssq[1], ssq[2], ssq[3]};
             }
         }
     }
     __syncthreads();
+    if (do_stats) {
+        // one row of partial statistics per WORKGROUP (fixed summation order over its wavefront rows): four times
+        // fewer partial rows for the finalize kernels to read than one row per wavefront row
+        for (int c = tid; c < 2 * BN_T; c += NTHREADS) {
+            const int which = c / BN_T, col = c - which * BN_T;
+            const float* ws = reinterpret_cast<const float*>(smem + BM_T * OPITCH) + which * WM_ * BN_T + col;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM_; ++w) a += ws[w * BN_T];
+            const int n = tile_n * BN_T + col;
+            if (n < p.Nn) (which ? p.stat_sq : p.stat_sum)[(size_t)tile_m * (size_t)p.Nn + n] = a;
+        }
+    }
     const int oc = tid % OCPR;               // chunk within the tile row
     const int orow0 = tid / OCPR;
     constexpr int RPP = NTHREADS / OCPR;     // tile rows per pass
@@ -740,7 +749,8 @@ void launch_nt_inst(const NTParams& p, size_t smem, hipStream_t st) {
 template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE>
 int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
     constexpr size_t smem_full = nt_stages(BM_T, BN_T) * (size_t)(BM_T * 64 + BN_T * 64);      // DMA ring
-    const size_t epi = BM_T * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16);
+    const size_t epi = BM_T * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16) +
+                       2 * WM_ * BN_T * sizeof(float);      // staged output tile + per-wavefront BN column sums
     size_t smem = smem_full;
     if (smem < epi) smem = epi;
     // pointwise taps without padding: the source pixel of a row never leaves the image
@@ -805,11 +815,11 @@ int launch_tn(const TNParams& p, int splits, hipStream_t st) {
 
 namespace saicv {
 
-// rows of per-wave BN partial statistics written by the forward kernel
+// rows of BN partial statistics written by the forward kernel: one per row of workgroups
 int conv_stat_rows(int M, int Nn, int Kd, int dtype) {
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
     const NTTile& g = kTiles[pick_tile(M, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32)];
-    return ((M + g.bm - 1) / g.bm) * g.wm;
+    return (M + g.bm - 1) / g.bm;
 }
 
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
