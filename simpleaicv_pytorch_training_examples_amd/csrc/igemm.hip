@@ -54,6 +54,7 @@ struct NTParams {
     int ldo;
     int tiles_n;
     int nblk;
+    int grid_x;         // resident workgroups (256 CUs x workgroups per CU)
     FastDiv fd_ohw, fd_ow;   // for OH*OW and OW (unit-stride row decomposition)
 };
 
@@ -134,9 +135,17 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
         Sc = s0 < p.S ? (p.S - s0 + cs - 1) / cs : 0;
         Kc = Rc * Sc * p.C;
         nblk = ((Mc + BM_T - 1) / BM_T) * p.tiles_n;
-        if ((int)blockIdx.x >= nblk) return;
     }
-    const int bid = xcd_remap(blockIdx.x, nblk);
+    // ---- persistent tile loop: the grid is one resident round of workgroups, each walks tiles tix, tix + grid, ...
+    // (no workgroup relaunch between tiles; the previous tile's stores drain under the next tile's prologue).
+    // Spreading the workgroups' start times over a tile period -- so that epilogue write bursts and MFMA loops of
+    // different CUs interleave -- was measured and bought nothing: the ramp costs what the steady state gains.
+    for (int tix = blockIdx.x; tix < nblk; tix += gridDim.x) {
+    if (tix != (int)blockIdx.x) {                  // the previous tile's LDS reads are done (its stores may still drain)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    const int bid = xcd_remap(tix, nblk);
     const int tile_n = bid % p.tiles_n;
     const int tile_m = bid / p.tiles_n;
 
@@ -460,6 +469,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
             }
         }
     }
+    }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------ TN
@@ -742,7 +752,7 @@ void launch_nt_inst(const NTParams& p, size_t smem, hipStream_t st) {
     auto k = igemm_nt_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN>;
     static bool once = (allow_lds(k, 160 * 1024), true);
     (void)once;
-    dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
+    dim3 grid(p.nblk < p.grid_x ? p.nblk : p.grid_x, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
 }
 
@@ -771,8 +781,9 @@ int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
 // co-resident 256 x 128 workgroups hide each other's epilogue (launch, prologue latency, store drain: ~11 us per
 // 64 K outputs per CU whatever the geometry), which beats one 256 x 256 workgroup until the K loop is long enough
 // (~100 K tiles) for its lower LDS traffic per flop to matter.
-struct NTTile { int bm, bn, wm, blocks_per_cu; float speed; };
-const NTTile kTiles[4] = {{256, 256, 2, 1, 0.80f}, {256, 128, 4, 2, 1.00f}, {128, 128, 2, 2, 0.60f}, {128, 64, 2, 3, 0.50f}};
+struct NTTile { int bm, bn, wm, blocks_per_cu; float speed; float fixed_us, step_us; };   // tile time = fixed + K tiles x step (fit)
+const NTTile kTiles[4] = {{256, 256, 2, 1, 0.80f, 11.8f, 0.905f}, {256, 128, 4, 2, 1.00f, 9.95f, 0.97f},
+                           {128, 128, 2, 2, 0.60f, 6.1f, 0.60f}, {128, 64, 2, 3, 0.50f, 4.55f, 0.685f}};
 
 int pick_tile(int M, int Nn, int nkt, bool f32_out_big) {
     if (const char* force = getenv("SAICV_NT_TILE")) {      // tuning aid: force a geometry
@@ -872,6 +883,7 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     const NTTile& g = kTiles[t];
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
+    p.grid_x = 256 * g.blocks_per_cu;
 #define NT_DISPATCH(TT, MODE_)                                                              \
     switch (t) {                                                                            \
         case 0: return launch_nt<TT, 256, 256, 2, 4, MODE_>(p, f32o, st);                   \
