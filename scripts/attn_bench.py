@@ -38,3 +38,5 @@ run('sam_global_b8', 8, 12, 64, 4096, (64, 64), False)
 run('sam_window_b8', 200, 12, 64, 196, (14, 14), False)
 run('detr_enc_b8', 8, 8, 32, 1764, None, True)
 run('plain_d64_n4096_b8', 8, 12, 64, 4096, None, False)
+run('vit_b256_n197', 256, 12, 64, 197, None, False)
+run('sam_window_norel_b8', 200, 12, 64, 196, None, False)
