@@ -206,7 +206,11 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    // XCD-aware mapping (workgroups are dealt to the 8 XCDs round-robin in launch order, x fastest): every row block
+    // of one (batch, head) reads the same K / V (Q / dO), so each XCD gets a contiguous (head, block) range
+    const int sa_lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
+    const int b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
     char* KV = smem;                                      // [2 buffers][K chunk | V chunk], filled by DMA
     float* rh = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES) + wave * SA_WROWS * (p.Sh + p.Sw + 2);
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
             kb = kbs;                                   // published by the first barrier of the loop
         }
     }
-    const int q0 = blockIdx.x * SA_BROWS + wave * SA_WROWS;
+    const int q0 = blk * SA_BROWS + wave * SA_WROWS;
     if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
     float rwreg[2][16];
     if constexpr (REL == 2) {
@@ -392,7 +396,11 @@ __global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel
     constexpr int EROWB = 32 * (int)sizeof(T);            // indicator rows: 32 columns
     constexpr int EBYTES = REL == 1 ? 256 * EROWB : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    // XCD-aware mapping (workgroups are dealt to the 8 XCDs round-robin in launch order, x fastest): every row block
+    // of one (batch, head) reads the same K / V (Q / dO), so each XCD gets a contiguous (head, block) range
+    const int sa_lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
+    const int b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
     char* KV = smem;                                      // [2 buffers][K chunk | V chunk], filled by DMA
     char* Es = smem + 4 * S::CHUNK_BYTES;
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel
             kb = kbs;
         }
     }
-    const int q0 = blockIdx.x * SA_BROWS + wave * SA_WROWS;
+    const int q0 = blk * SA_BROWS + wave * SA_WROWS;
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
     if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
     if constexpr (REL == 3) {
@@ -652,7 +660,11 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
     using S = SA<T, D>;
     constexpr bool TAB = REL == 1 || REL == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    // XCD-aware mapping (workgroups are dealt to the 8 XCDs round-robin in launch order, x fastest): every row block
+    // of one (batch, head) reads the same K / V (Q / dO), so each XCD gets a contiguous (head, block) range
+    const int sa_lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
+    const int b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     char* QO = smem;                                       // [2 buffers][Q chunk | dO chunk], filled by DMA
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
     const T* dog = (const T*)p.dout + (size_t)b * p.o_bs + h * D;
     const float* dsg = p.dsum + (size_t)bh * p.Nq;
     const float* lsg = p.lse + (size_t)bh * p.Nq;
-    const int key0 = blockIdx.x * SA_BROWS + wave * SA_WROWS;
+    const int key0 = blk * SA_BROWS + wave * SA_WROWS;
     u32x4 kf[2][S::STEPS], vf[2][S::STEPS];
     float kbias[2];
     int khl[2], kwl[2];
@@ -711,7 +723,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
                                                      16, (int)off, 0, 0, 0);
         }
     };
-    const float* rhg = REL == 2 ? p.rel_h + (size_t)bh * p.Nq * p.Sh + 2 * blockIdx.x : nullptr;
+    const float* rhg = REL == 2 ? p.rel_h + (size_t)bh * p.Nq * p.Sh + 2 * blk : nullptr;
     auto prefetch = [&](int q0) {
         char* nxt = QO + ((q0 / SA_CHUNK) & 1) * 2 * S::CHUNK_BYTES;
         S::dma(q_rsrc, nxt, p.q_rs, q0, p.Nq, wave, lane);
