@@ -199,12 +199,70 @@ DEVINL void sa_split_key(int key, float inv_sw, int Sw, int& kh, int& kw) {
     kw = key - kh * Sw;
 }
 
+// REL 1 (SAM windows: Sh + Sw <= 32, Nk <= 256): the decomposed relative-position bias rides on the MFMA.
+//   rel_h[q][kh(k)] + rel_w[q][kw(k)] = sum_e R[q][e] * E[k][e],   R[q] = [rel_h[q][0..Sh) | rel_w[q][0..Sw) | 0],
+//   E[k][e] = 1 for e == kh(k) and e == Sh + kw(k), else 0
+// i.e. 32 more columns of the q k^T contraction (one 16x16x32 bf16 MFMA per tile) instead of two LDS table reads
+// and two adds per logit.  R is pre-divided by the softmax scale so the sum lands in the same accumulator as q k^T.
+// bf16 mode rounds R to bf16 exactly as the reference's autocast einsum does; fp32 mode uses the exact-f32 MFMA.
+template <typename T> struct SARel {
+    static constexpr int EROWB = 32 * (int)sizeof(T);       // one row of E / R: 32 columns
+    static constexpr int CPR = EROWB / 16;                  // 16-byte chunks per row
+    static constexpr int ECH = CPR / 4;                     // MFMA k-steps (1 bf16, 2 f32)
+    static constexpr int EBYTES = 256 * EROWB;
+    // indicator matrix E[256 keys][32] into LDS (swizzled like every operand image)
+    static DEVINL void build_E(char* Es, const SAParams& p) {
+        const float inv_sw = 1.f / (float)p.Sw;
+        for (int i = threadIdx.x; i < 256 * CPR; i += SA_THREADS) {
+            const int row = i / CPR, ch = i - row * CPR;
+            int kh, kw;
+            sa_split_key(row, inv_sw, p.Sw, kh, kw);
+            float f[Chunk<T>::N];
+#pragma unroll
+            for (int j = 0; j < Chunk<T>::N; ++j) {
+                const int col = ch * Chunk<T>::N + j;
+                f[j] = (row < p.Nk && (col == kh || col == p.Sh + kw)) ? 1.f : 0.f;
+            }
+            st_chunk(Es + sa_off<EROWB>(row, ch), Chunk<T>::pack(f));
+        }
+    }
+    // the same rows for ONE key, straight into an operand fragment (chunk index ch)
+    static DEVINL u32x4 key_frag(const SAParams& p, int key, int ch) {
+        int kh, kw;
+        sa_split_key(key, 1.f / (float)p.Sw, p.Sw, kh, kw);
+        float f[Chunk<T>::N];
+#pragma unroll
+        for (int j = 0; j < Chunk<T>::N; ++j) {
+            const int col = ch * Chunk<T>::N + j;
+            f[j] = (key < p.Nk && (col == kh || col == p.Sh + kw)) ? 1.f : 0.f;
+        }
+        return Chunk<T>::pack(f);
+    }
+    // chunk ch of R[q] (scaled) from the fp32 rel_h / rel_w tensors
+    static DEVINL u32x4 row_frag(const SAParams& p, int bh, int q, int ch, float mul) {
+        float f[Chunk<T>::N];
+#pragma unroll
+        for (int j = 0; j < Chunk<T>::N; ++j) {
+            const int col = ch * Chunk<T>::N + j;
+            float v = 0.f;
+            if (q < p.Nq) {
+                if (col < p.Sh) v = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + col];
+                else if (col < p.Sh + p.Sw) v = p.rel_w[((size_t)bh * p.Nq + q) * p.Sw + col - p.Sh];
+            }
+            f[j] = v * mul;
+        }
+        return Chunk<T>::pack(f);
+    }
+};
+
 // ------------------------------------------------------------------------------------ forward
 template <typename T, int D, int REL, bool DROP>
 // (256, 2): two workgroups per CU; the backward kernels spill under that bound and are faster at one
 __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p) {
     using S = SA<T, D>;
-    constexpr bool TAB = REL == 1 || REL == 3;
+    constexpr bool TAB = REL == 3;         // per-wave LDS tables + VALU adds (generic table widths)
+    constexpr bool EMM = REL == 1;         // small tables: the bias rides on the MFMA (SARel)
+    using RL = SARel<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware mapping (workgroups are dealt to the 8 XCDs round-robin in launch order, x fastest): every row block
     // of one (batch, head) reads the same K / V (Q / dO), so each XCD gets a contiguous (head, block) range
@@ -228,6 +286,15 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     }
     const int q0 = blk * SA_BROWS + wave * SA_WROWS;
     if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
+    char* Es = smem + 4 * S::CHUNK_BYTES;                 // EMM: indicator matrix, published by the loop's first barrier
+    u32x4 rf[2][RL::ECH];
+    if constexpr (EMM) {
+        RL::build_E(Es, p);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int e = 0; e < RL::ECH; ++e) rf[qt][e] = RL::row_frag(p, bh, q0 + qt * 16 + l15, e * 4 + lg, 1.f / p.scale);
+    }
     float rwreg[2][16];
     if constexpr (REL == 2) {
 #pragma unroll
@@ -298,6 +365,14 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
             S::lds_frags(kf, Ks, kt * 16, l15, lg);
             st[0][kt] = S::tile(kf, qf[0]);
             st[1][kt] = S::tile(kf, qf[1]);
+            if constexpr (EMM) {
+#pragma unroll
+                for (int e = 0; e < RL::ECH; ++e) {
+                    const u32x4 ef = ld_chunk(Es + sa_off<RL::EROWB>(k0 + kt * 16 + l15, e * 4 + lg));
+                    Mma<T>::run(st[0][kt], ef, rf[0][e]);
+                    Mma<T>::run(st[1][kt], ef, rf[1][e]);
+                }
+            }
         }
         const bool tail = k0 + SA_CHUNK > p.Nk;
 #pragma unroll
@@ -827,7 +902,8 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
         auto k = sa_fwd_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
-        hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS), 4 * chunk + tab + kbl, st, p);
+        hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
+                           4 * chunk + (REL == 1 ? (size_t)SARel<T>::EBYTES : tab) + kbl, st, p);
     } else if (which == 1) {
         auto k = sa_bwd_dq_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
