@@ -463,13 +463,15 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
 // ------------------------------------------------------------------------------------ backward: dQ (+ D, d rel-pos)
 // LDS: K chunk | V chunk | REL 1: indicator [256][32] | REL 1/3: per-wave tables | REL 3: per-wave gradient tables
 template <typename T, int D, int REL, bool DROP>
-// without a relative-position bias the kernel fits 256 VGPRs: two workgroups per CU and VGPR-form MFMAs (no
-// AGPR <-> VGPR copies around the short-lived S / dP tiles); the rel-pos variants spill under that bound
-__global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel(const SAParams p) {
+// (256, 2): every instantiation fits 256 VGPRs -- two workgroups per CU and VGPR-form MFMAs (no AGPR <-> VGPR copies
+// around the short-lived S / dP tiles)
+__global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams p) {
     using S = SA<T, D>;
-    constexpr bool TAB = REL == 1 || REL == 3;
-    constexpr int EROWB = 32 * (int)sizeof(T);            // indicator rows: 32 columns
-    constexpr int EBYTES = REL == 1 ? 256 * EROWB : 0;
+    constexpr bool TAB = REL == 3;         // per-wave LDS tables + VALU adds
+    constexpr bool EMM = REL == 1;         // bias on the MFMA (SARel), gradients through the same indicator matrix
+    using RL = SARel<T>;
+    constexpr int EROWB = RL::EROWB;
+    constexpr int EBYTES = REL == 1 ? RL::EBYTES : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware mapping (workgroups are dealt to the 8 XCDs round-robin in launch order, x fastest): every row block
     // of one (batch, head) reads the same K / V (Q / dO), so each XCD gets a contiguous (head, block) range
@@ -508,20 +510,13 @@ __global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel
     if constexpr (REL == 3) {
         for (int i = lane; i < tabw; i += 64) gh[i] = 0.f;
     }
-    if constexpr (REL == 1) {        // E[key][kh] = E[key][Sh + kw] = 1
-        for (int i = threadIdx.x; i < 256 * 4 * (int)sizeof(T) / 2; i += SA_THREADS) {
-            constexpr int CPR = EROWB / 16;               // 16-byte chunks per row
-            const int row = i / CPR, ch = i - row * CPR;
-            int kh, kw;
-            sa_split_key(row, inv_sw, p.Sw, kh, kw);
-            float f[Chunk<T>::N];
+    u32x4 rf[2][RL::ECH];
+    if constexpr (EMM) {
+        RL::build_E(Es, p);
 #pragma unroll
-            for (int j = 0; j < Chunk<T>::N; ++j) {
-                const int col = ch * Chunk<T>::N + j;
-                f[j] = (row < p.Nk && (col == kh || col == p.Sh + kw)) ? 1.f : 0.f;
-            }
-            st_chunk(Es + sa_off<EROWB>(row, ch), Chunk<T>::pack(f));
-        }
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int e = 0; e < RL::ECH; ++e) rf[qt][e] = RL::row_frag(p, bh, q0 + qt * 16 + l15, e * 4 + lg, 1.f / p.scale);
     }
     float rwreg[2][16];
     if constexpr (REL == 2) {
@@ -623,6 +618,14 @@ __global__ __launch_bounds__(SA_THREADS, REL == 1 ? 1 : 2) void sa_bwd_dq_kernel
             for (int qt = 0; qt < 2; ++qt) {
                 sv2[qt] = S::tile(kf, qf[qt]);
                 dp[qt] = S::tile(vf, dof[qt]);
+            }
+            if constexpr (EMM) {
+#pragma unroll
+                for (int e = 0; e < RL::ECH; ++e) {
+                    const u32x4 ef = ld_chunk(Es + sa_off<EROWB>(k0 + kt * 16 + l15, e * 4 + lg));
+                    Mma<T>::run(sv2[0], ef, rf[0][e]);
+                    Mma<T>::run(sv2[1], ef, rf[1][e]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -733,7 +736,10 @@ DEVINL int sa_rw_off(int row, int kw) { return row * 64 + ((((kw >> 2) ^ (((row 
 template <typename T, int D, int REL, bool DROP>
 __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParams p) {
     using S = SA<T, D>;
-    constexpr bool TAB = REL == 1 || REL == 3;
+    constexpr bool TAB = REL == 3;         // per-chunk LDS tables + VALU adds
+    constexpr bool EMM = REL == 1;         // bias on the MFMA (SARel): R rows of the query chunk in LDS, E of the own keys in registers
+    using RL = SARel<T>;
+    constexpr int NPF = RL::CPR * SA_CHUNK / SA_THREADS;      // 16-byte chunks of R per thread per query chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware mapping (workgroups are dealt to the 8 XCDs round-robin in launch order, x fastest): every row block
     // of one (batch, head) reads the same K / V (Q / dO), so each XCD gets a contiguous (head, block) range
@@ -746,6 +752,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
     float* Dq = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
     float* Ls = Dq + SA_CHUNK;
     float* rhs = Ls + SA_CHUNK;                            // TAB: [64][Sh + 1]      REL 2: [2][64]
+    char* Rs = reinterpret_cast<char*>(Ls + SA_CHUNK);     // EMM: R[64 queries][32] operand image
     float* rws = TAB ? rhs + SA_CHUNK * (p.Sh + 1) : rhs + 2 * SA_CHUNK;   // TAB: [64][Sw + 1]   REL 2: [64][64] swizzled
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
@@ -771,6 +778,14 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
         S::gmem_frags(kf[t], kg, p.k_rs, key0 + t * 16, p.Nk, l15, lg);
         S::gmem_frags(vf[t], vg, p.v_rs, key0 + t * 16, p.Nk, l15, lg);
     }
+    u32x4 ek[2][RL::ECH];
+    if constexpr (EMM) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < RL::ECH; ++e) ek[t][e] = RL::key_frag(p, key0 + t * 16 + l15, e * 4 + lg);
+    }
+    float pf_rel[NPF][Chunk<T>::N];                          // raw rel_h / rel_w values of the next chunk's R rows
     f32x4 dv[2][S::DT], dk[2][S::DT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -808,6 +823,22 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
             pf_stat = r < p.Nq ? (tid < SA_CHUNK ? dsg[r] : lsg[r] * LOG2E) : 0.f;
             if constexpr (REL == 2) pf_rh = r < p.Nq ? rhg[(size_t)r * p.Sh + (tid >> 6)] * LOG2E : 0.f;
         }
+        if constexpr (EMM) {                               // converted and stored when the chunk becomes current
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int i = tid + j * SA_THREADS, row = i / RL::CPR, ch = i - row * RL::CPR, q = q0 + row;
+#pragma unroll
+                for (int n = 0; n < Chunk<T>::N; ++n) {
+                    const int col = ch * Chunk<T>::N + n;
+                    float v = 0.f;
+                    if (q < p.Nq) {
+                        if (col < p.Sh) v = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + col];
+                        else if (col < p.Sh + p.Sw) v = p.rel_w[((size_t)bh * p.Nq + q) * p.Sw + col - p.Sh];
+                    }
+                    pf_rel[j][n] = v;
+                }
+            }
+        }
     };
     prefetch(0);
     if constexpr (REL == 2) dma_rw(0, 0);
@@ -820,6 +851,17 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
         if (tid < 2 * SA_CHUNK) {
             Dq[tid] = pf_stat;                             // Dq[0..63] then Ls[0..63] (contiguous)
             if constexpr (REL == 2) rhs[tid] = pf_rh;
+        }
+        if constexpr (EMM) {
+            const float mul = 1.f / p.scale;
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int i = tid + j * SA_THREADS, row = i / RL::CPR, ch = i - row * RL::CPR;
+                float f[Chunk<T>::N];
+#pragma unroll
+                for (int n = 0; n < Chunk<T>::N; ++n) f[n] = pf_rel[j][n] * mul;
+                st_chunk(Rs + sa_off<RL::EROWB>(row, ch), Chunk<T>::pack(f));
+            }
         }
         if constexpr (TAB) {
             for (int i = tid; i < SA_CHUNK * p.Sh; i += SA_THREADS) {
@@ -848,8 +890,13 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
                 S::lds_frags(dof, Os, qt * 16, l15, lg);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const f32x4 sv2 = S::tile(qf, kf[t]);  // rows queries, col key
+                    f32x4 sv2 = S::tile(qf, kf[t]);        // rows queries, col key
                     const f32x4 dp = S::tile(dof, vf[t]);
+                    if constexpr (EMM) {
+#pragma unroll
+                        for (int e = 0; e < RL::ECH; ++e)
+                            Mma<T>::run(sv2, ld_chunk(Rs + sa_off<RL::EROWB>(qt * 16 + l15, e * 4 + lg)), ek[t][e]);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ql = qt * 16 + lg * 4 + r;
@@ -911,13 +958,14 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
         const size_t e = REL == 1 ? (size_t)256 * 32 * sizeof(T) : 0;
         const size_t g2 = REL == 2 ? (size_t)SA_WAVES * SA_WROWS * 68 * sizeof(float) : 0;
         hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
-                           4 * chunk + e + g2 + kbl + tab * (REL == 3 ? 2 : 1), st, p);
+                           4 * chunk + e + g2 + kbl + (REL == 3 ? 2 * tab : 0), st, p);
     } else {
         auto k = sa_bwd_dkv_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
         const size_t rel = REL == 2 ? (size_t)(2 * SA_CHUNK + 2 * SA_CHUNK * 64) * sizeof(float)
-                                    : REL ? (size_t)SA_CHUNK * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
+                         : REL == 1 ? (size_t)SA_CHUNK * SARel<T>::EROWB
+                         : REL ? (size_t)SA_CHUNK * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
         hipLaunchKernelGGL(k, dim3((p.Nk + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
                            4 * chunk + 2 * SA_CHUNK * sizeof(float) + rel, st, p);
     }
