@@ -36,7 +36,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes); None when the
     summary is absent.  Counters cannot be collected inside the timed run itself."""
-    path = os.path.join(ROOT, 'profiles', 'r01d_pmc_hbm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r01e_pmc_hbm_traffic.json')
     try:
         return json.load(open(path))['kernels'][kernel]['bytes_per_launch']
     except (OSError, KeyError, ValueError):

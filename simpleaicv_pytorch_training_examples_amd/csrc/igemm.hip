@@ -890,7 +890,10 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     const NTTile& g = kTiles[t];
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
-    p.grid_x = 256 * g.blocks_per_cu;
+    {
+        static const int persist = getenv("SAICV_NT_PERSIST") ? atoi(getenv("SAICV_NT_PERSIST")) : 1;   // tuning aid
+        p.grid_x = persist ? 256 * g.blocks_per_cu : 0x7fffffff;
+    }
 #define NT_DISPATCH(TT, MODE_)                                                              \
     switch (t) {                                                                            \
         case 0: return launch_nt<TT, 256, 256, 2, 4, MODE_>(p, f32o, st);                   \
