@@ -324,6 +324,9 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
     const int m_base = tile_m * BM_T + wm * WMR;
     const int n_base = tile_n * BN_T + wn * WN;
     const bool do_stats = p.stat_sum != nullptr;
+    // bf16 outputs: the BN statistics are taken from the STAGED tile by the matrix cores (below), not here
+    constexpr bool MSTAT = !OUT_F32 && sizeof(T) == 2;
+    const bool valu_stats = do_stats && !MSTAT;
 #pragma unroll
     for (int ni = 0; ni < NT_; ++ni) {
         const int n0 = n_base + ni * 16 + lg * 4;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bs[r];
-            if (do_stats) {
+            if (valu_stats) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float vr = OUT_F32 ? v[r] : round_through<T>(v[r]);
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
             }
         }
-        if (do_stats) {
+        if (valu_stats) {
             // rows m >= M were gathered as zeros (no bias when stats are requested) -> add 0.
 #pragma unroll
             for (int r = 0; r < 4; ++r) {        // over the 16 pixel lanes: four DPP adds each
@@ -373,6 +376,40 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
         }
     }
     __syncthreads();
+    if constexpr (MSTAT) {
+        if (do_stats) {
+            // Column sums of the staged bf16 tile on the matrix cores: with Y the [32 rows][16 cols] block read
+            // TRANSPOSED from LDS (ds_read_b64_tr_b16: lane (col, k-group) gets 8 consecutive rows of its column),
+            //   sum_m y      = (1 . Y)[any row][col]          -- A = ones
+            //   sum_m y * y  = (Y^T . Y)[col][col]            -- A = B = the same fragment, the diagonal
+            // exact products, fp32 accumulation, and exactly the values the next kernel reads (bf16-rounded).
+            // One wavefront owns 16 columns over ALL rows of the tile: no cross-wave combine, and the 14 VALU
+            // operations per output element + 128 DPP adds of the accumulator version are gone from the epilogue.
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            for (int cg = wave; cg < BN_T / 16; cg += NWAVES) {
+                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+                const char* q = smem + (lg * 8 + (l15 >> 2)) * OPITCH + (cg * 16 + (l15 & 3) * 4) * 2;
+#pragma unroll 4
+                for (int rb = 0; rb < BM_T / 32; ++rb, q += 32 * OPITCH) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * OPITCH));
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    const u32x4 y = {l2[0], l2[1], h2[0], h2[1]};
+                    Mma<T>::run(s1, ones, y);
+                    Mma<T>::run(s2, y, y);
+                }
+                const int n = tile_n * BN_T + cg * 16 + l15;          // D: row lg*4 + r, column l15
+                if (n < p.Nn) {
+                    if (lg == 0) p.stat_sum[(size_t)tile_m * (size_t)p.Nn + n] = s1[0];
+                    if (lg == (l15 >> 2)) {
+                        const int r = l15 & 3;
+                        p.stat_sq[(size_t)tile_m * (size_t)p.Nn + n] = r == 0 ? s2[0] : r == 1 ? s2[1] : r == 2 ? s2[2] : s2[3];
+                    }
+                }
+            }
+        }
+    } else
     if (do_stats) {
         // one row of partial statistics per WORKGROUP (fixed summation order over its wavefront rows): four times
         // fewer partial rows for the finalize kernels to read than one row per wavefront row
