@@ -455,19 +455,35 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
             }
         }
     } else if (ncol < p.Nn) {
+        // one copy of the fused-mode code in a ROLLED loop; the staged chunk and the addend chunk of the NEXT row are
+        // fetched before the current row is processed, so a row's global-load latency hides under its predecessor
         const bool whole = aligned && ncol + OEPC <= p.Nn;
-#pragma unroll 1
-        for (int rr = orow0; rr < BM_T; rr += RPP) {
+        const bool pre_add = whole && p.addend != nullptr;
+        auto out_row = [&](int rr) -> int {                // output row of tile row rr, -1 past the end
             const int mrow = tile_m * BM_T + rr;
-            if (mrow >= Mc) break;
-            int m = mrow;
-            if (remap) {
-                const int img = mrow / ohw;
-                const int rem = mrow - img * ohw;
-                const int hc = rem / Wc;
-                m = (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
+            if (rr >= BM_T || mrow >= Mc) return -1;
+            if (!remap) return mrow;
+            const int img = mrow / ohw;
+            const int rem = mrow - img * ohw;
+            const int hc = rem / Wc;
+            return (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
+        };
+        int rr = orow0;
+        int m = out_row(rr);
+        u32x4 v = {0u, 0u, 0u, 0u}, av = {0u, 0u, 0u, 0u};
+        if (m >= 0) {
+            v = ld_chunk(smem + rr * OPITCH + oc * 16);
+            if (pre_add) av = ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol);
+        }
+#pragma unroll 1
+        while (m >= 0) {
+            const int rn = rr + RPP;
+            const int mn = out_row(rn);
+            u32x4 vn = {0u, 0u, 0u, 0u}, an = {0u, 0u, 0u, 0u};
+            if (mn >= 0) {
+                vn = ld_chunk(smem + rn * OPITCH + oc * 16);
+                if (pre_add) an = ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)mn * p.ldo + ncol);
             }
-            u32x4 v = ld_chunk(smem + rr * OPITCH + oc * 16);
             TO* o = outp + (size_t)m * p.ldo + ncol;
             if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
                 float f[OEPC];
@@ -475,10 +491,10 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
 #pragma unroll
                 for (int j = 0; j < OEPC; ++j) f[j] = gelu_fwd_f(f[j]);
                 st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(f));
-            } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)
+            } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)   (rows are whole chunks)
                 float f[OEPC], a[OEPC];
                 Chunk<TO>::unpack(v, f);
-                Chunk<TO>::unpack(ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol), a);
+                Chunk<TO>::unpack(av, a);
 #pragma unroll
                 for (int j = 0; j < OEPC; ++j) f[j] *= gelu_grad_f(a[j]);
                 v = Chunk<TO>::pack(f);
@@ -486,8 +502,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 float f[OEPC], a[OEPC];
                 Chunk<TO>::unpack(v, f);
                 const float sc = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.f;
-                if (p.addend != nullptr && whole) {
-                    Chunk<TO>::unpack(ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol), a);
+                if (pre_add) {
+                    Chunk<TO>::unpack(av, a);
                 } else {
                     for (int j = 0; j < OEPC; ++j)
                         a[j] = (p.addend != nullptr && ncol + j < p.Nn)
@@ -504,6 +520,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 for (int j = 0; j < OEPC; ++j)
                     if (ncol + j < p.Nn) o[j] = e[j];
             }
+            rr = rn; m = mn; v = vn; av = an;
         }
     }
     }   // tile loop
