@@ -423,8 +423,12 @@ int bn_bwd_slabs(size_t M, int C, int dtype) {
     const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     const int cpr = C / n;
     const int rpp = cpr >= 256 ? 1 : 256 / cpr;
-    size_t s = M / ((size_t)rpp * 8);      // >= 8 passes per slab
-    if (s > 1024) s = 1024;
+    static const int cap = getenv("SAICV_BN_SLABS") ? atoi(getenv("SAICV_BN_SLABS")) : 512;     // tuning aid (sweep: 256..2048)
+    static const int passes = getenv("SAICV_BN_PASSES") ? atoi(getenv("SAICV_BN_PASSES")) : 16;
+    // >= 16 passes per slab and at most two blocks per CU: the [slabs][C] partials of a 7 x 7 x 2048 layer were a
+    // third of its tensor traffic at 1024 slabs
+    size_t s = M / ((size_t)rpp * passes);
+    if (s > (size_t)cap) s = cap;
     if (s < 1) s = 1;
     return (int)s;
 }
