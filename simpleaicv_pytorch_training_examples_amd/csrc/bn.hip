@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int kMaxBlocks = 2048;
+constexpr int kMaxBlocks = 1024;        // four 256-thread blocks per CU (sweep 512..16384: flat within 1 %, 2048 the slowest)
 
 // ---------------------------------------------------------------- partial reduce [P][C] -> [Y][C]
 __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __restrict__ a,
@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 inline int stream_grid(size_t nchunks) {
     size_t b = (nchunks + 255) / 256;
-    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    static const int cap = getenv("SAICV_BN_BLOCKS") ? atoi(getenv("SAICV_BN_BLOCKS")) : kMaxBlocks;     // tuning aid
+    if (b > (size_t)cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
 }
