@@ -59,34 +59,45 @@ __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __
     }
 }
 
-// column sums of P <= 32 partial rows by a 256-thread block: wave ty takes rows ty, ty+4, ... with all of its (at
-// most eight) loads in flight, LDS combines the four waves.  A one-wave serial loop over 32 rows costs ~10 us of pure
-// load latency per BatchNorm, twice per step.
+// column sums of the partial rows by one block of NW wavefronts per 64 channels: wave ty takes rows ty, ty + NW, ...
+// eight at a time with all of their loads in flight, LDS combines the waves.  NW = 4 serves P <= 32 (one batch); NW = 16
+// serves P <= 1024 in at most eight batches (~5 us), which is cheaper than a separate partial-reduction launch plus a
+// P <= 32 finalize (5 + 5 us): only the 56 x 56 layers (P = 3136..6272) still take the two-kernel route.
+// (A one-wave serial loop over 32 rows cost ~10 us of pure load latency per BatchNorm, twice per step.)
+template <int NW>
 DEVINL void finalize_colsum(const float* __restrict__ a, const float* __restrict__ b, int P, int C, int c, int ty,
                             float& sa, float& sb) {
-    float va[8], vb[8];
+    sa = 0.f;
+    sb = 0.f;
+    for (int p0 = ty; p0 < P; p0 += NW * 8) {
+        float va[8], vb[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int p = ty + 4 * u;
-        const bool ok = c < C && p < P;
-        va[u] = ok ? a[(size_t)p * C + c] : 0.f;
-        vb[u] = ok ? b[(size_t)p * C + c] : 0.f;
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + NW * u;
+            const bool ok = c < C && p < P;
+            va[u] = ok ? a[(size_t)p * C + c] : 0.f;
+            vb[u] = ok ? b[(size_t)p * C + c] : 0.f;
+        }
+        sa += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
+        sb += ((vb[0] + vb[1]) + (vb[2] + vb[3])) + ((vb[4] + vb[5]) + (vb[6] + vb[7]));
     }
-    sa = ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
-    sb = ((vb[0] + vb[1]) + (vb[2] + vb[3])) + ((vb[4] + vb[5]) + (vb[6] + vb[7]));
-    __shared__ float la[4][64], lb[4][64];
-    la[ty][threadIdx.x & 63] = sa;
-    lb[ty][threadIdx.x & 63] = sb;
-    __syncthreads();
+    __shared__ float la[NW][64], lb[NW][64];
     const int x = threadIdx.x & 63;
-    sa = (la[0][x] + la[1][x]) + (la[2][x] + la[3][x]);
-    sb = (lb[0][x] + lb[1][x]) + (lb[2][x] + lb[3][x]);
+    la[ty][x] = sa;
+    lb[ty][x] = sb;
+    __syncthreads();
+    sa = 0.f;
+    sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { sa += la[w][x]; sb += lb[w][x]; }
 }
+constexpr int kFinalizeDirect = 1024;    // partial rows a finalize kernel takes without a reduction launch
 
 // ---------------------------------------------------------------- forward finalize
 // Follows torch.nn.BatchNorm2d training semantics (biased var for normalisation, unbiased
 // var into running_var, momentum 0.1) as used by reference resnet.py:41.
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void bn_finalize_fwd_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
                                        int P, int C, float count, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* running_mean,
                                        float* running_var, float momentum, float eps,
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
     const int ty = threadIdx.x >> 6;
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;     // BatchNorm2d bookkeeping, no extra launch
     float s, q;
-    finalize_colsum(sum, sq, P, C, c, ty, s, q);
+    finalize_colsum<NW>(sum, sq, P, C, c, ty, s, q);
     if (c >= C || ty != 0) return;
     const float mean = s / count;
     float var = q / count - mean * mean;
@@ -272,7 +283,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // ---------------------------------------------------------------- backward finalize
 // dy = A*(g - mg) - A*xhat*mgx  with A = gamma*invstd, mg = sum(g)/M, mgx = sum(g*xhat)/M
 // written as dy = ca*g + cb*y + cc per channel.
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ pg, const float* __restrict__ pgx,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void bn_finalize_bwd_kernel(const float* __restrict__ pg, const float* __restrict__ pgx,
                                        int P, int C, float count, const float* __restrict__ gamma,
                                        const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ty = threadIdx.x >> 6;
     float sg, sx;
-    finalize_colsum(pg, pgx, P, C, c, ty, sg, sx);
+    finalize_colsum<NW>(pg, pgx, P, C, c, ty, sg, sx);
     if (c >= C || ty != 0) return;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sx : sx;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sg : sg;
@@ -356,7 +368,8 @@ inline int stream_grid(size_t nchunks) {
 
 // reduce [P][C] partial pairs down to at most 32 rows (in place into ws), returns new P
 int reduce_partials(const float*& a, const float*& b, int P, int C, float* ws, hipStream_t st) {
-    if (P <= 32) return P;
+    static const int direct = getenv("SAICV_BN_DIRECT") ? atoi(getenv("SAICV_BN_DIRECT")) : kFinalizeDirect;   // tuning aid
+    if (P <= direct) return P;
     const int Y = 32;
     const int rows_per = (P + Y - 1) / Y;
     const int y_used = (P + rows_per - 1) / rows_per;
@@ -381,7 +394,7 @@ int bn_finalize_fwd(const float* sum, const float* sq, int P, int C, double coun
                     double eps, float* mean, float* invstd, float* scale, float* shift, float* ws,
                     long long* num_batches_tracked, hipStream_t st) {
     P = reduce_partials(sum, sq, P, C, ws, st);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, sum, sq, P, C,
+    hipLaunchKernelGGL(P <= 32 ? bn_finalize_fwd_kernel<4> : bn_finalize_fwd_kernel<16>, dim3((C + 63) / 64), dim3(P <= 32 ? 256 : 1024), 0, st, sum, sq, P, C,
                        (float)count, gamma, beta, running_mean, running_var, (float)momentum, (float)eps,
                        mean, invstd, scale, shift, num_batches_tracked);
     return check_launch("bn_finalize_fwd");
@@ -458,7 +471,7 @@ static int bn_bwd_t(const void* dz, const void* z, const uint8_t* mask, const vo
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(used), dim3(256), 0, st, dzz, zz, mask, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
     const float* a = pg; const float* b = pgx;
     const int P = reduce_partials(a, b, used, C, ws2, st);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, a, b, P, C,
+    hipLaunchKernelGGL(P <= 32 ? bn_finalize_bwd_kernel<4> : bn_finalize_bwd_kernel<16>, dim3((C + 63) / 64), dim3(P <= 32 ? 256 : 1024), 0, st, a, b, P, C,
                        (float)M, gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, accumulate);
     const size_t nchunks = M * (size_t)C / N;
     const int grid = stream_grid(nchunks);
