@@ -136,8 +136,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
         Kc = Rc * Sc * p.C;
         nblk = ((Mc + BM_T - 1) / BM_T) * p.tiles_n;
     }
-    // ---- persistent tile loop: the grid is one resident round of workgroups, each walks tiles tix, tix + grid, ...
-    // (no workgroup relaunch between tiles; the previous tile's stores drain under the next tile's prologue).
+    // ---- tile loop: one tile per workgroup by default (the hardware dispatcher balances the load); with
+    // SAICV_NT_PERSIST=1 the grid is one resident round of workgroups, each walking tiles tix, tix + grid, ...
     // Spreading the workgroups' start times over a tile period -- so that epilogue write bursts and MFMA loops of
     // different CUs interleave -- was measured and bought nothing: the ramp costs what the steady state gains.
     for (int tix = blockIdx.x; tix < nblk; tix += gridDim.x) {
@@ -945,7 +945,11 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
     {
-        static const int persist = getenv("SAICV_NT_PERSIST") ? atoi(getenv("SAICV_NT_PERSIST")) : 1;   // tuning aid
+        // One workgroup per tile by default.  The persistent form (one resident round of workgroups walking all tiles,
+        // SAICV_NT_PERSIST=1) measured the same on one GPU, but its static tile partition doubles a kernel's time as
+        // soon as some of its workgroups cannot be resident from the start -- which is what happens under
+        // data-parallel training while RCCL's all-reduce kernels hold CU slots during backward.
+        static const int persist = getenv("SAICV_NT_PERSIST") ? atoi(getenv("SAICV_NT_PERSIST")) : 0;
         p.grid_x = persist ? 256 * g.blocks_per_cu : 0x7fffffff;
     }
 #define NT_DISPATCH(TT, MODE_)                                                              \
