@@ -1003,7 +1003,12 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     const int total_rt = (M + BR - 1) / BR;
     // 128-wide tiles: 2 workgroups per CU are resident (73 KiB LDS each); 256-wide: one (139 KiB)
     // rounded DOWN: one full round of resident workgroups beats a second, nearly empty one
-    int splits = (big ? 256 : 512) / tiles;
+    // The split count is sized for 85 % of the resident slots (SAICV_TN_SLOTS_PCT).  Sizing it for all of them is
+    // exact on an otherwise idle GPU (+0.6 % on the ResNet-50 step), but the one-round design has no slack: under
+    // data-parallel training RCCL's all-reduce kernels hold CU slots (and LDS) during backward, and every workgroup
+    // that cannot start with the others costs this kernel a whole second round.
+    static const int slots_pct = getenv("SAICV_TN_SLOTS_PCT") ? atoi(getenv("SAICV_TN_SLOTS_PCT")) : 85;
+    int splits = ((big ? 256 : 512) * slots_pct / 100) / tiles;
     if (splits > total_rt) splits = total_rt;
     if (splits < 1) splits = 1;
     int rt_per = (total_rt + splits - 1) / splits;
