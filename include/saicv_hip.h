@@ -148,12 +148,20 @@ int saicv_scale_by_scalar(int out_dtype, const float* in, const float* scale, vo
                           void* stream);
 
 /* ---- flat-arena optimizers / GradScaler (tools/utils.py:292-679, :199-200) ------------- */
+/* One launch over the flat arenas; every 1024-element block belongs to one parameter.
+ *   block_group[b]  optimizer param-group of block b (-1: not optimized)
+ *   hyper[g*8..]    lr, weight_decay, momentum|beta1, beta2, eps, -, -, nesterov flag
+ *   found_inf       nullable device flag: != 0 skips the whole step (GradScaler semantics)
+ *   has_grad        nullable, one byte per block: 0 = this parameter received no gradient this step and is
+ *                   skipped like torch.optim skips `grad is None` (no decay, no moment update, no step count)
+ *   step_blk        AdamW: per-block step counters (= torch's per-parameter state['step']), advanced on the
+ *                   device only when the block is really updated; bias corrections are computed from them */
 int saicv_sgd_flat(float* p, const float* g, float* mom, const int32_t* block_group,
-                   const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
-                   void* stream);
+                   const float* hyper, const float* inv_scale, const float* found_inf,
+                   const uint8_t* has_grad, size_t n, void* stream);
 int saicv_adamw_flat(float* p, const float* g, float* m, float* v, const int32_t* block_group,
-                     const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
-                     void* stream);
+                     const float* hyper, const float* inv_scale, const float* found_inf,
+                     const uint8_t* has_grad, float* step_blk, size_t n, void* stream);
 int saicv_grad_stats(const float* g, size_t n, float* found_inf, float* sumsq, void* stream);
 int saicv_grad_clip_scale(float* g, size_t n, const float* sumsq, const float* inv_scale,
                           double max_norm, void* stream);

@@ -69,8 +69,8 @@ SIGNATURES = {
     'saicv_avgpool_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     'saicv_scale_by_scalar': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
-    'saicv_sgd_flat': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    'saicv_adamw_flat': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'saicv_sgd_flat': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'saicv_adamw_flat': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'saicv_grad_stats': (c_int, [_P, c_size_t, _P, _P, _P]),
     'saicv_grad_clip_scale': (c_int, [_P, c_size_t, _P, _P, c_double, _P]),
     'saicv_scaler_update': (c_int, [_P, _P, c_double, c_double, c_int, _P]),

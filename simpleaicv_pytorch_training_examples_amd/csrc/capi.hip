@@ -49,8 +49,8 @@ int pack_weight(int, const float*, long, long, long, long, int, int, int, int, i
 int unpack_wgrad(const float*, int, int, int, int, int, float*, long, long, long, long, int, hipStream_t);
 int colsum(int, const void*, int, int, float*, hipStream_t);
 int row_scale(int, const void*, const float*, void*, size_t, int, int, hipStream_t);
-int sgd_flat(float*, const float*, float*, const int32_t*, const float*, const float*, const float*, size_t, hipStream_t);
-int adamw_flat(float*, const float*, float*, float*, const int32_t*, const float*, const float*, const float*, size_t, hipStream_t);
+int sgd_flat(float*, const float*, float*, const int32_t*, const float*, const float*, const float*, const uint8_t*, size_t, hipStream_t);
+int adamw_flat(float*, const float*, float*, float*, const int32_t*, const float*, const float*, const float*, const uint8_t*, float*, size_t, hipStream_t);
 int grad_stats(const float*, size_t, float*, float*, hipStream_t);
 int grad_clip_scale(float*, size_t, const float*, const float*, double, hipStream_t);
 int scaler_update(float*, const float*, double, double, int, hipStream_t);
@@ -235,14 +235,14 @@ int saicv_scale_by_scalar(int out_dtype, const float* in, const float* scale, vo
 }
 
 int saicv_sgd_flat(float* p, const float* g, float* mom, const int32_t* block_group,
-                   const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
-                   void* stream) {
-    return sgd_flat(p, g, mom, block_group, hyper, inv_scale, found_inf, n, S(stream));
+                   const float* hyper, const float* inv_scale, const float* found_inf,
+                   const uint8_t* has_grad, size_t n, void* stream) {
+    return sgd_flat(p, g, mom, block_group, hyper, inv_scale, found_inf, has_grad, n, S(stream));
 }
 int saicv_adamw_flat(float* p, const float* g, float* m, float* v, const int32_t* block_group,
-                     const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
-                     void* stream) {
-    return adamw_flat(p, g, m, v, block_group, hyper, inv_scale, found_inf, n, S(stream));
+                     const float* hyper, const float* inv_scale, const float* found_inf,
+                     const uint8_t* has_grad, float* step_blk, size_t n, void* stream) {
+    return adamw_flat(p, g, m, v, block_group, hyper, inv_scale, found_inf, has_grad, step_blk, n, S(stream));
 }
 int saicv_grad_stats(const float* g, size_t n, float* found_inf, float* sumsq, void* stream) {
     return grad_stats(g, n, found_inf, sumsq, S(stream));

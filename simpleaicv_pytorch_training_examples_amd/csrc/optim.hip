@@ -10,7 +10,11 @@
 
 namespace {
 
-constexpr int kHyper = 8;   // floats per group: lr, wd, momentum|beta1, beta2, eps, bc1, bc2, flags
+constexpr int kHyper = 8;   // floats per group: lr, wd, momentum|beta1, beta2, eps, -, -, flags
+
+// Every 1024-element block belongs to ONE parameter.  `has_grad` (nullable, one byte per block) is 0 for the
+// blocks of parameters that received no gradient this step: torch.optim skips those entirely (grad is None
+// after zero_grad(): no weight decay, no momentum / moment decay, no step count) and so do these kernels.
 
 // SGD with momentum (dampening 0), optional nesterov (flags bit 0)
 __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -18,10 +22,12 @@ __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, co
                                                        const int32_t* __restrict__ block_group,
                                                        const float* __restrict__ hyper,
                                                        const float* __restrict__ inv_scale,
-                                                       const float* __restrict__ found_inf, size_t n) {
+                                                       const float* __restrict__ found_inf,
+                                                       const uint8_t* __restrict__ has_grad, size_t n) {
     if (found_inf && found_inf[0] != 0.f) return;
     const int grp = block_group[blockIdx.x];
     if (grp < 0) return;
+    if (has_grad && !has_grad[blockIdx.x]) return;
     const float* h = hyper + grp * kHyper;
     const float lr = h[0], wd = h[1], mu = h[2];
     const bool nesterov = h[7] != 0.f;
@@ -50,12 +56,21 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
                                                          const int32_t* __restrict__ block_group,
                                                          const float* __restrict__ hyper,
                                                          const float* __restrict__ inv_scale,
-                                                         const float* __restrict__ found_inf, size_t n) {
-    if (found_inf && found_inf[0] != 0.f) return;
+                                                         const float* __restrict__ found_inf,
+                                                         const uint8_t* __restrict__ has_grad,
+                                                         float* __restrict__ step_blk, size_t n) {
+    if (found_inf && found_inf[0] != 0.f) return;        // a skipped step does not advance state['step'] either
     const int grp = block_group[blockIdx.x];
     if (grp < 0) return;
+    if (has_grad && !has_grad[blockIdx.x]) return;
     const float* h = hyper + grp * kHyper;
-    const float lr = h[0], wd = h[1], b1 = h[2], b2 = h[3], eps = h[4], bc1 = h[5], bc2 = h[6];
+    const float lr = h[0], wd = h[1], b1 = h[2], b2 = h[3], eps = h[4];
+    // per-parameter step count on the device (torch keeps state['step'] per parameter): bias corrections follow
+    // the steps this parameter really took, and nothing about them has to be uploaded by the host per iteration
+    const float t = step_blk[blockIdx.x] + 1.f;
+    __syncthreads();                                     // every wavefront has read the old count
+    if (threadIdx.x == 0) step_blk[blockIdx.x] = t;
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
     const float is = inv_scale ? inv_scale[0] : 1.f;
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
@@ -72,7 +87,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
         mv[k] = fmaf(b1, mv[k], (1.f - b1) * d);
         vv[k] = fmaf(b2, vv[k], (1.f - b2) * d * d);
         const float denom = sqrtf(vv[k]) * rs2 + eps;
-        pv[k] -= step * mv[k] / denom;
+        pv[k] = fmaf(-step, mv[k] / denom, pv[k]);
     }
     *reinterpret_cast<f32x4*>(p + i) = pv;
     *reinterpret_cast<f32x4*>(m + i) = mv;
@@ -144,17 +159,18 @@ __global__ void scaler_update_kernel(float* __restrict__ state, const float* __r
 namespace saicv {
 
 int sgd_flat(float* p, const float* g, float* mom, const int32_t* block_group, const float* hyper,
-             const float* inv_scale, const float* found_inf, size_t n, hipStream_t st) {
+             const float* inv_scale, const float* found_inf, const uint8_t* has_grad, size_t n, hipStream_t st) {
     SAICV_REQUIRE(n % 1024 == 0, "sgd_flat: arena length %zu must be a multiple of 1024", n);
-    hipLaunchKernelGGL(sgd_flat_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, st, p, g, mom, block_group, hyper, inv_scale, found_inf, n);
+    hipLaunchKernelGGL(sgd_flat_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, st, p, g, mom, block_group, hyper, inv_scale, found_inf, has_grad, n);
     return check_launch("sgd_flat");
 }
 
 int adamw_flat(float* p, const float* g, float* m, float* v, const int32_t* block_group,
-               const float* hyper, const float* inv_scale, const float* found_inf, size_t n,
-               hipStream_t st) {
+               const float* hyper, const float* inv_scale, const float* found_inf, const uint8_t* has_grad,
+               float* step_blk, size_t n, hipStream_t st) {
+    SAICV_REQUIRE(step_blk != nullptr, "adamw_flat: the per-block step counters are required");
     SAICV_REQUIRE(n % 1024 == 0, "adamw_flat: arena length %zu must be a multiple of 1024", n);
-    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, st, p, g, m, v, block_group, hyper, inv_scale, found_inf, n);
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, st, p, g, m, v, block_group, hyper, inv_scale, found_inf, has_grad, step_blk, n);
     return check_launch("adamw_flat");
 }
 

@@ -73,10 +73,46 @@ class FlatArena:
                 # model marks as used several times per step (SAM decoder: 1 + decoder_iters passes),
                 # whose gradient is only complete when autograd's own accumulation node has run
                 p._saicv_direct = not getattr(p, '_saicv_multi_use', False)
+        # "this parameter's gradient of the current backward is complete": autograd runs a leaf's
+        # AccumulateGrad node exactly once per backward, after every use of the leaf (also when the
+        # kernels wrote the gradient in place and returned None), and this hook with it
+        self.arrived = [False] * len(self.params)
+        self.listeners = []             # callables(index), e.g. the DDP engine's bucket counter
+        self._mask_cache = {}
+        for i, p in enumerate(self.params):
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
         ops.bump_weights_epoch()
+
+    def _make_hook(self, i):
+        def hook(param):
+            self.arrived[i] = True
+            for cb in self.listeners:
+                cb(i)
+        return hook
+
+    def has_grad_mask(self):
+        """uint8 [total/ALIGN] device table, 1 for the blocks of parameters that received a gradient since
+        the last zero_grad(); None when every trainable parameter did (the common case).  torch.optim
+        skips parameters whose .grad is None; the flat kernels skip the blocks this table zeroes."""
+        missing = tuple(i for i, p in enumerate(self.params) if p.requires_grad and not self.arrived[i])
+        if not missing:
+            return None
+        m = self._mask_cache.get(missing)
+        if m is None:
+            t = torch.ones(self.total // ALIGN, dtype=torch.uint8)
+            for i in missing:
+                o, nb = self.offsets[i] // ALIGN, (self.params[i].numel() + ALIGN - 1) // ALIGN
+                t[o:o + nb] = 0
+            m = t.to(self.device)
+            if len(self._mask_cache) > 64:
+                self._mask_cache.clear()
+            self._mask_cache[missing] = m
+        return m
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        self.arrived = [False] * len(self.params)
         # re-attach views in case someone set .grad = None (optimizer.zero_grad(set_to_none=True))
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
@@ -112,6 +148,7 @@ class _FlatOptimizer:
         if self.arena.device.type != 'cuda':
             raise RuntimeError('the fused flat optimizers run on MI355X only (HIP kernels, no CPU fallback); '
                                'move the model to the GPU before building the optimizer')
+        self._pidx = {id(p): k for k, p in enumerate(self.arena.params)}
         self.param_groups = []
         group_of = {}
         for gi, g in enumerate(param_groups):
@@ -125,7 +162,7 @@ class _FlatOptimizer:
         self._hyper_dev = torch.zeros(len(self.param_groups) * HYPER, dtype=torch.float32, device=self.arena.device)
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
-        self.steps = 0
+        self.track_missing_grads = True     # False: treat every parameter as having a gradient (static step graphs)
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
@@ -160,63 +197,146 @@ class _FlatOptimizer:
                                           ptr(inv_scale), float(max_norm), _lib.stream()), 'grad_clip_scale')
 
     def step(self, inv_scale=None, found_inf=None):
-        self.steps += 1
-        self._launch(inv_scale, found_inf)
+        mask = self.arena.has_grad_mask() if self.track_missing_grads else None
+        self._launch(inv_scale, found_inf, mask)
         ops.bump_weights_epoch()
 
+    # ---- torch.optim checkpoint layout: state[i] = {per-parameter tensors}, param_groups[g]['params'] = [i, ...]
+    # with i the running index over the groups' parameters; per-parameter tensors are views of the flat state
+    # arenas with the parameter's own shape and strides, so a reference `latest.pth` loads here and vice versa.
+    def _index_of_params(self):
+        order, i = {}, 0
+        for g in self.param_groups:
+            for p in g['params']:
+                order[id(p)] = i
+                i += 1
+        return order
+
+    def _param_view(self, flat, p):
+        return flat.as_strided(p.shape, p.stride(), self.arena.offsets[self._pidx[id(p)]])
+
     def state_dict(self):
-        return {'steps': self.steps,
-                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups],
-                'state': {k: v.detach().cpu() for k, v in self._state_tensors().items()}}
+        order = self._index_of_params()
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != 'params'}
+            d['params'] = [order[id(p)] for p in g['params']]
+            groups.append(d)
+        state = {}
+        for g in self.param_groups:
+            for p in g['params']:
+                entry = self._state_of(p)
+                if entry is not None:
+                    state[order[id(p)]] = entry
+        return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, sd):
-        self.steps = sd['steps']
+        if 'param_groups' not in sd or 'state' not in sd:
+            raise ValueError('optimizer state_dict must have the torch.optim layout {state, param_groups}')
+        if len(sd['param_groups']) != len(self.param_groups):
+            raise ValueError(f"optimizer state_dict has {len(sd['param_groups'])} param groups, "
+                             f'this optimizer {len(self.param_groups)}')
+        flat_params = []
         for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
-        for k, v in self._state_tensors().items():
-            v.copy_(sd['state'][k])
+            if len(s['params']) != len(g['params']):
+                raise ValueError('optimizer state_dict: a param group has a different number of parameters')
+            g.update({k: v for k, v in s.items() if k != 'params'})
+            flat_params.extend(zip(s['params'], g['params']))
+        self._reset_state()
+        for idx, p in flat_params:
+            entry = sd['state'].get(idx, sd['state'].get(str(idx)))
+            if entry is not None:
+                self._load_state_of(p, entry)
+        self._last_hyper = None
 
 
 class SGD(_FlatOptimizer):
     """torch.optim.SGD(momentum, weight_decay, nesterov) semantics, one launch for all params."""
 
     def __init__(self, model, param_groups, lr, momentum=0.0, weight_decay=0.0, nesterov=False):
-        defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov)
+        # every key torch.optim.SGD keeps in a param group, so a checkpoint written here loads into torch.optim
+        defaults = dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=nesterov,
+                        maximize=False, foreach=None, differentiable=False, fused=None)
         super().__init__(model, [{**defaults, **g} for g in param_groups])
+        for g in self.param_groups:
+            if g['dampening'] != 0 or g['maximize']:
+                raise NotImplementedError('flat SGD: dampening / maximize are not used by any reference config')
         self.momentum_buf = torch.zeros_like(self.arena.flat_param)
 
-    def _state_tensors(self):
-        return {'momentum_buffer': self.momentum_buf}
+    def _reset_state(self):
+        self.momentum_buf.zero_()
 
-    def _launch(self, inv_scale, found_inf):
+    def _state_of(self, p):
+        # torch creates momentum_buffer at a parameter's first step (= its first gradient); an all-zero buffer
+        # is indistinguishable from "not created yet" for the update rule, so it is always emitted
+        return {'momentum_buffer': self._param_view(self.momentum_buf, p).detach().clone()}
+
+    def _load_state_of(self, p, entry):
+        buf = entry.get('momentum_buffer')
+        if buf is not None:
+            if tuple(buf.shape) != tuple(p.shape):
+                raise ValueError(f'momentum_buffer shape {tuple(buf.shape)} does not match parameter {tuple(p.shape)}')
+            self._param_view(self.momentum_buf, p).copy_(buf)
+
+    def _launch(self, inv_scale, found_inf, has_grad):
         self._upload([[g['lr'], g['weight_decay'], g['momentum'], 0, 0, 0, 0, 1.0 if g['nesterov'] else 0.0]
                       for g in self.param_groups])
         a = self.arena
         check(lib().saicv_sgd_flat(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.momentum_buf),
                                    ptr(self.block_group), ptr(self._hyper_dev), ptr(inv_scale), ptr(found_inf),
-                                   a.total, _lib.stream()), 'sgd_flat')
+                                   ptr(has_grad), a.total, _lib.stream()), 'sgd_flat')
 
 
 class AdamW(_FlatOptimizer):
     """torch.optim.AdamW semantics (decoupled decay, bias correction), one launch."""
 
     def __init__(self, model, param_groups, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=True)
         super().__init__(model, [{**defaults, **g} for g in param_groups])
+        for g in self.param_groups:
+            if g['amsgrad'] or g['maximize']:
+                raise NotImplementedError('flat AdamW: amsgrad / maximize are not used by any reference config')
         self.exp_avg = torch.zeros_like(self.arena.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat_param)
+        # torch's per-parameter state['step'], one counter per 1024-element block, advanced by the kernel itself
+        # only when the block is really updated (a GradScaler-skipped step or a parameter without a gradient does
+        # not advance its bias correction) -- nothing about the step count is uploaded by the host
+        self.step_blk = torch.zeros(self.arena.total // ALIGN, dtype=torch.float32, device=self.arena.device)
 
-    def _state_tensors(self):
-        return {'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
+    def _reset_state(self):
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_blk.zero_()
 
-    def _launch(self, inv_scale, found_inf):
-        t = self.steps
-        self._upload([[g['lr'], g['weight_decay'], g['betas'][0], g['betas'][1], g['eps'],
-                       1 - g['betas'][0] ** t, 1 - g['betas'][1] ** t, 0] for g in self.param_groups])
+    def _blocks_of(self, p):
+        k = self._pidx[id(p)]
+        o = self.arena.offsets[k] // ALIGN
+        return o, o + (p.numel() + ALIGN - 1) // ALIGN
+
+    def _state_of(self, p):
+        b0, b1 = self._blocks_of(p)
+        step = self.step_blk[b0:b0 + 1].detach().cpu().reshape(())
+        if float(step) == 0:
+            return None                      # torch has no state for a parameter that never stepped
+        return {'step': step, 'exp_avg': self._param_view(self.exp_avg, p).detach().clone(),
+                'exp_avg_sq': self._param_view(self.exp_avg_sq, p).detach().clone()}
+
+    def _load_state_of(self, p, entry):
+        for key, flat in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+            if tuple(entry[key].shape) != tuple(p.shape):
+                raise ValueError(f'{key} shape {tuple(entry[key].shape)} does not match parameter {tuple(p.shape)}')
+            self._param_view(flat, p).copy_(entry[key])
+        b0, b1 = self._blocks_of(p)
+        self.step_blk[b0:b1] = float(entry['step'])
+
+    def _launch(self, inv_scale, found_inf, has_grad):
+        self._upload([[g['lr'], g['weight_decay'], g['betas'][0], g['betas'][1], g['eps'], 0, 0, 0]
+                      for g in self.param_groups])
         a = self.arena
         check(lib().saicv_adamw_flat(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                      ptr(self.block_group), ptr(self._hyper_dev), ptr(inv_scale), ptr(found_inf),
-                                     a.total, _lib.stream()), 'adamw_flat')
+                                     ptr(has_grad), ptr(self.step_blk), a.total, _lib.stream()), 'adamw_flat')
 
 
 # ------------------------------------------------------------------------------ GradScaler
@@ -293,7 +413,9 @@ class DistributedDataParallel(torch.nn.Module):
         self.arena = _arena_of(module)
         self._sync = True
         self._works = []
-        self._arrived = set()
+        self._next_bucket = 0           # buckets are launched in list order on every rank
+        self._callback_queued = False
+        self._done = True               # no backward with pending collectives
         self._build_buckets(int(bucket_cap_mb * 2 ** 20 // 4), int(last_bucket_cap_mb * 2 ** 20 // 4))
         self._flatten_buffers()
         if self.world > 1:
@@ -305,11 +427,7 @@ class DistributedDataParallel(torch.nn.Module):
                 if not b.dtype.is_floating_point:
                     dist.broadcast(b, 0, group=process_group)
             ops.bump_weights_epoch()
-        for i, p in enumerate(self.arena.params):
-            if p.requires_grad:
-                hook = self._make_hook(i)
-                p.register_post_accumulate_grad_hook(hook)      # gradients that arrive through autograd
-                p._saicv_grad_ready = hook                      # gradients written in place by the kernels
+        self.arena.listeners.append(self._on_grad_complete)
 
     # buckets are contiguous arena ranges; walking parameters in REVERSE registration order
     def _build_buckets(self, cap, last_cap):
@@ -337,20 +455,40 @@ class DistributedDataParallel(torch.nn.Module):
             for i in b['params']:
                 self.bucket_of[i] = bi
 
-    def _make_hook(self, i):
-        def hook(param):
-            if not self._sync or self.world == 1:
-                return
-            # a parameter counts once per step: for gradients the kernels write in place BOTH the kernel-side
-            # call and autograd's post-accumulate hook (invoked even though backward returned None) arrive
-            if i in self._arrived:
-                return
-            self._arrived.add(i)
-            b = self.buckets[self.bucket_of[i]]
-            b['count'] += 1
-            if b['count'] == len(b['params']):
-                self._reduce_bucket(b)
-        return hook
+    def _on_grad_complete(self, i):
+        """Arena listener: parameter i's gradient of the running backward is complete (fires once per
+        backward per parameter, after its last use).  Runs inside autograd's backward."""
+        if self.world == 1:
+            return
+        if not self._callback_queued:
+            # the reference loop (tools/scripts.py:183-226) calls optimizer.step() right after backward():
+            # the wait for the in-flight buckets therefore happens in autograd's end-of-backward callback
+            # (as nn.parallel.DistributedDataParallel does), not in a call the loop would have to add
+            self._callback_queued = True
+            self._done = False
+            torch.autograd.Variable._execution_engine.queue_callback(self._on_backward_end)
+        if not self._sync:
+            return
+        bi = self.bucket_of.get(i)
+        if bi is None:
+            return
+        self.buckets[bi]['count'] += 1
+        self._launch_ready_buckets()
+
+    def _launch_ready_buckets(self, force=False):
+        # strictly in list order: every rank issues the same sequence of collectives even when the ranks'
+        # graphs complete their buckets in different orders (SAM draws its prompt type per rank and step)
+        while self._next_bucket < len(self.buckets):
+            b = self.buckets[self._next_bucket]
+            if not force and b['count'] != len(b['params']):
+                break
+            self._reduce_bucket(b)
+            self._next_bucket += 1
+
+    def _on_backward_end(self):
+        self._callback_queued = False
+        if self._sync:
+            self.finish_gradient_sync()
 
     def _reduce_bucket(self, b):
         view = self.arena.flat_grad[b['start']:b['end']]
@@ -361,32 +499,34 @@ class DistributedDataParallel(torch.nn.Module):
         else:
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
             self._works.append((w, view))
-        b['count'] = -1 << 30        # reduced for this step
 
     def finish_gradient_sync(self):
-        """Waits (stream-wise on HIP) for every in-flight bucket; reduces buckets whose
-        parameters produced no gradient this step (find_unused_parameters semantics)."""
+        """Makes the compute stream wait for every in-flight bucket of the backward that just ran, after
+        reducing the buckets whose parameters produced no gradient (find_unused_parameters semantics).
+        Runs by itself as autograd's end-of-backward callback; calling it again afterwards is a no-op."""
+        if self._done:
+            return
         if self.world > 1 and self._sync:
-            for b in self.buckets:
-                if b['count'] >= 0:
-                    self._reduce_bucket(b)
+            self._launch_ready_buckets(force=True)
         for w, view in self._works:
             w.wait()
             if view is not None:
                 view.div_(self.world)
         self._works = []
-        self._arrived.clear()
+        self._next_bucket = 0
         for b in self.buckets:
             b['count'] = 0
+        self._done = True
 
     def allreduce_grads(self):
         """Stand-in for the reference's manual per-parameter all_reduce loop
         (tools/interactive_segmentation_scripts.py:446-449): one bucketed pass."""
-        if self.world > 1:
-            for b in self.buckets:
-                b['count'] = 0
-                self._reduce_bucket(b)
-        self.finish_gradient_sync()
+        self._done = False
+        old, self._sync = self._sync, True
+        try:
+            self.finish_gradient_sync()
+        finally:
+            self._sync = old
 
     @contextlib.contextmanager
     def no_sync(self):

@@ -60,21 +60,20 @@ def bump_weights_epoch():
 
 def _arena_grad(t):
     """t.grad when it is a persistent view into the engine's flat gradient arena that kernels
-    may accumulate into directly (set up by engine.FlatArena), else None."""
+    may accumulate into directly (set up by engine.FlatArena), else None.
+
+    A kernel that wrote in place returns None for that input; autograd still runs the leaf's
+    AccumulateGrad node -- exactly once per backward, after EVERY use of the parameter has run its
+    backward -- and with it the post-accumulate hook engine.FlatArena registers.  That hook is the
+    only "gradient complete" signal the DDP engine and the optimizers act on, so a parameter used
+    several times per step (DETR's shared decoder norm, the SAM decoder passes) is never reduced
+    or counted early."""
     if t is None or not getattr(t, '_saicv_direct', False):
         return None
     g = t.grad
     if g is None or g.dtype != torch.float32 or g.stride() != t.stride():
         return None
     return g
-
-
-def _grad_ready(t):
-    """Tells the DDP engine that t.grad received this step's contribution (the kernel wrote it
-    in place, so autograd's AccumulateGrad hook will not run for t)."""
-    cb = getattr(t, '_saicv_grad_ready', None)
-    if cb is not None:
-        cb(t)
 
 
 def compute_dtype():
@@ -282,8 +281,6 @@ class ConvBnActFn(torch.autograd.Function):
                                  ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), M, k, int(relu), int(direct_bn),
                                  ptr(ws), st), 'bn_act_bwd')
         if direct_bn:
-            _grad_ready(gamma)
-            _grad_ready(beta)
             dgamma = dbeta = None
         # two streaming passes: (dz, y) read twice (+ the 1-bit ReLU mask), dy (and dres) written once
         KernelTimer.end(t0, 'bn_act_bwd', 0, float(M) * k * y.element_size() *
@@ -315,9 +312,7 @@ class ConvBnActFn(torch.autograd.Function):
             t0 = KernelTimer.begin('igemm_tn')
             check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
             KernelTimer.end(t0, 'igemm_tn', flops, 0)
-            if direct:
-                _grad_ready(weight)
-            else:
+            if not direct:
                 dwt = _weight_grad(dw, weight, c)
         return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
                 dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None, None)
@@ -382,17 +377,13 @@ class ConvFn(torch.autograd.Function):
             t0 = KernelTimer.begin('igemm_tn')
             check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
             KernelTimer.end(t0, 'igemm_tn', flops, 0)
-            if direct:
-                _grad_ready(weight)
-            else:
+            if not direct:
                 dwt = _weight_grad(dw, weight, c)
         if bias is not None and ctx.needs_input_grad[2]:
             gb = _arena_grad(bias)
             tb = gb if gb is not None else torch.zeros(k, dtype=torch.float32, device=x.device)
             check(L.saicv_colsum(dtype_code(dt), ptr(dy), M, k, ptr(tb), st), 'colsum')
-            if gb is not None:
-                _grad_ready(bias)
-            else:
+            if gb is None:
                 db = tb
         return dx, dwt, db, None, None
 

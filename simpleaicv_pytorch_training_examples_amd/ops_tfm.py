@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import check, dtype_code, lib, ptr, require_gpu, stream
-from .ops import KernelTimer, _arena_grad, _grad_ready, packed_weight
+from .ops import KernelTimer, _arena_grad, packed_weight
 
 
 def _pad_to(n, e):
@@ -104,16 +104,12 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None):
         t0 = KernelTimer.begin('igemm_tn')
         check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), ptr(tb), m, k, op, st), 'linear_wgrad')
         KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, 0)
-        if gw is not None:
-            _grad_ready(weight)
-        else:
+        if gw is None:
             dw = tgt[:o]
     elif want_b:
         check(L.saicv_colsum(dtype_code(dt), ptr(dy), m, op, ptr(tb), st), 'colsum')
     if want_b:
-        if gb is not None:
-            _grad_ready(bias)
-        else:
+        if gb is None:
             db = tb[:o]
     return dx, dw, db
 
@@ -144,8 +140,6 @@ def ln_bwd(dy, x2, weight, bias, mean, rstd, addend=None):
     check(L.saicv_layernorm_bwd(dtype_code(x2.dtype), ptr(dy), ptr(x2), ptr(weight), ptr(mean), ptr(rstd), ptr(addend),
                                 ptr(dx), ptr(dg), ptr(db), ptr(ws), m, c, int(direct), stream()), 'layernorm_bwd')
     if direct:
-        _grad_ready(weight)
-        _grad_ready(bias)
         return dx, None, None
     return dx, dg, db
 
@@ -518,10 +512,7 @@ def relpos_bwd(q, dq, heads, sh, sw, rel_pos_h, rel_pos_w, drh, drw, want_tables
                                  ptr(rel_pos_w.detach()), ptr(drh), ptr(drw), ptr(th), ptr(tw), ptr(ws), bw, heads, sh, sw, stream()),
           'relpos_bwd')
     if want_tables:
-        if direct:
-            _grad_ready(rel_pos_h)
-            _grad_ready(rel_pos_w)
-        else:
+        if not direct:
             gh, gw = th, tw
     return gh, gw
 

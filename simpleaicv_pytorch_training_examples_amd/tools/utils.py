@@ -76,7 +76,6 @@ class EmaModel(nn.Module):
                 p.data = p.data.clone(memory_format=torch.preserve_format)
                 p.grad = None
                 p.__dict__.pop('_saicv_direct', None)
-                p.__dict__.pop('_saicv_grad_ready', None)
         self.ema_model.eval()
         self.decay = decay
 

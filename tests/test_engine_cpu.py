@@ -129,3 +129,89 @@ def test_gloo_world2_matches_single_process():
     ((m(x) - y) ** 2).mean().backward()
     ((m(x * 0.5) - y) ** 2).mean().backward()
     assert torch.allclose(arena.flat_grad, gb0, rtol=1e-4, atol=1e-6)    # accumulated, averaged once
+
+
+class _Shared(nn.Module):
+    """One layer used three times per forward (like DETR's decoder_norm, reference detection/models/detr.py:263)
+    plus a branch that only some ranks / steps take (like SAM's prompt encoders)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.inp = nn.Linear(6, 1100)
+        self.shared = nn.Linear(1100, 1100)
+        self.rare = nn.Linear(1100, 1100)
+        self.out = nn.Linear(1100, 3)
+
+    def forward(self, x, use_rare):
+        h = self.inp(x)
+        for _ in range(3):
+            h = torch.tanh(self.shared(h))
+        if use_rare:
+            h = h + self.rare(h)
+        return self.out(h)
+
+
+def _worker_shared(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    m = _Shared()
+    # one bucket per parameter: a multi-use parameter reduced after its FIRST contribution, or buckets issued in
+    # per-rank completion order, would corrupt the result / deadlock
+    ddp = engine.DistributedDataParallel(m, bucket_cap_mb=0.001, last_bucket_cap_mb=0.0005)
+    assert len(ddp.buckets) >= 6
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 6, generator=g)
+    xs = x[rank * 4:(rank + 1) * 4]
+    ddp.arena.zero_grad()
+    # rank 0 takes the rare branch, rank 1 does not; NO explicit finish_gradient_sync(): the reference loop
+    # (tools/scripts.py:183-226) goes from backward() straight to the optimizer
+    ddp(xs, use_rare=(rank == 0)).pow(2).mean().backward()
+    grads = ddp.arena.flat_grad.clone()
+    arrived = list(ddp.arena.arrived)
+    q.put((rank, grads.numpy(), arrived))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gloo_world2_shared_and_rank_dependent_parameters_reference_loop_shape():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_shared, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, a0), (_, g1, a1) = res
+    g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
+    assert torch.equal(g0, g1)
+    # single-process reference: mean over the two half batches of the per-rank losses
+    m = _Shared()
+    arena = engine.FlatArena(list(m.named_parameters()), torch.device('cpu'))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 6, generator=g)
+    (0.5 * m(x[:4], True).pow(2).mean() + 0.5 * m(x[4:], False).pow(2).mean()).backward()
+    assert torch.allclose(arena.flat_grad, g0, rtol=1e-4, atol=1e-7)
+    names = arena.names
+    assert all(a0)                                                     # rank 0 used everything
+    assert [n for n, a in zip(names, a1) if not a] == ['rare.weight', 'rare.bias']   # rank 1 never touched `rare`
+
+
+def test_arena_tracks_which_parameters_received_gradients():
+    m = _Shared()
+    arena = engine.FlatArena(list(m.named_parameters()), torch.device('cpu'))
+    assert arena.has_grad_mask() is not None and int(arena.has_grad_mask().sum()) == 0
+    m(torch.randn(2, 6), False).sum().backward()
+    mask = arena.has_grad_mask()
+    off = {n: o // engine.ALIGN for n, o in zip(arena.names, arena.offsets)}
+    assert mask[off['rare.weight']] == 0 and mask[off['rare.bias']] == 0
+    assert mask[off['shared.weight']] == 1 and mask[off['out.bias']] == 1
+    m(torch.randn(2, 6), True).sum().backward()                        # accumulation: now everything has a gradient
+    assert arena.has_grad_mask() is None
+    arena.zero_grad()
+    assert int(arena.has_grad_mask().sum()) == 0

@@ -260,3 +260,67 @@ def test_train_sam_segmentation_runs_and_updates(caplog):
     assert 'skip this batch!' not in caplog.text
     assert not torch.equal(before, model.arena.flat_param)
     assert torch.isfinite(model.arena.flat_param).all()
+
+
+@pytest.mark.parametrize('lr', [0.1, 0.01])
+def test_loss_trajectory_matches_the_reference_loop(lr):
+    """20 fp32 iterations of ResNet18Cifar at batch 64 through THIS package's loop / optimizer / scheduler against
+    the per-iteration losses the reference's own tools/scripts.py train_classification produced on CPU for the same
+    weights and batches (oracle/make_golden_traj.py).  Training amplifies rounding differences, so every iteration
+    is gated at max(1e-3 (north_star), 4 x how far the reference moved from ITSELF by then under another fp32
+    summation order); the first iterations -- before any amplification -- must agree to 1e-4."""
+    from conftest import load_golden
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones, losses
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts, utils
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import common
+    fx = load_golden('traj_resnet18cifar_b64')[f'lr{lr}']
+    c = fx['config']
+
+    class config:
+        pass
+    config.optimizer, config.scheduler, config.epochs = tuple(c['optimizer']), tuple(c['scheduler']), c['epochs']
+    config.batch_size, config.accumulation_steps, config.print_interval = c['batch'], 1, 5
+    config.use_amp, config.use_ema_model, config.local_rank, config.gpus_num, config.group = False, False, 0, 1, None
+    config.host_sync_lag = 2
+    torch.manual_seed(c['model_seed'])
+    model = backbones.resnet18cifar(num_classes=c['classes']).cuda()
+    optimizer, _ = utils.build_optimizer(config, model)
+    scheduler = utils.Scheduler(config, optimizer)
+    model, _, _ = utils.build_training_mode(config, model)
+    g = torch.Generator().manual_seed(c['data_seed'])
+    batches = []
+    for _ in range(c['steps']):
+        x = torch.randn(c['batch'], 32, 32, 3, generator=g).permute(0, 3, 1, 2)
+        y = torch.randint(0, c['classes'], (c['batch'],), generator=g)
+        batches.append({'image': x, 'label': y})
+
+    class Loader(list):
+        dataset = [None] * (c['steps'] * c['batch'])
+
+    got = []
+    orig = common.AverageMeter.update
+
+    def spy(self, val, n=1):
+        got.append(float(val))
+        return orig(self, val, n)
+
+    common.AverageMeter.update = spy
+    logger = logging.getLogger('saicv_traj')
+    try:
+        avg = scripts.train_classification(Loader(batches), model, losses.CELoss(), optimizer, scheduler, 1, logger, config)
+    finally:
+        common.AverageMeter.update = orig
+    ref = fx['losses']
+    assert len(got) == len(ref) == c['steps']
+    noise = fx['reference_noise']['loss_rel']
+    worst, report = 0.0, []
+    for i, (a, b) in enumerate(zip(got, ref)):
+        err = abs(a - b) / abs(b)
+        env = max(noise[:i + 1])
+        gate = 1e-4 if i < 2 else max(1e-3, 4 * env)
+        report.append(f'{i}:{err:.1e}/{gate:.1e}')
+        assert err < gate, (i, a, b, err, gate, report)
+        worst = max(worst, err)
+    print(f'[trajectory lr={lr}] worst relative loss error {worst:.2e}; reference self-noise up to {max(noise):.2e}')
+    assert abs(avg - fx['avg_loss']) / fx['avg_loss'] < max(1e-3, 4 * max(noise))
+    assert abs(scheduler.current_lr - fx['lr']) < 1e-12
