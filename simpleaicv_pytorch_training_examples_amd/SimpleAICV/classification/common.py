@@ -1,6 +1,6 @@
 """Per-step host helpers of the classification path (reference SimpleAICV/classification/
 common.py): ClassificationCollater (:645-665), AverageMeter (:668-684), AccMeter (:687-706),
-load_state_dict (:758-840) and get_amp_type (:843-881).
+load_state_dict (:758-840), get_amp_type (:843-881) and the Mixup / CutMix collater the ViT configs use (:19).
 
 Only what sits on the training-step path is mirrored; the cv2 / PIL / torchvision transforms
 of the reference (dataset side, CPU worker processes) are out of scope.
@@ -9,7 +9,10 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-__all__ = ['ClassificationCollater', 'AverageMeter', 'AccMeter', 'load_state_dict', 'get_amp_type']
+from .mixupcutmixclassificationcollator import MixupCutmixClassificationCollater
+
+__all__ = ['ClassificationCollater', 'MixupCutmixClassificationCollater', 'AverageMeter', 'AccMeter', 'load_state_dict',
+           'get_amp_type']
 
 
 class ClassificationCollater:

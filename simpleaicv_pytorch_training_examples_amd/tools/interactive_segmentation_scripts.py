@@ -152,7 +152,9 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
     def amp():
         return autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp))
 
+    micro = 0      # accumulation phase by issued micro-batch (see tools/scripts.py train_classification)
     for data in train_loader:
+        micro += 1
         images, masks = data['image'].to(device, non_blocking=True), data['mask'].to(device, non_blocking=True)
         prompts, decoder_iters = _choose_prompts(config, data['prompt_point'], data['prompt_box'], data['prompt_mask'],
                                                  device)
@@ -175,7 +177,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
         terms = torch.stack([loss_value[k].detach().float() for k in keys]) / acc_steps
         bad = bad | (loss == 0.) | ~torch.isfinite(loss) | ~torch.isfinite(terms).all()
         loss = loss / acc_steps
-        boundary = iter_index % acc_steps == 0
+        boundary = micro % acc_steps == 0
         scaled = scaler.scale(loss) if scaler is not None else loss
         if boundary:
             scaled.backward()

@@ -120,8 +120,8 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
             if log_fmt is not None and main:
                 logger.info(log_fmt.format(loss=loss * acc_steps))
 
-    for data in train_loader:
-        images, labels = data['image'].to(device, non_blocking=True), data['label'].to(device, non_blocking=True)
+    def forward_backward(images, labels, boundary):
+        """forward, loss, (scaled) backward; -> packed [skip flag, loss / acc_steps] of this rank"""
         # device-side replacement of the reference's isinf/isnan python branches (:147-151)
         bad = ~torch.isfinite(images).all()
         if labels.dtype.is_floating_point:
@@ -135,42 +135,80 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
             loss = criterion(outputs, labels)
         bad = bad | (loss == 0.) | ~torch.isfinite(loss)
         loss = loss / acc_steps
-        boundary = iter_index % acc_steps == 0
         scaled = scaler.scale(loss) if scaler is not None else loss
         if boundary:
             scaled.backward()
         else:
             with model.no_sync():       # no gradient exchange on non-boundary micro-steps
                 scaled.backward()
-
         # one tiny all-reduce carries the skip flag (any rank) and the loss (sum over ranks)
         packed = torch.stack([bad.float(), loss.detach().float()])
         if _dist_on(config.group):
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=config.group)
+        return packed
+
+    def update(packed):
+        """gradient sync wait, inf/nan check, unscale + clip, fused optimizer step, scaler update, zero_grad, EMA"""
+        if hasattr(model, 'finish_gradient_sync'):
+            model.finish_gradient_sync()
+        skip_flag = packed[0:1]
+        if getattr(config, 'skip_inf_nan_grad', False) or scaler is not None:
+            optimizer.check_finite()
+            skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
+        inv_scale = scaler.state[2:3] if scaler is not None else None
+        if clip_value > 0:
+            raise NotImplementedError('clip_grad_value is not used by the hot-path configs')
+        if clip_norm > 0:
+            optimizer.clip_grad_norm_(clip_norm, inv_scale)
+            inv_scale = None
+        optimizer.step(inv_scale, skip_flag)
+        if scaler is not None:
+            scaler._found_inf = optimizer.found_inf
+            scaler.update()
+        optimizer.zero_grad()
+        if config.use_ema_model:
+            config.ema_model.update(model)
+
+    # config.use_step_graph: the whole iteration (forward .. zero_grad) is captured once into a hipGraph and
+    # replayed (engine.StepGraph) -- the host then issues one graph launch instead of ~700 kernel launches.
+    # Needs accumulation_steps == 1 and static shapes (drop_last loaders); everything the host changes per
+    # iteration (the scheduler's learning rates) reaches the captured kernels through the optimizer's device table.
+    step_graph = None
+    if getattr(config, 'use_step_graph', False) and acc_steps == 1 and device.type == 'cuda':
+        from .. import engine
+
+        def whole_step(images, labels):
+            packed = forward_backward(images, labels, True)
+            update(packed)
+            return packed
+        cache = getattr(config, '_saicv_step_graphs', None)
+        if cache is None:
+            cache = {}
+            config._saicv_step_graphs = cache       # config is usually a class: the graph lives across epochs
+        key = (id(model), id(optimizer))
+        step_graph = cache.get(key)
+        if step_graph is None:
+            step_graph = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3),
+                                          before_replay=(optimizer.refresh_hyper,))
+            cache[key] = step_graph
+
+    micro = 0      # accumulation phase counts micro-batches as they are issued; the lagged skip correction below only
+                   # moves the logged / scheduled iteration index, never the phase of a window already under way
+    for data in train_loader:
+        images, labels = data['image'].to(device, non_blocking=True), data['label'].to(device, non_blocking=True)
+        micro += 1
+        boundary = micro % acc_steps == 0
+        if step_graph is not None:
+            packed = step_graph(images, labels).clone()     # the static output is overwritten by the next replay
+        else:
+            packed = forward_backward(images, labels, boundary)
         if carried_bad is not None:
             packed = torch.stack([torch.maximum(packed[0], carried_bad), packed[1]])
         carried_bad = None if boundary else packed[0]
 
         if boundary:
-            if hasattr(model, 'finish_gradient_sync'):
-                model.finish_gradient_sync()
-            skip_flag = packed[0:1]
-            if getattr(config, 'skip_inf_nan_grad', False) or scaler is not None:
-                optimizer.check_finite()
-                skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
-            inv_scale = scaler.state[2:3] if scaler is not None else None
-            if clip_value > 0:
-                raise NotImplementedError('clip_grad_value is not used by the hot-path configs')
-            if clip_norm > 0:
-                optimizer.clip_grad_norm_(clip_norm, inv_scale)
-                inv_scale = None
-            optimizer.step(inv_scale, skip_flag)
-            if scaler is not None:
-                scaler._found_inf = optimizer.found_inf
-                scaler.update()
-            optimizer.zero_grad()
-            if config.use_ema_model:
-                config.ema_model.update(model)
+            if step_graph is None:
+                update(packed)
             scheduler.step(optimizer, iter_index / iters + (epoch - 1))
             log_fmt = None
             if iter_index % int(config.print_interval * acc_steps) == 0:
@@ -221,7 +259,9 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
                 terms = ''.join(f'{k}: {v / float(config.gpus_num) * acc_steps:.4f}, ' for k, v in zip(keys, vals[2:]))
                 logger.info(log_fmt.format(loss=loss * acc_steps) + terms)
 
+    micro = 0      # accumulation phase by issued micro-batch (see train_classification)
     for data in train_loader:
+        micro += 1
         bad, loss_value, n = step_fn(data)
         if keys is None:
             keys = list(loss_value.keys())
@@ -229,7 +269,7 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
         terms = torch.stack([loss_value[k].detach().float() for k in keys]) / acc_steps
         bad = bad | (loss == 0.) | ~torch.isfinite(loss) | ~torch.isfinite(terms).all()
         loss = loss / acc_steps
-        boundary = iter_index % acc_steps == 0
+        boundary = micro % acc_steps == 0
         scaled = scaler.scale(loss) if scaler is not None else loss
         if boundary:
             scaled.backward()

@@ -1,6 +1,6 @@
 """The data-parallel engine with the real HIP kernels and world_size 2 on ONE GPU (both ranks on cuda:0, gloo
 transport -- RCCL refuses two ranks per device).  What this covers that the CPU gloo tests cannot: gradients that the
-kernels write straight into the flat arena and announce through `_saicv_grad_ready` (no autograd AccumulateGrad),
+kernels write straight into the flat arena (autograd only runs the leaf hook that announces them),
 bucket completion counting over such parameters, BatchNorm buffer broadcast, the fused optimizer after the sync.
 Each rank trains on its half of a batch; the synchronised gradient must equal the mean of the two local gradients
 (obtained under no_sync) and both ranks must end with bit-identical parameters."""
@@ -106,3 +106,87 @@ def test_world2_on_one_gpu_kernel_side_gradient_hooks(kind):
     err = float((s0.double() - mean).abs().max() / mean.abs().max())
     assert err < (2e-2 if kind == 'sam' else 2e-3), err               # fp32 atomics order only (SAM: bf16 best-mask picks)
     assert torch.equal(p0, p1)                                        # identical parameters after the fused step
+
+
+def _worker_rccl(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    from simpleaicv_pytorch_training_examples_amd import engine
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones, losses
+    torch.manual_seed(rank)
+    model = backbones.resnet18cifar(num_classes=10).cuda()
+    opt = engine.SGD(model, [{'params': list(model.parameters()), 'weight_decay': 0.0}], lr=0.05, momentum=0.9)
+    ddp = engine.DistributedDataParallel(model, device_ids=[rank], bucket_cap_mb=0.5, last_bucket_cap_mb=0.05)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (8,), generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4].cuda(), y[rank * 4:(rank + 1) * 4].cuda()
+    ddp.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.0
+    crit = losses.CELoss()
+
+    def run(sync):
+        opt.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss = crit(ddp(xs), ys)
+        if sync:
+            loss.backward()         # no finish_gradient_sync(): the end-of-backward callback waits for RCCL
+        else:
+            with ddp.no_sync():
+                loss.backward()
+        torch.cuda.synchronize()
+        return ddp.arena.flat_grad.clone()
+
+    local = run(False)
+    synced = run(True)
+    opt.step()
+    torch.cuda.synchronize()
+    q.put((rank, local.cpu().numpy(), synced.cpu().numpy(), ddp.arena.flat_param.detach().cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_world2_bucketed_allreduce_on_two_gpus():
+    """backend "nccl" (= RCCL over xGMI) with one rank per GPU; needs a box with at least two MI355X."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (RCCL refuses two ranks on one device)')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rccl, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, l0, s0, p0), (_, l1, s1, p1) = [(r,) + tuple(torch.from_numpy(a) for a in rest) for r, *rest in res]
+    assert torch.equal(s0, s1)
+    mean = (l0.double() + l1.double()) / 2
+    assert float((s0.double() - mean).abs().max() / mean.abs().max()) < 2e-3
+    assert torch.equal(p0, p1)
+
+
+def test_bench_spawns_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus N` starts N ranks itself and reports n_gpus = ranks that joined (needs N GPUs);
+    asking for more GPUs than are visible fails loudly instead of reporting a 1-GPU number."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    n = torch.cuda.device_count()
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n + 1), '--steps', '1', '--warmup', '1',
+                          '--no-cpu-baseline', '--no-secondary'], capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and 'only' in (bad.stderr + bad.stdout)
+    if n < 2:
+        pytest.skip('the positive case needs >= 2 GPUs')
+    ok = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '32',
+                         '--no-cpu-baseline', '--no-secondary', '--max-windows', '1'], capture_output=True, text=True, timeout=900)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    line = json.loads([l for l in ok.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['allreduce_bytes_per_step'] > 90e6

@@ -127,3 +127,19 @@ def test_sam_collater_contract():
     a = np.arange(35, dtype=np.float32).reshape(5, 7)
     r = resize_nearest(a, 3, 2)                       # cols floor(x * 7/3) = 0, 2, 4 ; rows floor(y * 5/2) = 0, 2
     assert np.array_equal(r, a[[0, 2]][:, [0, 2, 4]])
+
+
+def test_mixup_cutmix_collater_matches_reference_fixture():
+    """Same numpy seed -> same mixing plan, images and soft labels as the reference's collater
+    (oracle/make_golden_mixup.py ran reference mixupcutmixclassificationcollator.py:99-284)."""
+    import numpy as np
+    from conftest import load_golden
+    from oracle.make_golden_mixup import batch
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.common import MixupCutmixClassificationCollater
+    for case in load_golden('mixup_cutmix'):
+        np.random.seed(case['np_seed'])
+        got = MixupCutmixClassificationCollater(num_classes=10, **case['kwargs'])(batch(case['data_seed']))
+        assert got['image'].shape == case['image'].shape and got['label'].shape == case['label'].shape
+        assert float((got['image'] - case['image']).abs().max()) < 1e-6, case['kwargs']
+        assert float((got['label'] - case['label']).abs().max()) < 1e-6, case['kwargs']
+        assert got['image'].stride()[1] == 1          # NHWC-strided view, as the reference's permute returns it
