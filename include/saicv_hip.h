@@ -150,7 +150,7 @@ int saicv_scale_by_scalar(int out_dtype, const float* in, const float* scale, vo
 /* ---- flat-arena optimizers / GradScaler (tools/utils.py:292-679, :199-200) ------------- */
 /* One launch over the flat arenas; every 1024-element block belongs to one parameter.
  *   block_group[b]  optimizer param-group of block b (-1: not optimized)
- *   hyper[g*8..]    lr, weight_decay, momentum|beta1, beta2, eps, -, -, nesterov flag
+ *   hyper[g*8..]    lr, weight_decay, momentum|beta1, beta2, eps, 1-beta1, 1-beta2, nesterov flag
  *   found_inf       nullable device flag: != 0 skips the whole step (GradScaler semantics)
  *   has_grad        nullable, one byte per block: 0 = this parameter received no gradient this step and is
  *                   skipped like torch.optim skips `grad is None` (no decay, no moment update, no step count)

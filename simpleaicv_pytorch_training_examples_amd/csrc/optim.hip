@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int kHyper = 8;   // floats per group: lr, wd, momentum|beta1, beta2, eps, -, -, flags
+constexpr int kHyper = 8;   // floats per group: lr, wd, momentum|beta1, beta2, eps, 1-beta1, 1-beta2, flags
 
 // Every 1024-element block belongs to ONE parameter.  `has_grad` (nullable, one byte per block) is 0 for the
 // blocks of parameters that received no gradient this step: torch.optim skips those entirely (grad is None
@@ -64,13 +64,16 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     if (grp < 0) return;
     if (has_grad && !has_grad[blockIdx.x]) return;
     const float* h = hyper + grp * kHyper;
-    const float lr = h[0], wd = h[1], b1 = h[2], b2 = h[3], eps = h[4];
+    // 1 - beta comes from the host rounded from double, as torch passes it (`lerp_(grad, 1 - beta1)`,
+    // `addcmul_(grad, grad, value=1 - beta2)`): 1.f - 0.999f is 0.00100005, 4.7e-5 off
+    const float lr = h[0], wd = h[1], b1 = h[2], b2 = h[3], eps = h[4], omb1 = h[5], omb2 = h[6];
     // per-parameter step count on the device (torch keeps state['step'] per parameter): bias corrections follow
     // the steps this parameter really took, and nothing about them has to be uploaded by the host per iteration
     const float t = step_blk[blockIdx.x] + 1.f;
     __syncthreads();                                     // every wavefront has read the old count
     if (threadIdx.x == 0) step_blk[blockIdx.x] = t;
-    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    // 1 - beta^t = -expm1(t log1p(-(1 - beta))): accurate for beta2 = 0.999 at small t, where 1.f - powf(0.999f, t) is not
+    const float bc1 = -expm1f(t * log1pf(-omb1)), bc2 = -expm1f(t * log1pf(-omb2));
     const float is = inv_scale ? inv_scale[0] : 1.f;
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     for (int k = 0; k < 4; ++k) {
         const float d = gv[k] * is;
         pv[k] *= (1.f - lr * wd);
-        mv[k] = fmaf(b1, mv[k], (1.f - b1) * d);
-        vv[k] = fmaf(b2, vv[k], (1.f - b2) * d * d);
+        mv[k] = fmaf(omb1, d - mv[k], mv[k]);              // exp_avg.lerp_(grad, 1 - beta1)
+        vv[k] = fmaf(omb2 * d, d, b2 * vv[k]);             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
         const float denom = sqrtf(vv[k]) * rs2 + eps;
         pv[k] = fmaf(-step, mv[k] / denom, pv[k]);
     }

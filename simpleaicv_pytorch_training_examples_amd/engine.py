@@ -111,6 +111,7 @@ class FlatArena:
         return m
 
     def zero_grad(self):
+        ops.join_side_stream()
         self.flat_grad.zero_()
         self.arrived = [False] * len(self.params)
         # re-attach views in case someone set .grad = None (optimizer.zero_grad(set_to_none=True))
@@ -184,12 +185,14 @@ class _FlatOptimizer:
 
     def check_finite(self):
         """found_inf[0] = 1 if any gradient is inf / nan (device side, no host sync)."""
+        ops.join_side_stream()
         self.found_inf.zero_()
         check(lib().saicv_grad_stats(ptr(self.arena.flat_grad), self.arena.total, ptr(self.found_inf), 0,
                                      _lib.stream()), 'grad_stats')
 
     def clip_grad_norm_(self, max_norm, inv_scale=None):
         """torch.nn.utils.clip_grad_norm_ over the whole arena, fused with the unscale."""
+        ops.join_side_stream()
         self.sumsq.zero_()
         check(lib().saicv_grad_stats(ptr(self.arena.flat_grad), self.arena.total, 0, ptr(self.sumsq),
                                      _lib.stream()), 'grad_stats')
@@ -198,6 +201,7 @@ class _FlatOptimizer:
 
     def step(self, inv_scale=None, found_inf=None):
         mask = self.arena.has_grad_mask() if self.track_missing_grads else None
+        ops.join_side_stream()
         self.refresh_hyper()
         self._launch(inv_scale, found_inf, mask)
         ops.bump_weights_epoch()
@@ -342,7 +346,8 @@ class AdamW(_FlatOptimizer):
         self.step_blk[b0:b1] = float(entry['step'])
 
     def _hyper_rows(self):
-        return [[g['lr'], g['weight_decay'], g['betas'][0], g['betas'][1], g['eps'], 0, 0, 0] for g in self.param_groups]
+        return [[g['lr'], g['weight_decay'], g['betas'][0], g['betas'][1], g['eps'], 1 - g['betas'][0], 1 - g['betas'][1], 0]
+                for g in self.param_groups]
 
     def _launch(self, inv_scale, found_inf, has_grad):
         a = self.arena
@@ -450,6 +455,7 @@ class StepGraph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self.fn(*args)
+            ops.join_side_stream()      # every forked stream rejoins before the capture ends
         self.graph, self.static_out = graph, out
         torch.cuda.synchronize()
 
@@ -555,9 +561,19 @@ class DistributedDataParallel(torch.nn.Module):
         view = self.arena.flat_grad[b['start']:b['end']]
         backend = dist.get_backend(self.process_group)
         if backend == 'nccl':
-            w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)
+            side = ops.side_stream_in_use()
+            if side is not None:
+                # weight gradients are produced on the side stream, BatchNorm / LayerNorm / bias gradients on the
+                # compute stream: RCCL's stream is ordered after BOTH by issuing the collective from the side stream
+                # once that has waited for the compute stream -- the compute stream itself never waits here
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)
+            else:
+                w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)
             self._works.append((w, None))
         else:
+            ops.join_side_stream()
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
             self._works.append((w, view))
 

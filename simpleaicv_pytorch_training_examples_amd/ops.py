@@ -76,6 +76,57 @@ def _arena_grad(t):
     return g
 
 
+# ------------------------------------------------------------------------------ side stream for weight gradients
+# A layer's weight gradient (igemm_tn, MFMA-bound, accumulates straight into the gradient arena) has no consumer
+# until the all-reduce / optimizer, while the data-gradient -> BatchNorm-backward chain of the next layer (HBM-bound
+# streaming kernels) is on the critical path.  Launching the weight gradients on a second HIP stream lets the two
+# kinds of kernels share the GPU (and, inside a captured step graph, makes them parallel branches).
+# Measured on MI355X (r02b): neutral to -2 % on ResNet-50 / ViT-B -- both kernel families fill every CU slot by
+# themselves, so the two queues mostly alternate instead of overlapping.  Off by default; SAICV_WGRAD_SIDE=1 turns it on.
+import os as _os
+
+WGRAD_SIDE_STREAM = _os.environ.get('SAICV_WGRAD_SIDE', '0') == '1'
+_side = {'stream': None, 'dirty': False}
+
+
+class _SideStream:
+    """with _SideStream(tensors...): launches inside run on the side stream, ordered after everything already
+    enqueued on the current stream; `tensors` are kept alive for the side stream (record_stream)."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        if _side['stream'] is None:
+            _side['stream'] = torch.cuda.Stream()
+        side = _side['stream']
+        side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        _side['dirty'] = True
+        return side
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def side_stream_in_use():
+    """the side stream if weight gradients have been launched on it since the last join, else None"""
+    return _side['stream'] if _side['dirty'] else None
+
+
+def join_side_stream():
+    """Makes the current stream wait for the weight gradients launched on the side stream.  Called by every consumer
+    of the gradient arena (bucket all-reduce, inf/nan check, clipping, optimizer step) and at the end of a captured
+    step; cheap when nothing is pending."""
+    if _side['dirty']:
+        torch.cuda.current_stream().wait_stream(_side['stream'])
+        _side['dirty'] = False
+
+
 def compute_dtype():
     if torch.is_autocast_enabled('cuda'):
         dt = torch.get_autocast_dtype('cuda')
@@ -309,9 +360,15 @@ class ConvBnActFn(torch.autograd.Function):
                       weight.is_contiguous(memory_format=torch.channels_last))
             # KRSC fp32 gradient: straight into the arena (atomics accumulate), else a temporary
             dw = gw if direct else torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=dev)
-            t0 = KernelTimer.begin('igemm_tn')
-            check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
-            KernelTimer.end(t0, 'igemm_tn', flops, 0)
+            if direct and WGRAD_SIDE_STREAM:
+                with _SideStream(dy, x):
+                    t0 = KernelTimer.begin('igemm_tn')
+                    check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), stream()), 'conv2d_wgrad')
+                    KernelTimer.end(t0, 'igemm_tn', flops, 0)
+            else:
+                t0 = KernelTimer.begin('igemm_tn')
+                check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
+                KernelTimer.end(t0, 'igemm_tn', flops, 0)
             if not direct:
                 dwt = _weight_grad(dw, weight, c)
         return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
@@ -374,9 +431,15 @@ class ConvFn(torch.autograd.Function):
             gw = _arena_grad(weight)
             direct = gw is not None and weight.is_contiguous(memory_format=torch.channels_last)
             dw = gw if direct else torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=x.device)
-            t0 = KernelTimer.begin('igemm_tn')
-            check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
-            KernelTimer.end(t0, 'igemm_tn', flops, 0)
+            if direct and WGRAD_SIDE_STREAM:
+                with _SideStream(dy, x):
+                    t0 = KernelTimer.begin('igemm_tn')
+                    check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), stream()), 'conv2d_wgrad')
+                    KernelTimer.end(t0, 'igemm_tn', flops, 0)
+            else:
+                t0 = KernelTimer.begin('igemm_tn')
+                check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
+                KernelTimer.end(t0, 'igemm_tn', flops, 0)
             if not direct:
                 dwt = _weight_grad(dw, weight, c)
         if bias is not None and ctx.needs_input_grad[2]:

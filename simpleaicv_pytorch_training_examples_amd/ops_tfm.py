@@ -8,7 +8,7 @@ backward kernel -- no stand-alone add / mul / permute / contiguous kernels remai
 """
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check, dtype_code, lib, ptr, require_gpu, stream
 from .ops import KernelTimer, _arena_grad, packed_weight
 
@@ -101,9 +101,15 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None):
         gw = _arena_grad(weight) if (op == o and weight.is_contiguous()) else None
         tgt = gw if gw is not None else torch.zeros((op, k), dtype=torch.float32, device=x2.device)
         # the weight-gradient kernel also emits the bias gradient from the dY tiles it streams
-        t0 = KernelTimer.begin('igemm_tn')
-        check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), ptr(tb), m, k, op, st), 'linear_wgrad')
-        KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, 0)
+        if gw is not None and (not want_b or gb is not None) and ops.WGRAD_SIDE_STREAM:
+            with ops._SideStream(dy, x2):
+                t0 = KernelTimer.begin('igemm_tn')
+                check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), ptr(tb), m, k, op, stream()), 'linear_wgrad')
+                KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, 0)
+        else:
+            t0 = KernelTimer.begin('igemm_tn')
+            check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), ptr(tb), m, k, op, st), 'linear_wgrad')
+            KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, 0)
         if gw is None:
             dw = tgt[:o]
     elif want_b:

@@ -197,7 +197,8 @@ def test_clip_grad_norm_and_unscale_match_torch():
         torch.cuda.synchronize()
         assert abs(math.sqrt(float(opt.sumsq)) / scale - float(total)) < 1e-5 * float(total)
         for (n, a), b in zip(gpu.named_parameters(), cpu.parameters()):
-            assert rel_err(a.grad, b.grad) < 2e-6, (max_norm, scale, n)
+            # the clip factor carries the fp32 rounding of a 450 k-term sum of squares (different order on each side)
+            assert rel_err(a.grad, b.grad) < 5e-6, (max_norm, scale, n)
 
 
 def test_grad_scaler_follows_torch_amp_grad_scaler():

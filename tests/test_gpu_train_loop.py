@@ -361,12 +361,16 @@ def test_step_graph_replays_the_same_training_as_eager_launches():
         return got, model.arena.flat_param.clone(), scheduler.current_lr, graphs
 
     eager, p_eager, lr_e, _ = run(False)
+    eager2, p_eager2, _, _ = run(False)
     graph, p_graph, lr_g, graphs = run(True)
     assert len(graphs) == 1 and next(iter(graphs.values())).graph is not None      # really captured and replayed
     assert len(eager) == len(graph) == 20 and lr_e == lr_g
-    # bf16 + fp32-atomic weight gradients: not bit-identical run to run; the trajectories must stay together
-    for i, (a, b) in enumerate(zip(eager, graph)):
-        assert abs(a - b) < 5e-2 * max(abs(a), 0.1), (i, a, b)
-    assert eager[-1] < eager[0] * 0.7 and graph[-1] < graph[0] * 0.7               # both learn
+    # bf16 + fp32-atomic weight gradients: not bit-identical run to run.  The yardstick is how far two EAGER runs
+    # of the same thing end up from each other; the replayed graph must stay within a small multiple of that.
+    noise = float((p_eager - p_eager2).norm() / p_eager.norm())
     rel = float((p_eager - p_graph).norm() / p_eager.norm())
-    assert rel < 2e-2, rel
+    print(f'[step graph] parameters after 20 iterations: graph vs eager {rel:.2e}, eager vs eager {noise:.2e}')
+    assert rel < max(3 * noise, 5e-3), (rel, noise)
+    for i, (a, b, c) in enumerate(zip(eager, graph, eager2)):
+        assert abs(a - b) < max(3 * abs(a - c), 5e-2 * max(abs(a), 0.1)), (i, a, b, c)
+    assert eager[-1] < eager[0] * 0.7 and graph[-1] < graph[0] * 0.7               # both learn
