@@ -24,6 +24,9 @@ OUT = os.path.join(ROOT, 'tests', 'golden')
 sys.path.insert(0, ROOT)
 
 DETR_TINY = dict(hidden_inplanes=256, query_nums=20, num_classes=20)
+# resnet50_detr as the reference config builds it (res50_detr_yoloresize1024/train_config.py:28-31: 80 classes, 100
+# queries, the real ResNet-50 backbone with its 23 conv shapes) on a small canvas, so the CPU reference stays cheap
+DETR_R50 = dict(hidden_inplanes=256, query_nums=100, num_classes=80)
 
 
 def zero_dropout(model):
@@ -113,7 +116,11 @@ def main():
             sys.modules[name] = types.ModuleType(name)
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
-    detr_case('detr_r18_tiny', 'resnet18_detr', DETR_TINY, batch=4)
+    only = sys.argv[1:]
+    if not only or 'detr_r18_tiny' in only:
+        detr_case('detr_r18_tiny', 'resnet18_detr', DETR_TINY, batch=4)
+    if not only or 'detr_r50_small' in only:
+        detr_case('detr_r50_small', 'resnet50_detr', DETR_R50, batch=2)
 
 
 if __name__ == '__main__':

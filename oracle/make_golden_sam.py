@@ -25,6 +25,15 @@ ENC_TINY = dict(image_size=256, patch_size=16, inplanes=3, embedding_planes=128,
                 mlp_ratio=4, out_planes=32, window_size=7, global_attn_indexes=[1], use_gradient_checkpoint=False)
 
 
+# SAM ViT-B image encoder at its REAL dimensions (sam_b, reference segment_anything/sam.py: 768 planes, 12 blocks,
+# 12 heads x 64, window 14, global blocks 2/5/8/11, neck to 256) on a 256 x 256 image: 16 x 16 tokens, i.e. the
+# windowed blocks pad 16 -> 28 (2 x 2 windows of 196 tokens, rel-pos tables of 27) and the global blocks run the
+# decomposed rel-pos bias at Sw = 16 (tables of 31) -- BASELINE.json configs[4]'s kernels at head dim 64 x 12 heads.
+ENC_B_256 = dict(image_size=256, patch_size=16, inplanes=3, embedding_planes=768, block_nums=12, head_nums=12,
+                 mlp_ratio=4, out_planes=256, window_size=14, global_attn_indexes=[2, 5, 8, 11],
+                 use_gradient_checkpoint=False)
+
+
 def _rel(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
 
@@ -172,8 +181,13 @@ def main():
         sys.exit(f'{REF} not present: golden fixtures can only be (re)generated in the build container')
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
-    encoder_case('sam_encoder_tiny', ENC_TINY, batch=2)
-    sam_case('sam_tiny_two_pass', SAM_TINY, batch=2)
+    only = sys.argv[1:]
+    if not only or 'sam_encoder_tiny' in only:
+        encoder_case('sam_encoder_tiny', ENC_TINY, batch=2)
+    if not only or 'sam_tiny_two_pass' in only:
+        sam_case('sam_tiny_two_pass', SAM_TINY, batch=2)
+    if not only or 'sam_b_encoder_256' in only:
+        encoder_case('sam_b_encoder_256', ENC_B_256, batch=2)
 
 
 if __name__ == '__main__':

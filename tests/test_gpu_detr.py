@@ -28,8 +28,11 @@ def _build(fx):
     return m.cuda().train(), DETRLoss(num_classes=fx['kwargs']['num_classes']), images.cuda(), masks.cuda(), annots.cuda()
 
 
-def test_detr_fp32_matches_reference():
-    fx = load_golden('detr_r18_tiny')
+@pytest.mark.parametrize('name', ['detr_r18_tiny', 'detr_r50_small'])
+def test_detr_fp32_matches_reference(name):
+    """detr_r50_small: resnet50_detr as the reference config builds it (real ResNet-50 backbone, 100 queries, 80 classes)
+    on a 256 x 256 canvas -- fixture produced by the reference's DETR + DETRLoss (oracle/make_golden_detr.py)."""
+    fx = load_golden(name)
     m, crit, images, masks, annots = _build(fx)
     cls_out, reg_out = m(images, masks)
     ld = crit([cls_out, reg_out], annots)
@@ -56,11 +59,12 @@ def test_detr_fp32_matches_reference():
     for n, b in m.named_buffers():
         if n in fx['buffers_after'] and b.dtype.is_floating_point:
             assert rel_err(b, fx['buffers_after'][n]) < 1e-3, n
-    print(f'detr_r18_tiny fp32: worst gradient-sample error {worst:.2e}')
+    print(f'{name} fp32: worst gradient-sample error {worst:.2e}')
 
 
-def test_detr_bf16_tracks_reference_autocast():
-    fx = load_golden('detr_r18_tiny')
+@pytest.mark.parametrize('name', ['detr_r18_tiny', 'detr_r50_small'])
+def test_detr_bf16_tracks_reference_autocast(name):
+    fx = load_golden(name)
     m, crit, images, masks, annots = _build(fx)
     with torch.autocast('cuda', dtype=torch.bfloat16):
         cls_out, reg_out = m(images, masks)

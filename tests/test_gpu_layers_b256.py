@@ -1,0 +1,129 @@
+"""Oracle comparison AT BASELINE.json's shapes: every distinct ResNet-50 convolution at per-GPU batch 256 (the 23 shapes
+of SURVEY.md 8d: forward + BN partial statistics, data gradient, weight gradient) and the four ViT-B/16 GEMM shapes at
+M = 197 x 256 tokens, each against a plain PyTorch fp32 CPU computation on the same bf16-rounded operands.
+
+The model-level fixtures (tests/test_gpu_models.py) run at batch 2-8, where the tile picker chooses other geometries
+and the weight-gradient kernel other split counts than at batch 256; tests/test_gpu_fullsize.py checks batch 256 only
+against itself.  Here the 256 x 128 / 256 x 256 tile paths, the real reduction splits and the stride-2 parity classes
+are checked against the oracle.  Reference ops: F.conv2d / its autograd (reference resnet.py:33-43), F.linear.
+
+Tolerance: bf16 outputs 2e-2 of the tensor's scale (storage rounding 2^-8 of an element; conftest.rel_err is scale-
+relative), fp32 weight gradients 4e-3 (fp32 accumulation of bf16 products in another order), BN statistics 1e-3."""
+import ctypes
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+BATCH = int(os.environ.get('SAICV_TEST_BATCH', '256'))
+
+# (Cin, Cout, k, stride, Hin): the 23 distinct ResNet-50 convolutions at 224 x 224 input (stem: input packed to 8 channels)
+R50 = [(8, 64, 7, 2, 224), (64, 64, 1, 1, 56), (64, 64, 3, 1, 56), (64, 256, 1, 1, 56), (256, 64, 1, 1, 56),
+       (256, 128, 1, 1, 56), (128, 128, 3, 2, 56), (128, 512, 1, 1, 28), (256, 512, 1, 2, 56), (512, 128, 1, 1, 28),
+       (128, 128, 3, 1, 28), (512, 256, 1, 1, 28), (256, 256, 3, 2, 28), (256, 1024, 1, 1, 14), (512, 1024, 1, 2, 28),
+       (1024, 256, 1, 1, 14), (256, 256, 3, 1, 14), (1024, 512, 1, 1, 14), (512, 512, 3, 2, 14), (512, 2048, 1, 1, 7),
+       (1024, 2048, 1, 2, 14), (2048, 512, 1, 1, 7), (512, 512, 3, 1, 7)]
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('shape', R50, ids=[f'{ci}to{co}_k{k}s{s}_{h}' for ci, co, k, s, h in R50])
+def test_resnet50_conv_shapes_at_batch_256_match_cpu_fp32(shape):
+    from simpleaicv_pytorch_training_examples_amd import _lib, ops
+    from simpleaicv_pytorch_training_examples_amd._lib import check, lib, ptr
+    ci, co, k, s, h = shape
+    pad = k // 2
+    dt = torch.bfloat16
+    L, st = lib(), _lib.stream()
+    g = torch.Generator().manual_seed(ci * 7 + co * 3 + k + s + h)
+    x = _bf(torch.randn(BATCH, ci, h, h, generator=g)).contiguous(memory_format=torch.channels_last)
+    if ci == 8:
+        x[:, 3:] = 0            # the stem sees a 3-channel image padded to 8
+    w = _bf(torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5)
+    d = ops._desc(BATCH, h, h, ci, co, k, k, s, pad, dt)
+    oh, ow = d.OH, d.OW
+    dy = _bf(torch.randn(BATCH, co, oh, ow, generator=g)).contiguous(memory_format=torch.channels_last)
+
+    # ---- CPU fp32 oracle
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, s, pad)
+    y_ref.backward(dy)
+    yq = _bf(y_ref.detach())                                   # what the kernel stores and sums
+    sum_ref = yq.double().sum((0, 2, 3))
+    sq_ref = (yq.double() ** 2).sum((0, 2, 3))
+
+    # ---- device, through the C-ABI
+    xd = x.to(dt).cuda()                                       # NHWC memory
+    wf = w.permute(0, 2, 3, 1).contiguous().to(dt).cuda()      # [Cout][R][S][Cin]
+    wdg = w.permute(1, 2, 3, 0).contiguous().to(dt).cuda()     # [Cin][R][S][Cout]
+    y = torch.empty((BATCH, oh, ow, co), dtype=dt, device='cuda')
+    rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
+    stats = torch.zeros((2, rows, co), dtype=torch.float32, device='cuda')
+    check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(xd), ptr(wf), 0, ptr(y), 0, ptr(stats[0]), ptr(stats[1]), st), 'fwd')
+    dyd = dy.to(dt).cuda()
+    dx = torch.empty((BATCH, h, h, ci), dtype=dt, device='cuda')
+    check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dyd), ptr(wdg), ptr(dx), st), 'dgrad')
+    dw = torch.zeros((co, k, k, ci), dtype=torch.float32, device='cuda')
+    check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dyd), ptr(xd), ptr(dw), st), 'wgrad')
+    torch.cuda.synchronize()
+
+    tag = str(shape)
+    assert rel_err(y.permute(0, 3, 1, 2).float(), y_ref) < 2e-2, 'forward ' + tag
+    assert rel_err(stats[0].double().sum(0), sum_ref) < 1e-3, 'BN partial sums ' + tag
+    assert rel_err(stats[1].double().sum(0), sq_ref) < 1e-3, 'BN partial sums of squares ' + tag
+    if ci != 8:                                                # the network input needs no gradient (stem dgrad never runs)
+        assert rel_err(dx.permute(0, 3, 1, 2).float(), xr.grad) < 2e-2, 'data gradient ' + tag
+    gw = wr.grad
+    if ci == 8:
+        gw = gw[:, :3]
+        dw = dw[..., :3]
+    assert rel_err(dw.permute(0, 3, 1, 2), gw) < 4e-3, 'weight gradient ' + tag
+
+
+VIT = [(768, 2304, 'qkv'), (768, 768, 'proj'), (768, 3072, 'fc1'), (3072, 768, 'fc2')]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('kn', VIT, ids=[v[2] for v in VIT])
+def test_vit_base_gemm_shapes_at_batch_256_match_cpu_fp32(kn):
+    from simpleaicv_pytorch_training_examples_amd import _lib
+    from simpleaicv_pytorch_training_examples_amd._lib import check, lib, ptr
+    K, N, name = kn
+    M = 197 * BATCH
+    L, st = lib(), _lib.stream()
+    g = torch.Generator().manual_seed(K + N)
+    x = _bf(torch.randn(M, K, generator=g))
+    w = _bf(torch.randn(N, K, generator=g) * K ** -0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    dy = _bf(torch.randn(M, N, generator=g))
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    y_ref = F.linear(x, w, b)
+    dx_ref = dy @ w
+    dw_ref = dy.t() @ x
+    db_ref = dy.sum(0)
+
+    dt = torch.bfloat16
+    xd, wf, wd, dyd = x.to(dt).cuda(), w.to(dt).cuda(), w.t().contiguous().to(dt).cuda(), dy.to(dt).cuda()
+    y = torch.empty((M, N), dtype=dt, device='cuda')
+    bd = b.cuda()
+    check(L.saicv_linear_fwd(0, ptr(xd), ptr(wf), ptr(bd), ptr(y), M, K, N, 0, 0, 0, 1, st), 'linear_fwd')
+    dx = torch.empty((M, K), dtype=dt, device='cuda')
+    check(L.saicv_linear_dgrad(0, ptr(dyd), ptr(wd), ptr(dx), M, K, N, 0, st), 'linear_dgrad')
+    dw = torch.zeros((N, K), dtype=torch.float32, device='cuda')
+    db = torch.zeros(N, dtype=torch.float32, device='cuda')
+    check(L.saicv_linear_wgrad(0, ptr(dyd), ptr(xd), ptr(dw), ptr(db), M, K, N, st), 'linear_wgrad')
+    torch.cuda.synchronize()
+    assert rel_err(y.float(), y_ref) < 2e-2, name
+    assert rel_err(dx.float(), dx_ref) < 2e-2, name
+    assert rel_err(dw, dw_ref) < 4e-3, name
+    assert rel_err(db, db_ref) < 4e-3, name

@@ -120,8 +120,11 @@ def _sam_inputs(fx):
     return x.cuda(), probe.cuda()
 
 
-def test_sam_encoder_fp32_matches_reference():
-    fx = load_golden('sam_encoder_tiny')
+@pytest.mark.parametrize('name', ['sam_encoder_tiny', 'sam_b_encoder_256'])
+def test_sam_encoder_fp32_matches_reference(name):
+    """sam_b_encoder_256: the encoder at sam_b's real dimensions (768 planes, 12 heads x 64, window 14, global blocks
+    2/5/8/11) on a 256 x 256 image -- fixture produced by the reference's ViTImageEncoder (oracle/make_golden_sam.py)."""
+    fx = load_golden(name)
     m = _sam_model(fx)
     x, probe = _sam_inputs(fx)
     out = m(x)
@@ -139,11 +142,12 @@ def test_sam_encoder_fp32_matches_reference():
         assert e < 2e-2, (n, e)
         if n in fx['grad_full']:
             assert rel_err(p.grad, fx['grad_full'][n]) < 2e-2, n
-    print(f'sam_encoder_tiny fp32: worst gradient-sample error {worst:.2e}')
+    print(f'{name} fp32: worst gradient-sample error {worst:.2e}')
 
 
-def test_sam_encoder_bf16_tracks_reference_autocast():
-    fx = load_golden('sam_encoder_tiny')
+@pytest.mark.parametrize('name', ['sam_encoder_tiny', 'sam_b_encoder_256'])
+def test_sam_encoder_bf16_tracks_reference_autocast(name):
+    fx = load_golden(name)
     m = _sam_model(fx)
     x, probe = _sam_inputs(fx)
     with torch.autocast('cuda', dtype=torch.bfloat16):
