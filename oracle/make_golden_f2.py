@@ -1,0 +1,82 @@
+"""Fixtures for the backbones that REUSE the hot-path blocks, produced by running the reference:
+  det_resnet50backbone : SimpleAICV/detection/models/backbones/resnet.py resnet50backbone on a [2,3,96,96] batch -> C2..C5
+  mae_tiny             : SimpleAICV/masked_image_modeling/models/vit_mae.py VITMAEPretrainModel (encoder 128 planes x 2
+                         heads of 64, decoder 64 planes x 2 heads of 32, image 64, patch 16) + losses.MSELoss
+Build container only:   python oracle/make_golden_f2.py"""
+import os
+import sys
+import types
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+MAE_TINY = dict(patch_size=16, image_size=64, mask_ratio=0.75, encoder_embedding_planes=128, encoder_block_nums=2,
+                encoder_head_nums=2, decoder_embedding_planes=64, decoder_block_nums=2, decoder_head_nums=2)
+
+
+def _grads(m):
+    norms, samples = {}, {}
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach()
+        norms[n] = float(g.norm())
+        samples[n] = g.flatten()[:64].clone()
+    return norms, samples
+
+
+def backbone_case():
+    from SimpleAICV.detection.models.backbones.resnet import resnet50backbone
+    torch.manual_seed(0)
+    m = resnet50backbone().train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 96, 96, 3, generator=g).permute(0, 3, 1, 2)
+    outs = m(x)
+    probes = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+    norms, samples = _grads(m)
+    fx = {'model_seed': 0, 'data_seed': 1, 'shape': (2, 96, 96, 3), 'outputs': [o.detach().clone() for o in outs],
+          'out_channels': m.out_channels, 'grad_norm': norms, 'grad_sample': samples,
+          'buffers_after': {n: b.detach().clone() for n, b in m.named_buffers() if b.numel() <= 2048},
+          'input_checksum': float(x.double().sum())}
+    torch.save(fx, os.path.join(OUT, 'det_resnet50backbone.pt'))
+    print('det_resnet50backbone', [tuple(o.shape) for o in outs])
+
+
+def mae_case():
+    from SimpleAICV.masked_image_modeling.models.vit_mae import VITMAEPretrainModel
+    from SimpleAICV.masked_image_modeling.losses import MSELoss
+    torch.manual_seed(0)
+    m = VITMAEPretrainModel(**MAE_TINY).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    torch.manual_seed(77)                       # the forward's only random draw: torch.rand(B, L) in random_masking
+    pred, mask = m(x)
+    loss = MSELoss()(pred, m.images_to_patch(x), mask)
+    loss.backward()
+    norms, samples = _grads(m)
+    fx = {'kwargs': MAE_TINY, 'model_seed': 0, 'data_seed': 1, 'noise_seed': 77, 'batch': 4, 'pred': pred.detach().clone(),
+          'mask': mask.clone(), 'loss': float(loss), 'grad_norm': norms, 'grad_sample': samples,
+          'input_checksum': float(x.double().sum())}
+    torch.save(fx, os.path.join(OUT, 'mae_tiny.pt'))
+    print('mae_tiny loss', float(loss), 'pred', tuple(pred.shape), 'removed', int(mask.sum()))
+
+
+def main():
+    for name in ('cv2', 'torchvision', 'torchvision.transforms'):
+        try:
+            __import__(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+    sys.path.insert(0, REF)
+    torch.set_num_threads(8)
+    backbone_case()
+    mae_case()
+
+
+if __name__ == '__main__':
+    main()

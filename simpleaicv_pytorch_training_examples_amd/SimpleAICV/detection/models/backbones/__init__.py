@@ -1,1 +1,2 @@
 from .detr_resnet import *
+from .resnet import *

@@ -164,7 +164,7 @@ def gelu_bwd(dy, x):
 
 def attn_fwd(qkv, b, n, heads, scale):
     c = qkv.shape[1] // 3
-    if qkv.dtype == torch.bfloat16 and c // heads in (32, 64):
+    if c // heads == 32 or n > 256 or (qkv.dtype == torch.bfloat16 and c // heads == 64):
         # bf16: the streaming kernel's forward is ~1.9x faster than the whole-head one at N = 197 (102 vs 192 us at
         # b256), its backward slower (335 vs 283 us): forward from here, backward stays saicv_attention_bwd -- both
         # keep the same natural-log lse [B, heads, N]
@@ -181,6 +181,12 @@ def attn_fwd(qkv, b, n, heads, scale):
 def attn_bwd(qkv, out, dout, lse, b, n, heads, scale):
     c = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
+    if c // heads != 64 or n > 256:
+        # head dim 32 (the MAE decoder: 512 planes / 16 heads) or long sequences: the streaming kernels both ways
+        q3, g3 = qkv.view(b, n, 3 * c), dqkv.view(b, n, 3 * c)
+        sattn_bwd(q3[:, :, :c], q3[:, :, c:2 * c], q3[:, :, 2 * c:], out.view(b, n, c), dout.contiguous().view(b, n, c),
+                  lse.view(b * heads, n), heads, scale, g3[:, :, :c], g3[:, :, c:2 * c], g3[:, :, 2 * c:])
+        return dqkv
     check(lib().saicv_attention_bwd(dtype_code(qkv.dtype), ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), b, n,
                                     heads, c // heads, float(scale), stream()), 'attention_bwd')
     return dqkv
