@@ -1,5 +1,5 @@
 """Fixtures for the backbones that REUSE the hot-path blocks, produced by running the reference:
-  det_resnet50backbone : SimpleAICV/detection/models/backbones/resnet.py resnet50backbone on a [2,3,96,96] batch -> C2..C5
+  det_resnet50backbone : SimpleAICV/detection/models/backbones/resnet.py resnet50backbone on a [2,3,64,64] batch -> C2..C5
   mae_tiny             : SimpleAICV/masked_image_modeling/models/vit_mae.py VITMAEPretrainModel (encoder 128 planes x 2
                          heads of 64, decoder 64 planes x 2 heads of 32, image 64, patch 16) + losses.MSELoss
 Build container only:   python oracle/make_golden_f2.py"""
@@ -34,12 +34,12 @@ def backbone_case():
     torch.manual_seed(0)
     m = resnet50backbone().train()
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(2, 96, 96, 3, generator=g).permute(0, 3, 1, 2)
+    x = torch.randn(2, 64, 64, 3, generator=g).permute(0, 3, 1, 2)
     outs = m(x)
     probes = [torch.randn(o.shape, generator=g) for o in outs]
     sum((o * p).sum() for o, p in zip(outs, probes)).backward()
     norms, samples = _grads(m)
-    fx = {'model_seed': 0, 'data_seed': 1, 'shape': (2, 96, 96, 3), 'outputs': [o.detach().clone() for o in outs],
+    fx = {'model_seed': 0, 'data_seed': 1, 'shape': (2, 64, 64, 3), 'outputs': [o.detach().clone() for o in outs],
           'out_channels': m.out_channels, 'grad_norm': norms, 'grad_sample': samples,
           'buffers_after': {n: b.detach().clone() for n, b in m.named_buffers() if b.numel() <= 2048},
           'input_checksum': float(x.double().sum())}
