@@ -91,7 +91,14 @@ def detr_case(name, factory_name, kwargs, batch, model_seed=0, data_seed=1):
     sum(ld16.values()).backward()
     a = torch.cat([p.grad.flatten()[:64].double() for _, p in m2.named_parameters()])
     b = torch.cat([samples[n].double() for n, _ in m2.named_parameters()])
-    noise = {'bf16_cls': _rel(c16.detach().float(), cls_out.detach()), 'bf16_reg': _rel(r16.detach().float(), reg_out.detach()),
+    # fp32 self-noise: the same model on true-NCHW input with another thread count (other ATen kernels / summation order)
+    m3 = build()
+    torch.set_num_threads(3)
+    c3, r3 = m3(images.contiguous(), masks)
+    sum(crit([c3, r3], annots).values()).backward()
+    torch.set_num_threads(8)
+    reorder = max(_rel(p.grad.flatten()[:64], samples[n]) for n, p in m3.named_parameters() if norms[n] > 1e-7)
+    noise = {'fp32_reorder_grad_sample': reorder, 'bf16_cls': _rel(c16.detach().float(), cls_out.detach()), 'bf16_reg': _rel(r16.detach().float(), reg_out.detach()),
              'bf16_loss': abs(float(sum(ld16.values())) - float(total)) / abs(float(total)),
              'bf16_grad_sample_cos': float(a @ b / (a.norm() * b.norm()))}
     fx = {'name': name, 'factory': factory_name, 'kwargs': kwargs, 'batch': batch, 'model_seed': model_seed,

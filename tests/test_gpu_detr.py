@@ -48,6 +48,9 @@ def test_detr_fp32_matches_reference(name):
     for (i, j), (ri, rj) in zip(idx, fx['indices']):
         assert torch.equal(i, ri) and torch.equal(j, rj)
     worst = 0.0
+    # gradient samples: 5e-2, or twice what the reference moves from ITSELF under another fp32 summation order
+    # (stored by the generator): batch-2 BatchNorm backward + ReLU sign flips at near-zero pre-activations
+    gtol = max(5e-2, 2 * fx['reference_noise'].get('fp32_reorder_grad_sample', 0.0))
     for n, p in m.named_parameters():
         assert p.grad is not None, n
         ref_n = fx['grad_norm'][n]
@@ -55,7 +58,7 @@ def test_detr_fp32_matches_reference(name):
         if ref_n > 1e-7:
             e = rel_err(p.grad.flatten()[:64], fx['grad_sample'][n])
             worst = max(worst, e)
-            assert e < 5e-2, (n, e)
+            assert e < gtol, (n, e, gtol)
     for n, b in m.named_buffers():
         if n in fx['buffers_after'] and b.dtype.is_floating_point:
             assert rel_err(b, fx['buffers_after'][n]) < 1e-3, n

@@ -42,7 +42,8 @@ def test_detection_resnet50_backbone_matches_reference():
     torch.cuda.synchronize()
     for o, r in zip(outs, fx['outputs']):
         assert o.shape == r.shape and rel_err(o, r) < 1e-3
-    worst = _check_grads(m, fx, 1e-2, 5e-2)       # batch 2: BatchNorm backward noise, as for resnet50_b2_224
+    # batch 2: BatchNorm backward + ReLU sign flips; the gate follows the reference's own reorder noise (generator)
+    worst = _check_grads(m, fx, 1e-2, max(5e-2, 2 * fx['reference_noise']['fp32_reorder_grad_sample']))
     for n, b in m.named_buffers():
         if n in fx['buffers_after'] and b.dtype.is_floating_point:
             assert rel_err(b, fx['buffers_after'][n]) < 1e-3, n
