@@ -218,6 +218,22 @@ int saicv_mask_loss_stats(int dtype, const void* logits, const float* targets, f
 int saicv_mask_loss_grad(int dtype, const void* logits, const float* targets, const float* coef, void* dlogits, int B,
                          int M, size_t HW, double alpha, double gamma, void* stream);
 
+/* ---- SAM mask-decoder / loss tail (segment_anything/mask_decoder.py:137-140, sam.py:155-158, losses.py:136-198) ---- */
+/* masks[b][t][p] = <hyper[b][t][:], x[b][p][:]>, x [B][P][C = 32] (the upscaled embedding, NHWC), T <= 8 mask tokens */
+int saicv_hyper_product_fwd(int dtype, const void* x, const void* hyper, void* out, int B, int T, int P, int C, void* stream);
+/* dx [B][P][C] (compute dtype), dhyper [B][T][C] fp32 (zeroed here, then accumulated with atomics) */
+int saicv_hyper_product_bwd(int dtype, const void* x, const void* hyper, const void* dout, void* dx, float* dhyper, int B,
+                            int T, int P, int C, void* stream);
+/* F.interpolate(scale 4, mode="bilinear", align_corners=False) over `planes` [h][w] planes, and its backward */
+int saicv_upsample4_fwd(int dtype, const void* low, void* out, int planes, int h, int w, void* stream);
+int saicv_upsample4_bwd(int dtype, const void* dhi, void* dlow, int planes, int h, int w, void* stream);
+/* saicv_mask_loss_stats / _grad taken from the LOW-resolution logits [B][M][h][w] against full-resolution targets
+ * [B][4h][4w]: the x4-interpolated logits exist only in registers; the gradient is with respect to the low-resolution logits */
+int saicv_mask_loss_stats_up4(int dtype, const void* low, const float* targets, float* stats, int B, int M, int h, int w,
+                              double alpha, double gamma, double thr, void* stream);
+int saicv_mask_loss_grad_up4(int dtype, const void* low, const float* targets, const float* coef, void* dlow, int B, int M,
+                             int h, int w, double alpha, double gamma, void* stream);
+
 /* Streaming attention (any Nq / Nk, head dim 32 or 64, separate q / k / v with strides).
  * Replaces SAM Attention.forward + add_decomposed_rel_pos (reference interactive_segmentation/models/
  * segment_anything/image_encoder.py:116-184) and DETR's nn.MultiheadAttention calls with a float

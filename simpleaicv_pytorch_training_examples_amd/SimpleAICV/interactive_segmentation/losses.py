@@ -52,6 +52,38 @@ class MaskLossStatsFn(torch.autograd.Function):
         return dlogits, None, None, None, None
 
 
+class UpMaskLossStatsFn(torch.autograd.Function):
+    """MaskLossStatsFn over the x4 bilinear upsampling of LOW-resolution logits [B, M, h, w] (targets [B, 1, 4h, 4w]):
+    the full-resolution logits are interpolated in registers, forward and backward; the gradient comes out with
+    respect to the low-resolution logits (reference sam.py:155-158 + losses.py:136-198 in two kernels)."""
+
+    @staticmethod
+    def forward(ctx, low, targets, alpha, gamma, thr):
+        require_gpu(low, targets)
+        b, m, h, w = low.shape
+        if targets.shape[0] != b or targets.numel() != b * 16 * h * w:
+            raise ValueError(f'targets {tuple(targets.shape)} are not the x4 grid of logits {tuple(low.shape)}')
+        low = low.contiguous()
+        targets = targets.contiguous().float()
+        stats = torch.empty((b, m, 6), dtype=torch.float32, device=low.device)
+        check(lib().saicv_mask_loss_stats_up4(dtype_code(low.dtype), ptr(low), ptr(targets), ptr(stats), b, m, h, w,
+                                              float(alpha), float(gamma), float(thr), stream()), 'mask_loss_stats_up4')
+        ctx.save_for_backward(low, targets)
+        ctx.cfg = (float(alpha), float(gamma))
+        return stats
+
+    @staticmethod
+    def backward(ctx, dstats):
+        low, targets = ctx.saved_tensors
+        alpha, gamma = ctx.cfg
+        b, m, h, w = low.shape
+        coef = dstats[..., :3].float().contiguous()
+        dlow = torch.empty_like(low)
+        check(lib().saicv_mask_loss_grad_up4(dtype_code(low.dtype), ptr(low), ptr(targets), ptr(coef), ptr(dlow), b, m, h, w,
+                                             alpha, gamma, stream()), 'mask_loss_grad_up4')
+        return dlow, None, None, None, None
+
+
 class SAMLoss(nn.Module):
 
     def __init__(self, alpha=0.25, gamma=2, focal_loss_weight=20, dice_loss_weight=1, iou_predict_loss_weight=1,
@@ -86,7 +118,12 @@ class SAMLoss(nn.Module):
         (reference focal_loss :136-153, dice_loss :155-176, iou_predict_loss :178-198)."""
         batch_size = mask_preds.shape[0]
         hw = mask_preds.shape[2] * mask_preds.shape[3]
-        stats = MaskLossStatsFn.apply(mask_preds, targets, self.alpha, self.gamma, self.mask_threshold)
+        low = getattr(mask_preds, '_saicv_low', None)
+        if low is not None and low.shape[:2] == mask_preds.shape[:2] and low.shape[2] * 4 == mask_preds.shape[2]:
+            # the model handed its low-resolution logits along (sam.py): loss and gradient without the full-resolution tensor
+            stats = UpMaskLossStatsFn.apply(low, targets, self.alpha, self.gamma, self.mask_threshold)
+        else:
+            stats = MaskLossStatsFn.apply(mask_preds, targets, self.alpha, self.gamma, self.mask_threshold)
         focal = stats[..., 0] / float(hw) / batch_size
         dice = (1. - (2. * stats[..., 1] + 1) / (stats[..., 2] + stats[..., 3] + 1)) / batch_size
         with torch.no_grad():

@@ -101,9 +101,9 @@ class MaskDecoder(nn.Module):
         hyper_in = torch.stack([self.output_hypernetworks_mlps[i](mask_tokens_out[:, i, :])
                                 for i in range(self.num_mask_tokens)], dim=1)   # [B, T, C/8]
         b, h4, w4, c8 = x.shape
-        # masks[b, t, y, x] = <hyper_in[b, t, :], upscaled[b, y, x, :]>  -- a K = 32 product, HBM-bound
-        mask_preds = torch.matmul(x.view(b, h4 * w4, c8), hyper_in.transpose(1, 2)).permute(0, 2, 1).reshape(
-            b, -1, h4, w4)
+        # masks[b, t, y, x] = <hyper_in[b, t, :], upscaled[b, y, x, :]>  -- a K = 32 product, HBM-bound: one streaming
+        # HIP kernel each way (csrc/samtail.hip) instead of a skinny batched GEMM plus a permute copy
+        mask_preds = ops_tfm.hyper_product(x.view(b, h4 * w4, c8), hyper_in).view(b, -1, h4, w4)
         iou_preds = self.iou_prediction_head(iou_token_out)
         mask_preds = mask_preds[:, mask_out_idxs, :, :]
         iou_preds = iou_preds[:, mask_out_idxs]

@@ -8,6 +8,8 @@ declared but its encoder raises: the streaming attention kernel is instantiated 
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..... import ops_tfm
+
 from .image_encoder import ViTImageEncoder
 from .mask_decoder import MaskDecoder
 from .prompt_encoder import PromptEncoder
@@ -78,8 +80,16 @@ class SAM(nn.Module):
                                                   sparse_prompt_embeddings=sparse_embeddings,
                                                   dense_prompt_embeddings=dense_embeddings,
                                                   mask_out_idxs=mask_out_idxs)
-        mask_preds = F.interpolate(mask_preds, (self.image_encoder.image_size, self.image_encoder.image_size),
-                                   mode="bilinear")
+        size = self.image_encoder.image_size
+        if mask_preds.shape[-2] * 4 == size and mask_preds.shape[-1] * 4 == size:
+            # x4 bilinear on the HIP kernel.  The low-resolution logits ride along on the returned tensor: SAMLoss takes
+            # its statistics and its gradient straight from them (csrc/samtail.hip), so the [B, M, 1024, 1024] tensor
+            # is written once for the prompt sampler and never read, nor its gradient materialised, by the loss
+            low = mask_preds.contiguous()
+            mask_preds = ops_tfm.upsample4_bilinear(low)
+            mask_preds._saicv_low = low
+        else:
+            mask_preds = F.interpolate(mask_preds, (size, size), mode="bilinear")
         return mask_preds, iou_preds
 
 

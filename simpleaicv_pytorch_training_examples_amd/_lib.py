@@ -91,6 +91,12 @@ SIGNATURES = {
     'saicv_relpos_bwd_ws_floats': (c_size_t, [c_int, c_int]),
     'saicv_mask_loss_stats': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_size_t, c_double, c_double, c_double, _P]),
     'saicv_mask_loss_grad': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_size_t, c_double, c_double, _P]),
+    'saicv_hyper_product_fwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'saicv_hyper_product_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'saicv_upsample4_fwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_upsample4_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_mask_loss_stats_up4': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
+    'saicv_mask_loss_grad_up4': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
     'saicv_attention_stream_fwd': (c_int, [c_int, c_int, _PA, _P]),
     'saicv_attention_stream_bwd': (c_int, [c_int, c_int, _PA, _P]),
 }

@@ -305,6 +305,27 @@ int saicv_mask_loss_grad(int dtype, const void* logits, const float* targets, co
                          int M, size_t HW, double alpha, double gamma, void* stream) {
     return mask_loss_grad(dtype, logits, targets, coef, dlogits, B, M, HW, alpha, gamma, S(stream));
 }
+int saicv_hyper_product_fwd(int dtype, const void* x, const void* hyper, void* out, int B, int T, int P, int C, void* stream) {
+    return hyper_product_fwd(dtype, x, hyper, out, B, T, P, C, S(stream));
+}
+int saicv_hyper_product_bwd(int dtype, const void* x, const void* hyper, const void* dout, void* dx, float* dhyper, int B,
+                            int T, int P, int C, void* stream) {
+    return hyper_product_bwd(dtype, x, hyper, dout, dx, dhyper, B, T, P, C, S(stream));
+}
+int saicv_upsample4_fwd(int dtype, const void* low, void* out, int planes, int h, int w, void* stream) {
+    return upsample4_fwd(dtype, low, out, planes, h, w, S(stream));
+}
+int saicv_upsample4_bwd(int dtype, const void* dhi, void* dlow, int planes, int h, int w, void* stream) {
+    return upsample4_bwd(dtype, dhi, dlow, planes, h, w, S(stream));
+}
+int saicv_mask_loss_stats_up4(int dtype, const void* low, const float* targets, float* stats, int B, int M, int h, int w,
+                              double alpha, double gamma, double thr, void* stream) {
+    return mask_loss_stats_up4(dtype, low, targets, stats, B, M, h, w, alpha, gamma, thr, S(stream));
+}
+int saicv_mask_loss_grad_up4(int dtype, const void* low, const float* targets, const float* coef, void* dlow, int B, int M,
+                             int h, int w, double alpha, double gamma, void* stream) {
+    return mask_loss_grad_up4(dtype, low, targets, coef, dlow, B, M, h, w, alpha, gamma, S(stream));
+}
 int saicv_attention_stream_fwd(int dtype, int D, const saicv_attn_desc* desc, void* stream) {
     if (!desc) { set_error("attention_stream: null descriptor"); return -1; }
     return attention_stream(dtype, D, 0, desc, S(stream));

@@ -40,6 +40,16 @@ int mask_loss_stats(int dtype, const void* logits, const float* targets, float* 
                     double alpha, double gamma, double thr, hipStream_t st);
 int mask_loss_grad(int dtype, const void* logits, const float* targets, const float* coef, void* dlogits, int B, int M,
                    size_t HW, double alpha, double gamma, hipStream_t st);
+// samtail.hip
+int hyper_product_fwd(int dtype, const void* x, const void* hyper, void* out, int B, int Tm, int P, int C, hipStream_t st);
+int hyper_product_bwd(int dtype, const void* x, const void* hyper, const void* dout, void* dx, float* dhyper, int B, int Tm,
+                      int P, int C, hipStream_t st);
+int upsample4_fwd(int dtype, const void* low, void* out, int planes, int h, int w, hipStream_t st);
+int upsample4_bwd(int dtype, const void* dhi, void* dlow, int planes, int h, int w, hipStream_t st);
+int mask_loss_stats_up4(int dtype, const void* low, const float* targets, float* stats, int B, int M, int h, int w,
+                        double alpha, double gamma, double thr, hipStream_t st);
+int mask_loss_grad_up4(int dtype, const void* low, const float* targets, const float* coef, void* dlow, int B, int M, int h,
+                       int w, double alpha, double gamma, hipStream_t st);
 // attn_stream.hip: which = 0 forward, 1 dQ pass, 2 dK/dV pass; desc = const saicv_attn_desc*
 int attention_stream(int dtype, int D, int which, const void* desc, hipStream_t st);
 

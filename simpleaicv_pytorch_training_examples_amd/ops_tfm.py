@@ -641,3 +641,65 @@ class PatchEmbedFn(torch.autograd.Function):
 
 def patch_embed(x, weight, bias, stride):
     return PatchEmbedFn.apply(x, weight, bias, stride)
+
+
+# ------------------------------------------------------------------------------ SAM mask-decoder tail (csrc/samtail.hip)
+class HyperProductFn(torch.autograd.Function):
+    """masks[b, t, p] = <hyper[b, t, :], x[b, p, :]> -- the hyper-network product of the mask decoder (reference
+    segment_anything/mask_decoder.py:137-140) as one streaming kernel each way: x [B, P, 32] is read once, the
+    [B, T, P] logits written once; backward gives dx in one pass and dhyper by per-block partial sums."""
+
+    @staticmethod
+    def forward(ctx, x, hyper):
+        require_gpu(x, hyper)
+        b, p, c = x.shape
+        t = hyper.shape[1]
+        x = x.contiguous()
+        hyper = hyper.to(x.dtype).contiguous()
+        out = torch.empty((b, t, p), dtype=x.dtype, device=x.device)
+        check(lib().saicv_hyper_product_fwd(dtype_code(x.dtype), ptr(x), ptr(hyper), ptr(out), b, t, p, c, stream()),
+              'hyper_product_fwd')
+        ctx.save_for_backward(x, hyper)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, hyper = ctx.saved_tensors
+        b, p, c = x.shape
+        t = hyper.shape[1]
+        dout = dout.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        dh = torch.empty((b, t, c), dtype=torch.float32, device=x.device)
+        check(lib().saicv_hyper_product_bwd(dtype_code(x.dtype), ptr(x), ptr(hyper), ptr(dout), ptr(dx), ptr(dh), b, t, p, c,
+                                            stream()), 'hyper_product_bwd')
+        return dx, dh
+
+
+def hyper_product(x, hyper):
+    return HyperProductFn.apply(x, hyper)
+
+
+class Upsample4Fn(torch.autograd.Function):
+    """F.interpolate(x, scale 4, mode="bilinear", align_corners=False) on [B, M, h, w] (reference sam.py:155-158)."""
+
+    @staticmethod
+    def forward(ctx, low):
+        require_gpu(low)
+        b, m, h, w = low.shape
+        low = low.contiguous()
+        out = torch.empty((b, m, 4 * h, 4 * w), dtype=low.dtype, device=low.device)
+        check(lib().saicv_upsample4_fwd(dtype_code(low.dtype), ptr(low), ptr(out), b * m, h, w, stream()), 'upsample4_fwd')
+        ctx.shape = (b, m, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dhi):
+        b, m, h, w = ctx.shape
+        dhi = dhi.contiguous()
+        dlow = torch.empty((b, m, h, w), dtype=dhi.dtype, device=dhi.device)
+        check(lib().saicv_upsample4_bwd(dtype_code(dhi.dtype), ptr(dhi), ptr(dlow), b * m, h, w, stream()), 'upsample4_bwd')
+        return dlow
+
+
+def upsample4_bilinear(low):
+    return Upsample4Fn.apply(low)

@@ -199,6 +199,83 @@ def test_mask_loss_stats_kernel_matches_reference_formulas(dtype):
     assert rel_err(xl.grad, xr.grad) < gtol
 
 
+# ------------------------------------------------------------------------------------------ decoder tail kernels (samtail.hip)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_hyper_product_matches_matmul(dtype):
+    """masks = hyper_in @ upscaled_embedding (reference mask_decoder.py:137-140) and its gradients vs fp32 matmul."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    g = torch.Generator().manual_seed(3)
+    b, t, p, c = 3, 4, 1000, 32                           # P not a multiple of the block
+    x = torch.randn(b, p, c, generator=g).to(dtype).float()
+    hy = torch.randn(b, t, c, generator=g).to(dtype).float()
+    dout = torch.randn(b, t, p, generator=g).to(dtype).float()
+    xr, hr = x.clone().requires_grad_(True), hy.clone().requires_grad_(True)
+    ref = torch.matmul(hr, xr.transpose(1, 2))
+    ref.backward(dout)
+    xd, hd = x.cuda().to(dtype).requires_grad_(True), hy.cuda().to(dtype).requires_grad_(True)
+    out = ops_tfm.hyper_product(xd, hd)
+    out.backward(dout.cuda().to(dtype))
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert out.shape == (b, t, p) and rel_err(out.float(), ref) < tol
+    assert rel_err(xd.grad.float(), xr.grad) < tol
+    assert rel_err(hd.grad.float(), hr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 16, 16), (1, 4, 9, 23), (2, 1, 1, 5)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_upsample4_matches_interpolate(shape, dtype):
+    """x4 bilinear, align_corners=False (reference sam.py:155-158), forward and backward, borders included."""
+    import torch.nn.functional as F
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    g = torch.Generator().manual_seed(sum(shape))
+    low = torch.randn(shape, generator=g).to(dtype).float()
+    dhi = torch.randn(shape[0], shape[1], 4 * shape[2], 4 * shape[3], generator=g).to(dtype).float()
+    lr = low.clone().requires_grad_(True)
+    ref = F.interpolate(lr, scale_factor=4, mode='bilinear')
+    ref.backward(dhi)
+    ld = low.cuda().to(dtype).requires_grad_(True)
+    out = ops_tfm.upsample4_bilinear(ld)
+    out.backward(dhi.cuda().to(dtype))
+    torch.cuda.synchronize()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert out.shape == ref.shape and rel_err(out.float(), ref) < tol
+    assert rel_err(ld.grad.float(), lr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_mask_loss_from_low_resolution_logits_matches_interpolate_then_loss(dtype):
+    """SAMLoss statistics and gradient taken from the low-resolution logits (the x4 upsampled tensor never stored) vs
+    F.interpolate followed by the reference formulas (oracle sam_per_mask_losses), incl. the gradient through the
+    interpolation down to the low-resolution logits."""
+    import torch.nn.functional as F
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.losses import SAMLoss
+    g = torch.Generator().manual_seed(9)
+    b, m, h, w = 3, 4, 24, 40
+    low = (torch.randn(b, m, h, w, generator=g) * 3).to(dtype).float()
+    t = (torch.rand(b, 1, 4 * h, 4 * w, generator=g) > 0.6).float()
+    ious = torch.rand(b, m, generator=g)
+    lr = low.clone().requires_grad_(True)
+    rf, rd, ri = O.sam_per_mask_losses(F.interpolate(lr, scale_factor=4, mode='bilinear'), t, ious)
+    (rf.sum() * 20 + rd.sum() + ri.sum()).backward()
+    crit = SAMLoss()
+    ld = low.cuda().to(dtype).requires_grad_(True)
+    hi = ops_tfm.upsample4_bilinear(ld)
+    hi._saicv_low = ld                                    # what SAM.forward_prompt_encoder_mask_decoder attaches
+    f, d, i = crit.per_mask_losses(hi, ious.cuda(), t.cuda())
+    (f.sum() * 20 + d.sum() + i.sum()).backward()
+    torch.cuda.synchronize()
+    assert rel_err(f, rf) < 2e-5 and rel_err(d, rd) < 2e-5 and rel_err(i, ri) < 1e-5
+    assert rel_err(ld.grad.float(), lr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    # and the two routes agree: without the attribute the loss reads the materialised full-resolution tensor
+    ld2 = low.cuda().to(dtype).requires_grad_(True)
+    f2, d2, i2 = crit.per_mask_losses(ops_tfm.upsample4_bilinear(ld2), ious.cuda(), t.cuda())
+    (f2.sum() * 20 + d2.sum() + i2.sum()).backward()
+    assert rel_err(f2, rf) < (2e-5 if dtype == torch.float32 else 2e-3)
+    assert rel_err(ld2.grad.float(), lr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+
+
 def test_sam_full_model_two_pass_matches_reference():
     """SAM (encoder + prompt encoder + mask decoder) + SAMLoss, two decoder passes, against the fixture
     produced by the reference modules (oracle/make_golden_sam.py: sam_case)."""
