@@ -43,7 +43,8 @@ def test_detection_resnet50_backbone_matches_reference():
     for o, r in zip(outs, fx['outputs']):
         assert o.shape == r.shape and rel_err(o, r) < 1e-3
     # batch 2: BatchNorm backward + ReLU sign flips; the gate follows the reference's own reorder noise (generator)
-    worst = _check_grads(m, fx, 1e-2, max(5e-2, 2 * fx['reference_noise']['fp32_reorder_grad_sample']))
+    noise = fx['reference_noise']['fp32_reorder_grad_sample']      # 0.14: C5 is 2 x 2, BatchNorm over 8 samples
+    worst = _check_grads(m, fx, max(1e-2, 0.5 * noise), max(5e-2, 2 * noise))
     for n, b in m.named_buffers():
         if n in fx['buffers_after'] and b.dtype.is_floating_point:
             assert rel_err(b, fx['buffers_after'][n]) < 1e-3, n
