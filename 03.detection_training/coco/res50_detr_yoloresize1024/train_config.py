@@ -1,0 +1,72 @@
+"""Benchmark copy of reference 03.detection_training/coco/res50_detr_yoloresize1024/train_config.py (:20-166): network,
+DETRLoss weights, decoder, collater (1024 canvas, yolo style), global batch 64, AdamW 1e-4 with the backbone at 1e-5,
+MultiStepLR with one warm-up epoch, AMP, gradient-norm clipping 0.1 as the reference sets them; the COCO dataset +
+OpenCV transform block is replaced by a synthetic detection dataset and no pretrained backbone is loaded (neither exists
+in the bench image).  BASELINE.json configs[3]."""
+import os
+import sys
+
+BASE_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.append(BASE_DIR)
+
+from SimpleAICV.detection import models
+from SimpleAICV.detection import losses
+from SimpleAICV.detection import decode
+from SimpleAICV.detection.datasets.syntheticdataset import SyntheticDetectionDataset
+from SimpleAICV.detection.common import DETRDetectionCollater, load_state_dict
+
+
+class config:
+    network = 'resnet50_detr'
+    num_classes = 80
+    input_image_size = [1024, 1024]
+
+    backbone_pretrained_path = ''
+    model = models.__dict__[network](**{
+        'backbone_pretrained_path': backbone_pretrained_path,
+        'num_classes': num_classes,
+    })
+
+    trained_model_path = ''
+    load_state_dict(trained_model_path, model)
+
+    _loss_kwargs = {'cls_match_cost': 1.0, 'box_match_cost': 5.0, 'giou_match_cost': 2.0, 'cls_loss_weight': 1.0,
+                    'box_l1_loss_weight': 5.0, 'iou_loss_weight': 2.0, 'no_object_cls_weight': 0.1,
+                    'num_classes': num_classes}
+    train_criterion = losses.__dict__['DETRLoss'](**_loss_kwargs)
+    test_criterion = losses.__dict__['DETRLoss'](**_loss_kwargs)
+    decoder = decode.__dict__['DETRDecoder'](**{'num_classes': num_classes, 'max_object_num': 100,
+                                                'min_score_threshold': 0.05, 'topn': 100, 'nms_type': None,
+                                                'nms_threshold': 0.5})
+
+    train_dataset = SyntheticDetectionDataset(117266, 768, 1024, num_classes=num_classes, seed=0)
+    test_dataset = SyntheticDetectionDataset(4952, 768, 1024, num_classes=num_classes, seed=1)
+    train_collater = DETRDetectionCollater(resize=input_image_size[0], resize_type='yolo_style', max_annots_num=100)
+    test_collater = DETRDetectionCollater(resize=input_image_size[0], resize_type='yolo_style', max_annots_num=100)
+
+    seed = 0
+    batch_size = 64
+    num_workers = 32
+    accumulation_steps = 1
+
+    optimizer = ('AdamW', {'lr': 1e-4, 'global_weight_decay': False, 'weight_decay': 1e-3,
+                           'no_weight_decay_layer_name_list': [], 'sub_layer_lr': {'backbone': 1e-5}})
+    scheduler = ('MultiStepLR', {'warm_up_epochs': 1, 'gamma': 0.1, 'milestones': [400]})
+
+    epochs = 500
+    print_interval = 100
+
+    eval_type = 'COCO'
+    eval_epoch = [1] + [i for i in range(epochs) if i % 50 == 0]
+    eval_voc_iou_threshold_list = [0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95]
+    save_model_metric = 'IoU=0.50:0.95,area=all,maxDets=100,mAP'
+
+    sync_bn = False
+    use_amp = True
+    use_compile = False
+    compile_params = {'mode': 'default'}
+
+    use_ema_model = False
+    ema_model_decay = 0.9999
+
+    clip_max_norm = 0.1

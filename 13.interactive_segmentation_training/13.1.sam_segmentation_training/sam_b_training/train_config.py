@@ -1,0 +1,71 @@
+"""Benchmark copy of reference 13.interactive_segmentation_training/13.1.sam_segmentation_training/sam_b_training/
+train_config.py (:18-263): sam_b at 1024, four decoder refinement iterations, single-prompt mode with point / box at 0.5
+each, SAMLoss (20 focal + dice + IoU), global batch 160, AdamW 1e-5 without weight decay, AMP, gradient-norm clipping 1.0,
+find_unused_parameters as the reference sets them; the SA-1B dataset + OpenCV transform block is replaced by a synthetic
+dataset and the official SAM checkpoint is not loaded (neither exists in the bench image).  BASELINE.json configs[4].
+use_gradient_checkpoint is kept for the surface; the MI355X build keeps every block's activations in its 288 GB of HBM."""
+import os
+import sys
+
+BASE_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.append(BASE_DIR)
+
+from SimpleAICV.interactive_segmentation.models.segment_anything import sam
+from SimpleAICV.interactive_segmentation import losses
+from SimpleAICV.interactive_segmentation.datasets.syntheticdataset import SyntheticSAMDataset
+from SimpleAICV.interactive_segmentation.common import SAMBatchCollater, load_state_dict
+
+
+class config:
+    network = 'sam_b'
+    input_image_size = 1024
+    mask_out_idxs = [0, 1, 2, 3]
+    use_gradient_checkpoint = True
+    frozen_image_encoder = False
+    frozen_prompt_encoder = False
+    frozen_mask_decoder = False
+    mask_threshold = 0.0
+    decoder_iters = 4
+
+    model = sam.__dict__[network](**{
+        'image_size': input_image_size,
+        'use_gradient_checkpoint': use_gradient_checkpoint,
+        'frozen_image_encoder': frozen_image_encoder,
+        'frozen_prompt_encoder': frozen_prompt_encoder,
+        'frozen_mask_decoder': frozen_mask_decoder,
+    })
+
+    trained_model_path = ''
+    load_state_dict(trained_model_path, model)
+
+    use_single_prompt = True
+    prompt_probs = {'prompt_point': 0.5, 'prompt_box': 0.5, 'prompt_mask': 0.}
+
+    train_criterion = losses.__dict__['SAMLoss'](**{'alpha': 0.25, 'gamma': 2, 'focal_loss_weight': 20,
+                                                    'dice_loss_weight': 1, 'iou_predict_loss_weight': 1,
+                                                    'supervise_all_iou': True, 'mask_threshold': mask_threshold})
+
+    train_dataset = SyntheticSAMDataset(100000, image_size=input_image_size, seed=0)
+    train_collater = SAMBatchCollater(resize=input_image_size)
+
+    seed = 0
+    batch_size = 160
+    num_workers = 32
+    accumulation_steps = 1
+
+    optimizer = ('AdamW', {'lr': 1e-5, 'global_weight_decay': False, 'weight_decay': 0,
+                           'no_weight_decay_layer_name_list': []})
+    scheduler = ('MultiStepLR', {'warm_up_epochs': 0, 'gamma': 0.1, 'milestones': [100]})
+
+    epochs = 2
+    print_interval = 100
+    save_interval = 1
+
+    sync_bn = False
+    use_amp = True
+    use_compile = False
+    compile_params = {'mode': 'default'}
+
+    clip_max_norm = 1.
+
+    find_unused_parameters = True

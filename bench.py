@@ -1,6 +1,6 @@
 """Training-throughput bench of the SimpleAICV DDP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model resnet50|vit_base_patch16|sam_b_encoder|resnet50_detr]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model resnet50|vit_base_patch16|sam_b_encoder|resnet50_detr|resnet50_detr_config|sam_b]
                     [--batch B] [--no-cpu-baseline] [--no-secondary] [--eager]
 
 A step = forward + loss + backward + gradient all-reduce + optimizer step of one per-GPU batch of synthetic data that
@@ -44,7 +44,13 @@ TRAIN_GFLOP_PER_IMG = {'resnet50': 24.54, 'vit_base_patch16': 105.38, 'sam_b_enc
                        'resnet50_detr': 3 * 189.1 * (800 * 1333) / (800 * 1344)}
 IMAGE_SIZE = {'sam_b_encoder': 1024, 'resnet50_detr': 1333}
 CONFIG_DIR = {'resnet50': '00.classification_training/imagenet/resnet50',
-              'vit_base_patch16': '00.classification_training/imagenet/vit_base_patch16_for_self_train_mae_pretrain'}
+              'vit_base_patch16': '00.classification_training/imagenet/vit_base_patch16_for_self_train_mae_pretrain',
+              # the reference's own DETR / SAM training configurations (1024^2 canvases), through their loops
+              'resnet50_detr_config': '03.detection_training/coco/res50_detr_yoloresize1024',
+              'sam_b': '13.interactive_segmentation_training/13.1.sam_segmentation_training/sam_b_training'}
+LOOP_MODELS = {'resnet50_detr_config': ('tools.scripts.train_detection', 8, 1024, 3 * 189.1 * (768 * 1024) / (800 * 1344)),
+               # full SAM step: one encoder pass (972.1 GFLOP fwd) + 1 + decoder_iters light decoder passes
+               'sam_b': ('tools.interactive_segmentation_scripts.train_sam_segmentation', 8, 1024, 3 * 972.1)}
 PMC_FILE = 'profiles/r02_pmc_hbm_traffic.json'
 
 
@@ -165,6 +171,44 @@ def classification_workload(name, args, world, rank, device, use_graph):
     return run, model, config.scaler, state, info, batch, 224
 
 
+def loop_workload(name, args, world, rank, device):
+    """DETR / full SAM through the reference's own config and loop (eager launches: both loops have host-side work per
+    iteration -- the Hungarian assignment, the prompt-type draw)."""
+    import numpy as np
+    import torch
+    from simpleaicv_pytorch_training_examples_amd.tools import interactive_segmentation_scripts, scripts, utils
+    loop_name, default_batch, size, _ = LOOP_MODELS[name]
+    config, cfg_path = load_config(name)
+    _CONFIGS[name] = config
+    batch = args.batch or default_batch
+    utils.set_seed(config.seed)
+    np.random.seed(config.seed + rank)
+    config.local_rank, config.gpus_num, config.group = device.index, world, None
+    config.batch_size = batch * world
+    config.host_sync_lag = 2
+    config.print_interval = 10 ** 9
+    config.use_ema_model = getattr(config, 'use_ema_model', False)
+    model = config.model.to(device)
+    optimizer, _ = utils.build_optimizer(config, model)
+    scheduler = utils.Scheduler(config, optimizer)
+    model, config.ema_model, config.scaler = utils.build_training_mode(config, model)
+    data = config.train_collater([config.train_dataset[rank * batch + i] for i in range(batch)])
+    data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}
+    iters_per_epoch = max(1, len(config.train_dataset) // config.batch_size)
+    logger = logging.getLogger('saicv_bench')
+    logger.addHandler(logging.NullHandler())
+    logger.propagate = False
+    fn = scripts.train_detection if name == 'resnet50_detr_config' else interactive_segmentation_scripts.train_sam_segmentation
+    state = {'loss': float('nan')}
+
+    def run(k):
+        state['loss'] = fn(DeviceLoader([data] * k, config.batch_size, iters_per_epoch), model, config.train_criterion,
+                           optimizer, scheduler, 1, logger, config)
+
+    info = {'config_file': cfg_path, 'loop': loop_name, 'optimizer': config.optimizer[0], 'param_groups': len(optimizer.param_groups)}
+    return run, model, config.scaler, state, info, batch, size
+
+
 def step_workload(name, args, world, rank, device):
     """SAM image encoder / DETR: a hand-written step (the reference has no encoder-only loop in scope; DETR's loop
     does a host-side Hungarian assignment per step)."""
@@ -242,7 +286,10 @@ def measure(name, args, world, rank, device, use_graph, primary):
     import torch
     import torch.distributed as dist
     from simpleaicv_pytorch_training_examples_amd import ops
-    if name in CONFIG_DIR:
+    if name in LOOP_MODELS:
+        use_graph = False
+        run, model, scaler, state, info, batch, size = loop_workload(name, args, world, rank, device)
+    elif name in CONFIG_DIR:
         run, model, scaler, state, info, batch, size = classification_workload(name, args, world, rank, device, use_graph)
     else:
         use_graph = False
@@ -285,14 +332,14 @@ def measure(name, args, world, rank, device, use_graph, primary):
                    'model': name, 'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}',
                    'final_loss': round(float(state['loss']), 4), 'loss_scale': scaler.get_scale() if scaler is not None else None,
                    'step_graph': bool(use_graph), 'host_ms_per_step': round(statistics.median(host) / args.steps * 1e3, 3), **info},
-        'model_mfma_frac': round(TRAIN_GFLOP_PER_IMG.get(name, 0) * value / world / 1e3 / PEAK_BF16_TFLOPS, 4),
+        'model_mfma_frac': round((LOOP_MODELS[name][3] if name in LOOP_MODELS else TRAIN_GFLOP_PER_IMG.get(name, 0)) * value / world / 1e3 / PEAK_BF16_TFLOPS, 4),
         'rccl_ranks': dist.get_world_size() if world > 1 else 1,
         'allreduce_bytes_per_step': int(sum(b['end'] - b['start'] for b in model.buckets) * 4) if (world > 1 and hasattr(model, 'buckets')) else 0,
         'gradient_bytes': int(arena.total * 4) if arena is not None else None,
     }
     # ---- price the dominant kernel: an eager pass of the same steps with HIP events on the launch stream
     if not args.no_kernel_timer:
-        cfg_graph = name in CONFIG_DIR and use_graph
+        cfg_graph = name in CONFIG_DIR and name not in LOOP_MODELS and use_graph
         ops.KernelTimer.only = None if args.kernel_breakdown else {'igemm_nt'}
         ops.KernelTimer.records = []
         k = min(args.steps, 5)
@@ -473,7 +520,7 @@ def worker(args):
         try:
             return measure(name, args, world, rank, device, want_graph, primary)
         except Exception as e:      # noqa: BLE001
-            if not want_graph or name not in CONFIG_DIR:
+            if not want_graph or name not in CONFIG_DIR or name in LOOP_MODELS:
                 raise
             print(f'[bench] step graph failed for {name} ({type(e).__name__}: {e}); falling back to eager launches', file=sys.stderr)
             torch.cuda.synchronize()
