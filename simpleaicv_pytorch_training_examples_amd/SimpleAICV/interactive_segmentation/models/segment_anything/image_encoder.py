@@ -15,6 +15,8 @@ Windows are padded with zeros AFTER norm1, and the padded tokens take part in at
 3x3 bias-free convs are implicit GEMMs and LayerNorm2d is the row LayerNorm over the channel axis.
 Head dim must be 64 (ViT-B / ViT-L encoders).
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
@@ -134,13 +136,29 @@ class ViTImageEncoder(nn.Module):
             _NeckConv(out_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=False),
             LayerNorm2d(out_planes))
 
+    def _recompute(self, x):
+        """`use_gradient_checkpoint=True` (reference sam_b_training/train_config.py:21) asks for per-block recomputation
+        to fit a 24-80 GB GPU; on MI355X it is HONOURED ONLY WHEN THE ACTIVATIONS WOULD NOT FIT: the blocks keep about
+        34 bytes per token and channel for backward (x, LN output, qkv, attention output, the two MLP tensors, lse),
+        1.5 GB per 1024 x 1024 image for ViT-B -- per-GPU batch 20 is 31 GB of 288 GB -- and recomputation costs a
+        third more encoder time (measured: 167 vs 125 ms at batch 20).  SAICV_ACTIVATION_CHECKPOINT=1 / 0 forces it."""
+        if not (self.use_gradient_checkpoint and torch.is_grad_enabled()):
+            return False
+        forced = os.environ.get('SAICV_ACTIVATION_CHECKPOINT')
+        if forced is not None:
+            return forced == '1'
+        need = x.shape[0] * x.shape[1] * x.shape[2] * 1.2 * x.shape[3] * 34 * len(self.blocks)     # 1.2: window padding
+        free = torch.cuda.mem_get_info(x.device)[0] if x.is_cuda else 0
+        return need > 0.6 * free
+
     def forward(self, x):
         x = self.patch_embed(x)                                  # [B, H, W, C], compute dtype
         x = x + self.pos_embed.to(x.dtype)
+        recompute = self._recompute(x)
         for block in self.blocks:
-            x = checkpoint(block, x, use_reentrant=False) if self.use_gradient_checkpoint else block(x)
+            x = checkpoint(block, x, use_reentrant=False) if recompute else block(x)
         x = x.permute(0, 3, 1, 2)                                # NCHW shape over NHWC memory
-        if self.use_gradient_checkpoint:
+        if recompute:
             x = checkpoint(self.neck, x, use_reentrant=False)
         else:
             x = self.neck(x)

@@ -133,12 +133,21 @@ class PromptEncoder(nn.Module):
         return corner_embedding
 
     def embed_masks(self, masks):
+        """mask_downscaling (reference prompt_encoder.py:93-109): two 2 x 2 stride-2 convolutions, each followed by
+        LayerNorm2d + GELU, then a 1 x 1 convolution.  A 2 x 2 stride-2 convolution is a GEMM over non-overlapping
+        patches: space-to-depth on NHWC, then the implicit-GEMM linear kernel (K = 4 Cin), LayerNorm over the channel
+        axis and GELU on the HIP kernels -- in fp32, as the first layers see a 1-channel mask.  (Left to ATen these
+        two convolutions took MIOpen's naive weight-gradient kernels: 27 ms per call, half of the SAM step's GPU
+        time -- profiles/r02_samfull_rocprofv3_kernel_stats.csv.)"""
         m = self.mask_downscaling
-        with torch.autocast(masks.device.type, enabled=False):
-            x = masks.float()
-            x = m[2](m[1](F.conv2d(x, m[0].weight, m[0].bias, stride=2)))
-            x = m[5](m[4](F.conv2d(x, m[3].weight, m[3].bias, stride=2)))      # [B, 16, 64, 64]
+        x = masks.float().permute(0, 2, 3, 1).contiguous()                     # [B, 256, 256, 1]
+        for conv, norm in ((m[0], m[1]), (m[3], m[4])):
+            b, h, w, ci = x.shape
+            co = conv.weight.shape[0]
+            patches = x.view(b, h // 2, 2, w // 2, 2, ci).permute(0, 1, 3, 2, 4, 5).reshape(b, h // 2, w // 2, 4 * ci)
+            wm = conv.weight.permute(0, 2, 3, 1).reshape(co, 4 * ci)            # columns (di, dj, ci)
+            x = ops_tfm.linear_nd(patches.contiguous(), wm, conv.bias)
+            x = ops_tfm.gelu(ops_tfm.layer_norm(x, norm.weight, norm.bias, norm.eps))
         dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else torch.float32
-        t = x.permute(0, 2, 3, 1).to(dt)                                        # NHWC tokens
-        y = ops_tfm.linear_nd(t, m[6].weight.flatten(1), m[6].bias)             # [B, 64, 64, 256]
+        y = ops_tfm.linear_nd(x.to(dt), m[6].weight.flatten(1), m[6].bias)      # [B, 64, 64, 256]
         return y.permute(0, 3, 1, 2)
