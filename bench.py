@@ -334,6 +334,8 @@ def measure(name, args, world, rank, device, use_graph, primary):
                    'step_graph': bool(use_graph), 'host_ms_per_step': round(statistics.median(host) / args.steps * 1e3, 3), **info},
         'model_mfma_frac': round((LOOP_MODELS[name][3] if name in LOOP_MODELS else TRAIN_GFLOP_PER_IMG.get(name, 0)) * value / world / 1e3 / PEAK_BF16_TFLOPS, 4),
         'rccl_ranks': dist.get_world_size() if world > 1 else 1,
+        'gradient_allreduce': ('saicv_comm (library RCCL communicator)' if getattr(model, 'comm', None) is not None
+                               else 'torch.distributed') if world > 1 else None,
         'allreduce_bytes_per_step': int(sum(b['end'] - b['start'] for b in model.buckets) * 4) if (world > 1 and hasattr(model, 'buckets')) else 0,
         'gradient_bytes': int(arena.total * 4) if arena is not None else None,
     }

@@ -263,6 +263,26 @@ int saicv_attention_stream_fwd(int dtype, int D, const saicv_attn_desc* desc, vo
 /* backward = dQ pass (also writes dsum and d_rel_*) followed by the dK/dV pass */
 int saicv_attention_stream_bwd(int dtype, int D, const saicv_attn_desc* desc, void* stream);
 
+/* ---- gradient all-reduce over RCCL / xGMI ------------------------------------------------
+ * The reducer of nn.parallel.DistributedDataParallel (reference tools/train_classification_model.py:217-227 wraps the
+ * model; tools/scripts.py:183-226 relies on gradients being averaged when backward() returns): contiguous ranges of the
+ * flat fp32 gradient arena are averaged over the ranks on a communication stream while backward keeps running.
+ * One process per GPU, one communicator per process.  Bootstrap: rank 0 calls saicv_comm_unique_id and hands the 128
+ * bytes to the other ranks out of band (the host mirror uses the torch.distributed store); every rank then calls
+ * saicv_comm_create (collective).  All other calls only enqueue work; RCCL is resolved with dlopen at first use. */
+typedef struct saicv_comm saicv_comm;
+int saicv_comm_unique_id(void* id128);
+int saicv_comm_create(const void* id128, int world, int rank, saicv_comm** out);
+/* grads[0..n) (device, fp32) <- sum or mean over the ranks, in place, on the communication stream, ordered after
+ * everything enqueued on producer_stream so far (the stream whose kernels wrote this bucket). */
+int saicv_comm_allreduce_bucket(saicv_comm* c, float* grads, size_t n, int average, void* producer_stream);
+/* buf[0..bytes) <- root's copy, on `stream` itself (constructor-time parameter / per-forward buffer broadcast). */
+int saicv_comm_broadcast(saicv_comm* c, void* buf, size_t bytes, int root, void* stream);
+/* consumer_stream waits for every bucket enqueued so far (before the optimizer reads the gradients). */
+int saicv_comm_join(saicv_comm* c, void* consumer_stream);
+int saicv_comm_stats(const saicv_comm* c, int* world, int* rank, unsigned long long* buckets, unsigned long long* bytes);
+int saicv_comm_destroy(saicv_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'scripts'))
 
 from simpleaicv_pytorch_training_examples_amd import _lib, ops  # noqa: E402
 from simpleaicv_pytorch_training_examples_amd._lib import check, lib, ptr  # noqa: E402
@@ -23,6 +24,28 @@ R50 = [(8, 64, 7, 2, 224), (64, 64, 1, 1, 56), (64, 64, 3, 1, 56), (64, 256, 1, 
 
 
 ITERS = int(os.environ.get('KB_ITERS', '10'))
+PEAK_F, PEAK_B = 2.5e15, 8.0e12        # dense bf16 MFMA, HBM3E (MI355X_MICROARCH.md)
+
+
+def multiplicity():
+    """How many times each distinct shape occurs in ResNet-50 (stem counted as its 8-channel packed form)."""
+    from r50_roofline import resnet50_convs
+    n = {}
+    for ci, co, k, s, h in resnet50_convs():
+        key = (8 if ci == 3 else ci, co, k, s, h)
+        n[key] = n.get(key, 0) + 1
+    return n
+
+
+def bounds(batch, ci, co, k, s, h, oh):
+    """Lower bound (s) of each leg = max(flops / MFMA peak, algorithmic bytes / HBM peak); scripts/r50_roofline.py."""
+    cin = 3 if ci == 8 else ci
+    flops = 2.0 * batch * oh * oh * co * cin * k * k
+    xin = batch * (oh * oh if (k == 1 and s == 2) else h * h) * ci * 2
+    yout = batch * oh * oh * co * 2
+    w = co * ci * k * k
+    by = {'fwd': xin + w * 2 + yout, 'dgrad': yout + w * 2 + batch * h * h * ci * 2, 'wgrad': xin + yout + w * 4}
+    return {leg: max(flops / PEAK_F, b / PEAK_B) for leg, b in by.items()}
 
 
 def timeit(fn, iters=None, warm=2):
@@ -46,6 +69,9 @@ def main():
     L = lib()
     st = _lib.stream()
     tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0, 'flops': 0.0}
+    mult = multiplicity()
+    model = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
+    model_bound = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
     only = [int(i) for i in os.environ['KB_ONLY'].split(',')] if os.environ.get('KB_ONLY') else None
     for idx, (ci, co, k, s, h) in enumerate(R50):
         if only is not None and idx not in only:
@@ -70,6 +96,15 @@ def main():
                'fwd_us': round(t_f * 1e6, 1), 'fwd_tflops': round(flops / t_f / 1e12, 1),
                'dgrad_us': round(t_d * 1e6, 1), 'dgrad_tflops': round(flops / t_d / 1e12, 1) if t_d else None,
                'wgrad_us': round(t_w * 1e6, 1), 'wgrad_tflops': round(flops / t_w / 1e12, 1)}
+        lb = bounds(batch, ci, co, k, s, h, d.OH)
+        n = mult.get((ci, co, k, s, h), 1)
+        rec['count'] = n
+        for leg, t in (('fwd', t_f), ('dgrad', t_d), ('wgrad', t_w)):
+            if t:
+                rec[leg + '_bound_us'] = round(lb[leg] * 1e6, 1)
+                rec[leg + '_frac_of_bound'] = round(lb[leg] / t, 3)
+                model[leg] += n * t
+                model_bound[leg] += n * lb[leg]
         print(json.dumps(rec), flush=True)
         tot['fwd'] += t_f
         tot['dgrad'] += t_d
@@ -77,6 +112,9 @@ def main():
         tot['flops'] += flops
         del x, wf, wd, y, dy, dx, dw
     print(json.dumps({'distinct_shape_totals_ms': {k: round(v * 1e3, 3) for k, v in tot.items() if k != 'flops'}}))
+    print(json.dumps({'resnet50_all_53_convs_ms': {k: round(v * 1e3, 3) for k, v in model.items()},
+                      'lower_bound_ms': {k: round(v * 1e3, 3) for k, v in model_bound.items()},
+                      'frac_of_bound': {k: round(model_bound[k] / v, 3) for k, v in model.items() if v}}))
 
     if os.environ.get('KB_CONV_ONLY'):
         return

@@ -97,6 +97,13 @@ SIGNATURES = {
     'saicv_upsample4_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_mask_loss_stats_up4': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
     'saicv_mask_loss_grad_up4': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
+    'saicv_comm_unique_id': (c_int, [_P]),
+    'saicv_comm_create': (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
+    'saicv_comm_allreduce_bucket': (c_int, [_P, _P, c_size_t, c_int, _P]),
+    'saicv_comm_broadcast': (c_int, [_P, _P, c_size_t, c_int, _P]),
+    'saicv_comm_join': (c_int, [_P, _P]),
+    'saicv_comm_stats': (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(ctypes.c_ulonglong), POINTER(ctypes.c_ulonglong)]),
+    'saicv_comm_destroy': (c_int, [_P]),
     'saicv_attention_stream_fwd': (c_int, [c_int, c_int, _PA, _P]),
     'saicv_attention_stream_bwd': (c_int, [c_int, c_int, _PA, _P]),
 }

@@ -14,15 +14,17 @@ Design (MI355X-first, one process per GPU):
     their strides (as_strided views), so state_dict()/load_state_dict() are unchanged;
   * gradient buckets are contiguous slices of the gradient arena in reverse registration
     order (the order backward produces them); a post-accumulate hook counts parameters and,
-    when a bucket is complete, enqueues one torch.distributed all_reduce (backend "nccl" ==
-    RCCL over xGMI) asynchronously -- ProcessGroupNCCL runs it on its own HIP stream, ordered
-    after the producing kernels by an event, so it overlaps the rest of backward;
+    when a bucket is complete, enqueues one all-reduce on the library's own RCCL communicator
+    (`saicv_comm_allreduce_bucket`, csrc/comm.hip: communication stream ordered after the
+    producing kernels by an event, so it overlaps the rest of backward); process groups on another
+    backend (gloo in the CPU tests) go through torch.distributed instead;
   * xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce moves 1.75x the bucket
     over one link per GPU, so buckets are large (default 48 MiB) and only the LAST bucket to
     complete (stem + first stage) is small (4 MiB) to shorten the exposed tail;
   * `no_sync()` only suppresses the enqueue; gradients keep accumulating in the arena.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -461,6 +463,67 @@ class StepGraph:
 
 
 # ------------------------------------------------------------------------------ DDP engine
+class NativeComm:
+    """The library's RCCL communicator (include/saicv_hip.h, saicv_comm_*) for one process group member.
+
+    Bootstrap: rank 0 draws the RCCL unique id and publishes it in the torch.distributed store (the rendezvous the
+    reference's launcher already set up: tools/train_classification_model.py:76-84, `init_process_group`), the other
+    ranks read it there; `saicv_comm_create` is then the collective every rank joins.  torch.distributed carries no
+    gradient traffic afterwards."""
+
+    _serial = 0
+
+    def __init__(self, world, rank):
+        import ctypes
+        L = lib()
+        key = f'saicv_comm_id_{NativeComm._serial}'
+        NativeComm._serial += 1
+        buf = ctypes.create_string_buffer(128)
+        if world == 1 or not (dist.is_available() and dist.is_initialized()):
+            check(L.saicv_comm_unique_id(buf), 'comm_unique_id')
+        else:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                check(L.saicv_comm_unique_id(buf), 'comm_unique_id')
+                store.set(key, buf.raw)
+            else:
+                buf.raw = bytes(store.get(key))            # blocks until rank 0 has published it
+        handle = ctypes.c_void_p()
+        check(L.saicv_comm_create(buf, world, rank, ctypes.byref(handle)), 'comm_create')
+        self.handle, self.world, self.rank = handle, world, rank
+
+    def allreduce_bucket(self, view, producer_stream, average=True):
+        check(lib().saicv_comm_allreduce_bucket(self.handle, ptr(view), view.numel(), int(average),
+                                                producer_stream.cuda_stream), 'comm_allreduce_bucket')
+
+    def broadcast(self, t, root=0):
+        check(lib().saicv_comm_broadcast(self.handle, ptr(t), t.numel() * t.element_size(), root, _lib.stream()),
+              'comm_broadcast')
+
+    def join(self):
+        check(lib().saicv_comm_join(self.handle, _lib.stream()), 'comm_join')
+
+    def stats(self):
+        import ctypes
+        w, r = ctypes.c_int(), ctypes.c_int()
+        nb, by = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        check(lib().saicv_comm_stats(self.handle, ctypes.byref(w), ctypes.byref(r), ctypes.byref(nb), ctypes.byref(by)),
+              'comm_stats')
+        return {'world': w.value, 'rank': r.value, 'buckets': nb.value, 'bytes': by.value}
+
+    def close(self):
+        if self.handle:
+            lib().saicv_comm_destroy(self.handle)
+            self.handle = None
+
+    def self_check(self, device):
+        """One small all-reduce with a known answer: sum over ranks of (rank + 1)."""
+        t = torch.full((1024,), float(self.rank + 1), dtype=torch.float32, device=device)
+        self.allreduce_bucket(t, torch.cuda.current_stream(), average=False)
+        self.join()
+        return bool((t == self.world * (self.world + 1) / 2).all().item())
+
+
 class DistributedDataParallel(torch.nn.Module):
     """Drop-in for nn.parallel.DistributedDataParallel on the flat gradient arena.
 
@@ -477,7 +540,11 @@ class DistributedDataParallel(torch.nn.Module):
         self.find_unused_parameters = find_unused_parameters
         self.broadcast_buffers = broadcast_buffers
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # SAICV_DDP_FORCE_SYNC=1: run the whole bucket / all-reduce machinery in a world of one (a mean over one rank is
+        # the identity): how the RCCL path is exercised end to end on a single-GPU box (tests/test_gpu_ddp.py)
+        self._active = self.world > 1 or os.environ.get('SAICV_DDP_FORCE_SYNC') == '1'
         self.arena = _arena_of(module)
+        self.comm = self._native_comm(process_group)
         self._sync = True
         self._works = []
         self._next_bucket = 0           # buckets are launched in list order on every rank
@@ -485,16 +552,51 @@ class DistributedDataParallel(torch.nn.Module):
         self._done = True               # no backward with pending collectives
         self._build_buckets(int(bucket_cap_mb * 2 ** 20 // 4), int(last_bucket_cap_mb * 2 ** 20 // 4))
         self._flatten_buffers()
-        if self.world > 1:
+        if self._active:
             # identical start on every rank (DDP ctor broadcast, C3 in SURVEY.md section 2.4)
-            dist.broadcast(self.arena.flat_param, 0, group=process_group)
+            self._broadcast(self.arena.flat_param)
             if self.flat_buffers is not None:
-                dist.broadcast(self.flat_buffers, 0, group=process_group)
+                self._broadcast(self.flat_buffers)
             for b in self.module.buffers():
                 if not b.dtype.is_floating_point:
-                    dist.broadcast(b, 0, group=process_group)
+                    self._broadcast(b)
             ops.bump_weights_epoch()
         self.arena.listeners.append(self._on_grad_complete)
+
+    def _native_comm(self, process_group):
+        """The library's own RCCL communicator when the job runs on RCCL over the default group; None (torch.distributed
+        carries the collectives) for gloo groups, sub-groups, or SAICV_NATIVE_COMM=0.  Every rank must reach the same
+        decision: the outcome of creation + a known-answer all-reduce is agreed on with one MIN all-reduce."""
+        if not self._active or os.environ.get('SAICV_NATIVE_COMM', '1') == '0' or process_group is not None:
+            return None
+        if not (dist.is_available() and dist.is_initialized()):
+            if self.world == 1 and torch.cuda.is_available():
+                comm = NativeComm(1, 0)
+                return comm if comm.self_check(self.arena.flat_grad.device) else None
+            return None
+        if dist.get_backend() != 'nccl':
+            return None
+        comm, ok = None, 1
+        try:
+            comm = NativeComm(self.world, dist.get_rank())
+            ok = int(comm.self_check(self.arena.flat_grad.device))
+        except Exception as e:                                     # noqa: BLE001 -- any failure means "use torch.distributed"
+            ok = 0
+            if dist.get_rank() == 0:
+                print(f'[saicv] native RCCL communicator unavailable ({e}); gradients go through torch.distributed')
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.arena.flat_grad.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            if comm is not None:
+                comm.close()
+            return None
+        return comm
+
+    def _broadcast(self, t):
+        if self.comm is not None:
+            self.comm.broadcast(t, 0)
+        elif self.world > 1:
+            dist.broadcast(t, 0, group=self.process_group)
 
     # buckets are contiguous arena ranges; walking parameters in REVERSE registration order
     def _build_buckets(self, cap, last_cap):
@@ -525,7 +627,7 @@ class DistributedDataParallel(torch.nn.Module):
     def _on_grad_complete(self, i):
         """Arena listener: parameter i's gradient of the running backward is complete (fires once per
         backward per parameter, after its last use).  Runs inside autograd's backward."""
-        if self.world == 1:
+        if not self._active:
             return
         if not self._callback_queued:
             # the reference loop (tools/scripts.py:183-226) calls optimizer.step() right after backward():
@@ -559,6 +661,20 @@ class DistributedDataParallel(torch.nn.Module):
 
     def _reduce_bucket(self, b):
         view = self.arena.flat_grad[b['start']:b['end']]
+        if self.comm is not None:
+            # weight gradients may be produced on the side stream, BatchNorm / LayerNorm / bias gradients on the compute
+            # stream: the communication stream is ordered after BOTH by recording its event on the side stream once
+            # that has waited for the compute stream -- the compute stream itself never waits here
+            side = ops.side_stream_in_use()
+            producer = torch.cuda.current_stream()
+            if side is not None:
+                side.wait_stream(producer)
+                producer = side
+            self.comm.allreduce_bucket(view, producer)
+            self._works.append((None, None))
+            return
+        if self.world == 1:
+            return
         backend = dist.get_backend(self.process_group)
         if backend == 'nccl':
             side = ops.side_stream_in_use()
@@ -583,10 +699,13 @@ class DistributedDataParallel(torch.nn.Module):
         Runs by itself as autograd's end-of-backward callback; calling it again afterwards is a no-op."""
         if self._done:
             return
-        if self.world > 1 and self._sync:
+        if self._active and self._sync:
             self._launch_ready_buckets(force=True)
+        if self.comm is not None and self._works:
+            self.comm.join()
         for w, view in self._works:
-            w.wait()
+            if w is not None:
+                w.wait()
             if view is not None:
                 view.div_(self.world)
         self._works = []
@@ -637,6 +756,6 @@ class DistributedDataParallel(torch.nn.Module):
                 o += ((b.numel() + 3) // 4) * 4
 
     def forward(self, *args, **kwargs):
-        if self.world > 1 and self.broadcast_buffers and self.module.training and self.flat_buffers is not None:
-            dist.broadcast(self.flat_buffers, 0, group=self.process_group)
+        if self._active and self.broadcast_buffers and self.module.training and self.flat_buffers is not None:
+            self._broadcast(self.flat_buffers)
         return self.module(*args, **kwargs)

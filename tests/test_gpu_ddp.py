@@ -172,6 +172,85 @@ def test_rccl_world2_bucketed_allreduce_on_two_gpus():
     assert torch.equal(p0, p1)
 
 
+def _worker_native(port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', SAICV_DDP_FORCE_SYNC='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from simpleaicv_pytorch_training_examples_amd import engine
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones, losses
+    out = {}
+    # the C-ABI by itself: a bucket written by a kernel on the compute stream, reduced on the communication stream
+    comm = engine.NativeComm(1, 0)
+    a = torch.randn(1 << 20, device='cuda')
+    b = a * 3.0                                        # producer kernel on the current stream
+    comm.allreduce_bucket(b, torch.cuda.current_stream(), average=True)
+    comm.join()
+    c = b + 1.0                                        # consumer on the current stream, ordered by join()
+    torch.cuda.synchronize()
+    out['raw_ok'] = bool(torch.equal(c, a * 3.0 + 1.0))
+    out['raw_stats'] = comm.stats()
+    comm.close()
+
+    def train(wrap):
+        torch.manual_seed(3)
+        model = backbones.resnet18cifar(num_classes=10).cuda()
+        opt = engine.SGD(model, [{'params': list(model.parameters()), 'weight_decay': 1e-4}], lr=0.05, momentum=0.9)
+        net = engine.DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=0.5, last_bucket_cap_mb=0.05) if wrap else model
+        net.train()
+        crit = losses.CELoss()
+        g = torch.Generator().manual_seed(11)
+        losses_ = []
+        for _ in range(4):
+            x = torch.randn(16, 3, 32, 32, generator=g).cuda()
+            y = torch.randint(0, 10, (16,), generator=g).cuda()
+            opt.zero_grad()
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                loss = crit(net(x), y)
+            loss.backward()          # the reference loop: no explicit gradient sync call
+            opt.step()
+            losses_.append(float(loss))
+        torch.cuda.synchronize()
+        return net, losses_, engine._arena_of(model).flat_param.detach().clone()
+
+    ddp, l_ddp, p_ddp = train(True)
+    out['native'] = ddp.comm is not None
+    out['buckets'] = len(ddp.buckets)
+    out['stats'] = ddp.comm.stats() if ddp.comm is not None else None
+    _, l_ref, p_ref = train(False)
+    _, l_ref2, p_ref2 = train(False)
+    out['loss_ddp'], out['loss_ref'] = l_ddp, l_ref
+    out['param_err'] = float((p_ddp - p_ref).abs().max() / p_ref.abs().max())
+    # run-to-run spread of the unwrapped model itself (fp32 atomics order in the weight-gradient kernels, amplified
+    # by four SGD steps at batch 16)
+    out['noise'] = float((p_ref2 - p_ref).abs().max() / p_ref.abs().max())
+    out['loss_noise'] = max(abs(a - b) for a, b in zip(l_ref, l_ref2))
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_native_rccl_communicator_in_a_world_of_one():
+    """libsaicv_hip's own RCCL side (saicv_comm_*, csrc/comm.hip) end to end on one GPU: unique id -> communicator ->
+    bucketed all-reduce on the communication stream -> join, driven by the engine's gradient hooks from the reference's
+    loop shape (backward(); step()).  A mean over one rank is the identity, so training must match the unwrapped model
+    up to the order of the fp32 atomics in the weight-gradient kernels."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_native, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=500)
+    p.join(120)
+    assert p.exitcode == 0
+    assert out['raw_ok'] and out['raw_stats']['buckets'] == 1 and out['raw_stats']['bytes'] == 4 << 20
+    assert out['native'], 'the DDP wrapper did not pick the native communicator on an RCCL process group'
+    assert out['buckets'] >= 3
+    assert out['stats']['buckets'] == 1 + 4 * out['buckets']          # self-check + every bucket of every step
+    assert out['loss_ddp'][0] == out['loss_ref'][0]                   # same start: the first forward is bit-identical
+    assert out['param_err'] <= max(3 * out['noise'], 1e-6), out
+    assert max(abs(a - b) for a, b in zip(out['loss_ddp'], out['loss_ref'])) <= max(3 * out['loss_noise'], 1e-5), out
+
+
 def test_bench_spawns_the_ranks_it_is_asked_for():
     """`python bench.py --gpus N` starts N ranks itself and reports n_gpus = ranks that joined (needs N GPUs);
     asking for more GPUs than are visible fails loudly instead of reporting a 1-GPU number."""
