@@ -93,6 +93,28 @@ int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, floa
 /* conv data-gradient that adds an existing gradient (residual branch) in its epilogue */
 int saicv_conv2d_dgrad_add(const saicv_conv_desc* d, const void* dy, const void* wd, const void* addend, void* dx,
                            void* stream);
+/* Data gradient of a conv inside a residual network, with what the neighbouring BatchNorm / shortcut nodes need folded
+ * into its epilogue (every field optional; all tensors share dx's [N*H*W][C] coordinates):
+ *   dx = dgrad(dy, wd) + addend * [addend_gate bit]      -- the shortcut gradient behind the block's final ReLU
+ *        (resnet.py:94-95,152-153: `x = x + inputs; x = self.relu(x)`); addend_gate is the mask saicv_bn_act_fwd wrote,
+ *        so the masked copy `dres` of saicv_bn_act_bwd is never materialised;
+ *   part_g[row][c] = sum g, part_gx[row][c] = sum g * (bn_y - bn_mean) * bn_invstd,  g = dx * [bn_mask bit]
+ *        -- the reduction pass of the BatchNorm (+ReLU) that produced this conv's input, whose backward receives dx as
+ *        its dz (`native_batch_norm_backward`); rows = saicv_conv2d_dgrad_stat_rows(d), fed to
+ *        saicv_bn_act_bwd_from_partials.  bn_mask NULL = no ReLU between that BatchNorm and this conv. */
+typedef struct saicv_dgrad_fuse {
+    const void* addend;
+    const void* addend_gate;
+    const void* bn_y;
+    const void* bn_mask;
+    const float* bn_mean;
+    const float* bn_invstd;
+    float* part_g;
+    float* part_gx;
+} saicv_dgrad_fuse;
+int saicv_conv2d_dgrad_stat_rows(const saicv_conv_desc* d);
+int saicv_conv2d_dgrad_fused(const saicv_conv_desc* d, const void* dy, const void* wd, const saicv_dgrad_fuse* f, void* dx,
+                             void* stream);
 /* out[r][:] = x[r][:] * scale[r / rows_per_scale] */
 int saicv_row_scale(int dtype, const void* x, const float* scale, void* out, size_t rows, int row_len,
                     int rows_per_scale, void* stream);
@@ -126,6 +148,13 @@ int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* relu_
                      const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
                      float* dbeta, size_t M, int C, int relu, int accumulate, float* ws,
                      void* stream);
+
+/* the same with the reduction pass already done by saicv_conv2d_dgrad_fused (part_g / part_gx, `rows` rows of C);
+ * ws as for saicv_bn_act_bwd */
+int saicv_bn_act_bwd_from_partials(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,
+                                   const float* mean, const float* invstd, const float* part_g, const float* part_gx,
+                                   int rows, void* dy, void* dres, float* dgamma, float* dbeta, size_t M, int C, int relu,
+                                   int accumulate, float* ws, void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------- */
 /* nn.MaxPool2d(3,2,1), resnet.py:184; idx = window position of the first maximum */

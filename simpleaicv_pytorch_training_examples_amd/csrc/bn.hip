@@ -455,7 +455,8 @@ size_t bn_bwd_ws_floats(size_t M, int C, int dtype) {
 template <typename T>
 static int bn_bwd_t(const void* dz, const void* z, const uint8_t* mask, const void* y, const float* gamma,
                     const float* mean, const float* invstd, void* dy, void* dres, float* dgamma,
-                    float* dbeta, size_t M, int C, int relu, int accumulate, float* ws, hipStream_t st) {
+                    float* dbeta, size_t M, int C, int relu, int accumulate, float* ws, hipStream_t st,
+                    const float* ext_g = nullptr, const float* ext_gx = nullptr, int ext_rows = 0) {
     constexpr int N = Chunk<T>::N;
     const int slabs = bn_bwd_slabs(M, C, sizeof(T) == 2 ? SAICV_DTYPE_BF16 : SAICV_DTYPE_F32);
     const int rows_per = (int)((M + slabs - 1) / slabs);
@@ -465,12 +466,15 @@ static int bn_bwd_t(const void* dz, const void* z, const uint8_t* mask, const vo
     float* ws2 = ws + (size_t)2 * slabs * C;
     float* coef = ws2 + (size_t)64 * C;
     const T* dzz = (const T*)dz; const T* zz = (const T*)z; const T* yy = (const T*)y;
-    if (relu)
+    const float* a = pg; const float* b = pgx;
+    int P0 = used;
+    if (ext_g != nullptr) {          // the partial sums came out of the producing data-gradient's epilogue: no reduce pass
+        a = ext_g; b = ext_gx; P0 = ext_rows;
+    } else if (relu)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(used), dim3(256), 0, st, dzz, zz, mask, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(used), dim3(256), 0, st, dzz, zz, mask, yy, mean, invstd, (int)M, C, rows_per, pg, pgx);
-    const float* a = pg; const float* b = pgx;
-    const int P = reduce_partials(a, b, used, C, ws2, st);
+    const int P = reduce_partials(a, b, P0, C, ws2, st);
     hipLaunchKernelGGL(P <= 32 ? bn_finalize_bwd_kernel<4> : bn_finalize_bwd_kernel<16>, dim3((C + 63) / 64), dim3(P <= 32 ? 256 : 1024), 0, st, a, b, P, C,
                        (float)M, gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, accumulate);
     const size_t nchunks = M * (size_t)C / N;
@@ -483,6 +487,22 @@ static int bn_bwd_t(const void* dz, const void* z, const uint8_t* mask, const vo
     else      { if (dres) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
     return check_launch("bn_bwd");
+}
+
+int bn_bwd_from_partials(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,
+                         const float* mean, const float* invstd, const float* part_g, const float* part_gx, int rows,
+                         void* dy, void* dres, float* dgamma, float* dbeta, size_t M, int C, int relu, int accumulate,
+                         float* ws, hipStream_t st) {
+    const uint8_t* mask = (const uint8_t*)relu_mask;
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0, "bn_bwd_from_partials: C=%d must be a multiple of %d", C, n);
+    SAICV_REQUIRE(part_g != nullptr && part_gx != nullptr && rows > 0, "bn_bwd_from_partials: partial sums missing");
+    SAICV_REQUIRE(!relu || mask != nullptr, "bn_bwd_from_partials: relu needs the sign mask");
+    if (dtype == SAICV_DTYPE_BF16)
+        return bn_bwd_t<bf16_t>(dz, nullptr, mask, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, st,
+                                part_g, part_gx, rows);
+    return bn_bwd_t<float>(dz, nullptr, mask, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws, st,
+                           part_g, part_gx, rows);
 }
 
 int bn_bwd(int dtype, const void* dz, const void* z, const void* relu_mask, const void* y, const float* gamma,

@@ -38,6 +38,8 @@ int bn_act_fwd(int, const void*, const void*, void*, const float*, const float*,
 size_t bn_bwd_ws_floats(size_t, int, int);
 int bn_bwd(int, const void*, const void*, const void*, const void*, const float*, const float*, const float*, void*,
            void*, float*, float*, size_t, int, int, int, float*, hipStream_t);
+int bn_bwd_from_partials(int, const void*, const void*, const void*, const float*, const float*, const float*, const float*,
+                         const float*, int, void*, void*, float*, float*, size_t, int, int, int, float*, hipStream_t);
 int maxpool_fwd(int, const void*, void*, uint8_t*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int maxpool_bwd(int, const void*, const uint8_t*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int avgpool_fwd(int, const void*, void*, int, int, int, hipStream_t);
@@ -174,6 +176,34 @@ int saicv_conv2d_dgrad_add(const saicv_conv_desc* d, const void* dy, const void*
                     d->R, d->S, d->stride, d->pad, M, d->C, d->R * d->S * d->K, d->C, 0, S(stream),
                     addend ? &ex : nullptr);
 }
+int saicv_conv2d_dgrad_stat_rows(const saicv_conv_desc* d) {
+    if (!d) return -1;
+    return conv_bwd_stat_rows(d->N * d->H * d->W, d->H, d->W, d->C, d->R * d->S * d->K, d->stride, d->dtype);
+}
+int saicv_conv2d_dgrad_fused(const saicv_conv_desc* d, const void* dy, const void* wd, const saicv_dgrad_fuse* f, void* dx,
+                             void* stream) {
+    if (check_desc(d, "saicv_conv2d_dgrad_fused")) return -1;
+    if (!f) { set_error("saicv_conv2d_dgrad_fused: null fusion descriptor"); return -1; }
+    const int M = d->N * d->H * d->W;
+    EpiExtra ex;
+    ex.addend = f->addend;
+    ex.addend_gate = static_cast<const uint8_t*>(f->addend_gate);
+    ex.bs_y = f->bn_y;
+    ex.bs_mask = static_cast<const uint8_t*>(f->bn_mask);
+    ex.bs_mean = f->bn_mean;
+    ex.bs_invstd = f->bn_invstd;
+    ex.bs_g = f->part_g;
+    ex.bs_gx = f->part_gx;
+    if (f->bn_y && d->stride > 1) {
+        // parity classes smaller than the largest one leave their last partial rows unwritten
+        const size_t bytes = (size_t)saicv_conv2d_dgrad_stat_rows(d) * d->C * sizeof(float);
+        if (f->part_g) hipMemsetAsync(f->part_g, 0, bytes, S(stream));
+        if (f->part_gx) hipMemsetAsync(f->part_gx, 0, bytes, S(stream));
+    }
+    return igemm_nt(d->dtype, 1, dy, wd, dx, nullptr, nullptr, nullptr, d->OH, d->OW, d->K, d->H, d->W,
+                    d->R, d->S, d->stride, d->pad, M, d->C, d->R * d->S * d->K, d->C, 0, S(stream),
+                    (f->addend || f->bn_y) ? &ex : nullptr);
+}
 int saicv_row_scale(int dtype, const void* x, const float* scale, void* out, size_t rows, int row_len,
                     int rows_per_scale, void* stream) {
     return row_scale(dtype, x, scale, out, rows, row_len, rows_per_scale, S(stream));
@@ -208,6 +238,14 @@ int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* relu_
                      float* dbeta, size_t M, int C, int relu, int accumulate, float* ws, void* stream) {
     return bn_bwd(dtype, dz, z, relu_mask, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws,
                   S(stream));
+}
+
+int saicv_bn_act_bwd_from_partials(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,
+                                   const float* mean, const float* invstd, const float* part_g, const float* part_gx,
+                                   int rows, void* dy, void* dres, float* dgamma, float* dbeta, size_t M, int C, int relu,
+                                   int accumulate, float* ws, void* stream) {
+    return bn_bwd_from_partials(dtype, dz, relu_mask, y, gamma, mean, invstd, part_g, part_gx, rows, dy, dres, dgamma, dbeta,
+                                M, C, relu, accumulate, ws, S(stream));
 }
 
 int saicv_maxpool_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C,

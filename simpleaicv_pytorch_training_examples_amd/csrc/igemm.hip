@@ -46,6 +46,16 @@ struct NTParams {
     int act_mode;               // 0 none | 1 out2 = gelu(out) | 2 out = (acc + bias) * gelu'(addend)
     const float* row_scale;
     int rows_per_scale;
+    // data-gradient epilogue extras of a residual network (all tensors share out's [M][ldo] coordinates):
+    const uint8_t* addend_gate; // addend counts only where its bit is set (the shortcut gradient behind a ReLU: one bit per
+                                // element, one byte per 16-byte chunk -- the mask bn_act_fwd wrote)
+    const void* bs_y;           // BatchNorm-backward partial sums of THIS output, for the BatchNorm whose dz it is:
+    const uint8_t* bs_mask;     //   g = out * [mask bit];  bs_g[row][c] = sum g,  bs_gx[row][c] = sum g * (y - mean) * invstd
+    const float* bs_mean;       //   over the rows of one tile; row = parity class * bs_rows + tile_m
+    const float* bs_invstd;
+    float* bs_g;
+    float* bs_gx;
+    int bs_rows;
     uint32_t src_bytes, wgt_bytes;
     int H, W, C;        // gather-source spatial dims / channels
     int OH, OW;         // pixel grid that indexes the GEMM rows
@@ -87,7 +97,7 @@ DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
 // (BM_T/WM_) x (BN_T/WN_) sub-tile): 256x256 / 2x4, 256x128 / 4x2, 128x128 / 2x2, 128x64 / 2x2.
 // Wider tiles raise flop per LDS-fill byte and the MFMAs issued per barrier and per DMA.
 template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
-__global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams p) {
+__global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT_F32) ? 4 : 1) void igemm_nt_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = 4 * EPC;                  // one 64-byte row per K tile
     constexpr int NWAVES = WM_ * WN_;
@@ -431,7 +441,12 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
     TO* const outp = reinterpret_cast<TO*>(p.out);
     const bool aligned = ((p.ldo * (int)sizeof(TO)) & 15) == 0;
     const bool remap = MODE == 1 && cs > 1;
-    const bool plain = aligned && !remap && p.act_mode == 0 && p.addend == nullptr && p.row_scale == nullptr;   // uniform
+    constexpr bool DGRAD_EXTRAS = MODE == 1 && sizeof(TO) == sizeof(T);       // gated shortcut / BatchNorm-backward sums: data gradient only
+    const bool bstats = DGRAD_EXTRAS && p.bs_y != nullptr;                                                        // uniform
+    const bool plain = aligned && !remap && p.act_mode == 0 && p.addend == nullptr && p.row_scale == nullptr && !bstats;   // uniform
+    float bag[OEPC], bax[OEPC];                                // this thread's sum g, sum g * y over its rows of the tile
+#pragma unroll
+    for (int j = 0; j < OEPC; ++j) { bag[j] = 0.f; bax[j] = 0.f; }
     if (plain && ncol + OEPC <= p.Nn) {
         // the common case: a branch-free copy, the LDS reads of eight rows in flight before the first store
         constexpr int GRP = NIT < 8 ? NIT : 8;
@@ -454,11 +469,86 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                     if (mrow0 + (g + j) * RPP < Mc) st_chunk(o + (g + j) * ostep, v[j]);
             }
         }
+    } else if (aligned && !remap && p.act_mode == 0 && (p.Nn % OEPC) == 0) {   // uniform
+        // residual add / drop-path scale (forward and data gradient) and the data gradient's gated shortcut and
+        // BatchNorm-backward sums, on dense rows of whole chunks: four rows at a time, every global load of the group
+        // (addend, y, the two mask bytes) in flight before the first use
+        if (ncol < p.Nn) {
+            constexpr int GRP = NIT < 4 ? NIT : 4;
+            const int mrow0 = tile_m * BM_T + orow0;
+            const char* ls = smem + orow0 * OPITCH + oc * 16;
+            const bool addp = p.addend != nullptr, scalep = p.row_scale != nullptr;
+            const bool gatep = DGRAD_EXTRAS && p.addend_gate != nullptr, maskp = DGRAD_EXTRAS && p.bs_mask != nullptr;
+            const TO* const addend = reinterpret_cast<const TO*>(p.addend);
+            const TO* const ybn = reinterpret_cast<const TO*>(p.bs_y);
+#pragma unroll 1
+            for (int g = 0; g < NIT; g += GRP) {
+                u32x4 v[GRP], av[GRP], yv[GRP];
+                unsigned gb[GRP], mb[GRP];
+                float sc[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int mrow = mrow0 + (g + j) * RPP;
+                    const bool ok = mrow < Mc;
+                    const size_t off = (size_t)mrow * p.ldo + ncol;
+                    v[j] = ld_chunk(ls + (g + j) * RPP * OPITCH);
+                    av[j] = u32x4{0u, 0u, 0u, 0u};
+                    yv[j] = u32x4{0u, 0u, 0u, 0u};
+                    gb[j] = 0xffu;
+                    mb[j] = 0xffu;
+                    sc[j] = 1.f;
+                    if (ok) {
+                        if (scalep) sc[j] = p.row_scale[mrow / p.rows_per_scale];
+                        if (addp) av[j] = ld_chunk(addend + off);
+                        if (bstats) yv[j] = ld_chunk(ybn + off);
+                        if (gatep) gb[j] = p.addend_gate[off / OEPC];
+                        if (bstats && maskp) mb[j] = p.bs_mask[off / OEPC];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int mrow = mrow0 + (g + j) * RPP;
+                    if (mrow < Mc) {
+                        float f[OEPC];
+                        Chunk<TO>::unpack(v[j], f);
+                        if (addp || scalep) {
+                            float a[OEPC];
+                            Chunk<TO>::unpack(av[j], a);
+#pragma unroll
+                            for (int e = 0; e < OEPC; ++e) f[e] = fmaf(sc[j], f[e], ((gb[j] >> e) & 1u) ? a[e] : 0.f);
+                            v[j] = Chunk<TO>::pack(f);
+                            if (bstats) Chunk<TO>::unpack(v[j], f);      // the sums are over what is stored
+                        }
+                        if (bstats) {
+                            float yy[OEPC];
+                            Chunk<TO>::unpack(yv[j], yy);
+#pragma unroll
+                            for (int e = 0; e < OEPC; ++e) {
+                                const float ge = ((mb[j] >> e) & 1u) ? f[e] : 0.f;
+                                bag[e] += ge;
+                                bax[e] = fmaf(ge, yy[e], bax[e]);
+                            }
+                        }
+                        st_chunk(outp + (size_t)mrow * p.ldo + ncol, v[j]);
+                    }
+                }
+            }
+        }
     } else if (ncol < p.Nn) {
         // one copy of the fused-mode code in a ROLLED loop; the staged chunk and the addend chunk of the NEXT row are
         // fetched before the current row is processed, so a row's global-load latency hides under its predecessor
         const bool whole = aligned && ncol + OEPC <= p.Nn;
         const bool pre_add = whole && p.addend != nullptr;
+        const bool gated = DGRAD_EXTRAS && pre_add && p.addend_gate != nullptr;   // host: the gate needs whole, aligned chunks
+        const bool bst = bstats && whole;
+        // per row: gate byte of the addend (bits 0-7) | ReLU-mask byte of the statistics (bits 8-15)
+        auto side_bits = [&](int mrow) -> unsigned {
+            const size_t ch = ((size_t)mrow * p.ldo + ncol) / OEPC;
+            unsigned b = 0xffffu;
+            if (gated) b = (b & 0xff00u) | p.addend_gate[ch];
+            if (bst && p.bs_mask != nullptr) b = (b & 0x00ffu) | ((unsigned)p.bs_mask[ch] << 8);
+            return b;
+        };
         auto out_row = [&](int rr) -> int {                // output row of tile row rr, -1 past the end
             const int mrow = tile_m * BM_T + rr;
             if (rr >= BM_T || mrow >= Mc) return -1;
@@ -470,19 +560,25 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
         };
         int rr = orow0;
         int m = out_row(rr);
-        u32x4 v = {0u, 0u, 0u, 0u}, av = {0u, 0u, 0u, 0u};
+        u32x4 v = {0u, 0u, 0u, 0u}, av = {0u, 0u, 0u, 0u}, yv = {0u, 0u, 0u, 0u};
+        unsigned sb = 0xffffu;
         if (m >= 0) {
             v = ld_chunk(smem + rr * OPITCH + oc * 16);
             if (pre_add) av = ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol);
+            if (bst) yv = ld_chunk(reinterpret_cast<const TO*>(p.bs_y) + (size_t)m * p.ldo + ncol);
+            if (gated || bst) sb = side_bits(m);
         }
 #pragma unroll 1
         while (m >= 0) {
             const int rn = rr + RPP;
             const int mn = out_row(rn);
-            u32x4 vn = {0u, 0u, 0u, 0u}, an = {0u, 0u, 0u, 0u};
+            u32x4 vn = {0u, 0u, 0u, 0u}, an = {0u, 0u, 0u, 0u}, yn = {0u, 0u, 0u, 0u};
+            unsigned sbn = 0xffffu;
             if (mn >= 0) {
                 vn = ld_chunk(smem + rn * OPITCH + oc * 16);
                 if (pre_add) an = ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)mn * p.ldo + ncol);
+                if (bst) yn = ld_chunk(reinterpret_cast<const TO*>(p.bs_y) + (size_t)mn * p.ldo + ncol);
+                if (gated || bst) sbn = side_bits(mn);
             }
             TO* o = outp + (size_t)m * p.ldo + ncol;
             if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
@@ -504,6 +600,10 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 const float sc = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.f;
                 if (pre_add) {
                     Chunk<TO>::unpack(av, a);
+                    if (gated) {
+#pragma unroll
+                        for (int j = 0; j < OEPC; ++j) a[j] = ((sb >> j) & 1u) ? a[j] : 0.f;
+                    }
                 } else {
                     for (int j = 0; j < OEPC; ++j)
                         a[j] = (p.addend != nullptr && ncol + j < p.Nn)
@@ -513,6 +613,17 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 for (int j = 0; j < OEPC; ++j) f[j] = fmaf(sc, f[j], a[j]);
                 v = Chunk<TO>::pack(f);
             }
+            if (bst) {                        // BatchNorm-backward sums of what is stored (rounded to TO), behind its ReLU gate
+                float f[OEPC], yy[OEPC];
+                Chunk<TO>::unpack(v, f);
+                Chunk<TO>::unpack(yv, yy);
+#pragma unroll
+                for (int j = 0; j < OEPC; ++j) {
+                    const float gj = ((sb >> (8 + j)) & 1u) ? f[j] : 0.f;
+                    bag[j] += gj;
+                    bax[j] = fmaf(gj, yy[j], bax[j]);
+                }
+            }
             if (whole) {
                 st_chunk(o, v);
             } else {                          // N tail, or a leading dimension without 16-byte alignment
@@ -520,7 +631,29 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void igemm_nt_kernel(const NTParams
                 for (int j = 0; j < OEPC; ++j)
                     if (ncol + j < p.Nn) o[j] = e[j];
             }
-            rr = rn; m = mn; v = vn; av = an;
+            rr = rn; m = mn; v = vn; av = an; yv = yn; sb = sbn;
+        }
+    }
+    if (bstats) {       // uniform: combine the row lanes of every column through the (now consumed) staging area
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);                      // [RPP][2][BN_T]
+        const bool have = ncol + OEPC <= p.Nn;
+#pragma unroll
+        for (int j = 0; j < OEPC; ++j) {
+            // sum g * (y - mean) * invstd = invstd * (sum g y - mean * sum g): the mean leaves after this thread's few
+            // rows (BM_T / RPP of them), while the sums are still small -- not after the whole column
+            const float mu = have ? p.bs_mean[ncol + j] : 0.f, is = have ? p.bs_invstd[ncol + j] : 0.f;
+            red[(orow0 * 2 + 0) * BN_T + oc * OEPC + j] = bag[j];
+            red[(orow0 * 2 + 1) * BN_T + oc * OEPC + j] = is * fmaf(-mu, bag[j], bax[j]);
+        }
+        __syncthreads();
+        const size_t prow = (size_t)((MODE == 1 && cs > 1) ? blockIdx.y : 0) * p.bs_rows + tile_m;
+        for (int c = tid; c < 2 * BN_T; c += NTHREADS) {
+            const int which = c / BN_T, col = c - which * BN_T;
+            float a = 0.f;
+            for (int r = 0; r < RPP; ++r) a += red[(r * 2 + which) * BN_T + col];
+            const int n = tile_n * BN_T + col;
+            if (n < p.Nn) (which ? p.bs_gx : p.bs_g)[prow * (size_t)p.Nn + n] = a;
         }
     }
     }   // tile loop
@@ -894,6 +1027,15 @@ int conv_stat_rows(int M, int Nn, int Kd, int dtype) {
     return (M + g.bm - 1) / g.bm;
 }
 
+// partial rows the data gradient writes with EpiExtra::bs_*: (rows of tiles of the largest parity class) x classes
+int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype) {
+    const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
+    int M_tile = M;
+    if (stride > 1) M_tile = (M / (OH * OW)) * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);
+    const NTTile& g = kTiles[pick_tile(M_tile, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32)];
+    return ((M_tile + g.bm - 1) / g.bm) * stride * stride;
+}
+
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
              int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st,
@@ -910,6 +1052,23 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.rows_per_scale = ex ? ex->rows_per_scale : 1;
     p.out2 = ex ? ex->out2 : nullptr;
     p.act_mode = ex ? ex->act_mode : 0;
+    p.addend_gate = ex ? ex->addend_gate : nullptr;
+    p.bs_y = ex ? ex->bs_y : nullptr;
+    p.bs_mask = ex ? ex->bs_mask : nullptr;
+    p.bs_mean = ex ? ex->bs_mean : nullptr;
+    p.bs_invstd = ex ? ex->bs_invstd : nullptr;
+    p.bs_g = ex ? ex->bs_g : nullptr;
+    p.bs_gx = ex ? ex->bs_gx : nullptr;
+    p.bs_rows = 0;
+    if (p.addend_gate || p.bs_y) {
+        const int osz1 = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
+        SAICV_REQUIRE(mode == 1 && p.act_mode == 0 && (!out_f32 || dtype == SAICV_DTYPE_F32), "igemm_nt: gated shortcut / BatchNorm-backward sums belong to the data gradient");
+        SAICV_REQUIRE((ldo * osz1) % 16 == 0 && Nn % (16 / osz1) == 0 && ldo == Nn,
+                      "igemm_nt: gated shortcut / BatchNorm-backward sums need dense rows of whole 16-byte chunks (N=%d)", Nn);
+        SAICV_REQUIRE(!p.addend_gate || p.addend, "igemm_nt: a gate without an addend");
+        SAICV_REQUIRE(!p.bs_y || (p.bs_mean && p.bs_invstd && p.bs_g && p.bs_gx),
+                      "igemm_nt: BatchNorm-backward sums need mean, invstd and both partial buffers");
+    }
     if (p.act_mode) {
         const int osz0 = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
         SAICV_REQUIRE((ldo * osz0) % 16 == 0 && Nn % (16 / osz0) == 0,
@@ -944,6 +1103,7 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     const NTTile& g = kTiles[t];
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
+    p.bs_rows = (M_tile + g.bm - 1) / g.bm;
     {
         // One workgroup per tile by default.  The persistent form (one resident round of workgroups walking all tiles,
         // SAICV_NT_PERSIST=1) measured the same on one GPU, but its static tile partition doubles a kernel's time as

@@ -16,7 +16,17 @@ struct EpiExtra {
     int rows_per_scale = 1;
     int act_mode = 0;                  // 1: out2 = gelu(out) ; 2: out = (acc + bias) * gelu'(addend)
     void* out2 = nullptr;
+    // data-gradient extras (igemm.hip NTParams): gate bits of the addend; BatchNorm-backward partial sums of the output
+    const uint8_t* addend_gate = nullptr;
+    const void* bs_y = nullptr;
+    const uint8_t* bs_mask = nullptr;      // nullptr: no ReLU in front (every element counts)
+    const float* bs_mean = nullptr;
+    const float* bs_invstd = nullptr;
+    float* bs_g = nullptr;
+    float* bs_gx = nullptr;
 };
+// partial rows the data gradient (mode 1; M rows on the OH x OW pixel grid) writes with bs_*
+int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype);
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
              int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st,

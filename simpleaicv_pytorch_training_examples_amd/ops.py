@@ -86,6 +86,56 @@ def _arena_grad(t):
 import os as _os
 
 WGRAD_SIDE_STREAM = _os.environ.get('SAICV_WGRAD_SIDE', '0') == '1'
+# BatchNorm-backward traffic cuts in residual networks: the shortcut gradient travels as
+# (dz, ReLU-mask) instead of a masked copy, and a BatchNorm's backward reduction comes out of the epilogue of the data
+# gradient that produces its dz.  SAICV_BN_FUSE=0 restores the three-pass form (A/B runs, tests of both paths).
+BN_FUSE = _os.environ.get('SAICV_BN_FUSE', '1') == '1'
+
+
+class _BnLink:
+    """What the data gradient of the NEXT conv needs to produce the backward partial sums of a BatchNorm(+ReLU) node,
+    and where that node finds them.  Travels forward as an attribute of the node's output tensor."""
+    __slots__ = ('y', 'mask', 'mean', 'invstd', 'part', 'rows', 'dx')
+
+    def __init__(self, y, mask, mean, invstd):
+        self.y, self.mask, self.mean, self.invstd = y, mask, mean, invstd
+        self.part = self.dx = None
+        self.rows = 0
+
+
+class _GateLedger:
+    """Gated shortcut gradients handed out in the running backward and not yet consumed.  A gradient that reaches a
+    node that does not know about its gate would silently be used unmasked: the end-of-backward check turns that into
+    an error."""
+    pending = 0
+    queued = False
+
+    @classmethod
+    def hand_out(cls):
+        cls.pending += 1
+        if not cls.queued:
+            cls.queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(cls._check)
+
+    @classmethod
+    def consume(cls):
+        cls.pending -= 1
+
+    @classmethod
+    def _check(cls):
+        n, cls.pending, cls.queued = cls.pending, 0, False
+        if n != 0:
+            raise RuntimeError(f'{n} gated shortcut gradient(s) did not reach a node that applies the gate (a residual '
+                               'tensor with several consumers?); rerun with SAICV_BN_FUSE=0')
+
+
+def _take_gate(t):
+    """ReLU-mask that still has to be applied to gradient tensor t (handed out by a residual node), or None."""
+    g = getattr(t, '_saicv_gate', None) if t is not None else None
+    if g is not None:
+        _GateLedger.consume()
+        t._saicv_gate = None
+    return g
 _side = {'stream': None, 'dirty': False}
 
 
@@ -236,6 +286,9 @@ class ConvBnActFn(torch.autograd.Function):
         through that alias, so the shortcut's gradient reaches THIS node's backward and is added in the
         dgrad kernel's epilogue instead of by a separate elementwise add."""
         require_gpu(x, weight)
+        in_link = getattr(x, '_saicv_bn', None) if BN_FUSE else None
+        xin = x
+        res_gate_ok = bool(residual is not None and getattr(residual, '_saicv_gate_ok', False))
         x = _nhwc(x)
         dt = x.dtype
         n, c, h, w = x.shape
@@ -243,6 +296,10 @@ class ConvBnActFn(torch.autograd.Function):
         if c < ci:
             raise ValueError(f'input has {c} channels, weight expects {ci}')
         need_dx = ctx.needs_input_grad[0]
+        # this conv's data gradient IS the dz of the BatchNorm(+ReLU) node that produced x (when x has no other consumer):
+        # it can leave that node's backward partial sums behind
+        ctx.in_link = in_link if (in_link is not None and x is xin and need_dx and c == ci and in_link.y.shape == x.shape
+                                  and in_link.y.dtype == dt) else None
         wf, wd = packed_weight(weight, dt, c, need_dx and c == ci)
         d = _desc(n, h, w, c, k, r, s, stride, pad, dt)
         L = lib()
@@ -297,6 +354,13 @@ class ConvBnActFn(torch.autograd.Function):
             ctx.save_for_backward(x, weight, gamma, y, None, None, scale)
         ctx.cfg = (stride, pad, bool(relu), residual is not None, training, d, wd)
         ctx.beta_ref = beta
+        # the shortcut gradient may come back as (gradient, gate) only from nodes that apply gates: the alias below
+        # (its gradient joins in this node's dgrad epilogue) and BatchNorm nodes without a ReLU of their own
+        ctx.gated_res = bool(BN_FUSE and res_gate_ok and mask is not None and ctx.needs_input_grad[4]
+                             and residual.shape == z.shape)
+        # conv_bn_act() below hangs these on the OUTPUT tensors (the objects autograd hands back, not the ones made here)
+        ctx.link = _BnLink(y, mask, mean, invstd) if (BN_FUSE and mask is not None) else None
+        ctx.applies_gate = bool(BN_FUSE and training and not relu)
         if want_skip:
             return z, x
         return z
@@ -311,13 +375,28 @@ class ConvBnActFn(torch.autograd.Function):
         st = stream()
         dt = y.dtype
         dev = y.device
+        gate_in = _take_gate(dz)          # dz is a shortcut gradient still waiting for the ReLU mask of the block's tail
+        dz0 = dz
         dz = _nhwc(dz)
         if dz.dtype != dt:
             dz = dz.to(dt)
         n, k, oh, ow = y.shape
         M = n * oh * ow
+        if gate_in is not None:
+            if relu:
+                raise RuntimeError('a gated shortcut gradient reached a BatchNorm node with its own ReLU')
+            relu, mask = True, gate_in      # same [M][C] coordinates: the tail's mask gates this node's dz
         dy = _empty_nhwc(n, k, oh, ow, dt, dev)
-        dres = _empty_nhwc(n, k, oh, ow, dt, dev) if (has_res and ctx.needs_input_grad[4]) else None
+        dres = None
+        if has_res and ctx.needs_input_grad[4]:
+            if ctx.gated_res and dz is dz0:
+                # the masked copy g = dz * [z > 0] is not written: the consumer gets dz and the mask
+                dres = dz
+                dres._saicv_gate = mask
+                _GateLedger.hand_out()
+            else:
+                dres = _empty_nhwc(n, k, oh, ow, dt, dev)
+        dres_out = dres if (dres is not None and dres is not dz) else None
         beta = ctx.beta_ref
         gg, gb = _arena_grad(gamma), _arena_grad(beta)
         direct_bn = gg is not None and gb is not None
@@ -327,15 +406,27 @@ class ConvBnActFn(torch.autograd.Function):
             dgamma = torch.empty(k, dtype=torch.float32, device=dev)
             dbeta = torch.empty(k, dtype=torch.float32, device=dev)
         ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, k, dtype_code(dt)), dtype=torch.float32, device=dev)
+        link = ctx.link
+        fused_reduce = (link is not None and link.part is not None and link.dx is not None and gate_in is None
+                        and dz.data_ptr() == link.dx.data_ptr() and dz.shape == link.dx.shape)
         t0 = KernelTimer.begin('bn_act_bwd')
-        check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), 0, ptr(mask), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
-                                 ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), M, k, int(relu), int(direct_bn),
-                                 ptr(ws), st), 'bn_act_bwd')
+        if fused_reduce:
+            # the data gradient that wrote dz also left the partial sums of this reduction (no pass over dz and y here)
+            check(L.saicv_bn_act_bwd_from_partials(dtype_code(dt), ptr(dz), ptr(mask), ptr(y), ptr(gamma), ptr(mean),
+                                                   ptr(invstd), ptr(link.part[0]), ptr(link.part[1]), link.rows, ptr(dy),
+                                                   ptr(dres_out), ptr(dgamma), ptr(dbeta), M, k, int(relu), int(direct_bn),
+                                                   ptr(ws), st), 'bn_act_bwd_from_partials')
+        else:
+            check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), 0, ptr(mask), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
+                                     ptr(dy), ptr(dres_out), ptr(dgamma), ptr(dbeta), M, k, int(relu), int(direct_bn),
+                                     ptr(ws), st), 'bn_act_bwd')
+        if link is not None:
+            link.part = link.dx = None
         if direct_bn:
             dgamma = dbeta = None
-        # two streaming passes: (dz, y) read twice (+ the 1-bit ReLU mask), dy (and dres) written once
+        # streaming passes over (dz, y) (+ the 1-bit ReLU mask): reduction unless fused away, then apply; dy (and dres) written
         KernelTimer.end(t0, 'bn_act_bwd', 0, float(M) * k * y.element_size() *
-                        (2 * (2 + (1.0 / 16 if relu else 0)) + (2 if dres is not None else 1)))
+                        ((1 if fused_reduce else 2) * (2 + (1.0 / 16 if relu else 0)) + (2 if dres_out is not None else 1)))
         c = x.shape[1]
         flops = 2.0 * M * k * d.R * d.S * min(c, weight.shape[1])
         dx = None
@@ -344,10 +435,26 @@ class ConvBnActFn(torch.autograd.Function):
                 _, wd = packed_weight(weight, dt, c, True)
             dx = _empty_nhwc(n, c, x.shape[2], x.shape[3], dt, dev)
             t0 = KernelTimer.begin('igemm_nt')
+            gate = None
             if dskip is not None:           # gradient of the shortcut alias joins in the dgrad epilogue
+                gate = _take_gate(dskip)
                 dskip = _nhwc(dskip)
                 if dskip.dtype != dt:
                     dskip = dskip.to(dt)
+            in_link = ctx.in_link
+            if gate is not None or in_link is not None:
+                fuse = _lib.DgradFuse()
+                fuse.addend, fuse.addend_gate = ptr(dskip), ptr(gate)
+                if in_link is not None:
+                    rows = L.saicv_conv2d_dgrad_stat_rows(ctypes.byref(d))
+                    part = torch.empty((2, rows, c), dtype=torch.float32, device=dev)
+                    fuse.bn_y, fuse.bn_mask = ptr(in_link.y), ptr(in_link.mask)
+                    fuse.bn_mean, fuse.bn_invstd = ptr(in_link.mean), ptr(in_link.invstd)
+                    fuse.part_g, fuse.part_gx = ptr(part[0]), ptr(part[1])
+                    in_link.part, in_link.rows, in_link.dx = part, rows, dx
+                check(L.saicv_conv2d_dgrad_fused(ctypes.byref(d), ptr(dy), ptr(wd), ctypes.byref(fuse), ptr(dx), st),
+                      'conv2d_dgrad_fused')
+            elif dskip is not None:
                 check(L.saicv_conv2d_dgrad_add(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dskip), ptr(dx), st),
                       'conv2d_dgrad_add')
             else:
@@ -376,7 +483,17 @@ class ConvBnActFn(torch.autograd.Function):
 
 
 def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None, want_skip=False):
-    return ConvBnActFn.apply(x, weight, bn.weight, bn.bias, residual, bn, stride, pad, relu, want_skip)
+    out = ConvBnActFn.apply(x, weight, bn.weight, bn.bias, residual, bn, stride, pad, relu, want_skip)
+    z = out[0] if want_skip else out
+    node = z.grad_fn
+    if BN_FUSE and node is not None and hasattr(node, 'link'):
+        if node.link is not None:
+            z._saicv_bn = node.link            # the next conv's data gradient can do this node's backward reduction
+        if node.applies_gate:
+            z._saicv_gate_ok = True            # as a residual, its gradient may arrive as (dz, ReLU mask)
+        if want_skip:
+            out[1]._saicv_gate_ok = True       # the alias: its gradient joins in this node's dgrad epilogue
+    return out
 
 
 # ------------------------------------------------------------------------------ plain conv / linear

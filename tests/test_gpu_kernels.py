@@ -385,3 +385,92 @@ def test_fused_gelu_linear_epilogues_equal_the_unfused_kernels(dtype):
     dpre, _, _ = ops_tfm.lin_bwd(act, w2, None, dy, gelu_pre=pre)
     dact, _, _ = ops_tfm.lin_bwd(act, w2, None, dy)
     assert torch.equal(dpre, ops_tfm.gelu_bwd(dact, pre))
+
+
+FUSED_DGRAD_CASES = [
+    # N, C, H, W, K, R, stride, pad   (C = channels of dx = the previous BatchNorm's channels)
+    (2, 64, 14, 14, 64, 3, 1, 1),
+    (3, 64, 15, 13, 128, 3, 2, 1),      # stride 2: four parity classes of different sizes, zero-filled partial rows
+    (2, 256, 9, 9, 64, 1, 1, 0),        # bottleneck conv1: 1x1, wide dx (two 128-column tiles)
+    (9, 128, 28, 28, 128, 3, 1, 1),     # several 256-row tiles
+]
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', FUSED_DGRAD_CASES)
+def test_dgrad_epilogue_gated_shortcut_and_bn_backward_sums(case, dt):
+    """saicv_conv2d_dgrad_fused: dx = dgrad(dy) + addend * gate bits, plus the BatchNorm-backward partial sums of dx
+    (sum g, sum g * (y - mean) * invstd with g = dx * mask bits), against an fp32 CPU computation; and
+    saicv_bn_act_bwd_from_partials against saicv_bn_act_bwd on the same dz."""
+    import ctypes
+    from simpleaicv_pytorch_training_examples_amd import _lib, ops
+    from simpleaicv_pytorch_training_examples_amd._lib import check, lib, ptr
+    n, c, h, w, k, r, stride, pad = case
+    L, st = lib(), _lib.stream()
+    epc = _lib.epc(dt)
+    g = torch.Generator().manual_seed(sum(case))
+    d = ops._desc(n, h, w, c, k, r, r, stride, pad, dt)
+    oh, ow = d.OH, d.OW
+    wgt = _q(torch.randn(k, c, r, r, generator=g) * (2.0 / (c * r * r)) ** 0.5, dt)
+    dy = _q(torch.randn(n, k, oh, ow, generator=g), dt)
+    addend = _q(torch.randn(n, c, h, w, generator=g), dt)
+    y_bn = _q(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.7, dt)
+    mean = torch.randn(c, generator=g) * 0.5 + 0.7
+    invstd = torch.rand(c, generator=g) + 0.5
+    gamma = torch.rand(c, generator=g) + 0.5
+    M = n * h * w
+    gate_bits = torch.rand(M, c, generator=g) > 0.4            # [pixel][channel], NHWC order
+    mask_bits = torch.rand(M, c, generator=g) > 0.5
+
+    def pack(bits):                                            # one byte per 16-byte chunk, bit j = element j of the chunk
+        b = bits.view(M, c // epc, epc).to(torch.int32)
+        return (b << torch.arange(epc, dtype=torch.int32)).sum(-1).to(torch.uint8).contiguous()
+
+    # ---- CPU fp32 reference
+    xr = torch.zeros(n, c, h, w, requires_grad=True)
+    F.conv2d(xr, wgt, None, stride, pad).backward(dy)
+    gate_nchw = gate_bits.view(n, h, w, c).permute(0, 3, 1, 2)
+    dx_ref = xr.grad + addend * gate_nchw
+
+    # ---- device
+    wd = wgt.permute(1, 2, 3, 0).contiguous().to(dt).cuda()     # [Cin][R][S][Cout]
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    add_d = addend.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    y_d = y_bn.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    gate_d, mask_d = pack(gate_bits).cuda(), pack(mask_bits).cuda()
+    mean_d, invstd_d, gamma_d = mean.cuda(), invstd.cuda(), gamma.cuda()
+    rows = L.saicv_conv2d_dgrad_stat_rows(ctypes.byref(d))
+    part = torch.full((2, rows, c), float('nan'), device='cuda')
+    dx = torch.empty(n, h, w, c, dtype=dt, device='cuda')
+    f = _lib.DgradFuse()
+    f.addend, f.addend_gate = ptr(add_d), ptr(gate_d)
+    f.bn_y, f.bn_mask, f.bn_mean, f.bn_invstd = ptr(y_d), ptr(mask_d), ptr(mean_d), ptr(invstd_d)
+    f.part_g, f.part_gx = ptr(part[0]), ptr(part[1])
+    check(L.saicv_conv2d_dgrad_fused(ctypes.byref(d), ptr(dyd), ptr(wd), ctypes.byref(f), ptr(dx), st), 'dgrad_fused')
+    torch.cuda.synchronize()
+    assert rel_err(dx.permute(0, 3, 1, 2).float(), dx_ref) < TOL[dt]
+    # the sums are over what was STORED (dx rounded to dt), so they are checked against the device dx itself
+    gd = dx.float().cpu().view(M, c) * mask_bits
+    sg_ref = gd.double().sum(0)
+    sgx_ref = (gd.double() * (y_bn.permute(0, 2, 3, 1).reshape(M, c).double() - mean.double()) * invstd.double()).sum(0)
+    assert torch.isfinite(part).all()
+    assert rel_err(part[0].double().sum(0), sg_ref) < 1e-4
+    assert rel_err(part[1].double().sum(0), sgx_ref) < 1e-4
+
+    # ---- BatchNorm backward from those partial sums == the three-pass kernel on the same dz
+    ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, c, _lib.dtype_code(dt)), device='cuda')
+    out = []
+    for fused in (False, True):
+        dyb = torch.empty_like(dx)
+        dgam, dbet = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+        if fused:
+            check(L.saicv_bn_act_bwd_from_partials(_lib.dtype_code(dt), ptr(dx), ptr(mask_d), ptr(y_d), ptr(gamma_d), ptr(mean_d),
+                                                   ptr(invstd_d), ptr(part[0]), ptr(part[1]), rows, ptr(dyb), 0, ptr(dgam),
+                                                   ptr(dbet), M, c, 1, 0, ptr(ws), st), 'bn_from_partials')
+        else:
+            check(L.saicv_bn_act_bwd(_lib.dtype_code(dt), ptr(dx), 0, ptr(mask_d), ptr(y_d), ptr(gamma_d), ptr(mean_d), ptr(invstd_d),
+                                     ptr(dyb), 0, ptr(dgam), ptr(dbet), M, c, 1, 0, ptr(ws), st), 'bn_bwd')
+        torch.cuda.synchronize()
+        out.append((dyb.float(), dgam.clone(), dbet.clone()))
+    assert rel_err(out[1][1], out[0][1]) < 1e-4 and rel_err(out[1][2], out[0][2]) < 1e-4
+    assert rel_err(out[1][0], out[0][0]) < (1e-4 if dt == torch.float32 else 8e-3)     # a flipped bf16 rounding at most
