@@ -366,6 +366,12 @@ def measure(name, args, world, rank, device, use_graph, primary):
                                'traffic_source': (f'{PMC_FILE} (separate rocprofv3 --pmc passes of this command, not this run)'
                                                   if traffic is not None else None),
                                'launches': kk['calls'], 'avg_launch_us': round(kk['ms'] * 1e3 / kk['calls'], 2),
+                               # what the SHAPES allow: sum over the launches of max(flops / MFMA peak, algorithmic bytes /
+                               # HBM peak) -- many ResNet-50 launches (K <= 256, and the data gradients that also carry a
+                               # BatchNorm-backward reduction in their epilogue) are HBM-bound at these peaks
+                               'shape_bound': {'lower_bound_ms': round(kk['bound_ms'] / k, 3), 'measured_ms': round(kk['ms'] / k, 3),
+                                               'frac': round(kk['bound_ms'] / kk['ms'], 4) if kk['ms'] else None,
+                                               'algorithmic_GB': round(kk['bytes'] / k / 1e9, 2)},
                                'measured_in': f'{k} eager steps after the timed windows (HIP events on the launch stream; '
                                               'events cannot bracket kernels inside a replayed hipGraph)'}
             res['kernel_breakdown_ms_per_step'] = {t: round(v['ms'] / k, 3) for t, v in summ.items()}

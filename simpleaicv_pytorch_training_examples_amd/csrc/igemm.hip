@@ -11,9 +11,11 @@
 //
 // Replaces the ATen `convolution` / `convolution_backward` / `addmm` / `mm` dispatches of
 // reference SimpleAICV/classification/backbones/resnet.py:33-43 (ConvBnActBlock) and
-// resnet.py:204 (fc).  Tiles are 128x{64,128} with 128-byte K slices, 4 wavefronts (2x2),
-// MFMA 16x16x32 bf16 (perf mode) or 16x16x4 f32 (parity mode), register-staged double
-// buffered LDS with an XOR swizzle that makes ds_read_b128 fragment reads conflict free.
+// resnet.py:204 (fc).  NT: four tile geometries (256x256 / 8 wavefronts, 256x128 / 8, 128x128 / 4, 128x64 / 4), 64-byte
+// K slices streamed global -> LDS by DMA (buffer_load ... lds) into a 3- or 4-stage ring, counted vmcnt and one raw
+// barrier per K step, MFMA 16x16x32 bf16 (perf mode) or 16x16x4 f32 (parity mode), an XOR swizzle that makes the
+// ds_read_b128 fragment reads conflict free, LDS-staged epilogue with the fused modes listed at NTParams.
+// TN: 64x64 .. 256x256 tiles, register-staged loads, ds_read_b64_tr_b16 fragments, one resident round of workgroups.
 #include <type_traits>
 
 #include <stdlib.h>

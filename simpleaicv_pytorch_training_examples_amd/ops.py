@@ -23,6 +23,7 @@ class KernelTimer:
     only = None           # optional set of tags to bracket (every event pair costs host time: ~1400 per ResNet-50 step
                           # with all tags made the bench host-bound and 7 % slower; bench.py brackets the dominant kernel)
     records = []          # (tag, start_event, end_event, algorithmic_flops, algorithmic_bytes)
+    PEAK_FLOPS, PEAK_BYTES = 2.5e15, 8.0e12      # dense bf16 MFMA, HBM3E (MI355X_MICROARCH.md)
 
     @classmethod
     def begin(cls, tag=None):
@@ -42,14 +43,16 @@ class KernelTimer:
 
     @classmethod
     def summary(cls):
-        """{tag: dict(calls, ms, flops, bytes)}; call after torch.cuda.synchronize()."""
+        """{tag: dict(calls, ms, flops, bytes, bound_ms)}; call after torch.cuda.synchronize().
+        bound_ms = sum over the launches of max(flops / MFMA peak, bytes / HBM peak): what the SHAPES allow."""
         out = {}
         for tag, e0, e1, fl, by in cls.records:
-            d = out.setdefault(tag, {'calls': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            d = out.setdefault(tag, {'calls': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'bound_ms': 0.0})
             d['calls'] += 1
             d['ms'] += e0.elapsed_time(e1)
             d['flops'] += fl
             d['bytes'] += by
+            d['bound_ms'] += max(fl / cls.PEAK_FLOPS, by / cls.PEAK_BYTES) * 1e3
         return out
 
 
@@ -317,7 +320,10 @@ class ConvBnActFn(torch.autograd.Function):
             t0 = KernelTimer.begin('igemm_nt')
             check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, ptr(stats[0]),
                                      ptr(stats[1]), st), 'conv2d_fwd')
-            KernelTimer.end(t0, 'igemm_nt', 2.0 * M * k * r * s * min(c, ci), 0)
+            es = x.element_size()
+            xin_px = M if (r == 1 and stride > 1) else n * h * w          # a strided 1x1 reads a quarter of its input
+            KernelTimer.end(t0, 'igemm_nt', 2.0 * M * k * r * s * min(c, ci),
+                            float(xin_px) * c * es + float(k) * r * s * c * es + float(M) * k * es)
             mean = torch.empty(k, dtype=torch.float32, device=dev)
             invstd = torch.empty(k, dtype=torch.float32, device=dev)
             ws = torch.empty(L.saicv_bn_ws_floats(k), dtype=torch.float32, device=dev)
@@ -459,7 +465,14 @@ class ConvBnActFn(torch.autograd.Function):
                       'conv2d_dgrad_add')
             else:
                 check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
-            KernelTimer.end(t0, 'igemm_nt', flops, 0)
+            es = dy.element_size()
+            px = float(n) * x.shape[2] * x.shape[3] * c          # elements of dx (and of every epilogue tensor)
+            nbytes = float(M) * k * es + float(k) * d.R * d.S * c * es + px * es
+            if dskip is not None:
+                nbytes += px * es + (px / 8 if gate is not None else 0)
+            if in_link is not None:
+                nbytes += px * es + px / 8
+            KernelTimer.end(t0, 'igemm_nt', flops, nbytes)
         dwt = None
         if ctx.needs_input_grad[1]:
             gw = _arena_grad(weight)
