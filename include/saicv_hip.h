@@ -305,7 +305,8 @@ int saicv_comm_create(const void* id128, int world, int rank, saicv_comm** out);
 /* grads[0..n) (device, fp32) <- sum or mean over the ranks, in place, on the communication stream, ordered after
  * everything enqueued on producer_stream so far (the stream whose kernels wrote this bucket). */
 int saicv_comm_allreduce_bucket(saicv_comm* c, float* grads, size_t n, int average, void* producer_stream);
-/* buf[0..bytes) <- root's copy, on `stream` itself (constructor-time parameter / per-forward buffer broadcast). */
+/* buf[0..bytes) <- root's copy (constructor-time parameter / per-forward buffer broadcast): on the communication stream,
+ * ordered after what `stream` has enqueued so far; `stream` waits for it. */
 int saicv_comm_broadcast(saicv_comm* c, void* buf, size_t bytes, int root, void* stream);
 /* consumer_stream waits for every bucket enqueued so far (before the optimizer reads the gradients). */
 int saicv_comm_join(saicv_comm* c, void* consumer_stream);

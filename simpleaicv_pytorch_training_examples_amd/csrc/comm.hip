@@ -158,7 +158,14 @@ int saicv_comm_broadcast(saicv_comm* c, void* buf, size_t bytes, int root, void*
     if (!buf) { saicv::set_error("saicv_comm_broadcast: null buffer"); return -1; }
     const Rccl* r = rccl();
     if (!r) return -1;
-    COMM_RCCL(r, r->Broadcast(buf, buf, bytes, ncclUint8, root, c->nccl, static_cast<hipStream_t>(stream)), "broadcast");
+    // every collective of this communicator runs on ITS stream, in issue order; the caller's stream is ordered before
+    // (buf is ready) and after (buf is overwritten) by events
+    hipStream_t user = static_cast<hipStream_t>(stream);
+    COMM_HIP(hipEventRecord(c->ev_in, user), "broadcast (record)");
+    COMM_HIP(hipStreamWaitEvent(c->side, c->ev_in, 0), "broadcast (wait)");
+    COMM_RCCL(r, r->Broadcast(buf, buf, bytes, ncclUint8, root, c->nccl, c->side), "broadcast");
+    COMM_HIP(hipEventRecord(c->ev_out, c->side), "broadcast (record out)");
+    COMM_HIP(hipStreamWaitEvent(user, c->ev_out, 0), "broadcast (wait out)");
     return 0;
 }
 

@@ -496,6 +496,12 @@ class NativeComm:
         check(lib().saicv_comm_allreduce_bucket(self.handle, ptr(view), view.numel(), int(average),
                                                 producer_stream.cuda_stream), 'comm_allreduce_bucket')
 
+    def allreduce_now(self, t, average=False):
+        """Small fp32 tensor written on the current stream: reduced on the communication stream (behind every bucket
+        already enqueued there), and the current stream waits for it."""
+        self.allreduce_bucket(t, torch.cuda.current_stream(), average=average)
+        self.join()
+
     def broadcast(self, t, root=0):
         check(lib().saicv_comm_broadcast(self.handle, ptr(t), t.numel() * t.element_size(), root, _lib.stream()),
               'comm_broadcast')

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from torch.amp.autocast_mode import autocast
 
 from ..SimpleAICV.classification.common import AverageMeter, get_amp_type
-from .scripts import _device_of, _dist_on
+from .scripts import _device_of, _dist_on, all_reduce_sum_packed
 
 
 def sample_random_point(gt_masks, pred_masks, num_pt=1):
@@ -186,8 +186,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
                 scaled.backward()
 
         packed = torch.cat([torch.stack([bad.float(), loss.detach().float()]), terms])
-        if _dist_on(config.group):
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=config.group)
+        all_reduce_sum_packed(packed, model, config.group)
         if carried_bad is not None:
             packed = torch.cat([torch.maximum(packed[0:1], carried_bad), packed[1:]])
         carried_bad = None if boundary else packed[0:1]

@@ -36,6 +36,20 @@ def _dist_on(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+def all_reduce_sum_packed(packed, model, group):
+    """SUM over the ranks of a small fp32 device tensor (skip flag + loss terms), in place.  With the engine's DDP wrapper on
+    RCCL it travels on the SAME communicator and communication stream as the gradient buckets (saicv_comm_*), so the step
+    never has collectives of two communicators in flight at once; otherwise torch.distributed carries it."""
+    if not _dist_on(group):
+        return packed
+    comm = getattr(model, 'comm', None)
+    if comm is not None and packed.dtype == torch.float32 and packed.is_contiguous():
+        comm.allreduce_now(packed, average=False)
+    else:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed
+
+
 def all_reduce_operation_in_group_for_variables(variables, operator, group):
     """python scalars / 0-d tensors -> all-reduced python scalars (blocking; eval path only)."""
     device = 'cuda' if torch.cuda.is_available() else 'cpu'
@@ -71,8 +85,7 @@ def test_classification(test_loader, model, criterion, config):
             # one fused all-reduce instead of the reference's 1 + 3 scalar ones (C8)
             packed = torch.stack([loss.float(), correct[:, :1].sum(), correct[:, :5].sum(),
                                   torch.tensor(float(images.size(0)), device=device)])
-            if _dist_on(config.group):
-                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=config.group)
+            all_reduce_sum_packed(packed, model, config.group)
             loss_sum, acc1_n, acc5_n, n = packed.tolist()
             losses.update(loss_sum / float(config.gpus_num), images.size(0))
             accs.update(acc1_n, acc5_n, n)
@@ -143,8 +156,7 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
                 scaled.backward()
         # one tiny all-reduce carries the skip flag (any rank) and the loss (sum over ranks)
         packed = torch.stack([bad.float(), loss.detach().float()])
-        if _dist_on(config.group):
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=config.group)
+        all_reduce_sum_packed(packed, model, config.group)
         return packed
 
     def update(packed):
@@ -277,8 +289,7 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
             with model.no_sync():
                 scaled.backward()
         packed = torch.cat([torch.stack([bad.float(), loss.detach().float()]), terms])
-        if _dist_on(config.group):
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=config.group)
+        all_reduce_sum_packed(packed, model, config.group)
         if carried_bad is not None:
             packed = torch.cat([torch.maximum(packed[0:1], carried_bad), packed[1:]])
         carried_bad = None if boundary else packed[0:1]

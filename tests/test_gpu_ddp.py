@@ -190,6 +190,12 @@ def _worker_native(port, q):
     torch.cuda.synchronize()
     out['raw_ok'] = bool(torch.equal(c, a * 3.0 + 1.0))
     out['raw_stats'] = comm.stats()
+    t = torch.arange(8, dtype=torch.float32, device='cuda') * 2.0
+    comm.allreduce_now(t, average=False)                # the loops' packed skip-flag / loss all-reduce
+    comm.broadcast(t, 0)                                # parameter / BatchNorm-buffer broadcast
+    u = t + 1.0
+    torch.cuda.synchronize()
+    out['raw_ok'] = out['raw_ok'] and bool(torch.equal(u, torch.arange(8, dtype=torch.float32, device='cuda') * 2.0 + 1.0))
     comm.close()
 
     def train(wrap):

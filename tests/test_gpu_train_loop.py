@@ -371,6 +371,7 @@ def test_step_graph_replays_the_same_training_as_eager_launches():
     rel = float((p_eager - p_graph).norm() / p_eager.norm())
     print(f'[step graph] parameters after 20 iterations: graph vs eager {rel:.2e}, eager vs eager {noise:.2e}')
     assert rel < max(3 * noise, 5e-3), (rel, noise)
+    spread = max(abs(a - c) for a, c in zip(eager, eager2))      # two eager runs of the same thing, worst iteration
     for i, (a, b, c) in enumerate(zip(eager, graph, eager2)):
-        assert abs(a - b) < max(3 * abs(a - c), 5e-2 * max(abs(a), 0.1)), (i, a, b, c)
+        assert abs(a - b) < max(3 * abs(a - c), 3 * spread, 0.1 * max(abs(a), 0.1)), (i, a, b, c)
     assert eager[-1] < eager[0] * 0.7 and graph[-1] < graph[0] * 0.7               # both learn
