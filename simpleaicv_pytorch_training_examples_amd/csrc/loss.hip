@@ -25,9 +25,10 @@ __global__ __launch_bounds__(256) void ce_hard_kernel(const float* __restrict__ 
     se = wave_sum(se);
     const float lse = mx + logf(se);
     const int64_t t = label[row];
-    if (lane == 0) row_loss[row] = (t >= 0 && t < C) ? (lse - x[t]) : 0.f;
+    const bool valid = t >= 0 && t < C;          // a label outside [0, C) contributes neither loss nor gradient
+    if (lane == 0) row_loss[row] = valid ? (lse - x[t]) : 0.f;
     if (dlogits) {
-        const float invB = 1.f / (float)B;
+        const float invB = valid ? 1.f / (float)B : 0.f;
         float* d = dlogits + (size_t)row * C;
         for (int c = lane; c < C; c += 64) {
             float pr = expf(x[c] - lse);

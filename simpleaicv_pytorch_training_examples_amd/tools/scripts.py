@@ -179,7 +179,7 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
             scaler.update()
         optimizer.zero_grad()
         if config.use_ema_model:
-            config.ema_model.update(model)
+            config.ema_model.update(model, skip_flag)
 
     # config.use_step_graph: the whole iteration (forward .. zero_grad) is captured once into a hipGraph and
     # replayed (engine.StepGraph) -- the host then issues one graph launch instead of ~700 kernel launches.
@@ -310,7 +310,7 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
                 scaler.update()
             optimizer.zero_grad()
             if getattr(config, 'use_ema_model', False):
-                config.ema_model.update(model)
+                config.ema_model.update(model, skip_flag)
             scheduler.step(optimizer, iter_index / iters + (epoch - 1))
             log_fmt = None
             if iter_index % int(config.print_interval * acc_steps) == 0:

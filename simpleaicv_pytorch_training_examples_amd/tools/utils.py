@@ -79,7 +79,9 @@ class EmaModel(nn.Module):
         self.ema_model.eval()
         self.decay = decay
 
-    def update(self, model):
+    def update(self, model, skip_flag=None):
+        """skip_flag (device scalar, 1 = this iteration was skipped on the device): the average does not move, as the
+        reference's `continue` leaves it (tools/scripts.py:196-200), without a host read of the flag."""
         src = model.module if hasattr(model, 'module') else model
         dst = self.ema_model.module if hasattr(self.ema_model, 'module') else self.ema_model
         with torch.no_grad():
@@ -91,7 +93,11 @@ class EmaModel(nn.Module):
                     mv.append(m.detach())
                 else:
                     e.copy_(m)
-            torch._foreach_lerp_(ev, mv, 1.0 - self.decay)
+            if skip_flag is None:
+                torch._foreach_lerp_(ev, mv, 1.0 - self.decay)
+            else:
+                w = ((1.0 - self.decay) * (1.0 - skip_flag.reshape(()).float().clamp(0, 1)))
+                torch._foreach_lerp_(ev, mv, [w.to(e.dtype) for e in ev])
         from .. import ops
         ops.bump_weights_epoch()
 

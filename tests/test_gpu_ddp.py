@@ -41,6 +41,19 @@ def _worker(rank, world, port, q, kind):
         sam_batch = (images[sl].cuda(), masks[sl].cuda(), points[sl].cuda(), boxes[sl].cuda())
         sam_crit = sam_losses.SAMLoss()
         shape, crit, soft = (4, 3, 256, 256), None, False
+    elif kind == 'detr':
+        # transformer.decoder_norm runs once per decoder layer (6 uses per step): with buckets this small its bucket
+        # completes long before the last use -- the arena hook must not announce the gradient before that
+        from oracle.make_golden_detr import DETR_TINY, detr_inputs, zero_dropout
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import detr
+        model = detr.__dict__['resnet18_detr'](**DETR_TINY).cuda()
+        zero_dropout(model)
+        d_images, d_masks, d_annots = detr_inputs(4, 7)
+        sl = slice(rank * 2, rank * 2 + 2)
+        detr_batch = (d_images[sl].cuda(), d_masks[sl].cuda(), d_annots[sl].cuda())
+        detr_crit = DETRLoss(num_classes=DETR_TINY['num_classes'])
+        shape, crit, soft = (4, 3, 256, 256), None, False
     elif kind == 'resnet':
         model = backbones.resnet18cifar(num_classes=10).cuda()
         shape, crit, soft = (8, 3, 32, 32), losses.CELoss(), False
@@ -65,6 +78,10 @@ def _worker(rank, world, port, q, kind):
         if kind == 'sam':       # encoder once, prompt encoder + mask decoder twice: multi-use parameters
             _, loss, _, _ = sam_two_pass_loss(ddp.module, sam_crit, *sam_batch, 256, autocast_dtype=torch.bfloat16,
                                               device_type='cuda')
+        elif kind == 'detr':
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                cls_out, reg_out = ddp(detr_batch[0], detr_batch[1])
+            loss = sum(detr_crit([cls_out.float(), reg_out.float()], detr_batch[2]).values())
         else:
             with torch.autocast('cuda', dtype=torch.bfloat16):
                 loss = crit(ddp(xs), ys)
@@ -87,7 +104,7 @@ def _worker(rank, world, port, q, kind):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('kind', ['resnet', 'vit', 'sam'])
+@pytest.mark.parametrize('kind', ['resnet', 'vit', 'sam', 'detr'])
 def test_world2_on_one_gpu_kernel_side_gradient_hooks(kind):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -104,7 +121,7 @@ def test_world2_on_one_gpu_kernel_side_gradient_hooks(kind):
     assert torch.equal(s0, s1)                                        # one all-reduced gradient on both ranks
     mean = (l0.double() + l1.double()) / 2
     err = float((s0.double() - mean).abs().max() / mean.abs().max())
-    assert err < (2e-2 if kind == 'sam' else 2e-3), err               # fp32 atomics order only (SAM: bf16 best-mask picks)
+    assert err < (2e-2 if kind in ('sam', 'detr') else 2e-3), err     # fp32 atomics order only (SAM: bf16 best-mask picks; DETR: bf16 matching costs)
     assert torch.equal(p0, p1)                                        # identical parameters after the fused step
 
 
