@@ -302,13 +302,14 @@ int saicv_attention_stream_bwd(int dtype, int D, const saicv_attn_desc* desc, vo
 typedef struct saicv_comm saicv_comm;
 int saicv_comm_unique_id(void* id128);
 int saicv_comm_create(const void* id128, int world, int rank, saicv_comm** out);
-/* grads[0..n) (device, fp32) <- sum or mean over the ranks, in place, on the communication stream, ordered after
- * everything enqueued on producer_stream so far (the stream whose kernels wrote this bucket). */
+/* grads[0..n) (device, fp32) <- sum or mean over the ranks, in place, ordered after everything enqueued on producer_stream
+ * so far (the stream whose kernels wrote this bucket): on the library's communication stream while producer_stream is being
+ * captured into a hipGraph (or with SAICV_COMM_MODE=events), on producer_stream itself otherwise. */
 int saicv_comm_allreduce_bucket(saicv_comm* c, float* grads, size_t n, int average, void* producer_stream);
-/* buf[0..bytes) <- root's copy (constructor-time parameter / per-forward buffer broadcast): on the communication stream,
- * ordered after what `stream` has enqueued so far; `stream` waits for it. */
+/* buf[0..bytes) <- root's copy (constructor-time parameter / per-forward buffer broadcast), ordered after what `stream` has
+ * enqueued so far and before what it enqueues next (same stream choice as the all-reduce). */
 int saicv_comm_broadcast(saicv_comm* c, void* buf, size_t bytes, int root, void* stream);
-/* consumer_stream waits for every bucket enqueued so far (before the optimizer reads the gradients). */
+/* consumer_stream is ordered after every bucket enqueued so far (before the optimizer reads the gradients). */
 int saicv_comm_join(saicv_comm* c, void* consumer_stream);
 int saicv_comm_stats(const saicv_comm* c, int* world, int* rank, unsigned long long* buckets, unsigned long long* bytes);
 int saicv_comm_destroy(saicv_comm* c);

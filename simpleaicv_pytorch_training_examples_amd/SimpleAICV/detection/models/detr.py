@@ -50,13 +50,14 @@ def _mha(mha, q_in, k_in, v_in, key_bias, same_qk):
     """nn.MultiheadAttention.forward(need_weights=False) with batch-first [B, L, C] tensors."""
     c = mha.embed_dim
     w, b = mha.in_proj_weight, mha.in_proj_bias
+    # the packed parameters enter whole (row ranges): their gradients land in the arena rows directly
     if same_qk:
-        qk = ops_tfm.linear_nd(q_in, w[:2 * c], b[:2 * c])
+        qk = ops_tfm.linear_rows(q_in, w, b, 0, 2 * c)
         q, k = qk[..., :c], qk[..., c:]
     else:
-        q = ops_tfm.linear_nd(q_in, w[:c], b[:c])
-        k = ops_tfm.linear_nd(k_in, w[c:2 * c], b[c:2 * c])
-    v = ops_tfm.linear_nd(v_in, w[2 * c:], b[2 * c:])
+        q = ops_tfm.linear_rows(q_in, w, b, 0, c)
+        k = ops_tfm.linear_rows(k_in, w, b, c, 2 * c)
+    v = ops_tfm.linear_rows(v_in, w, b, 2 * c, 3 * c)
     p = mha.dropout if mha.training else 0.0
     out = ops_tfm.stream_attention(q, k, v, mha.num_heads, (c // mha.num_heads) ** -0.5, key_bias, p)
     return ops_tfm.linear_nd(out, mha.out_proj.weight, mha.out_proj.bias)

@@ -2,12 +2,15 @@
 //
 // What it replaces: the reducer of nn.parallel.DistributedDataParallel that the reference wraps its model in
 // (reference tools/train_classification_model.py:217-227, tools/scripts.py:183-226): contiguous ranges of the flat
-// fp32 gradient arena ("buckets") are averaged over the ranks while the rest of backward still runs.
+// fp32 gradient arena ("buckets") are averaged over the ranks as soon as their last gradient has been produced.
 //
+// Inside a hipGraph capture (engine.StepGraph) the collectives go to a communication stream and overlap backward:
 //   compute stream      ... wgrad kernels of bucket b ...  record(ev_in) ............ wait(ev_out) optimizer
 //   communication stream                                   wait(ev_in) ncclAllReduce(bucket b) ... record(ev_out)
+// In an eagerly launched step they run on the producing stream itself, in order (see on_side_stream() below for the
+// measurement behind that choice).
 //
-// One communicator per process (= per GPU), one high-priority communication stream; every call only enqueues.
+// One communicator per process (= per GPU); every call only enqueues.
 // RCCL is resolved at run time with dlopen/dlsym: the copy PyTorch already loaded (soname librccl.so.1) when the
 // host is the Python mirror, the ROCm one for a C/C++ host -- the library has no link-time RCCL dependency, and a
 // process must never hold two RCCL copies.  xGMI is point-to-point (7 links per GPU): the bucket size is the caller's
@@ -88,9 +91,27 @@ struct saicv_comm {
     hipEvent_t ev_in = nullptr;       // producer stream -> communication stream
     hipEvent_t ev_out = nullptr;      // communication stream -> consumer stream
     int world = 0, rank = 0;
+    bool overlap_eager = false;       // SAICV_COMM_MODE=events: communication stream also outside graph capture
     unsigned long long buckets = 0;   // buckets enqueued since creation
     unsigned long long bytes = 0;
 };
+
+namespace {
+
+// Where a collective runs.  Inside a hipGraph capture: on the communication stream, ordered by events -- they become graph
+// edges and the all-reduce overlaps the rest of backward.  In an eagerly launched step: on the PRODUCER stream itself.
+// Measured on MI355X (profiles/r02_ddp_eager_path.md): as soon as the communication stream has to be ordered after a point
+// of a busy compute stream -- event wait, stream wait-value, or a helper thread that waits on the host and then launches
+// -- every kernel of the step runs 20-40 us longer (ResNet-50: 23.6 -> 31-38 ms per step in a world of one), whereas a
+// ring all-reduce of the whole 102 MB gradient costs well under a millisecond on xGMI.  Serialising it is the cheap side.
+bool on_side_stream(const saicv_comm* c, void* stream) {
+    if (c->overlap_eager) return true;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cap != hipStreamCaptureStatusNone;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -132,6 +153,8 @@ int saicv_comm_create(const void* id128, int world, int rank, saicv_comm** out) 
         saicv_comm_destroy(c);
         return -2;
     }
+    const char* mode = getenv("SAICV_COMM_MODE");
+    c->overlap_eager = mode && strcmp(mode, "events") == 0;
     *out = c;
     return 0;
 }
@@ -142,10 +165,15 @@ int saicv_comm_allreduce_bucket(saicv_comm* c, float* grads, size_t n, int avera
     if (n == 0) return 0;
     const Rccl* r = rccl();
     if (!r) return -1;
-    COMM_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(producer_stream)), "allreduce_bucket (record)");
-    COMM_HIP(hipStreamWaitEvent(c->side, c->ev_in, 0), "allreduce_bucket (wait)");
-    COMM_RCCL(r, r->AllReduce(grads, grads, n, ncclFloat32, average ? ncclAvg : ncclSum, c->nccl, c->side),
-              "allreduce_bucket");
+    if (on_side_stream(c, producer_stream)) {
+        COMM_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(producer_stream)), "allreduce_bucket (record)");
+        COMM_HIP(hipStreamWaitEvent(c->side, c->ev_in, 0), "allreduce_bucket (wait)");
+        COMM_RCCL(r, r->AllReduce(grads, grads, n, ncclFloat32, average ? ncclAvg : ncclSum, c->nccl, c->side),
+                  "allreduce_bucket");
+    } else {
+        COMM_RCCL(r, r->AllReduce(grads, grads, n, ncclFloat32, average ? ncclAvg : ncclSum, c->nccl,
+                                  static_cast<hipStream_t>(producer_stream)), "allreduce_bucket");
+    }
     c->buckets += 1;
     c->bytes += n * sizeof(float);
     return 0;
@@ -161,6 +189,10 @@ int saicv_comm_broadcast(saicv_comm* c, void* buf, size_t bytes, int root, void*
     // every collective of this communicator runs on ITS stream, in issue order; the caller's stream is ordered before
     // (buf is ready) and after (buf is overwritten) by events
     hipStream_t user = static_cast<hipStream_t>(stream);
+    if (!on_side_stream(c, stream)) {
+        COMM_RCCL(r, r->Broadcast(buf, buf, bytes, ncclUint8, root, c->nccl, user), "broadcast");
+        return 0;
+    }
     COMM_HIP(hipEventRecord(c->ev_in, user), "broadcast (record)");
     COMM_HIP(hipStreamWaitEvent(c->side, c->ev_in, 0), "broadcast (wait)");
     COMM_RCCL(r, r->Broadcast(buf, buf, bytes, ncclUint8, root, c->nccl, c->side), "broadcast");
@@ -171,6 +203,7 @@ int saicv_comm_broadcast(saicv_comm* c, void* buf, size_t bytes, int root, void*
 
 int saicv_comm_join(saicv_comm* c, void* consumer_stream) {
     if (!c) { saicv::set_error("saicv_comm_join: no communicator"); return -1; }
+    if (!on_side_stream(c, consumer_stream)) return 0;        // the collectives ran on the consumer's own stream
     COMM_HIP(hipEventRecord(c->ev_out, c->side), "join (record)");
     COMM_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), c->ev_out, 0), "join (wait)");
     return 0;

@@ -63,10 +63,16 @@ def lin_gelu_fwd(x2, weight, bias):
     return pre, act
 
 
-def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None):
+_AUTO = object()
+
+
+def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None, grad_w=_AUTO, grad_b=_AUTO, want_w=None,
+            want_bias=None):
     """-> (dx or None, dw or None, db or None); a None dw/db means it was accumulated in place
     into the parameter's arena gradient.  gelu_pre: x2 = gelu(gelu_pre) and the caller wants the gradient
-    with respect to gelu_pre -- the activation's backward is applied in the dgrad epilogue."""
+    with respect to gelu_pre -- the activation's backward is applied in the dgrad epilogue.
+    grad_w / grad_b / want_w / want_bias: a caller whose weight / bias are row blocks of a larger parameter
+    (LinearRowsFn) names the arena-gradient views and whether gradients are wanted itself."""
     dt = x2.dtype
     m, k = x2.shape
     o = weight.shape[0]
@@ -94,11 +100,18 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None):
         else:
             check(L.saicv_linear_dgrad(dtype_code(dt), ptr(dy), ptr(wd), ptr(dx), m, k, op, ptr(addend), st), 'linear_dgrad')
         KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, 0)
-    want_b = bias is not None and bias.requires_grad
-    gb = _arena_grad(bias) if (want_b and op == o) else None
+    want_b = (bias is not None and bias.requires_grad) if want_bias is None else (bias is not None and want_bias)
+    want_w = weight.requires_grad if want_w is None else want_w
+    if grad_b is _AUTO:
+        gb = _arena_grad(bias) if (want_b and op == o) else None
+    else:
+        gb = grad_b if (want_b and op == o) else None
     tb = (gb if gb is not None else torch.zeros(op, dtype=torch.float32, device=x2.device)) if want_b else None
-    if weight.requires_grad:
-        gw = _arena_grad(weight) if (op == o and weight.is_contiguous()) else None
+    if want_w:
+        if grad_w is _AUTO:
+            gw = _arena_grad(weight) if (op == o and weight.is_contiguous()) else None
+        else:
+            gw = grad_w if (op == o and weight.is_contiguous()) else None
         tgt = gw if gw is not None else torch.zeros((op, k), dtype=torch.float32, device=x2.device)
         # the weight-gradient kernel also emits the bias gradient from the dY tiles it streams
         if gw is not None and (not want_b or gb is not None) and ops.WGRAD_SIDE_STREAM:
@@ -325,6 +338,50 @@ class LinearNdFn(torch.autograd.Function):
 
 def linear_nd(x, weight, bias=None, out_f32=False):
     return LinearNdFn.apply(x, weight, bias, out_f32)
+
+
+class LinearRowsFn(torch.autograd.Function):
+    """x @ W[r0:r1]^T + b[r0:r1]: one projection out of a packed parameter (nn.MultiheadAttention.in_proj_weight /
+    in_proj_bias, reference detection/models/detr.py:72-78 through F.multi_head_attention_forward).  The parameters
+    enter WHOLE, so their row-block gradients go straight into the arena rows -- slicing them outside would cost a
+    slice, a zero-filled full-size gradient, a copy and an accumulate per projection and step in autograd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, r0, r1):
+        require_gpu(x, weight)
+        x2 = _as2d(x)
+        w = weight.detach()[r0:r1]
+        b = bias.detach()[r0:r1] if bias is not None else None
+        y = lin_fwd(x2, w, b, False, need_wd=ctx.needs_input_grad[0])
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.cfg = (x.shape, r0, r1)
+        return y.reshape(*x.shape[:-1], r1 - r0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        shape, r0, r1 = ctx.cfg
+        w = weight.detach()[r0:r1]
+        b = bias.detach()[r0:r1] if bias is not None else None
+        gw_full = ops._arena_grad(weight) if weight.is_contiguous() else None
+        gb_full = ops._arena_grad(bias) if bias is not None else None
+        dx, dw, db = lin_bwd(x2, w, b, _as2d(dy), ctx.needs_input_grad[0],
+                             grad_w=gw_full[r0:r1] if gw_full is not None else None,
+                             grad_b=gb_full[r0:r1] if gb_full is not None else None,
+                             want_w=ctx.needs_input_grad[1], want_bias=bias is not None and ctx.needs_input_grad[2])
+        if dw is not None:                       # no arena: a full-size gradient with this block filled in
+            full = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+            full[r0:r1] = dw
+            dw = full
+        if db is not None:
+            full = torch.zeros(bias.shape, dtype=torch.float32, device=bias.device)
+            full[r0:r1] = db
+            db = full
+        return (dx.view(shape) if dx is not None else None), dw, db, None, None
+
+
+def linear_rows(x, weight, bias, r0, r1):
+    return LinearRowsFn.apply(x, weight, bias, r0, r1)
 
 
 class AttentionFn(torch.autograd.Function):

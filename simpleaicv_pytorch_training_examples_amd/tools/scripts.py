@@ -21,6 +21,8 @@ iterations late:
 import collections
 import time
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch.amp.autocast_mode import autocast
