@@ -15,9 +15,11 @@ Design (MI355X-first, one process per GPU):
   * gradient buckets are contiguous slices of the gradient arena in reverse registration
     order (the order backward produces them); a post-accumulate hook counts parameters and,
     when a bucket is complete, enqueues one all-reduce on the library's own RCCL communicator
-    (`saicv_comm_allreduce_bucket`, csrc/comm.hip: communication stream ordered after the
-    producing kernels by an event, so it overlaps the rest of backward); process groups on another
-    backend (gloo in the CPU tests) go through torch.distributed instead;
+    (`saicv_comm_allreduce_bucket`, csrc/comm.hip).  Inside a captured step (StepGraph) it runs on a
+    communication stream, ordered by events, and overlaps the rest of backward; in an eagerly
+    launched step it runs on the compute stream itself -- on this runtime any cross-stream ordering
+    against a busy compute stream costs more than the collective (profiles/r02_ddp_eager_path.md).
+    Process groups on another backend (gloo in the CPU tests) go through torch.distributed instead;
   * xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce moves 1.75x the bucket
     over one link per GPU, so buckets are large (default 48 MiB) and only the LAST bucket to
     complete (stem + first stage) is small (4 MiB) to shorten the exposed tail;
