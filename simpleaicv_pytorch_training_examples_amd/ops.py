@@ -98,12 +98,12 @@ BN_FUSE = _os.environ.get('SAICV_BN_FUSE', '1') == '1'
 class _BnLink:
     """What the data gradient of the NEXT conv needs to produce the backward partial sums of a BatchNorm(+ReLU) node,
     and where that node finds them.  Travels forward as an attribute of the node's output tensor."""
-    __slots__ = ('y', 'mask', 'mean', 'invstd', 'part', 'rows', 'dx')
+    __slots__ = ('y', 'mask', 'mean', 'invstd', 'part', 'rows', 'dx', 'dx_version')
 
     def __init__(self, y, mask, mean, invstd):
         self.y, self.mask, self.mean, self.invstd = y, mask, mean, invstd
         self.part = self.dx = None
-        self.rows = 0
+        self.rows = self.dx_version = 0
 
 
 class _GateLedger:
@@ -136,6 +136,10 @@ def _take_gate(t):
     """ReLU-mask that still has to be applied to gradient tensor t (handed out by a residual node), or None."""
     g = getattr(t, '_saicv_gate', None) if t is not None else None
     if g is not None:
+        if t._version != t._saicv_gate_version:
+            # autograd summed another gradient into this tensor in place: the gate no longer describes its content
+            raise RuntimeError('a gated shortcut gradient was accumulated into before its gate was applied (a residual '
+                               'tensor with several consumers); rerun with SAICV_BN_FUSE=0')
         _GateLedger.consume()
         t._saicv_gate = None
     return g
@@ -399,6 +403,7 @@ class ConvBnActFn(torch.autograd.Function):
                 # the masked copy g = dz * [z > 0] is not written: the consumer gets dz and the mask
                 dres = dz
                 dres._saicv_gate = mask
+                dres._saicv_gate_version = dres._version
                 _GateLedger.hand_out()
             else:
                 dres = _empty_nhwc(n, k, oh, ow, dt, dev)
@@ -413,8 +418,11 @@ class ConvBnActFn(torch.autograd.Function):
             dbeta = torch.empty(k, dtype=torch.float32, device=dev)
         ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, k, dtype_code(dt)), dtype=torch.float32, device=dev)
         link = ctx.link
+        # dz IS the tensor that data gradient wrote (same memory, never written since): with another consumer of z autograd
+        # hands over a sum in a different tensor and the three-pass form runs
         fused_reduce = (link is not None and link.part is not None and link.dx is not None and gate_in is None
-                        and dz.data_ptr() == link.dx.data_ptr() and dz.shape == link.dx.shape)
+                        and dz.data_ptr() == link.dx.data_ptr() and dz.shape == link.dx.shape
+                        and dz._version == link.dx_version)
         t0 = KernelTimer.begin('bn_act_bwd')
         if fused_reduce:
             # the data gradient that wrote dz also left the partial sums of this reduction (no pass over dz and y here)
@@ -457,7 +465,7 @@ class ConvBnActFn(torch.autograd.Function):
                     fuse.bn_y, fuse.bn_mask = ptr(in_link.y), ptr(in_link.mask)
                     fuse.bn_mean, fuse.bn_invstd = ptr(in_link.mean), ptr(in_link.invstd)
                     fuse.part_g, fuse.part_gx = ptr(part[0]), ptr(part[1])
-                    in_link.part, in_link.rows, in_link.dx = part, rows, dx
+                    in_link.part, in_link.rows, in_link.dx, in_link.dx_version = part, rows, dx, dx._version
                 check(L.saicv_conv2d_dgrad_fused(ctypes.byref(d), ptr(dy), ptr(wd), ctypes.byref(fuse), ptr(dx), st),
                       'conv2d_dgrad_fused')
             elif dskip is not None:

@@ -474,3 +474,59 @@ def test_dgrad_epilogue_gated_shortcut_and_bn_backward_sums(case, dt):
         out.append((dyb.float(), dgam.clone(), dbet.clone()))
     assert rel_err(out[1][1], out[0][1]) < 1e-4 and rel_err(out[1][2], out[0][2]) < 1e-4
     assert rel_err(out[1][0], out[0][0]) < (1e-4 if dt == torch.float32 else 8e-3)     # a flipped bf16 rounding at most
+
+
+def _two_layer_grads(fuse, branch):
+    """conv-bn-relu -> conv-bn-relu (+ residual), optionally with a second consumer of the first block's output."""
+    import torch.nn as nn
+    ops = _ops()
+    ops.BN_FUSE = fuse
+    torch.manual_seed(5)
+    c = 32
+    w1 = (torch.randn(c, c, 3, 3) * 0.1).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w2 = (torch.randn(c, c, 3, 3) * 0.1).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bn1, bn2 = nn.BatchNorm2d(c).cuda(), nn.BatchNorm2d(c).cuda()
+    x = torch.randn(4, c, 12, 12).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    z1 = ops.conv_bn_act(x, w1, bn1, 1, 1, True)
+    out, skip = ops.conv_bn_act(z1, w2, bn2, 1, 1, True, want_skip=True)       # skip aliases z1
+    z2 = ops.conv_bn_act(out, w1, bn1, 1, 1, True, residual=skip)
+    loss = (z2.float() ** 2).sum()
+    if branch:
+        loss = loss + (z1.float() * 0.5).sum()          # a second consumer of z1: autograd sums two gradients for it
+    loss.backward()
+    torch.cuda.synchronize()
+    return [t.grad.float().clone() for t in (x, w1, w2, bn1.weight, bn1.bias, bn2.weight, bn2.bias)]
+
+
+@pytest.mark.parametrize('branch', [False, True])
+def test_bn_backward_fusions_equal_the_three_pass_form(branch):
+    """SAICV_BN_FUSE paths (gated shortcut gradient, reduction in the data-gradient epilogue) against the three-pass
+    BatchNorm backward on a small residual chain in fp32 -- also when a block output has a second consumer, where
+    autograd hands the BatchNorm node a SUM in another tensor and the fused reduction must not be used."""
+    ops = _ops()
+    old = ops.BN_FUSE
+    try:
+        ref = _two_layer_grads(False, branch)
+        got = _two_layer_grads(True, branch)
+    finally:
+        ops.BN_FUSE = old
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 1e-4
+
+
+def test_gated_shortcut_gradient_fails_loudly_when_its_tensor_has_another_consumer():
+    """The shortcut alias used twice: autograd accumulates into (or replaces) the gated gradient before the node that
+    applies the gate sees it.  That must be an error, never a silently unmasked gradient."""
+    import torch.nn as nn
+    ops = _ops()
+    if not ops.BN_FUSE:
+        pytest.skip('SAICV_BN_FUSE=0')
+    c = 32
+    w = (torch.randn(c, c, 3, 3) * 0.1).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bn = nn.BatchNorm2d(c).cuda()
+    x = torch.randn(2, c, 8, 8).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out, skip = ops.conv_bn_act(x, w, bn, 1, 1, True, want_skip=True)
+    z = ops.conv_bn_act(out, w, bn, 1, 1, True, residual=skip)
+    with pytest.raises(RuntimeError, match='SAICV_BN_FUSE=0'):
+        ((z.float() ** 2).sum() + (skip.float() ** 2).sum()).backward()
+    ops._GateLedger.pending, ops._GateLedger.queued = 0, False
