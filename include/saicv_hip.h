@@ -58,6 +58,18 @@ int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, floa
                        long sI, long sR, long sS, int accumulate, void* stream);
 
 /* ---- convolution / linear (implicit GEMM on MFMA) ------------------------------------- */
+/* The stride-2 stem as a stride-1 convolution over a space-to-depth image (reference resnet.py:172-174, `conv1` = 7x7,
+ * stride 2, padding 3 on 3 channels): dst[N][Hq][Wq][Cq], Hq = (H + 2 pad + 1) / 2, channel (a, b, c) of pixel (u, v) =
+ * x[2u + a - pad][2v + b - pad][c] (zero outside the image, channels 4C..Cq zero); the weights regroup the same way into
+ * Wf[O][(R+1)/2][(S+1)/2][Cq]; saicv_conv2d_fwd / _wgrad then run with H = Hq, W = Wq, C = Cq, R = (R+1)/2, stride 1, pad 0
+ * (GEMM K 392 -> 256 for the ResNet stem) and saicv_unpack_wgrad_s2d scatters dW back to the [O, I, R, S] gradient. */
+int saicv_pack_input_s2d(int dtype, const float* src, long sN, long sC, long sH, long sW, void* dst, int N, int C, int H,
+                         int W, int pad, int Cq, void* stream);
+int saicv_pack_weight_s2d(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I, int R, int S, int Cq,
+                          void* wf, void* stream);
+int saicv_unpack_wgrad_s2d(const float* dw, int O, int I, int R, int S, int Cq, float* grad, long sO, long sI, long sR,
+                           long sS, int accumulate, void* stream);
+
 /* rows of BN partial statistics saicv_conv2d_fwd writes when stat_sum != NULL */
 int saicv_conv2d_stat_rows(const saicv_conv_desc* d);
 /* y = conv(x, wf) [+ bias]; optionally per-channel partial sum / sum-of-squares of y

@@ -164,7 +164,7 @@ class ResNet(_ResNetBase):
         _init_like_reference(self)
 
     def forward(self, x):
-        x = ops.pack_input(x)                           # NHWC, compute dtype, 3 -> 8 channels
+        x = ops.pack_stem_input(x, self.conv1.layer[0])  # compute dtype; the 7x7 stride-2 stem takes a space-to-depth image
         x = self.conv1(x)
         x = ops.max_pool2d(x, self.maxpool1.kernel_size, self.maxpool1.stride, self.maxpool1.padding)
         x = self._stages(x, self.use_gradient_checkpoint)

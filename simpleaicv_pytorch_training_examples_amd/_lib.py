@@ -56,6 +56,9 @@ SIGNATURES = {
     'saicv_pack_input': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_pack_weight': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'saicv_unpack_wgrad': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_long, c_long, c_long, c_long, c_int, _P]),
+    'saicv_pack_input_s2d': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_pack_weight_s2d': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    'saicv_unpack_wgrad_s2d': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_long, c_long, c_long, c_long, c_int, _P]),
     'saicv_conv2d_stat_rows': (c_int, [_PD]),
     'saicv_conv2d_fwd': (c_int, [_PD, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'saicv_conv2d_dgrad': (c_int, [_PD, _P, _P, _P, _P]),

@@ -28,6 +28,9 @@ int check_launch(const char* what) {
 }
 
 // declared in the other translation units
+int pack_input_s2d(int, const float*, long, long, long, long, void*, int, int, int, int, int, int, hipStream_t);
+int pack_weight_s2d(int, const float*, long, long, long, long, int, int, int, int, int, void*, hipStream_t);
+int unpack_wgrad_s2d(const float*, int, int, int, int, int, float*, long, long, long, long, int, hipStream_t);
 size_t bn_ws_floats(int C);
 int bn_finalize_fwd(const float*, const float*, int, int, double, const float*, const float*, float*,
                     float*, double, double, float*, float*, float*, float*, float*, long long*, hipStream_t);
@@ -104,6 +107,19 @@ int saicv_pack_weight(int dtype, const float* w, long sO, long sI, long sR, long
 int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int Sx, int Ip, float* grad, long sO,
                        long sI, long sR, long sS, int accumulate, void* stream) {
     return unpack_wgrad(dw, O, I, R, Sx, Ip, grad, sO, sI, sR, sS, accumulate, S(stream));
+}
+
+int saicv_pack_input_s2d(int dtype, const float* src, long sN, long sC, long sH, long sW, void* dst, int N, int C, int H,
+                         int W, int pad, int Cq, void* stream) {
+    return pack_input_s2d(dtype, src, sN, sC, sH, sW, dst, N, C, H, W, pad, Cq, S(stream));
+}
+int saicv_pack_weight_s2d(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I, int R, int Sx,
+                          int Cq, void* wf, void* stream) {
+    return pack_weight_s2d(dtype, w, sO, sI, sR, sS, O, I, R, Sx, Cq, wf, S(stream));
+}
+int saicv_unpack_wgrad_s2d(const float* dw, int O, int I, int R, int Sx, int Cq, float* grad, long sO, long sI, long sR,
+                           long sS, int accumulate, void* stream) {
+    return unpack_wgrad_s2d(dw, O, I, R, Sx, Cq, grad, sO, sI, sR, sS, accumulate, S(stream));
 }
 
 int saicv_conv2d_stat_rows(const saicv_conv_desc* d) {

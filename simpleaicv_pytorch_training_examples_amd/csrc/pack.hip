@@ -75,6 +75,74 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
     }
 }
 
+// ---- stride-2 stem as a stride-1 convolution on a space-to-depth image -------------------------------------------------
+// A K x K stride-2 convolution with padding p over x[H][W][C] equals a ceil(K/2) x ceil(K/2) stride-1, unpadded convolution
+// over Q[u][v][(a, b, c)] = P[2u + a][2v + b][c], P = x shifted by p with a zero border, with the weights regrouped as
+// W'[o][R][S][(a, b, c)] = W[o][2R + a][2S + b][c] (taps beyond K are zero).  For the 7 x 7 x 3 ResNet stem the GEMM's K
+// dimension drops from 7*7*8 = 392 (3 channels padded to a 16-byte chunk) to 4*4*16 = 256, and the packed input shrinks
+// from 8 to 4 bf16 per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_s2d_kernel(const float* __restrict__ src, long sN, long sC, long sH,
+                                                             long sW, T* __restrict__ dst, int Nimg, int C, int H, int W,
+                                                             int pad, int Hq, int Wq, int Cq) {
+    const size_t total = (size_t)Nimg * Hq * Wq * 4;              // one (pixel of Q, a, b) group of C channels per thread
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        size_t t = i;
+        const int ab = (int)(t & 3); t >>= 2;
+        const int v = (int)(t % Wq); t /= Wq;
+        const int u = (int)(t % Hq);
+        const int n = (int)(t / Hq);
+        const int h = 2 * u + (ab >> 1) - pad, w = 2 * v + (ab & 1) - pad;
+        const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        const float* sp = src + (size_t)n * sN + (size_t)(in ? h : 0) * sH + (size_t)(in ? w : 0) * sW;
+        T* d = dst + (((size_t)n * Hq + u) * Wq + v) * Cq + ab * C;
+        for (int c = 0; c < C; ++c) d[c] = from_f32<T>(in ? sp[(size_t)c * sC] : 0.f);
+        if (ab == 3)
+            for (int c = 4 * C; c < Cq; ++c) dst[(((size_t)n * Hq + u) * Wq + v) * Cq + c] = from_f32<T>(0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_s2d_kernel(const float* __restrict__ w, long sO, long sI, long sR,
+                                                              long sS, int O, int I, int R, int S, int R2, int S2, int Cq,
+                                                              T* __restrict__ wf) {
+    const size_t total = (size_t)O * R2 * S2 * Cq;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gstride) {
+        size_t t = e;
+        const int q = (int)(t % Cq); t /= Cq;
+        const int s2 = (int)(t % S2); t /= S2;
+        const int r2 = (int)(t % R2);
+        const int o = (int)(t / R2);
+        float v = 0.f;
+        if (q < 4 * I) {
+            const int ab = q / I, c = q - ab * I;
+            const int r = 2 * r2 + (ab >> 1), sx = 2 * s2 + (ab & 1);
+            if (r < R && sx < S) v = w[(size_t)o * sO + (size_t)c * sI + (size_t)r * sR + (size_t)sx * sS];
+        }
+        wf[e] = from_f32<T>(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_s2d_kernel(const float* __restrict__ dw, int O, int I, int R, int S,
+                                                               int R2, int S2, int Cq, float* __restrict__ g, long sO,
+                                                               long sI, long sR, long sS, int accumulate) {
+    const size_t total = (size_t)O * R * S * I;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gstride) {
+        size_t t = e;
+        const int i = (int)(t % I); t /= I;
+        const int s = (int)(t % S); t /= S;
+        const int r = (int)(t % R);
+        const int o = (int)(t / R);
+        const int ab = ((r & 1) << 1) | (s & 1);
+        const float v = dw[(((size_t)o * R2 + (r >> 1)) * S2 + (s >> 1)) * Cq + ab * I + i];
+        float* d = g + (size_t)o * sO + (size_t)i * sI + (size_t)r * sR + (size_t)s * sS;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+
 // column sums of a [M][N] matrix (bias gradient), T in, fp32 out (accumulating atomics).
 // A workgroup streams a slab of rows with 16-byte loads: a thread owns one chunk column and
 // strides over rows; the row lanes are combined through LDS; one atomic per column per slab.
@@ -175,6 +243,38 @@ int unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, float* g, 
     const size_t total = (size_t)O * R * S * I;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(sgrid(total)), dim3(256), 0, st, dw, O, I, R, S, Ip, g, sO, sI, sR, sS, accumulate);
     return check_launch("unpack_wgrad");
+}
+
+int pack_input_s2d(int dtype, const float* src, long sN, long sC, long sH, long sW, void* dst, int Nimg, int C, int H,
+                   int W, int pad, int Cq, hipStream_t st) {
+    SAICV_REQUIRE(Cq >= 4 * C && pad >= 0, "pack_input_s2d: Cq=%d < 4*C=%d", Cq, 4 * C);
+    const int Hq = (H + 2 * pad + 1) / 2, Wq = (W + 2 * pad + 1) / 2;
+    const size_t total = (size_t)Nimg * Hq * Wq * 4;
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_input_s2d_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, src, sN, sC, sH, sW, (bf16_t*)dst, Nimg, C, H, W, pad, Hq, Wq, Cq);
+    else
+        hipLaunchKernelGGL(pack_input_s2d_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, src, sN, sC, sH, sW, (float*)dst, Nimg, C, H, W, pad, Hq, Wq, Cq);
+    return check_launch("pack_input_s2d");
+}
+
+int pack_weight_s2d(int dtype, const float* w, long sO, long sI, long sR, long sS, int O, int I, int R, int S, int Cq,
+                    void* wf, hipStream_t st) {
+    SAICV_REQUIRE(Cq >= 4 * I, "pack_weight_s2d: Cq=%d < 4*I=%d", Cq, 4 * I);
+    const int R2 = (R + 1) / 2, S2 = (S + 1) / 2;
+    const size_t total = (size_t)O * R2 * S2 * Cq;
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_weight_s2d_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, R2, S2, Cq, (bf16_t*)wf);
+    else
+        hipLaunchKernelGGL(pack_weight_s2d_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, R2, S2, Cq, (float*)wf);
+    return check_launch("pack_weight_s2d");
+}
+
+int unpack_wgrad_s2d(const float* dw, int O, int I, int R, int S, int Cq, float* g, long sO, long sI, long sR, long sS,
+                     int accumulate, hipStream_t st) {
+    const size_t total = (size_t)O * R * S * I;
+    hipLaunchKernelGGL(unpack_wgrad_s2d_kernel, dim3(sgrid(total)), dim3(256), 0, st, dw, O, I, R, S, (R + 1) / 2, (S + 1) / 2, Cq, g,
+                       sO, sI, sR, sS, accumulate);
+    return check_launch("unpack_wgrad_s2d");
 }
 
 int row_scale(int dtype, const void* x, const float* scale, void* out, size_t rows, int row_len,

@@ -238,6 +238,49 @@ def pack_input(x, dtype=None, cp=8):
     return out.permute(0, 3, 1, 2)
 
 
+STEM_S2D = _os.environ.get('SAICV_STEM_S2D', '1') == '1'
+
+
+def pack_stem_input(x, conv, dtype=None):
+    """Input of a stem convolution in the layout its kernel wants: for a K x K stride-2 stem (ResNet: 7 x 7, padding 3,
+    reference resnet.py:172-174) the space-to-depth image of saicv_pack_input_s2d -- the convolution then runs as a
+    stride-1 (K+1)/2-tap one with 4C (padded to 16) channels, K dimension 256 instead of 392 -- else pack_input()."""
+    k = conv.kernel_size[0]
+    if (STEM_S2D and not x.requires_grad and conv.stride == (2, 2) and conv.kernel_size[0] == conv.kernel_size[1] and k % 2 == 1
+            and conv.padding == (k // 2, k // 2) and conv.groups == 1 and 4 * x.shape[1] <= 16):
+        require_gpu(x)
+        dtype = dtype or compute_dtype()
+        if x.dtype != torch.float32:
+            x = x.float()
+        n, c, h, w = x.shape
+        pad = k // 2
+        hq, wq, cq = (h + 2 * pad + 1) // 2, (w + 2 * pad + 1) // 2, 16
+        out = torch.empty((n, hq, wq, cq), dtype=dtype, device=x.device)
+        sn, sc, sh, sw = x.stride()
+        check(lib().saicv_pack_input_s2d(dtype_code(dtype), ptr(x), sn, sc, sh, sw, ptr(out), n, c, h, w, pad, cq, stream()),
+              'pack_input_s2d')
+        out = out.permute(0, 3, 1, 2)
+        out._saicv_s2d = (c, h, w, k, pad)
+        return out
+    return pack_input(x, dtype)
+
+
+def _packed_weight_s2d(weight, dtype, cq):
+    """Wf[O][(R+1)/2][(S+1)/2][cq] of a stride-2 stem weight regrouped for the space-to-depth input; cached like packed_weight."""
+    key = (weight._version, _weights_epoch[0], dtype, cq, weight.data_ptr())
+    cache = getattr(weight, '_saicv_pack_s2d', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    w = weight.detach()
+    o, i, r, s = w.shape
+    so, si, sr, ss = w.stride()
+    wf = torch.empty((o, (r + 1) // 2, (s + 1) // 2, cq), dtype=dtype, device=w.device)
+    check(lib().saicv_pack_weight_s2d(dtype_code(dtype), ptr(w), so, si, sr, ss, o, i, r, s, cq, ptr(wf), stream()),
+          'pack_weight_s2d')
+    weight._saicv_pack_s2d = (key, wf)
+    return wf
+
+
 def packed_weight(weight, dtype, cin_padded, need_wd, cout_padded=None):
     """Compute-dtype copies of a conv / linear master weight, cached until the weight changes.
 
@@ -280,6 +323,18 @@ def _weight_grad(dw, weight, cin_padded):
     return g
 
 
+def _weight_grad_s2d(dw, weight, cq, arena_grad):
+    """fp32 dW'[O][(R+1)/2][(S+1)/2][cq] of the space-to-depth stem -> the [O, I, R, S] gradient: added straight into the
+    arena gradient when there is one (returns None), else a tensor laid out like `weight`."""
+    o, i, r, s = weight.shape
+    g = arena_grad if arena_grad is not None else torch.empty_strided(weight.shape, weight.stride(), dtype=torch.float32,
+                                                                      device=weight.device)
+    so, si, sr, ss = g.stride()
+    check(lib().saicv_unpack_wgrad_s2d(ptr(dw), o, i, r, s, cq, ptr(g), so, si, sr, ss, int(arena_grad is not None), stream()),
+          'unpack_wgrad_s2d')
+    return None if arena_grad is not None else g
+
+
 # ------------------------------------------------------------------------------ conv + BN + act
 class ConvBnActFn(torch.autograd.Function):
     """conv -> [BatchNorm2d (train: batch stats, eval: running stats)] -> [+residual] -> [ReLU].
@@ -307,8 +362,17 @@ class ConvBnActFn(torch.autograd.Function):
         # it can leave that node's backward partial sums behind
         ctx.in_link = in_link if (in_link is not None and x is xin and need_dx and c == ci and in_link.y.shape == x.shape
                                   and in_link.y.dtype == dt) else None
-        wf, wd = packed_weight(weight, dt, c, need_dx and c == ci)
-        d = _desc(n, h, w, c, k, r, s, stride, pad, dt)
+        s2d = getattr(xin, '_saicv_s2d', None)
+        if s2d is not None:
+            # stride-2 stem on the space-to-depth image (pack_stem_input): a stride-1 convolution with (R+1)/2 taps
+            if need_dx or (s2d[0], s2d[3], s2d[4]) != (ci, r, pad) or stride != 2 or r != s:
+                raise ValueError('space-to-depth stem input does not match this convolution')
+            wf, wd = _packed_weight_s2d(weight, dt, c), None
+            d = _desc(n, h, w, c, k, (r + 1) // 2, (s + 1) // 2, 1, 0, dt)
+        else:
+            wf, wd = packed_weight(weight, dt, c, need_dx and c == ci)
+            d = _desc(n, h, w, c, k, r, s, stride, pad, dt)
+        ctx.s2d = s2d
         L = lib()
         st = stream()
         dev = x.device
@@ -442,7 +506,7 @@ class ConvBnActFn(torch.autograd.Function):
         KernelTimer.end(t0, 'bn_act_bwd', 0, float(M) * k * y.element_size() *
                         ((1 if fused_reduce else 2) * (2 + (1.0 / 16 if relu else 0)) + (2 if dres_out is not None else 1)))
         c = x.shape[1]
-        flops = 2.0 * M * k * d.R * d.S * min(c, weight.shape[1])
+        flops = 2.0 * M * k * weight.shape[2] * weight.shape[3] * min(c, weight.shape[1])
         dx = None
         if ctx.needs_input_grad[0]:
             if wd is None:
@@ -498,7 +562,7 @@ class ConvBnActFn(torch.autograd.Function):
                 check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
                 KernelTimer.end(t0, 'igemm_tn', flops, 0)
             if not direct:
-                dwt = _weight_grad(dw, weight, c)
+                dwt = _weight_grad_s2d(dw, weight, c, gw) if ctx.s2d is not None else _weight_grad(dw, weight, c)
         return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
                 dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None, None)
 

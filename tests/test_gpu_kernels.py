@@ -530,3 +530,37 @@ def test_gated_shortcut_gradient_fails_loudly_when_its_tensor_has_another_consum
     with pytest.raises(RuntimeError, match='SAICV_BN_FUSE=0'):
         ((z.float() ** 2).sum() + (skip.float() ** 2).sum()).backward()
     ops._GateLedger.pending, ops._GateLedger.queued = 0, False
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('hw', [(32, 32), (37, 45)])
+def test_stem_on_the_space_to_depth_image_equals_the_strided_convolution(hw, dt):
+    """7x7 stride-2 padding-3 stem (reference resnet.py:172-174) through saicv_pack_input_s2d / saicv_pack_weight_s2d /
+    saicv_unpack_wgrad_s2d against F.conv2d + batch_norm + relu on the CPU in fp32; odd image sizes included."""
+    import torch.nn as nn
+    ops = _ops()
+    h, w = hw
+    torch.manual_seed(h * w)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    bn = nn.BatchNorm2d(64)
+    x = torch.randn(3, h, w, 3).permute(0, 3, 1, 2)              # NHWC memory, as the collater hands it over
+    wq = _q(conv.weight.detach(), dt)
+    xq = _q(x, dt)
+    ref_w = wq.clone().requires_grad_(True)
+    y_ref = F.relu(F.batch_norm(F.conv2d(xq, ref_w, None, 2, 3), None, None, bn.weight.detach(), bn.bias.detach(), True, 0.1, bn.eps))
+    g = torch.randn_like(y_ref)
+    y_ref.backward(g)
+    conv_d, bn_d = nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda(), nn.BatchNorm2d(64).cuda()
+    with torch.no_grad():
+        conv_d.weight.copy_(wq)
+    conv_d.weight.data = conv_d.weight.data.contiguous(memory_format=torch.channels_last)
+    assert ops.STEM_S2D
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+        xp = ops.pack_stem_input(x.cuda(), conv_d, dt)
+        assert getattr(xp, '_saicv_s2d', None) is not None and xp.shape[1] == 16
+        y = ops.conv_bn_act(xp, conv_d.weight, bn_d, 2, 3, True)
+    y.backward(g.cuda().to(y.dtype).contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+    assert rel_err(y.float(), y_ref) < TOL[dt]
+    assert rel_err(conv_d.weight.grad, ref_w.grad) < (1e-3 if dt == torch.float32 else 3e-2)
+    assert rel_err(bn_d.running_var, torch.ones(64) * 0.9 + 0.1 * F.conv2d(xq, wq, None, 2, 3).transpose(0, 1).flatten(1).var(1)) < (1e-3 if dt == torch.float32 else 2e-2)
