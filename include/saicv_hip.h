@@ -58,6 +58,19 @@ int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, floa
                        long sI, long sR, long sS, int accumulate, void* stream);
 
 /* ---- convolution / linear (implicit GEMM on MFMA) ------------------------------------- */
+/* All weights of a model repacked in one launch (after the optimizer step): `descs` is a DEVICE array of n descriptors,
+ * each as for saicv_pack_weight plus its first tile index; tiles of one weight = tiles_i * tiles_o * R * S with
+ * tiles_i = ceil(Ip / 32), tiles_o = ceil(Op / 32); total_tiles = the sum.  wd may be NULL per weight. */
+typedef struct saicv_pack_desc {
+    const float* w;
+    long sO, sI, sR, sS;
+    int O, I, R, S, Ip, Op;
+    void* wf;
+    void* wd;
+    int tile_begin, tiles_i, tiles_o, reserved;
+} saicv_pack_desc;
+int saicv_pack_weight_batched(int dtype, const saicv_pack_desc* descs, int n, int total_tiles, void* stream);
+
 /* The stride-2 stem as a stride-1 convolution over a space-to-depth image (reference resnet.py:172-174, `conv1` = 7x7,
  * stride 2, padding 3 on 3 channels): dst[N][Hq][Wq][Cq], Hq = (H + 2 pad + 1) / 2, channel (a, b, c) of pixel (u, v) =
  * x[2u + a - pad][2v + b - pad][c] (zero outside the image, channels 4C..Cq zero); the weights regroup the same way into

@@ -49,6 +49,14 @@ class DgradFuse(Structure):
 
 _PF = POINTER(DgradFuse)
 
+
+class PackDesc(Structure):
+    """saicv_pack_desc (include/saicv_hip.h)"""
+    _fields_ = [('w', c_void_p), ('sO', c_long), ('sI', c_long), ('sR', c_long), ('sS', c_long),
+                ('O', c_int), ('I', c_int), ('R', c_int), ('S', c_int), ('Ip', c_int), ('Op', c_int),
+                ('wf', c_void_p), ('wd', c_void_p), ('tile_begin', c_int), ('tiles_i', c_int), ('tiles_o', c_int),
+                ('reserved', c_int)]
+
 # name -> (restype, argtypes); mirrors include/saicv_hip.h one to one
 SIGNATURES = {
     'saicv_version': (c_int, []),
@@ -56,6 +64,7 @@ SIGNATURES = {
     'saicv_pack_input': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_pack_weight': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'saicv_unpack_wgrad': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_long, c_long, c_long, c_long, c_int, _P]),
+    'saicv_pack_weight_batched': (c_int, [c_int, _P, c_int, c_int, _P]),
     'saicv_pack_input_s2d': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_pack_weight_s2d': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     'saicv_unpack_wgrad_s2d': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_long, c_long, c_long, c_long, c_int, _P]),

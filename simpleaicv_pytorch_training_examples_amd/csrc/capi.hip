@@ -28,6 +28,7 @@ int check_launch(const char* what) {
 }
 
 // declared in the other translation units
+int pack_weight_batched(int, const saicv_pack_desc*, int, int, hipStream_t);
 int pack_input_s2d(int, const float*, long, long, long, long, void*, int, int, int, int, int, int, hipStream_t);
 int pack_weight_s2d(int, const float*, long, long, long, long, int, int, int, int, int, void*, hipStream_t);
 int unpack_wgrad_s2d(const float*, int, int, int, int, int, float*, long, long, long, long, int, hipStream_t);
@@ -109,6 +110,9 @@ int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int Sx, int Ip, flo
     return unpack_wgrad(dw, O, I, R, Sx, Ip, grad, sO, sI, sR, sS, accumulate, S(stream));
 }
 
+int saicv_pack_weight_batched(int dtype, const saicv_pack_desc* descs, int n, int total_tiles, void* stream) {
+    return pack_weight_batched(dtype, descs, n, total_tiles, S(stream));
+}
 int saicv_pack_input_s2d(int dtype, const float* src, long sN, long sC, long sH, long sW, void* dst, int N, int C, int H,
                          int W, int pad, int Cq, void* stream) {
     return pack_input_s2d(dtype, src, sN, sC, sH, sW, dst, N, C, H, W, pad, Cq, S(stream));

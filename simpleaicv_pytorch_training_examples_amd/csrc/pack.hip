@@ -8,6 +8,7 @@
 //  - unpack_wgrad: fp32 dW[O][R][S][Ip] -> gradient tensor [O,I,R,S] with arbitrary strides.
 #include "common.h"
 #include "saicv_internal.h"
+#include "../../include/saicv_hip.h"
 
 namespace {
 
@@ -33,13 +34,11 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 // (The element-per-thread version spent four integer divisions per element and scattered 2-byte Wd writes: 18 us for
 // a ViT fc1 matrix that is 4 us of traffic; it ran 50-54 times per step.)
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, long sO, long sI,
-                                                          long sR, long sS, int O, int I, int R, int S,
-                                                          int Ip, int Op, T* __restrict__ wf, T* __restrict__ wd) {
-    __shared__ float tile[32][33];
+DEVINL void pack_weight_tile(float (*tile)[33], const float* __restrict__ w, long sO, long sI, long sR, long sS, int O, int I,
+                             int R, int S, int Ip, int Op, T* __restrict__ wf, T* __restrict__ wd, int bi, int bo, int tap) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
-    const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
-    const int r = blockIdx.z / S, s = blockIdx.z - r * S;
+    const int i0 = bi * 32, o0 = bo * 32;
+    const int r = tap / S, s = tap - r * S;
 #pragma unroll
     for (int oo = ty; oo < 32; oo += 8) {
         const int o = o0 + oo, i = i0 + tx;
@@ -55,6 +54,34 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
             if (i < I && o < Op) wd[(((size_t)i * R + r) * S + s) * Op + o] = from_f32<T>(tile[tx][ii]);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, long sO, long sI,
+                                                          long sR, long sS, int O, int I, int R, int S,
+                                                          int Ip, int Op, T* __restrict__ wf, T* __restrict__ wd) {
+    __shared__ float tile[32][33];
+    pack_weight_tile<T>(tile, w, sO, sI, sR, sS, O, I, R, S, Ip, Op, wf, wd, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Every weight of a model in ONE launch (the per-step repack after the optimizer: 54 launches of ~5 us for ResNet-50):
+// a block finds its weight by bisection over the tile prefix, then handles one 32 x 32 tile of one tap as above.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_batched_kernel(const saicv_pack_desc* __restrict__ descs, int n) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                   // last descriptor with tile_begin <= t (uniform per block)
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile_begin <= t) lo = mid; else hi = mid - 1;
+    }
+    const saicv_pack_desc d = descs[lo];
+    int local = t - d.tile_begin;
+    const int bi = local % d.tiles_i; local /= d.tiles_i;
+    const int bo = local % d.tiles_o;
+    const int tap = local / d.tiles_o;
+    pack_weight_tile<T>(tile, d.w, d.sO, d.sI, d.sR, d.sS, d.O, d.I, d.R, d.S, d.Ip, d.Op, static_cast<T*>(d.wf),
+                        static_cast<T*>(d.wd), bi, bo, tap);
 }
 
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dw, int O, int I,
@@ -236,6 +263,15 @@ int pack_weight(int dtype, const float* w, long sO, long sI, long sR, long sS, i
     else
         hipLaunchKernelGGL(pack_weight_kernel<float>, grid, dim3(256), 0, st, w, sO, sI, sR, sS, O, I, R, S, Ip, Op, (float*)wf, (float*)wd);
     return check_launch("pack_weight");
+}
+
+int pack_weight_batched(int dtype, const saicv_pack_desc* descs, int n, int total_tiles, hipStream_t st) {
+    SAICV_REQUIRE(descs != nullptr && n > 0 && total_tiles > 0, "pack_weight_batched: empty descriptor table");
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_weight_batched_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, st, descs, n);
+    else
+        hipLaunchKernelGGL(pack_weight_batched_kernel<float>, dim3(total_tiles), dim3(256), 0, st, descs, n);
+    return check_launch("pack_weight_batched");
 }
 
 int unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, float* g, long sO, long sI,

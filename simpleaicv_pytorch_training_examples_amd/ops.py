@@ -281,11 +281,96 @@ def _packed_weight_s2d(weight, dtype, cq):
     return wf
 
 
+class _PackRegistry:
+    """Compute-dtype copies of every parameter that went through packed_weight(), refreshed by ONE batched launch
+    (saicv_pack_weight_batched) the first time one of them is asked for after the optimizer changed the weights, instead of
+    one launch per layer and step.  The copies keep their storage, so a captured step replays against the same pointers."""
+    BATCH = _os.environ.get('SAICV_PACK_BATCH', '1') == '1'
+    entries = {}            # (id(param), dtype, cin_padded, cout_padded) -> dict
+    table = None            # (signature, device descriptor tensor, n, total tiles, dtype)
+
+    @classmethod
+    def get(cls, weight, dtype, cin_padded, cout_padded, need_wd):
+        import weakref
+        k = (id(weight), dtype, cin_padded, cout_padded)
+        e = cls.entries.get(k)
+        if e is not None and e['ref']() is not weight:
+            e = None                                            # id() reused by another tensor
+        if e is None:
+            w = weight.detach()
+            if w.dim() == 2:
+                o, i, r, s = w.shape[0], w.shape[1], 1, 1
+            else:
+                o, i, r, s = w.shape
+            alloc = torch.empty if cout_padded == o else torch.zeros
+            e = {'ref': weakref.ref(weight), 'dtype': dtype, 'ip': cin_padded, 'op': cout_padded, 'dims': (o, i, r, s),
+                 'wf': alloc((cout_padded, r, s, cin_padded), dtype=dtype, device=w.device), 'wd': None, 'key': None, 'used': 0}
+            cls.entries[k] = e
+            cls.table = None
+        if need_wd and e['wd'] is None:
+            o, i, r, s = e['dims']
+            alloc = torch.empty if cout_padded == o else torch.zeros
+            e['wd'] = alloc((i, r, s, cout_padded), dtype=dtype, device=weight.device)
+            e['key'] = None                                     # the new matrix has not been filled yet
+            cls.table = None
+        e['used'] = _weights_epoch[0]
+        return e
+
+    @classmethod
+    def refresh(cls):
+        """One launch over every live entry; stamps each with the key its weight has NOW."""
+        live = [(k, e, e['ref']()) for k, e in cls.entries.items()]
+        for k, e, w in live:
+            if w is None:
+                del cls.entries[k]
+                cls.table = None
+        # weights nobody asked for since the epoch before last (another model of the process) wait until they are wanted
+        live = [(k, e, w) for k, e, w in live if w is not None and w.is_cuda and e['used'] >= _weights_epoch[0] - 1]
+        if not live:
+            return
+        by_dtype = {}
+        for k, e, w in live:
+            by_dtype.setdefault(e['dtype'], []).append((e, w))
+        sig = tuple((id(e), w.data_ptr(), w.stride(), ptr(e['wf']), ptr(e['wd'])) for _, e, w in live)
+        if cls.table is None or cls.table[0] != sig:
+            tables = []
+            for dt, items in by_dtype.items():
+                arr = (_lib.PackDesc * len(items))()
+                t0 = 0
+                for j, (e, w) in enumerate(items):
+                    o, i, r, s = e['dims']
+                    wv = w.detach()
+                    if wv.dim() == 2:
+                        so, si = wv.stride()
+                        sr = ss = 0
+                    else:
+                        so, si, sr, ss = wv.stride()
+                    d = arr[j]
+                    d.w, d.sO, d.sI, d.sR, d.sS = wv.data_ptr(), so, si, sr, ss
+                    d.O, d.I, d.R, d.S, d.Ip, d.Op = o, i, r, s, e['ip'], e['op']
+                    d.wf, d.wd = ptr(e['wf']), ptr(e['wd'])
+                    d.tiles_i, d.tiles_o = (e['ip'] + 31) // 32, (e['op'] + 31) // 32
+                    d.tile_begin = t0
+                    t0 += d.tiles_i * d.tiles_o * r * s
+                dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][1].device)
+                tables.append((dt, dev, len(items), t0))
+            cls.table = (sig, tables)
+        for dt, dev, n, tiles in cls.table[1]:
+            check(lib().saicv_pack_weight_batched(dtype_code(dt), ptr(dev), n, tiles, stream()), 'pack_weight_batched')
+        for _, e, w in live:
+            e['key'] = (w._version, _weights_epoch[0], w.data_ptr())
+
+
 def packed_weight(weight, dtype, cin_padded, need_wd, cout_padded=None):
     """Compute-dtype copies of a conv / linear master weight, cached until the weight changes.
 
     Returns (wf [Op][R][S][Ip], wd [I][R][S][Op] or None); rows/cols beyond O are zero."""
     cout_padded = cout_padded or weight.shape[0]
+    if _PackRegistry.BATCH and isinstance(weight, torch.nn.Parameter) and weight.is_cuda:
+        e = _PackRegistry.get(weight, dtype, cin_padded, cout_padded, need_wd)
+        if e['key'] != (weight._version, _weights_epoch[0], weight.data_ptr()):
+            _PackRegistry.refresh()
+        return e['wf'], (e['wd'] if need_wd else None)
     key = (weight._version, _weights_epoch[0], dtype, cin_padded, cout_padded, weight.data_ptr())
     cache = getattr(weight, '_saicv_pack', None)
     if cache is not None and cache[0] == key and (cache[2] is not None or not need_wd):
