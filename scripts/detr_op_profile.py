@@ -12,7 +12,7 @@ import bench  # noqa: E402
 
 def main():
     sys.argv = ['bench.py', '--model', sys.argv[1] if len(sys.argv) > 1 else 'resnet50_detr_config', '--batch', sys.argv[2] if len(sys.argv) > 2 else '8',
-                '--steps', '2', '--warmup', '2', '--no-cpu-baseline', '--no-secondary', '--max-windows', '1', '--no-kernel-timer']
+                '--steps', '2', '--warmup', '2', '--eager', '--no-cpu-baseline', '--no-secondary', '--max-windows', '1', '--no-kernel-timer']
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False) as prof:
         try:
