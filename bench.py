@@ -553,10 +553,19 @@ def worker(args):
             out['secondary'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **secondary}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, AFTER this line:
+        # flush it first so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(line, flush=True)
 
 
 def main():

@@ -55,22 +55,44 @@ class DETRLoss(nn.Module):
         cls_preds, reg_preds = preds
         reg_preds = torch.clamp(reg_preds, min=1e-4, max=1. - 1e-4).float()
         cls_preds = cls_preds.float()
-        annotations = annotations.float()
-        indices = self.get_matched_pred_target_idxs(cls_preds[-1], reg_preds[-1], annotations)
-        # flat (image, query) <-> ground-truth correspondence, shared by all layers
-        valid = [a[a[:, 4] >= 0] for a in annotations]
-        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)]).to(cls_preds.device)
-        src_idx = torch.cat([src for src, _ in indices]).to(cls_preds.device)
-        matched = torch.cat([v[j.to(v.device)] for v, (_, j) in zip(valid, indices)], dim=0)     # [n, 5]
-        target_num = sum(v.shape[0] for v in valid)
+        gt, counts = self._valid_targets(annotations)
+        indices = self._match(cls_preds[-1], reg_preds[-1], gt, counts)
+        # flat (image, query) <-> ground-truth correspondence, shared by all layers; built on the host, one upload
+        offs = np.concatenate([[0], np.cumsum(counts)[:-1]]) if counts else np.zeros(0, dtype=np.int64)
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)]).to(cls_preds.device, non_blocking=True)
+        src_idx = torch.cat([src for src, _ in indices]).to(cls_preds.device, non_blocking=True)
+        rows = torch.cat([j + int(o) for (_, j), o in zip(indices, offs)]).to(cls_preds.device, non_blocking=True)
+        matched = gt[rows]                                                                       # [n, 5]
+        target_num = int(sum(counts))
+        # all decoder layers at once ([L, B, Q, *] tensors): the per-layer arithmetic of the reference's loop
+        # (losses.py:905-935) in one pass -- six times fewer tiny launches on a path that is host-bound
+        cls_l = self._cls_loss_layers(cls_preds, batch_idx, src_idx, matched[:, 4])
+        l1_l, iou_l = self._box_losses_layers(reg_preds[:, batch_idx, src_idx], matched[:, 0:4], target_num)
         loss_dict = {}
-        for idx, (layer_cls, layer_reg) in enumerate(zip(cls_preds, reg_preds)):
-            cls_loss = self._cls_loss(layer_cls, batch_idx, src_idx, matched[:, 4])
-            l1_loss, iou_loss = self._box_losses(layer_reg[batch_idx, src_idx], matched[:, 0:4], target_num)
-            loss_dict[f'layer_{idx}_cls_loss'] = self.cls_loss_weight * cls_loss
-            loss_dict[f'layer_{idx}_box_l1_loss'] = self.box_l1_loss_weight * l1_loss
-            loss_dict[f'layer_{idx}_box_iou_loss'] = self.iou_loss_weight * iou_loss
+        for idx in range(cls_preds.shape[0]):
+            loss_dict[f'layer_{idx}_cls_loss'] = self.cls_loss_weight * cls_l[idx]
+            loss_dict[f'layer_{idx}_box_l1_loss'] = self.box_l1_loss_weight * l1_l[idx]
+            loss_dict[f'layer_{idx}_box_iou_loss'] = self.iou_loss_weight * iou_l[idx]
         return loss_dict
+
+    def _cls_loss_layers(self, cls_preds, batch_idx, src_idx, target_classes):
+        """Weighted cross-entropy of every layer: [L, B, Q, C+1] logits -> [L] losses (F.cross_entropy(..., weight) per layer:
+        sum of w[gt] * nll over sum of w[gt])."""
+        l, b, q = cls_preds.shape[0], cls_preds.shape[1], cls_preds.shape[2]
+        gt = torch.full((b, q), self.num_classes, dtype=torch.long, device=cls_preds.device)
+        gt[batch_idx, src_idx] = target_classes.long()
+        weight = torch.ones(self.num_classes + 1, device=cls_preds.device)
+        weight[-1] = self.no_object_cls_weight
+        nll = -F.log_softmax(cls_preds, dim=-1).gather(-1, gt.view(1, b, q, 1).expand(l, b, q, 1)).squeeze(-1)
+        wgt = weight[gt]
+        return (nll * wgt).sum(dim=(1, 2)) / wgt.sum()
+
+    def _box_losses_layers(self, matched_preds, target_boxes, target_num):
+        """[L, n, 4] matched predictions against [n, 4] targets -> ([L] L1, [L] 1 - GIoU), each summed over the pairs and
+        divided by the number of ground-truth boxes."""
+        l1 = (matched_preds - target_boxes).abs().sum(dim=(1, 2)) / target_num
+        giou = _giou(_cxcywh_to_xyxy(matched_preds), _cxcywh_to_xyxy(target_boxes))
+        return l1, (1 - giou).sum(dim=1) / target_num
 
     def _cls_loss(self, cls_preds, batch_idx, src_idx, target_classes):
         b, q = cls_preds.shape[0], cls_preds.shape[1]
@@ -107,14 +129,31 @@ class DETRLoss(nn.Module):
         """[N, 4] x [M, 4] xyxy -> [N, M] pairwise GIoU."""
         return _giou(boxes1[:, None, :], boxes2[None, :, :])
 
+    @staticmethod
+    def _valid_targets(annotations):
+        """-> (gt [n, 5] fp32 on the annotations' device: the rows with class >= 0, image after image; boxes per image).
+        When the loop attached the host copy the collater produced (`annotations._saicv_host`), the row selection is
+        computed there and costs one small upload; else one boolean-mask index per image (a device sync each)."""
+        host = getattr(annotations, '_saicv_host', None)
+        if host is not None and host.shape == annotations.shape:
+            keep = host[:, :, 4] >= 0
+            counts = keep.sum(dim=1).tolist()
+            rows = keep.flatten().nonzero().squeeze(1)
+            return annotations.float().flatten(0, 1)[rows.to(annotations.device, non_blocking=True)], counts
+        ann = annotations.float()
+        valid = [a[a[:, 4] >= 0] for a in ann]
+        return torch.cat(valid, dim=0), [v.shape[0] for v in valid]
+
     @torch.no_grad()
     def get_matched_pred_target_idxs(self, cls_preds, reg_preds, annotations):
+        gt, counts = self._valid_targets(annotations)
+        return self._match(cls_preds, reg_preds, gt, counts)
+
+    @torch.no_grad()
+    def _match(self, cls_preds, reg_preds, gt, counts):
         b, q = cls_preds.shape[0], cls_preds.shape[1]
         prob = torch.clamp(F.softmax(cls_preds.flatten(0, 1), dim=-1), min=1e-4, max=1. - 1e-4)
         boxes = reg_preds.flatten(0, 1)
-        valid = [a[a[:, 4] >= 0] for a in annotations]
-        counts = [v.shape[0] for v in valid]
-        gt = torch.cat(valid, dim=0)
         cls_cost = -prob[:, gt[:, 4].long()]
         box_cost = torch.cdist(boxes, gt[:, 0:4], p=1)
         giou_cost = -self.compute_box_giou(_cxcywh_to_xyxy(boxes), _cxcywh_to_xyxy(gt[:, 0:4]))

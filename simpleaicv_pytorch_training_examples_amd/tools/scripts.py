@@ -338,7 +338,10 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
 
     def step_fn(data):
         images = data['image'].to(device, non_blocking=True)
-        targets = (data['scaled_annots'] if is_detr else data['annots']).to(device, non_blocking=True)
+        host_targets = data['scaled_annots'] if is_detr else data['annots']
+        targets = host_targets.to(device, non_blocking=True)
+        if is_detr and not host_targets.is_cuda:
+            targets._saicv_host = host_targets           # DETRLoss selects the valid rows on the host (no per-image device sync)
         bad = ~torch.isfinite(images).all() | ~torch.isfinite(targets).all()
         with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
             outs = model(images, data['mask'].to(device, non_blocking=True)) if is_detr else model(images)
