@@ -45,10 +45,8 @@ class SAM(nn.Module):
             iou_prediction_head_block_nums=mask_decoder_iou_prediction_head_block_nums,
             iou_prediction_head_hidden_planes=mask_decoder_iou_prediction_head_hidden_planes)
         # the prompt encoder / mask decoder run 1 + decoder_iters times per training step
-        # (tools/interactive_segmentation_scripts.py): their gradients are final only after autograd's
-        # own accumulation, so the engine must not treat a kernel's in-place write as "gradient ready"
-        for param in list(self.prompt_encoder.parameters()) + list(self.mask_decoder.parameters()):
-            param._saicv_multi_use = True
+        # (tools/interactive_segmentation_scripts.py): every pass adds its share to the arena gradient in place; the
+        # engine learns that a gradient is complete from autograd's post-accumulate hook, which runs after the last use
         if frozen_image_encoder:
             for param in self.image_encoder.parameters():
                 param.requires_grad = False

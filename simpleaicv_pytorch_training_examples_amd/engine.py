@@ -73,10 +73,10 @@ class FlatArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad.as_strided(p.shape, p.stride(), o)
-                # kernels may accumulate into p.grad in place (ops._arena_grad) -- except for parameters a
-                # model marks as used several times per step (SAM decoder: 1 + decoder_iters passes),
-                # whose gradient is only complete when autograd's own accumulation node has run
-                p._saicv_direct = not getattr(p, '_saicv_multi_use', False)
+                # kernels accumulate into p.grad in place (ops._arena_grad), also for parameters used several times per
+                # step (SAM decoder: 1 + decoder_iters passes; DETR's shared decoder norm): every use adds its share, and
+                # "complete" is signalled by the post-accumulate hook below, which autograd runs after the LAST use
+                p._saicv_direct = True
         # "this parameter's gradient of the current backward is complete": autograd runs a leaf's
         # AccumulateGrad node exactly once per backward, after every use of the leaf (also when the
         # kernels wrote the gradient in place and returned None), and this hook with it
