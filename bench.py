@@ -165,6 +165,8 @@ def classification_workload(name, args, world, rank, device, use_graph):
     def run(k):
         state['loss'] = scripts.train_classification(DeviceLoader([data] * k, config.batch_size, iters_per_epoch), model,
                                                      config.train_criterion, optimizer, scheduler, 1, logger, config)
+        graphs = getattr(config, '_saicv_step_graphs', None)
+        state['step_graph'] = next(iter(graphs.values())) if graphs else None
 
     info = {'config_file': cfg_path, 'loop': 'tools.scripts.train_classification', 'optimizer': config.optimizer[0],
             'param_groups': len(optimizer.param_groups)}
@@ -281,6 +283,13 @@ def step_workload(name, args, world, rank, device):
     return run, ddp, scaler, state, info, batch, size
 
 
+def _replay_host_ms(state):
+    g = state.get('step_graph') if isinstance(state, dict) else None
+    if g is None or not getattr(g, 'replays', 0):
+        return None
+    return round(g.replay_host_s / g.replays * 1e3, 3)
+
+
 def measure(name, args, world, rank, device, use_graph, primary):
     """-> result dict of one workload (timed windows, kernel pricing pass)."""
     import torch
@@ -331,7 +340,10 @@ def measure(name, args, world, rank, device, use_graph, primary):
         'config': {'workload': f'{name} 3x{size}x{size} synthetic training step (fwd+loss+bwd+all-reduce+optimizer), per-GPU batch {batch}',
                    'model': name, 'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}',
                    'final_loss': round(float(state['loss']), 4), 'loss_scale': scaler.get_scale() if scaler is not None else None,
-                   'step_graph': bool(use_graph), 'host_ms_per_step': round(statistics.median(host) / args.steps * 1e3, 3), **info},
+                   'step_graph': bool(use_graph), 'host_ms_per_step': round(statistics.median(host) / args.steps * 1e3, 3),
+                   # host time spent ISSUING a step when it is a graph replay (input copies, hyper-parameter refresh,
+                   # hipGraphLaunch); host_ms_per_step above also contains the loop's lagged read of the loss, i.e. waiting
+                   'host_enqueue_ms_per_step': _replay_host_ms(state), **info},
         'model_mfma_frac': round((LOOP_MODELS[name][3] if name in LOOP_MODELS else TRAIN_GFLOP_PER_IMG.get(name, 0)) * value / world / 1e3 / PEAK_BF16_TFLOPS, 4),
         'rccl_ranks': dist.get_world_size() if world > 1 else 1,
         'gradient_allreduce': ('saicv_comm (library RCCL communicator)' if getattr(model, 'comm', None) is not None

@@ -136,6 +136,10 @@ typedef struct saicv_dgrad_fuse {
     const float* bn_invstd;
     float* part_g;
     float* part_gx;
+    int part_rows;      /* 0: one row per tile row (saicv_conv2d_dgrad_stat_rows rows, for saicv_bn_act_bwd_from_partials);
+                         * > 0: the sums are ADDED (fp32 atomics) into this many rows of a buffer the caller zeroed, for
+                         * saicv_bn_act_bwd_inline */
+    int reserved;
 } saicv_dgrad_fuse;
 int saicv_conv2d_dgrad_stat_rows(const saicv_conv_desc* d);
 int saicv_conv2d_dgrad_fused(const saicv_conv_desc* d, const void* dy, const void* wd, const saicv_dgrad_fuse* f, void* dx,
@@ -174,6 +178,23 @@ int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* relu_
                      float* dbeta, size_t M, int C, int relu, int accumulate, float* ws,
                      void* stream);
 
+/* BatchNorm statistics without the partial-reduce / finalize launches: the convolution ADDS its per-tile sums (fp32 atomics)
+ * into stat_rows (1..64) rows of [stat_rows][K] buffers the caller zeroed (row = tile row mod stat_rows), and
+ * saicv_bn_act_fwd_stats derives mean / invstd / scale / shift from them in every workgroup (K <= 2048), applies them, and --
+ * workgroup 0 -- stores mean / invstd and updates running statistics and num_batches_tracked as saicv_bn_finalize_fwd does.
+ * The summation order of the atomics is not fixed: statistics differ from run to run in the last bit or two. */
+int saicv_conv2d_fwd_stats(const saicv_conv_desc* d, const void* x, const void* wf, void* y, float* stat_sum, float* stat_sq,
+                           int stat_rows, void* stream);
+int saicv_bn_act_fwd_stats(int dtype, const void* y, const void* res, void* z, const float* stat_sum, const float* stat_sq,
+                           int stat_rows, double count, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, double momentum, double eps, long long* num_batches_tracked, float* mean,
+                           float* invstd, size_t M, int C, int relu, void* relu_mask, void* stream);
+/* backward counterpart: part_g / part_gx are `rows` atomically accumulated rows (saicv_conv2d_dgrad_fused with part_rows > 0);
+ * coefficients, dgamma and dbeta come out of the one streaming kernel */
+int saicv_bn_act_bwd_inline(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,
+                            const float* mean, const float* invstd, const float* part_g, const float* part_gx, int rows,
+                            void* dy, void* dres, float* dgamma, float* dbeta, size_t M, int C, int relu, int accumulate,
+                            void* stream);
 /* the same with the reduction pass already done by saicv_conv2d_dgrad_fused (part_g / part_gx, `rows` rows of C);
  * ws as for saicv_bn_act_bwd */
 int saicv_bn_act_bwd_from_partials(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,

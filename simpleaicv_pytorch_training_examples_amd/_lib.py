@@ -44,7 +44,8 @@ _PA = POINTER(AttnDesc)
 class DgradFuse(Structure):
     """saicv_dgrad_fuse (include/saicv_hip.h)"""
     _fields_ = [('addend', c_void_p), ('addend_gate', c_void_p), ('bn_y', c_void_p), ('bn_mask', c_void_p),
-                ('bn_mean', c_void_p), ('bn_invstd', c_void_p), ('part_g', c_void_p), ('part_gx', c_void_p)]
+                ('bn_mean', c_void_p), ('bn_invstd', c_void_p), ('part_g', c_void_p), ('part_gx', c_void_p),
+                ('part_rows', c_int), ('reserved', c_int)]
 
 
 _PF = POINTER(DgradFuse)
@@ -79,6 +80,11 @@ SIGNATURES = {
     'saicv_conv2d_dgrad_add': (c_int, [_PD, _P, _P, _P, _P, _P]),
     'saicv_conv2d_dgrad_stat_rows': (c_int, [_PD]),
     'saicv_conv2d_dgrad_fused': (c_int, [_PD, _P, _P, _PF, _P, _P]),
+    'saicv_conv2d_fwd_stats': (c_int, [_PD, _P, _P, _P, _P, _P, c_int, _P]),
+    'saicv_bn_act_fwd_stats': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_double, _P, _P, _P, _P, c_double, c_double, _P, _P, _P,
+                                       c_size_t, c_int, c_int, _P, _P]),
+    'saicv_bn_act_bwd_inline': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_size_t, c_int, c_int,
+                                        c_int, _P]),
     'saicv_bn_act_bwd_from_partials': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_size_t, c_int,
                                                c_int, c_int, _P, _P]),
     'saicv_row_scale': (c_int, [c_int, _P, _P, _P, c_size_t, c_int, c_int, _P]),

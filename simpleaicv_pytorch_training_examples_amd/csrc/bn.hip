@@ -145,15 +145,53 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma,
 // ---------------------------------------------------------------- forward apply
 // HOIST: the launch guarantees (gridDim.x*256) % (C/N) == 0, so a thread sees the same N
 // channels on every grid-stride iteration and keeps scale/shift in registers.
-template <typename T, bool RELU, bool RES, bool HOIST>
+// SELF: the statistics arrive as a few rows of atomically accumulated sums (igemm.hip, stat_atomic_rows) and EVERY block
+// finalises all channels into LDS first (C <= kInlineMaxC; block 0 also stores mean / invstd and updates the running
+// statistics): the partial-reduce and finalize launches between the convolution and this kernel disappear.
+constexpr int kInlineMaxC = 2048;
+struct BnFwdInline {
+    const float* sum; const float* sq; int rows; float count;
+    const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; long long* num_batches_tracked;
+    float* mean_out; float* invstd_out;
+};
+
+template <typename T, bool RELU, bool RES, bool HOIST, bool SELF>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y,
                                                          const T* __restrict__ res, T* __restrict__ z,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
-                                                         size_t nchunks, int C, uint8_t* __restrict__ mask) {
+                                                         size_t nchunks, int C, uint8_t* __restrict__ mask,
+                                                         const BnFwdInline st) {
     constexpr int N = Chunk<T>::N;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float lsc[SELF ? kInlineMaxC : 4], lsh[SELF ? kInlineMaxC : 4];
+    if (SELF) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && st.num_batches_tracked != nullptr) *st.num_batches_tracked += 1;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = 0.f, q = 0.f;
+            for (int r = 0; r < st.rows; ++r) { s += st.sum[(size_t)r * C + c]; q += st.sq[(size_t)r * C + c]; }
+            const float mean = s / st.count;
+            const float var = fmaxf(q / st.count - mean * mean, 0.f);
+            const float invstd = rsqrtf(var + st.eps);
+            const float g = st.gamma ? st.gamma[c] : 1.f, bt = st.beta ? st.beta[c] : 0.f;
+            lsc[c] = g * invstd;
+            lsh[c] = bt - mean * g * invstd;
+            if (blockIdx.x == 0) {
+                st.mean_out[c] = mean;
+                st.invstd_out[c] = invstd;
+                if (st.running_mean) {
+                    const float unbiased = st.count > 1.f ? var * st.count / (st.count - 1.f) : var;
+                    st.running_mean[c] = (1.f - st.momentum) * st.running_mean[c] + st.momentum * mean;
+                    st.running_var[c] = (1.f - st.momentum) * st.running_var[c] + st.momentum * unbiased;
+                }
+            }
+        }
+        __syncthreads();
+        scale = lsc;
+        shift = lsh;
+    }
     float sc[N], sh[N];
     auto load_coeffs = [&](int c0) {
 #pragma unroll
@@ -307,7 +345,15 @@ __global__ __launch_bounds__(64 * NW) void bn_finalize_bwd_kernel(const float* _
 }
 
 // ---------------------------------------------------------------- backward apply
-template <typename T, bool RELU, bool RES, bool HOIST>
+// SELF: as in the forward kernel -- the sums arrive as a few atomically accumulated rows, every block derives the
+// per-channel coefficients into LDS, block 0 also writes dgamma / dbeta.
+struct BnBwdInline {
+    const float* pg; const float* pgx; int rows; float count;
+    const float* gamma; const float* mean; const float* invstd;
+    float* dgamma; float* dbeta; int accumulate;
+};
+
+template <typename T, bool RELU, bool RES, bool HOIST, bool SELF>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz,
                                                            const T* __restrict__ z,
                                                            const T* __restrict__ y,
@@ -315,10 +361,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ cb,
                                                            const float* __restrict__ cc,
                                                            T* __restrict__ dy, T* __restrict__ dres,
-                                                           size_t nchunks, int C, const uint8_t* __restrict__ mask) {
+                                                           size_t nchunks, int C, const uint8_t* __restrict__ mask,
+                                                           const BnBwdInline st) {
     constexpr int N = Chunk<T>::N;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float la[SELF ? kInlineMaxC : 4], lb[SELF ? kInlineMaxC : 4], lc[SELF ? kInlineMaxC : 4];
+    if (SELF) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float sg = 0.f, sx = 0.f;
+            for (int r = 0; r < st.rows; ++r) { sg += st.pg[(size_t)r * C + c]; sx += st.pgx[(size_t)r * C + c]; }
+            if (blockIdx.x == 0) {
+                if (st.dgamma) st.dgamma[c] = st.accumulate ? st.dgamma[c] + sx : sx;
+                if (st.dbeta) st.dbeta[c] = st.accumulate ? st.dbeta[c] + sg : sg;
+            }
+            const float g = st.gamma ? st.gamma[c] : 1.f;
+            const float A = g * st.invstd[c];
+            const float mg = sg / st.count, mgx = sx / st.count;
+            const float B = -A * st.invstd[c] * mgx;
+            la[c] = A;
+            lb[c] = B;
+            lc[c] = -A * mg - B * st.mean[c];
+        }
+        __syncthreads();
+        ca = la; cb = lb; cc = lc;
+    }
     float ka[N], kb[N], kc[N];
     auto load_coeffs = [&](int c0) {
 #pragma unroll
@@ -409,17 +476,21 @@ int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* ru
 
 template <typename T>
 static int bn_act_fwd_t(const void* y, const void* res, void* z, const float* scale,
-                        const float* shift, size_t M, int C, int relu, uint8_t* mask, hipStream_t st) {
+                        const float* shift, size_t M, int C, int relu, uint8_t* mask, hipStream_t st,
+                        const BnFwdInline* inl = nullptr) {
     constexpr int N = Chunk<T>::N;
     const size_t nchunks = M * (size_t)C / N;
     const int grid = stream_grid(nchunks);
     const T* yy = (const T*)y; const T* rr = (const T*)res; T* zz = (T*)z;
     const bool hoist = ((size_t)grid * 256) % (size_t)(C / N) == 0;
-#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, true>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C, mask); \
-                          else hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, false>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C, mask); } while (0)
+    const BnFwdInline none = {};
+#define LAUNCH2(R, S, H) do { if (inl) hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, H, true>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C, mask, *inl); \
+                              else hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, H, false>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C, mask, none); } while (0)
+#define LAUNCH(R, S) do { if (hoist) LAUNCH2(R, S, true); else LAUNCH2(R, S, false); } while (0)
     if (relu) { if (res) LAUNCH(true, true); else LAUNCH(true, false); }
     else      { if (res) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
+#undef LAUNCH2
     return check_launch("bn_act_fwd");
 }
 
@@ -430,6 +501,19 @@ int bn_act_fwd(int dtype, const void* y, const void* res, void* z, const float* 
     SAICV_REQUIRE(C % n == 0, "bn_act_fwd: C=%d must be a multiple of %d", C, n);
     if (dtype == SAICV_DTYPE_BF16) return bn_act_fwd_t<bf16_t>(y, res, z, scale, shift, M, C, relu, mask, st);
     return bn_act_fwd_t<float>(y, res, z, scale, shift, M, C, relu, mask, st);
+}
+
+int bn_act_fwd_stats(int dtype, const void* y, const void* res, void* z, const float* sum, const float* sq, int rows,
+                     double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     double momentum, double eps, long long* num_batches_tracked, float* mean_out, float* invstd_out, size_t M,
+                     int C, int relu, void* relu_mask, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && C <= kInlineMaxC, "bn_act_fwd_stats: C=%d must be a multiple of %d and <= %d", C, n, kInlineMaxC);
+    SAICV_REQUIRE(sum && sq && rows >= 1 && rows <= 64 && mean_out && invstd_out, "bn_act_fwd_stats: statistics rows / outputs missing");
+    BnFwdInline inl = {sum, sq, rows, (float)count, gamma, beta, (float)eps, (float)momentum, running_mean, running_var,
+                       num_batches_tracked, mean_out, invstd_out};
+    if (dtype == SAICV_DTYPE_BF16) return bn_act_fwd_t<bf16_t>(y, res, z, nullptr, nullptr, M, C, relu, (uint8_t*)relu_mask, st, &inl);
+    return bn_act_fwd_t<float>(y, res, z, nullptr, nullptr, M, C, relu, (uint8_t*)relu_mask, st, &inl);
 }
 
 // rows of partials produced by bn_bwd (so the caller can size the workspace)
@@ -481,12 +565,44 @@ static int bn_bwd_t(const void* dz, const void* z, const uint8_t* mask, const vo
     const int grid = stream_grid(nchunks);
     T* dyy = (T*)dy; T* drr = (T*)dres;
     const bool hoist = ((size_t)grid * 256) % (size_t)(C / N) == 0;
-#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, true>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C, mask); \
-                          else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, false>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C, mask); } while (0)
+    const BnBwdInline none = {};
+#define LAUNCH(R, S) do { if (hoist) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, true, false>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C, mask, none); \
+                          else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, false, false>), dim3(grid), dim3(256), 0, st, dzz, zz, yy, coef, coef + C, coef + 2 * C, dyy, drr, nchunks, C, mask, none); } while (0)
     if (relu) { if (dres) LAUNCH(true, true); else LAUNCH(true, false); }
     else      { if (dres) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
     return check_launch("bn_bwd");
+}
+
+template <typename T>
+static int bn_bwd_inline_t(const void* dz, const uint8_t* mask, const void* y, void* dy, void* dres, size_t M, int C, int relu,
+                           const BnBwdInline& inl, hipStream_t st) {
+    constexpr int N = Chunk<T>::N;
+    const size_t nchunks = M * (size_t)C / N;
+    const int grid = stream_grid(nchunks);
+    const bool hoist = ((size_t)grid * 256) % (size_t)(C / N) == 0;
+    const T* dzz = (const T*)dz; const T* yy = (const T*)y; T* dyy = (T*)dy; T* drr = (T*)dres;
+#define LAUNCH2(R, S, H) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, S, H, true>), dim3(grid), dim3(256), 0, st, dzz, (const T*)nullptr, yy, \
+                                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dyy, drr, nchunks, C, mask, inl)
+#define LAUNCH(R, S) do { if (hoist) LAUNCH2(R, S, true); else LAUNCH2(R, S, false); } while (0)
+    if (relu) { if (dres) LAUNCH(true, true); else LAUNCH(true, false); }
+    else      { if (dres) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+#undef LAUNCH2
+    return check_launch("bn_bwd_inline");
+}
+
+// backward with the reduction already done into a few atomically accumulated rows: ONE launch (coefficients in-kernel)
+int bn_bwd_inline(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma, const float* mean,
+                  const float* invstd, const float* part_g, const float* part_gx, int rows, void* dy, void* dres, float* dgamma,
+                  float* dbeta, size_t M, int C, int relu, int accumulate, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && C <= kInlineMaxC, "bn_bwd_inline: C=%d must be a multiple of %d and <= %d", C, n, kInlineMaxC);
+    SAICV_REQUIRE(part_g && part_gx && rows >= 1 && rows <= 64, "bn_bwd_inline: partial sums missing");
+    SAICV_REQUIRE(!relu || relu_mask != nullptr, "bn_bwd_inline: relu needs the sign mask");
+    const BnBwdInline inl = {part_g, part_gx, rows, (float)M, gamma, mean, invstd, dgamma, dbeta, accumulate};
+    if (dtype == SAICV_DTYPE_BF16) return bn_bwd_inline_t<bf16_t>(dz, (const uint8_t*)relu_mask, y, dy, dres, M, C, relu, inl, st);
+    return bn_bwd_inline_t<float>(dz, (const uint8_t*)relu_mask, y, dy, dres, M, C, relu, inl, st);
 }
 
 int bn_bwd_from_partials(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,

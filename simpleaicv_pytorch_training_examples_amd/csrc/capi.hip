@@ -42,6 +42,10 @@ int bn_act_fwd(int, const void*, const void*, void*, const float*, const float*,
 size_t bn_bwd_ws_floats(size_t, int, int);
 int bn_bwd(int, const void*, const void*, const void*, const void*, const float*, const float*, const float*, void*,
            void*, float*, float*, size_t, int, int, int, float*, hipStream_t);
+int bn_act_fwd_stats(int, const void*, const void*, void*, const float*, const float*, int, double, const float*, const float*,
+                     float*, float*, double, double, long long*, float*, float*, size_t, int, int, void*, hipStream_t);
+int bn_bwd_inline(int, const void*, const void*, const void*, const float*, const float*, const float*, const float*,
+                  const float*, int, void*, void*, float*, float*, size_t, int, int, int, hipStream_t);
 int bn_bwd_from_partials(int, const void*, const void*, const void*, const float*, const float*, const float*, const float*,
                          const float*, int, void*, void*, float*, float*, size_t, int, int, int, float*, hipStream_t);
 int maxpool_fwd(int, const void*, void*, uint8_t*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -214,7 +218,8 @@ int saicv_conv2d_dgrad_fused(const saicv_conv_desc* d, const void* dy, const voi
     ex.bs_invstd = f->bn_invstd;
     ex.bs_g = f->part_g;
     ex.bs_gx = f->part_gx;
-    if (f->bn_y && d->stride > 1) {
+    ex.stat_atomic_rows = f->part_rows;        // > 0: the caller zeroed part_rows rows and wants the sums added into them
+    if (f->bn_y && d->stride > 1 && f->part_rows == 0) {
         // parity classes smaller than the largest one leave their last partial rows unwritten
         const size_t bytes = (size_t)saicv_conv2d_dgrad_stat_rows(d) * d->C * sizeof(float);
         if (f->part_g) hipMemsetAsync(f->part_g, 0, bytes, S(stream));
@@ -258,6 +263,31 @@ int saicv_bn_act_bwd(int dtype, const void* dz, const void* z, const void* relu_
                      float* dbeta, size_t M, int C, int relu, int accumulate, float* ws, void* stream) {
     return bn_bwd(dtype, dz, z, relu_mask, y, gamma, mean, invstd, dy, dres, dgamma, dbeta, M, C, relu, accumulate, ws,
                   S(stream));
+}
+
+int saicv_conv2d_fwd_stats(const saicv_conv_desc* d, const void* x, const void* wf, void* y, float* stat_sum, float* stat_sq,
+                           int stat_rows, void* stream) {
+    if (check_desc(d, "saicv_conv2d_fwd_stats")) return -1;
+    if (!stat_sum || !stat_sq || stat_rows < 1) { set_error("saicv_conv2d_fwd_stats: statistics rows missing"); return -1; }
+    const int M = d->N * d->OH * d->OW;
+    EpiExtra ex;
+    ex.stat_atomic_rows = stat_rows;
+    return igemm_nt(d->dtype, 0, x, wf, y, nullptr, stat_sum, stat_sq, d->H, d->W, d->C, d->OH, d->OW,
+                    d->R, d->S, d->stride, d->pad, M, d->K, d->R * d->S * d->C, d->K, 0, S(stream), &ex);
+}
+int saicv_bn_act_fwd_stats(int dtype, const void* y, const void* res, void* z, const float* stat_sum, const float* stat_sq,
+                           int stat_rows, double count, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, double momentum, double eps, long long* num_batches_tracked, float* mean,
+                           float* invstd, size_t M, int C, int relu, void* relu_mask, void* stream) {
+    return bn_act_fwd_stats(dtype, y, res, z, stat_sum, stat_sq, stat_rows, count, gamma, beta, running_mean, running_var,
+                            momentum, eps, num_batches_tracked, mean, invstd, M, C, relu, relu_mask, S(stream));
+}
+int saicv_bn_act_bwd_inline(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,
+                            const float* mean, const float* invstd, const float* part_g, const float* part_gx, int rows,
+                            void* dy, void* dres, float* dgamma, float* dbeta, size_t M, int C, int relu, int accumulate,
+                            void* stream) {
+    return bn_bwd_inline(dtype, dz, relu_mask, y, gamma, mean, invstd, part_g, part_gx, rows, dy, dres, dgamma, dbeta, M, C,
+                         relu, accumulate, S(stream));
 }
 
 int saicv_bn_act_bwd_from_partials(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,

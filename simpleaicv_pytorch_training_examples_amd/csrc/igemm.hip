@@ -58,6 +58,10 @@ struct NTParams {
     float* bs_g;
     float* bs_gx;
     int bs_rows;
+    // > 0: the statistics (forward sum / sum of squares, backward bs_g / bs_gx) are ADDED with fp32 atomics into this many
+    // rows (row = tile row mod count) of a zeroed buffer instead of written one row per tile row: few enough rows that the
+    // consuming BatchNorm kernel finalises them itself (no partial-reduce / finalize launches)
+    int stat_atomic_rows;
     uint32_t src_bytes, wgt_bytes;
     int H, W, C;        // gather-source spatial dims / channels
     int OH, OW;         // pixel grid that indexes the GEMM rows
@@ -413,10 +417,16 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
                 }
                 const int n = tile_n * BN_T + cg * 16 + l15;          // D: row lg*4 + r, column l15
                 if (n < p.Nn) {
-                    if (lg == 0) p.stat_sum[(size_t)tile_m * (size_t)p.Nn + n] = s1[0];
+                    const size_t srow = p.stat_atomic_rows ? (size_t)(tile_m % p.stat_atomic_rows) : (size_t)tile_m;
+                    if (lg == 0) {
+                        if (p.stat_atomic_rows) unsafeAtomicAdd(&p.stat_sum[srow * (size_t)p.Nn + n], s1[0]);
+                        else p.stat_sum[srow * (size_t)p.Nn + n] = s1[0];
+                    }
                     if (lg == (l15 >> 2)) {
                         const int r = l15 & 3;
-                        p.stat_sq[(size_t)tile_m * (size_t)p.Nn + n] = r == 0 ? s2[0] : r == 1 ? s2[1] : r == 2 ? s2[2] : s2[3];
+                        const float qv = r == 0 ? s2[0] : r == 1 ? s2[1] : r == 2 ? s2[2] : s2[3];
+                        if (p.stat_atomic_rows) unsafeAtomicAdd(&p.stat_sq[srow * (size_t)p.Nn + n], qv);
+                        else p.stat_sq[srow * (size_t)p.Nn + n] = qv;
                     }
                 }
             }
@@ -432,7 +442,11 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
 #pragma unroll
             for (int w = 0; w < WM_; ++w) a += ws[w * BN_T];
             const int n = tile_n * BN_T + col;
-            if (n < p.Nn) (which ? p.stat_sq : p.stat_sum)[(size_t)tile_m * (size_t)p.Nn + n] = a;
+            if (n < p.Nn) {
+                float* dst = (which ? p.stat_sq : p.stat_sum) +
+                             (size_t)(p.stat_atomic_rows ? tile_m % p.stat_atomic_rows : tile_m) * (size_t)p.Nn + n;
+                if (p.stat_atomic_rows) unsafeAtomicAdd(dst, a); else *dst = a;
+            }
         }
     }
     const int oc = tid % OCPR;               // chunk within the tile row
@@ -655,7 +669,10 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
             float a = 0.f;
             for (int r = 0; r < RPP; ++r) a += red[(r * 2 + which) * BN_T + col];
             const int n = tile_n * BN_T + col;
-            if (n < p.Nn) (which ? p.bs_gx : p.bs_g)[prow * (size_t)p.Nn + n] = a;
+            if (n < p.Nn) {
+                float* dst = (which ? p.bs_gx : p.bs_g) + (p.stat_atomic_rows ? prow % p.stat_atomic_rows : prow) * (size_t)p.Nn + n;
+                if (p.stat_atomic_rows) unsafeAtomicAdd(dst, a); else *dst = a;
+            }
         }
     }
     }   // tile loop
@@ -1062,6 +1079,8 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.bs_g = ex ? ex->bs_g : nullptr;
     p.bs_gx = ex ? ex->bs_gx : nullptr;
     p.bs_rows = 0;
+    p.stat_atomic_rows = ex ? ex->stat_atomic_rows : 0;
+    SAICV_REQUIRE(p.stat_atomic_rows >= 0 && p.stat_atomic_rows <= 64, "igemm_nt: stat_atomic_rows=%d outside [0, 64]", p.stat_atomic_rows);
     if (p.addend_gate || p.bs_y) {
         const int osz1 = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
         SAICV_REQUIRE(mode == 1 && p.act_mode == 0 && (!out_f32 || dtype == SAICV_DTYPE_F32), "igemm_nt: gated shortcut / BatchNorm-backward sums belong to the data gradient");

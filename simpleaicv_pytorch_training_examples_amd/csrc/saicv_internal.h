@@ -24,6 +24,7 @@ struct EpiExtra {
     const float* bs_invstd = nullptr;
     float* bs_g = nullptr;
     float* bs_gx = nullptr;
+    int stat_atomic_rows = 0;              // > 0: statistics added atomically into this many rows of a zeroed buffer
 };
 // partial rows the data gradient (mode 1; M rows on the OH x OW pixel grid) writes with bs_*
 int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype);

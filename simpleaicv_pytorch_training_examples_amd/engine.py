@@ -27,6 +27,7 @@ Design (MI355X-first, one process per GPU):
 """
 import contextlib
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -434,6 +435,7 @@ class StepGraph:
         self.calls = 0
         self.graph = None
         self.static_in = self.static_out = None
+        self.replays, self.replay_host_s = 0, 0.0        # host time spent issuing replays (input copies + hipGraphLaunch)
 
     def __call__(self, *inputs):
         if self.graph is None:
@@ -441,6 +443,7 @@ class StepGraph:
                 self.calls += 1
                 return self.fn(*inputs)
             self._capture(inputs)
+        t0 = time.perf_counter()
         for s, x in zip(self.static_in, inputs):
             if s is not None and s.data_ptr() != x.data_ptr():
                 s.copy_(x, non_blocking=True)
@@ -448,6 +451,8 @@ class StepGraph:
             cb()
         self.graph.replay()
         ops.bump_weights_epoch()        # the replayed optimizer kernels rewrote the parameters
+        self.replays += 1
+        self.replay_host_s += time.perf_counter() - t0
         return self.static_out
 
     def _capture(self, inputs):

@@ -57,8 +57,48 @@ class KernelTimer:
 
 
 def bump_weights_epoch():
-    """Called by the flat-arena optimizer after it rewrote parameters through raw pointers."""
+    """Called by the flat-arena optimizer after it rewrote parameters through raw pointers: the step boundary."""
     _weights_epoch[0] += 1
+    _ZeroPool.reset()
+
+
+class _ZeroPool:
+    """fp32 scratch that is all zeros when handed out: the few-row buffers BatchNorm statistics are added into with atomics
+    (ConvBnActFn, SAICV_BN_INLINE).  One memset per step boundary instead of one per layer; the slices keep their addresses
+    from step to step, so a captured step replays against the same memory."""
+    CHUNK = 1 << 20            # floats
+    LIMIT = 64 << 20           # floats handed out without a step boundary before falling back to torch.zeros per request
+    chunks = []                # [tensor, used]
+    handed = 0
+
+    @classmethod
+    def take(cls, want, device):
+        n = (want + 63) // 64 * 64                 # slices start on 256-byte boundaries
+        if cls.handed > cls.LIMIT:                 # nobody calls the step boundary (a foreign optimizer): stay bounded
+            return torch.zeros(want, dtype=torch.float32, device=device)
+        cls.handed += n
+        for ch in cls.chunks:
+            if ch[0].device == device and ch[1] + n <= ch[0].numel():
+                v = ch[0][ch[1]:ch[1] + want]
+                ch[1] += n
+                return v
+        t = torch.zeros(max(n, cls.CHUNK), dtype=torch.float32, device=device)
+        cls.chunks.append([t, n])
+        return t[:want]
+
+    @classmethod
+    def reset(cls):
+        for ch in cls.chunks:
+            if ch[1]:
+                ch[0][:ch[1]].zero_()
+                ch[1] = 0
+        cls.handed = 0
+
+
+def _stat_rows(tile_rows):
+    """Rows the atomically accumulated statistics are spread over: enough to keep the atomics of a many-tile layer apart,
+    few enough for every workgroup of the consuming kernel to sum them."""
+    return 8 if tile_rows >= 512 else 4 if tile_rows >= 64 else 2 if tile_rows >= 8 else 1
 
 
 def _arena_grad(t):
@@ -93,17 +133,21 @@ WGRAD_SIDE_STREAM = _os.environ.get('SAICV_WGRAD_SIDE', '0') == '1'
 # (dz, ReLU-mask) instead of a masked copy, and a BatchNorm's backward reduction comes out of the epilogue of the data
 # gradient that produces its dz.  SAICV_BN_FUSE=0 restores the three-pass form (A/B runs, tests of both paths).
 BN_FUSE = _os.environ.get('SAICV_BN_FUSE', '1') == '1'
+# BatchNorm statistics added atomically into a few zeroed rows and finalised inside the consuming kernel (no partial-reduce /
+# finalize launches); SAICV_BN_INLINE=0 keeps one partial row per tile row and the finalize kernels (bit-reproducible sums)
+BN_INLINE = _os.environ.get('SAICV_BN_INLINE', '1') == '1'
 
 
 class _BnLink:
     """What the data gradient of the NEXT conv needs to produce the backward partial sums of a BatchNorm(+ReLU) node,
     and where that node finds them.  Travels forward as an attribute of the node's output tensor."""
-    __slots__ = ('y', 'mask', 'mean', 'invstd', 'part', 'rows', 'dx', 'dx_version')
+    __slots__ = ('y', 'mask', 'mean', 'invstd', 'part', 'rows', 'dx', 'dx_version', 'inline')
 
     def __init__(self, y, mask, mean, invstd):
         self.y, self.mask, self.mean, self.invstd = y, mask, mean, invstd
         self.part = self.dx = None
         self.rows = self.dx_version = 0
+        self.inline = False
 
 
 class _GateLedger:
@@ -467,28 +511,36 @@ class ConvBnActFn(torch.autograd.Function):
         scale = torch.empty(k, dtype=torch.float32, device=dev)
         shift = torch.empty(k, dtype=torch.float32, device=dev)
         mean = invstd = None
+        inline = training and BN_INLINE and k <= 2048
         if training:
             rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
-            stats = torch.empty((2, rows, k), dtype=torch.float32, device=dev)
             t0 = KernelTimer.begin('igemm_nt')
-            check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, ptr(stats[0]),
-                                     ptr(stats[1]), st), 'conv2d_fwd')
+            if inline:
+                rows = _stat_rows(rows)
+                stats = _ZeroPool.take(2 * rows * k, dev).view(2, rows, k)
+                check(L.saicv_conv2d_fwd_stats(ctypes.byref(d), ptr(x), ptr(wf), ptr(y), ptr(stats[0]), ptr(stats[1]), rows, st),
+                      'conv2d_fwd_stats')
+            else:
+                stats = torch.empty((2, rows, k), dtype=torch.float32, device=dev)
+                check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, ptr(stats[0]),
+                                         ptr(stats[1]), st), 'conv2d_fwd')
             es = x.element_size()
             xin_px = M if (r == 1 and stride > 1) else n * h * w          # a strided 1x1 reads a quarter of its input
             KernelTimer.end(t0, 'igemm_nt', 2.0 * M * k * r * s * min(c, ci),
                             float(xin_px) * c * es + float(k) * r * s * c * es + float(M) * k * es)
             mean = torch.empty(k, dtype=torch.float32, device=dev)
             invstd = torch.empty(k, dtype=torch.float32, device=dev)
-            ws = torch.empty(L.saicv_bn_ws_floats(k), dtype=torch.float32, device=dev)
             if bn.momentum is None:
                 raise NotImplementedError('BatchNorm2d(momentum=None) is not supported')
             track = bn.track_running_stats and bn.running_mean is not None
             nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
-            check(L.saicv_bn_finalize_fwd(ptr(stats[0]), ptr(stats[1]), rows, k, float(M), ptr(gamma),
-                                          ptr(beta), ptr(bn.running_mean) if track else 0,
-                                          ptr(bn.running_var) if track else 0, float(bn.momentum),
-                                          float(bn.eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                          ptr(ws), ptr(nbt), st), 'bn_finalize_fwd')      # also num_batches_tracked += 1
+            if not inline:
+                ws = torch.empty(L.saicv_bn_ws_floats(k), dtype=torch.float32, device=dev)
+                check(L.saicv_bn_finalize_fwd(ptr(stats[0]), ptr(stats[1]), rows, k, float(M), ptr(gamma),
+                                              ptr(beta), ptr(bn.running_mean) if track else 0,
+                                              ptr(bn.running_var) if track else 0, float(bn.momentum),
+                                              float(bn.eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                              ptr(ws), ptr(nbt), st), 'bn_finalize_fwd')      # also num_batches_tracked += 1
         else:
             check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, 0, 0, st), 'conv2d_fwd')
             check(L.saicv_bn_eval_coeffs(k, ptr(gamma), ptr(beta), ptr(bn.running_mean),
@@ -503,8 +555,16 @@ class ConvBnActFn(torch.autograd.Function):
         mask = (torch.empty(M * k // _lib.epc(dt), dtype=torch.uint8, device=dev)
                 if (relu and training and any(ctx.needs_input_grad)) else None)
         t0 = KernelTimer.begin('bn_act_fwd')
-        check(L.saicv_bn_act_fwd(dtype_code(dt), ptr(y), ptr(residual), ptr(z), ptr(scale), ptr(shift), M,
-                                 k, int(relu), ptr(mask), st), 'bn_act_fwd')
+        if inline:
+            # the kernel derives mean / invstd / scale / shift from the few statistics rows itself (and updates the running
+            # statistics and num_batches_tracked): no finalize launch between the convolution and this one
+            check(L.saicv_bn_act_fwd_stats(dtype_code(dt), ptr(y), ptr(residual), ptr(z), ptr(stats[0]), ptr(stats[1]), rows,
+                                           float(M), ptr(gamma), ptr(beta), ptr(bn.running_mean) if track else 0,
+                                           ptr(bn.running_var) if track else 0, float(bn.momentum), float(bn.eps), ptr(nbt),
+                                           ptr(mean), ptr(invstd), M, k, int(relu), ptr(mask), st), 'bn_act_fwd_stats')
+        else:
+            check(L.saicv_bn_act_fwd(dtype_code(dt), ptr(y), ptr(residual), ptr(z), ptr(scale), ptr(shift), M,
+                                     k, int(relu), ptr(mask), st), 'bn_act_fwd')
         KernelTimer.end(t0, 'bn_act_fwd', 0, float(M) * k * y.element_size() * (3 if residual is not None else 2))
         if training:
             ctx.save_for_backward(x, weight, gamma, y, mask, mean, invstd)
@@ -573,7 +633,12 @@ class ConvBnActFn(torch.autograd.Function):
                         and dz.data_ptr() == link.dx.data_ptr() and dz.shape == link.dx.shape
                         and dz._version == link.dx_version)
         t0 = KernelTimer.begin('bn_act_bwd')
-        if fused_reduce:
+        if fused_reduce and link.inline:
+            # ... as a few atomically accumulated rows: coefficients, dgamma and dbeta come out of the one streaming kernel
+            check(L.saicv_bn_act_bwd_inline(dtype_code(dt), ptr(dz), ptr(mask), ptr(y), ptr(gamma), ptr(mean), ptr(invstd),
+                                            ptr(link.part[0]), ptr(link.part[1]), link.rows, ptr(dy), ptr(dres_out), ptr(dgamma),
+                                            ptr(dbeta), M, k, int(relu), int(direct_bn), st), 'bn_act_bwd_inline')
+        elif fused_reduce:
             # the data gradient that wrote dz also left the partial sums of this reduction (no pass over dz and y here)
             check(L.saicv_bn_act_bwd_from_partials(dtype_code(dt), ptr(dz), ptr(mask), ptr(y), ptr(gamma), ptr(mean),
                                                    ptr(invstd), ptr(link.part[0]), ptr(link.part[1]), link.rows, ptr(dy),
@@ -610,7 +675,13 @@ class ConvBnActFn(torch.autograd.Function):
                 fuse.addend, fuse.addend_gate = ptr(dskip), ptr(gate)
                 if in_link is not None:
                     rows = L.saicv_conv2d_dgrad_stat_rows(ctypes.byref(d))
-                    part = torch.empty((2, rows, c), dtype=torch.float32, device=dev)
+                    in_link.inline = BN_INLINE and c <= 2048
+                    if in_link.inline:
+                        rows = _stat_rows(rows)
+                        part = _ZeroPool.take(2 * rows * c, dev).view(2, rows, c)
+                        fuse.part_rows = rows
+                    else:
+                        part = torch.empty((2, rows, c), dtype=torch.float32, device=dev)
                     fuse.bn_y, fuse.bn_mask = ptr(in_link.y), ptr(in_link.mask)
                     fuse.bn_mean, fuse.bn_invstd = ptr(in_link.mean), ptr(in_link.invstd)
                     fuse.part_g, fuse.part_gx = ptr(part[0]), ptr(part[1])

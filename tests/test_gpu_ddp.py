@@ -24,7 +24,9 @@ def _free_port():
 
 
 def _worker(rank, world, port, q, kind):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    # the test compares gradients of SEPARATE passes element by element: BatchNorm statistics in a fixed summation order
+    # (SAICV_BN_INLINE sums them with fp32 atomics; last-bit differences flip ReLU gates of these batch-2..4 models)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), SAICV_BN_INLINE='0')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from simpleaicv_pytorch_training_examples_amd import engine
@@ -127,7 +129,7 @@ def test_world2_on_one_gpu_kernel_side_gradient_hooks(kind):
 
 def _worker_rccl(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0', SAICV_BN_INLINE='0')
     torch.cuda.set_device(rank)
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
     from simpleaicv_pytorch_training_examples_amd import engine
@@ -191,7 +193,7 @@ def test_rccl_world2_bucketed_allreduce_on_two_gpus():
 
 def _worker_native(port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', SAICV_DDP_FORCE_SYNC='1')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', SAICV_DDP_FORCE_SYNC='1', SAICV_BN_INLINE='0')
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     from simpleaicv_pytorch_training_examples_amd import engine
