@@ -194,3 +194,34 @@ def test_ema_average_does_not_move_on_a_skipped_iteration():
     assert torch.allclose(ema.ema_model[0].weight, w0 + 0.1 * (m[0].weight - w0))
     ema.update(m)
     assert int(ema.ema_model[1].num_batches_tracked) == 5
+
+
+def test_zero_pool_hands_out_zeroed_distinct_slices_and_resets_at_the_step_boundary():
+    """ops._ZeroPool (the scratch BatchNorm statistics are added into with atomics): slices never overlap within a step,
+    come back zeroed after the step boundary, keep their addresses from step to step, and the pool stays bounded when
+    nobody announces a step boundary."""
+    import torch
+    from simpleaicv_pytorch_training_examples_amd import ops
+    pool = ops._ZeroPool
+    saved = (pool.chunks, pool.handed, pool.LIMIT)
+    pool.chunks, pool.handed = [], 0
+    try:
+        dev = torch.device('cpu')
+        a = pool.take(2 * 8 * 40, dev)
+        b = pool.take(100, dev)
+        assert a.numel() == 640 and b.numel() == 100 and float(a.abs().sum()) == 0 and float(b.abs().sum()) == 0
+        assert a.data_ptr() % 256 == b.data_ptr() % 256                     # slices start on 256-byte boundaries
+        a.fill_(1.0)
+        b.fill_(2.0)
+        assert float(a.sum()) == 640 and float(b.sum()) == 200              # distinct memory
+        ptr_a = a.data_ptr()
+        ops.bump_weights_epoch()                                            # the step boundary
+        a2 = pool.take(2 * 8 * 40, dev)
+        assert a2.data_ptr() == ptr_a and float(a2.abs().sum()) == 0 and float(a.abs().sum()) == 0
+        pool.LIMIT = 1000
+        c = pool.take(5000, dev)                                            # beyond the limit without a boundary:
+        d = pool.take(64, dev)                                              # plain zero tensors, the pool does not grow
+        assert float(c.abs().sum()) == 0 and float(d.abs().sum()) == 0 and sum(ch[0].numel() for ch in pool.chunks) <= pool.CHUNK + 5056
+        assert [ops._stat_rows(t) for t in (1, 7, 8, 63, 64, 511, 512, 3136)] == [1, 1, 2, 2, 4, 4, 8, 8]
+    finally:
+        pool.chunks, pool.handed, pool.LIMIT = saved
