@@ -480,21 +480,34 @@ class NativeComm:
 
     _serial = 0
 
+    @classmethod
+    def exchange_id(cls, world, rank, make_id):
+        """128 bytes drawn by rank 0 (`make_id()`), identical on every rank afterwards: through the torch.distributed
+        store (TCPStore / FileStore of the rendezvous), no collective and no device involved."""
+        key = f'saicv_comm_id_{cls._serial}'
+        cls._serial += 1
+        if world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return bytes(make_id())
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            raw = bytes(make_id())
+            store.set(key, raw)
+            return raw
+        return bytes(store.get(key))                       # blocks until rank 0 has published it
+
     def __init__(self, world, rank):
         import ctypes
         L = lib()
-        key = f'saicv_comm_id_{NativeComm._serial}'
-        NativeComm._serial += 1
-        buf = ctypes.create_string_buffer(128)
-        if world == 1 or not (dist.is_available() and dist.is_initialized()):
-            check(L.saicv_comm_unique_id(buf), 'comm_unique_id')
-        else:
-            store = dist.distributed_c10d._get_default_store()
-            if rank == 0:
-                check(L.saicv_comm_unique_id(buf), 'comm_unique_id')
-                store.set(key, buf.raw)
-            else:
-                buf.raw = bytes(store.get(key))            # blocks until rank 0 has published it
+
+        def make_id():
+            b = ctypes.create_string_buffer(128)
+            check(L.saicv_comm_unique_id(b), 'comm_unique_id')
+            return b.raw
+
+        raw = self.exchange_id(world, rank, make_id)
+        if len(raw) != 128:
+            raise RuntimeError(f'RCCL unique id of {len(raw)} bytes came out of the store (expected 128)')
+        buf = ctypes.create_string_buffer(raw, 128)
         handle = ctypes.c_void_p()
         check(L.saicv_comm_create(buf, world, rank, ctypes.byref(handle)), 'comm_create')
         self.handle, self.world, self.rank = handle, world, rank

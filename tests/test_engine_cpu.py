@@ -215,3 +215,32 @@ def test_arena_tracks_which_parameters_received_gradients():
     assert arena.has_grad_mask() is None
     arena.zero_grad()
     assert int(arena.has_grad_mask().sum()) == 0
+
+
+def _worker_id_exchange(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from simpleaicv_pytorch_training_examples_amd import engine
+    # every byte value incl. NUL: the store must carry the id as binary, not as text
+    first = engine.NativeComm.exchange_id(world, rank, lambda: bytes(range(128)))
+    second = engine.NativeComm.exchange_id(world, rank, lambda: bytes((255 - i) % 256 for i in range(128)))
+    q.put((rank, first, second))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_unique_id_travels_through_the_process_group_store():
+    """The communicator bootstrap of the N-rank path (engine.NativeComm.exchange_id): rank 0 publishes 128 binary bytes
+    in the torch.distributed store, every rank ends up with the same 128 bytes, a second communicator gets a fresh key."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_id_exchange, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == bytes(range(128))
+    assert res[0][2] == res[1][2] == bytes((255 - i) % 256 for i in range(128))
