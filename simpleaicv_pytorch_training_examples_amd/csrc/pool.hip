@@ -77,26 +77,49 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         const int oh_hi = min(OH - 1, (h + pad) / stride);
         const int ow_lo = max(0, (w + pad - (K - 1) + stride - 1) / stride);
         const int ow_hi = min(OW - 1, (w + pad) / stride);
-        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-            const int kh = h - (oh * stride - pad);
-            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                const int kw = w - (ow * stride - pad);
-                const int want = kh * K + kw;
-                const size_t o = (((size_t)(n * OH + oh)) * OW + ow) * C + cb * N;
-                float g[N];
-                Chunk<T>::unpack(ld_chunk(dout + o), g);
-                // N index bytes, contiguous
-                uint8_t ib[N];
-                if (N == 8) {
-                    const uint2 raw = *reinterpret_cast<const uint2*>(idx + o);
-                    __builtin_memcpy(ib, &raw, 8);
-                } else {
-                    const uint32_t raw = *reinterpret_cast<const uint32_t*>(idx + o);
-                    __builtin_memcpy(ib, &raw, 4);
-                }
+        auto gather = [&](int oh, int ow, const u32x4& cg, const uint8_t* ib) {
+            const int want = (h - (oh * stride - pad)) * K + (w - (ow * stride - pad));
+            float g[N];
+            Chunk<T>::unpack(cg, g);
 #pragma unroll
-                for (int j = 0; j < N; ++j) acc[j] += (ib[j] == want) ? g[j] : 0.f;
+            for (int j = 0; j < N; ++j) acc[j] += (ib[j] == want) ? g[j] : 0.f;
+        };
+        auto load_idx = [&](size_t o, uint8_t* ib) {                 // N index bytes, contiguous
+            if (N == 8) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(idx + o);
+                __builtin_memcpy(ib, &raw, 8);
+            } else {
+                const uint32_t raw = *reinterpret_cast<const uint32_t*>(idx + o);
+                __builtin_memcpy(ib, &raw, 4);
             }
+        };
+        if (oh_hi < oh_lo || ow_hi < ow_lo) {
+            // no window covers this pixel: the gradient is zero
+        } else if (oh_hi - oh_lo <= 1 && ow_hi - ow_lo <= 1) {
+            // the usual case (K <= 2 * stride + 1... at most 2 x 2 windows cover a pixel): all eight loads in flight before
+            // the first use -- the one-window-at-a-time loop ran at 2.5 TB/s
+            u32x4 cg[4];
+            uint8_t ib[4][N];
+            bool ok[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oh = oh_lo + (q >> 1), ow = ow_lo + (q & 1);
+                ok[q] = oh <= oh_hi && ow <= ow_hi;
+                const size_t o = (((size_t)(n * OH + min(oh, oh_hi))) * OW + min(ow, ow_hi)) * C + cb * N;
+                cg[q] = ld_chunk(dout + o);
+                load_idx(o, ib[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok[q]) gather(oh_lo + (q >> 1), ow_lo + (q & 1), cg[q], ib[q]);
+        } else {
+            for (int oh = oh_lo; oh <= oh_hi; ++oh)
+                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                    const size_t o = (((size_t)(n * OH + oh)) * OW + ow) * C + cb * N;
+                    uint8_t ib[N];
+                    load_idx(o, ib);
+                    gather(oh, ow, ld_chunk(dout + o), ib);
+                }
         }
         st_chunk(dx + ((size_t)(n * H + h) * W + w) * C + cb * N, Chunk<T>::pack(acc));
     }
