@@ -127,3 +127,81 @@ def test_vit_base_gemm_shapes_at_batch_256_match_cpu_fp32(kn):
     assert rel_err(dx.float(), dx_ref) < 2e-2, name
     assert rel_err(dw, dw_ref) < 4e-3, name
     assert rel_err(db, db_ref) < 4e-3, name
+
+
+INLINE_SHAPES = [(64, 256, 1, 1, 56), (128, 128, 3, 2, 56), (256, 256, 3, 1, 14), (512, 2048, 1, 1, 7)]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('shape', INLINE_SHAPES, ids=[f'{ci}to{co}_k{k}s{s}_{h}' for ci, co, k, s, h in INLINE_SHAPES])
+def test_batchnorm_statistics_through_atomic_rows_at_batch_256(shape):
+    """The default training path of a conv + BatchNorm + ReLU layer at BASELINE.json's batch: saicv_conv2d_fwd_stats adds
+    the per-tile sums into a few rows with fp32 atomics, saicv_bn_act_fwd_stats finalises them in-kernel (mean, invstd,
+    running statistics, z = relu(bn(y)) + sign mask).  Against F.batch_norm on the CPU over the conv output the device
+    stored (bf16), and the backward pair saicv_conv2d_dgrad_fused(part_rows) -> saicv_bn_act_bwd_inline against the three-pass
+    saicv_bn_act_bwd on the same tensors."""
+    from simpleaicv_pytorch_training_examples_amd import _lib, ops
+    from simpleaicv_pytorch_training_examples_amd._lib import check, lib, ptr
+    ci, co, k, s, h = shape
+    pad = k // 2
+    dt = torch.bfloat16
+    L, st = lib(), _lib.stream()
+    g = torch.Generator().manual_seed(ci + co + k + s + h)
+    x = _bf(torch.randn(BATCH, ci, h, h, generator=g)).contiguous(memory_format=torch.channels_last)
+    w = _bf(torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5)
+    gamma, beta = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.2
+    d = ops._desc(BATCH, h, h, ci, co, k, k, s, pad, dt)
+    oh, ow = d.OH, d.OW
+    M = BATCH * oh * ow
+    xd = x.to(dt).cuda()
+    wf = w.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    y = torch.empty((BATCH, oh, ow, co), dtype=dt, device='cuda')
+    rows = ops._stat_rows(L.saicv_conv2d_stat_rows(ctypes.byref(d)))
+    stats = torch.zeros((2, rows, co), dtype=torch.float32, device='cuda')
+    check(L.saicv_conv2d_fwd_stats(ctypes.byref(d), ptr(xd), ptr(wf), ptr(y), ptr(stats[0]), ptr(stats[1]), rows, st), 'fwd_stats')
+    z = torch.empty_like(y)
+    mask = torch.empty(M * co // 8, dtype=torch.uint8, device='cuda')
+    mean, invstd = torch.empty(co, device='cuda'), torch.empty(co, device='cuda')
+    rm, rv = torch.zeros(co, device='cuda'), torch.ones(co, device='cuda')
+    nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+    gd, bd = gamma.cuda(), beta.cuda()
+    check(L.saicv_bn_act_fwd_stats(0, ptr(y), 0, ptr(z), ptr(stats[0]), ptr(stats[1]), rows, float(M), ptr(gd), ptr(bd), ptr(rm),
+                                   ptr(rv), 0.1, 1e-5, ptr(nbt), ptr(mean), ptr(invstd), M, co, 1, ptr(mask), st), 'bn_act_fwd_stats')
+    torch.cuda.synchronize()
+    yc = y.float().cpu().permute(0, 3, 1, 2)                       # what the device stored; its statistics are the truth
+    mu = yc.double().mean((0, 2, 3))
+    var = yc.double().var((0, 2, 3), unbiased=False)
+    assert rel_err(mean.double().cpu(), mu) < 1e-4
+    assert rel_err(invstd.double().cpu(), (var + 1e-5).rsqrt()) < 1e-4
+    assert rel_err(rm.double().cpu(), 0.1 * mu) < 1e-4
+    assert rel_err(rv.double().cpu(), 0.9 + 0.1 * var * M / (M - 1)) < 1e-4 and int(nbt) == 1
+    z_ref = F.relu(F.batch_norm(yc, None, None, gamma, beta, True, 0.1, 1e-5))
+    assert rel_err(z.float().cpu().permute(0, 3, 1, 2), z_ref) < 2e-2
+
+    # ---- backward: a following 1x1 convolution's data gradient leaves this layer's sums in atomic rows
+    k2 = 64
+    d2 = ops._desc(BATCH, oh, ow, co, k2, 1, 1, 1, 0, dt)
+    w2 = (torch.randn(co, 1, 1, k2, generator=g) * 0.05).to(dt).cuda()        # [Cin][R][S][Cout] for the data gradient
+    dy2 = _bf(torch.randn(BATCH, oh, ow, k2, generator=g)).to(dt).cuda()
+    rows_b = ops._stat_rows(L.saicv_conv2d_dgrad_stat_rows(ctypes.byref(d2)))
+    part = torch.zeros((2, rows_b, co), dtype=torch.float32, device='cuda')
+    dz = torch.empty_like(z)
+    f = _lib.DgradFuse()
+    f.bn_y, f.bn_mask, f.bn_mean, f.bn_invstd = ptr(y), ptr(mask), ptr(mean), ptr(invstd)
+    f.part_g, f.part_gx, f.part_rows = ptr(part[0]), ptr(part[1]), rows_b
+    check(L.saicv_conv2d_dgrad_fused(ctypes.byref(d2), ptr(dy2), ptr(w2), ctypes.byref(f), ptr(dz), st), 'dgrad_fused')
+    out = []
+    ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, co, 0), device='cuda')
+    for inline in (False, True):
+        dyb = torch.empty_like(y)
+        dgam, dbet = torch.empty(co, device='cuda'), torch.empty(co, device='cuda')
+        if inline:
+            check(L.saicv_bn_act_bwd_inline(0, ptr(dz), ptr(mask), ptr(y), ptr(gd), ptr(mean), ptr(invstd), ptr(part[0]), ptr(part[1]),
+                                            rows_b, ptr(dyb), 0, ptr(dgam), ptr(dbet), M, co, 1, 0, st), 'bn_bwd_inline')
+        else:
+            check(L.saicv_bn_act_bwd(0, ptr(dz), 0, ptr(mask), ptr(y), ptr(gd), ptr(mean), ptr(invstd), ptr(dyb), 0, ptr(dgam),
+                                     ptr(dbet), M, co, 1, 0, ptr(ws), st), 'bn_bwd')
+        torch.cuda.synchronize()
+        out.append((dyb.float(), dgam.clone(), dbet.clone()))
+    assert rel_err(out[1][1], out[0][1]) < 1e-4 and rel_err(out[1][2], out[0][2]) < 1e-4
+    assert rel_err(out[1][0], out[0][0]) < 8e-3
