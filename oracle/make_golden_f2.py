@@ -2,6 +2,8 @@
   det_resnet50backbone : SimpleAICV/detection/models/backbones/resnet.py resnet50backbone on a [2,3,64,64] batch -> C2..C5
   mae_tiny             : SimpleAICV/masked_image_modeling/models/vit_mae.py VITMAEPretrainModel (encoder 128 planes x 2
                          heads of 64, decoder 64 planes x 2 heads of 32, image 64, patch 16) + losses.MSELoss
+  det_vitbackbone_tiny : SimpleAICV/detection/models/backbones/vit.py ViTBackbone (128 planes x 2 heads of 64, 2 blocks,
+                         image 64, patch 16) -> [B, 128, 4, 4] and VitPyramidNeck(128, 64) -> P2..P5
 Build container only:   python oracle/make_golden_f2.py"""
 import os
 import sys
@@ -78,6 +80,33 @@ def mae_case():
     print('mae_tiny loss', float(loss), 'pred', tuple(pred.shape), 'removed', int(mask.sum()))
 
 
+VITDET_TINY = dict(patch_size=16, embedding_planes=128, block_nums=2, head_nums=2, feedforward_ratio=4, image_size=64)
+
+
+def vitdet_case():
+    from SimpleAICV.detection.models.backbones.vit import ViTBackbone, VitPyramidNeck
+    torch.manual_seed(0)
+    m = ViTBackbone(**VITDET_TINY).train()
+    neck = VitPyramidNeck(128, 64).train()
+    init = {('backbone.' + n): (float(p.double().sum()), float(p.double().abs().sum())) for n, p in m.named_parameters()}
+    init.update({('neck.' + n): (float(p.double().sum()), float(p.double().abs().sum())) for n, p in neck.named_parameters()})
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 64, 64, 3, generator=g).permute(0, 3, 1, 2)
+    feat = m(x)
+    outs = neck(feat)
+    probes = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+    nb, sb = _grads(m)
+    nn_, sn = _grads(neck)
+    fx = {'kwargs': VITDET_TINY, 'neck': (128, 64), 'model_seed': 0, 'data_seed': 1, 'shape': (3, 64, 64, 3),
+          'init_checksums': init, 'feature': feat.detach().clone(), 'outputs': [o.detach().clone() for o in outs],
+          'grad_norm': {**{'backbone.' + k: v for k, v in nb.items()}, **{'neck.' + k: v for k, v in nn_.items()}},
+          'grad_sample': {**{'backbone.' + k: v for k, v in sb.items()}, **{'neck.' + k: v for k, v in sn.items()}},
+          'input_checksum': float(x.double().sum())}
+    torch.save(fx, os.path.join(OUT, 'det_vitbackbone_tiny.pt'))
+    print('det_vitbackbone_tiny', tuple(feat.shape), [tuple(o.shape) for o in outs])
+
+
 def main():
     for name in ('cv2', 'torchvision', 'torchvision.transforms'):
         try:
@@ -86,8 +115,13 @@ def main():
             sys.modules[name] = types.ModuleType(name)
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
-    backbone_case()
-    mae_case()
+    only = set(sys.argv[1:])
+    if not only or 'det_resnet50backbone' in only:
+        backbone_case()
+    if not only or 'mae_tiny' in only:
+        mae_case()
+    if not only or 'det_vitbackbone_tiny' in only:
+        vitdet_case()
 
 
 if __name__ == '__main__':

@@ -1,2 +1,3 @@
 from .detr_resnet import *
 from .resnet import *
+from .vit import *
