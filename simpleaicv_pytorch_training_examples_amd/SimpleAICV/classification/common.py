@@ -102,7 +102,7 @@ def load_state_dict(saved_model_path, model, excluded_layer_name=(),
         print(f'load/model weight nums:{len(keep)}/{len(own)}')
         print(f'not loaded save layer weight:\n{skipped}')
         model.load_state_dict(keep, strict=False)
-        from .... import ops
+        from ... import ops
         ops.bump_weights_epoch()
 
 

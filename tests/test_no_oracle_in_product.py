@@ -27,3 +27,21 @@ def test_product_fails_loudly_on_cpu_tensors():
     model = backbones.resnet18cifar(num_classes=10)
     with pytest.raises(RuntimeError):
         model(torch.randn(2, 3, 32, 32))
+
+
+def test_relative_imports_stay_inside_the_package():
+    """Every `from .. import x` in the product package resolves inside it -- also the lazy ones inside functions that no
+    CPU test executes (a `from .... import ops` one level too deep sat in load_state_dict unnoticed for a round)."""
+    import ast
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if not f.endswith('.py'):
+                continue
+            path = os.path.join(dirpath, f)
+            rel = os.path.relpath(path, os.path.dirname(PKG)).split(os.sep)
+            depth = len(rel) - 1                       # packages above the module, counting the top-level package
+            for node in ast.walk(ast.parse(open(path).read())):
+                if isinstance(node, ast.ImportFrom) and node.level > depth:
+                    bad.append(f'{os.path.relpath(path, PKG)}:{node.lineno} level {node.level} > depth {depth}')
+    assert not bad, bad
