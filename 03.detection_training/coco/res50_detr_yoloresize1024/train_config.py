@@ -39,22 +39,23 @@ class config:
                                                 'min_score_threshold': 0.05, 'topn': 100, 'nms_type': None,
                                                 'nms_threshold': 0.5})
 
-    train_dataset = SyntheticDetectionDataset(117266, 768, 1024, num_classes=num_classes, seed=0)
-    test_dataset = SyntheticDetectionDataset(4952, 768, 1024, num_classes=num_classes, seed=1)
+    # sizes of COCO train2017 / val2017; SAICV_DET_* shorten a smoke run of the entry script
+    train_dataset = SyntheticDetectionDataset(int(os.environ.get('SAICV_DET_TRAIN', 117266)), 768, 1024, num_classes=num_classes, seed=0)
+    test_dataset = SyntheticDetectionDataset(int(os.environ.get('SAICV_DET_TEST', 4952)), 768, 1024, num_classes=num_classes, seed=1)
     train_collater = DETRDetectionCollater(resize=input_image_size[0], resize_type='yolo_style', max_annots_num=100)
     test_collater = DETRDetectionCollater(resize=input_image_size[0], resize_type='yolo_style', max_annots_num=100)
 
     seed = 0
-    batch_size = 64
-    num_workers = 32
+    batch_size = int(os.environ.get('SAICV_DET_BATCH', 64))
+    num_workers = int(os.environ.get('SAICV_DET_WORKERS', 32))
     accumulation_steps = 1
 
     optimizer = ('AdamW', {'lr': 1e-4, 'global_weight_decay': False, 'weight_decay': 1e-3,
                            'no_weight_decay_layer_name_list': [], 'sub_layer_lr': {'backbone': 1e-5}})
     scheduler = ('MultiStepLR', {'warm_up_epochs': 1, 'gamma': 0.1, 'milestones': [400]})
 
-    epochs = 500
-    print_interval = 100
+    epochs = int(os.environ.get('SAICV_DET_EPOCHS', 500))
+    print_interval = int(os.environ.get('SAICV_DET_PRINT', 100))
 
     eval_type = 'COCO'
     eval_epoch = [1] + [i for i in range(epochs) if i % 50 == 0]

@@ -45,19 +45,19 @@ class config:
                                                     'dice_loss_weight': 1, 'iou_predict_loss_weight': 1,
                                                     'supervise_all_iou': True, 'mask_threshold': mask_threshold})
 
-    train_dataset = SyntheticSAMDataset(100000, image_size=input_image_size, seed=0)
+    train_dataset = SyntheticSAMDataset(int(os.environ.get('SAICV_SAM_TRAIN', 100000)), image_size=input_image_size, seed=0)
     train_collater = SAMBatchCollater(resize=input_image_size)
 
     seed = 0
-    batch_size = 160
-    num_workers = 32
+    batch_size = int(os.environ.get('SAICV_SAM_BATCH', 160))
+    num_workers = int(os.environ.get('SAICV_SAM_WORKERS', 32))
     accumulation_steps = 1
 
     optimizer = ('AdamW', {'lr': 1e-5, 'global_weight_decay': False, 'weight_decay': 0,
                            'no_weight_decay_layer_name_list': []})
     scheduler = ('MultiStepLR', {'warm_up_epochs': 0, 'gamma': 0.1, 'milestones': [100]})
 
-    epochs = 2
+    epochs = int(os.environ.get('SAICV_SAM_EPOCHS', 2))
     print_interval = 100
     save_interval = 1
 
