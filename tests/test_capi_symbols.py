@@ -43,3 +43,20 @@ def test_python_binding_covers_header():
     assert L.saicv_conv2d_stat_rows(None) == -1
     rc = L.saicv_conv2d_fwd(None, 0, 0, 0, 0, 0, 0, 0, 0)
     assert rc != 0 and b'null descriptor' in L.saicv_last_error_string()
+
+
+def test_integration_guide_names_every_entry_point():
+    """INTEGRATION.md maps each exported symbol to the reference call it replaces: none may be missing from that table
+    (families are written as `saicv_x_fwd / _bwd`: a documented stem plus a documented suffix)."""
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    missing = []
+    for name in _declared():
+        if name in doc:
+            continue
+        cuts = [i for i, ch in enumerate(name) if ch == '_' and i > len('saicv')]
+        if any(('`' + name[:i]) in doc and re.search(r'[ /`]' + re.escape(name[i:]) + r'\b', doc) for i in cuts):
+            continue
+        if any(('`' + name[:i] + '_*`') in doc for i in cuts):          # `saicv_maxpool_*`
+            continue
+        missing.append(name)
+    assert not missing, missing
