@@ -246,3 +246,43 @@ def test_load_state_dict_filters_and_resizes_the_position_embedding_like_the_ref
         assert sorted(k for k in after if not torch.equal(after[k], before[k])) == case['changed'], key
         for k, v in case['after'].items():
             assert torch.allclose(after[k].double(), v.double(), rtol=0, atol=1e-6), (key, k)
+
+
+def test_bench_spawn_gives_every_rank_the_torchrun_environment(monkeypatch):
+    """`python bench.py --gpus N` (bench.spawn): N worker processes with RANK / LOCAL_RANK / WORLD_SIZE, a 127.0.0.1
+    rendezvous on one free port, dmabuf IPC mode for RCCL; only rank 0 keeps stdout (the ONE JSON line); a failing rank fails
+    the run and takes the others down."""
+    import importlib
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            self.env, self.stdout, self.rank = env, stdout, int(env['RANK'])
+            self.terminated = False
+            started.append(self)
+
+        def poll(self):
+            return 3 if self.rank == 1 else (-15 if self.terminated else None)
+
+        def terminate(self):
+            self.terminated = True
+
+        def kill(self):
+            self.terminated = True
+
+    monkeypatch.setattr(bench.subprocess, 'Popen', FakeProc)
+    monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
+    args = type('A', (), {'gpus': 4})()
+    rc = bench.spawn(args)
+    assert rc == 3 and len(started) == 4
+    ports = {p.env['MASTER_PORT'] for p in started}
+    assert len(ports) == 1
+    for r, p in enumerate(started):
+        assert (p.env['RANK'], p.env['LOCAL_RANK'], p.env['WORLD_SIZE'], p.env['MASTER_ADDR']) == (str(r), str(r), '4', '127.0.0.1')
+        assert p.env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and p.env['SAICV_BENCH_SPAWNED'] == '1'
+        assert (p.stdout is None) == (r == 0)
+    assert all(p.terminated for p in started if p.rank not in (1,))
