@@ -43,6 +43,9 @@ DEVINL u32x4 zero_chunk() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
 
 DEVINL u32x4 ld_chunk(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 DEVINL void st_chunk(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+// streaming store: the line is not kept in L2 for a reader that will not come before it is evicted anyway (the vendor
+// library's GEMMs store their output this way, "NTD" in its kernel names)
+DEVINL void st_chunk_nt(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
 
 DEVINL float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
 

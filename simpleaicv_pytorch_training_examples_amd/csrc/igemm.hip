@@ -62,6 +62,7 @@ struct NTParams {
     // rows (row = tile row mod count) of a zeroed buffer instead of written one row per tile row: few enough rows that the
     // consuming BatchNorm kernel finalises them itself (no partial-reduce / finalize launches)
     int stat_atomic_rows;
+    int nt_store;       // 1: the plain epilogue stores the output tile with non-temporal (streaming) stores
     uint32_t src_bytes, wgt_bytes;
     int H, W, C;        // gather-source spatial dims / channels
     int OH, OW;         // pixel grid that indexes the GEMM rows
@@ -476,7 +477,10 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
             u32x4 v[GRP];
 #pragma unroll
             for (int j = 0; j < GRP; ++j) v[j] = ld_chunk(ls + (g + j) * RPP * OPITCH);
-            if (full) {
+            if (full && p.nt_store) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) st_chunk_nt(o + (g + j) * ostep, v[j]);
+            } else if (full) {
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) st_chunk(o + (g + j) * ostep, v[j]);
             } else {
@@ -1080,6 +1084,8 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.bs_gx = ex ? ex->bs_gx : nullptr;
     p.bs_rows = 0;
     p.stat_atomic_rows = ex ? ex->stat_atomic_rows : 0;
+    static const int nt_store_env = getenv("SAICV_NT_STORE") ? atoi(getenv("SAICV_NT_STORE")) : 0;
+    p.nt_store = nt_store_env;
     SAICV_REQUIRE(p.stat_atomic_rows >= 0 && p.stat_atomic_rows <= 64, "igemm_nt: stat_atomic_rows=%d outside [0, 64]", p.stat_atomic_rows);
     if (p.addend_gate || p.bs_y) {
         const int osz1 = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
