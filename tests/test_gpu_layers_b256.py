@@ -90,6 +90,59 @@ def test_resnet50_conv_shapes_at_batch_256_match_cpu_fp32(shape):
     assert rel_err(dw.permute(0, 3, 1, 2), gw) < 4e-3, 'weight gradient ' + tag
 
 
+@pytest.mark.timeout(900)
+def test_s2d_stem_at_batch_256_matches_cpu_fp32():
+    """The stem the benchmark actually runs since the space-to-depth change: saicv_pack_input_s2d + the 4 x 4 x 16
+    stride-1 convolution + BatchNorm + ReLU (ops.pack_stem_input / ops.conv_bn_act) at 256 x 3 x 224 x 224 in bf16, forward
+    and weight gradient, against F.conv2d(7 x 7, stride 2, padding 3) + batch_norm + relu in fp32 on the CPU on the same
+    bf16-rounded operands (reference resnet.py:172-174)."""
+    import torch.nn as nn
+    from simpleaicv_pytorch_training_examples_amd import ops
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(224)
+    x = _bf(torch.randn(BATCH, 224, 224, 3, generator=g)).permute(0, 3, 1, 2)          # NHWC memory, NCHW shape (the collater's form)
+    w = _bf(torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5)
+    gamma = torch.rand(64, generator=g) + 0.5
+    beta = torch.randn(64, generator=g) * 0.1
+    dz = _bf(torch.randn(BATCH, 112, 112, 64, generator=g)).permute(0, 3, 1, 2)
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(x, wr, None, 2, 3)
+    z_ref = F.relu(F.batch_norm(y_ref, None, None, gamma, beta, True, 0.1, 1e-5))
+    z_ref.backward(dz)
+    conv, bn = nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda(), nn.BatchNorm2d(64).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    assert ops.STEM_S2D
+    with torch.autocast('cuda', dtype=dt):
+        xp = ops.pack_stem_input(x.cuda(), conv, dt)
+        assert getattr(xp, '_saicv_s2d', None) is not None and xp.shape[1] == 16
+        z = ops.conv_bn_act(xp, conv.weight, bn, 2, 3, True)
+    z.backward(dz.cuda().to(z.dtype).contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+    assert tuple(z.shape) == (BATCH, 64, 112, 112)
+    assert rel_err(z.float(), z_ref) < 2e-2
+    mean_ref = y_ref.detach().transpose(0, 1).flatten(1).double().mean(1)
+    var_ref = y_ref.detach().transpose(0, 1).flatten(1).double().var(1)
+    assert rel_err(bn.running_mean, 0.1 * mean_ref) < 2e-3          # y is stored in bf16: statistics of the rounded values
+    assert rel_err(bn.running_var, 0.9 + 0.1 * var_ref) < 2e-3
+    assert rel_err(conv.weight.grad, wr.grad) < 1e-2
+    dgamma_ref, dbeta_ref = _bn_grads(y_ref.detach(), dz, z_ref.detach())
+    assert rel_err(bn.weight.grad, dgamma_ref) < 1e-2
+    assert rel_err(bn.bias.grad, dbeta_ref) < 1e-2
+
+
+def _bn_grads(y, dz, z):
+    """dgamma / dbeta of relu(batch_norm(y)) in fp64 on the CPU."""
+    yd = y.double().transpose(0, 1).flatten(1)
+    g = (dz.double() * (z > 0)).transpose(0, 1).flatten(1)
+    xhat = (yd - yd.mean(1, keepdim=True)) / (yd.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()
+    return (g * xhat).sum(1), g.sum(1)
+
+
 VIT = [(768, 2304, 'qkv'), (768, 768, 'proj'), (768, 3072, 'fc1'), (3072, 768, 'fc2')]
 
 

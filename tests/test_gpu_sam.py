@@ -47,6 +47,7 @@ CASES = [
     (2, 8, 32, 330, 330, True, None),          # DETR encoder self-attention
     (1, 1, 64, 1, 70, False, None),            # single query
     (1, 2, 32, 130, 5, True, None),            # fewer keys than one tile
+    (1, 2, 64, 4096, 4096, False, (64, 64)),   # BASELINE.json configs[4]: a SAM-B global block at 1024 x 1024 (64 x 64 tokens)
 ]
 
 
@@ -160,6 +161,51 @@ def test_sam_encoder_bf16_tracks_reference_autocast(name):
     b = torch.cat([fx['grad_sample'][n].double() for n, _ in m.named_parameters()])
     cos = float(a @ b / (a.norm() * b.norm()))
     assert cos > noise['bf16_grad_sample_cos'] - 0.1, cos
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_sam_b_blocks_at_1024_match_reference(dtype):
+    """BASELINE.json configs[4] at bench resolution: one 3 x 1024 x 1024 image through patch embedding, ONE windowed block
+    (64 x 64 tokens padded to 70 x 70, 25 windows of 196), ONE global block (4096 tokens, decomposed rel-pos over 64 x 64) and
+    the neck, at sam_b's real dimensions -- fixture produced by the reference's ViTImageEncoder on the CPU
+    (oracle/make_golden_r03.py; reference image_encoder.py:82-184, 201-239).  fp32: output 1e-3, gradient norms 1e-2,
+    samples 2e-2; bf16 autocast against the reference's own bf16-vs-fp32 deviation."""
+    fx = load_golden('sam_b_blocks_1024')
+    m = _sam_model(fx)
+    g = torch.Generator().manual_seed(fx['data_seed'])
+    x = torch.randn(1, 3, 1024, 1024, generator=g)
+    probe = torch.randn(fx['output_shape'], generator=g)
+    assert abs(float(x.double().sum()) - fx['input_checksum']) < 1e-6
+    assert abs(float(probe.double().sum()) - fx['probe_checksum']) < 1e-6
+    x, probe = x.cuda(), probe.cuda()
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        out = m(x)
+    assert list(out.shape) == fx['output_shape']
+    (out.float() * probe).sum().backward()
+    torch.cuda.synchronize()
+    noise = fx['reference_noise']
+    otol = 1e-3 if dtype == torch.float32 else 1.5 * noise['bf16_output'] + 2e-2
+    assert rel_err(out.float()[:, :, ::2, ::2], fx['output_sub']) < otol
+    assert rel_err(out.float()[:, :, 37, :], fx['output_row']) < otol * float(fx['output_sub'].abs().max() / fx['output_row'].abs().max())
+    assert abs(float(out.float().norm()) - fx['output_norm']) < (1e-3 if dtype == torch.float32 else 2e-2) * fx['output_norm']
+    if dtype == torch.float32:
+        worst = 0.0
+        for n, p in m.named_parameters():
+            assert p.grad is not None, n
+            ref_n = fx['grad_norm'][n]
+            assert abs(float(p.grad.norm()) - ref_n) <= 1e-2 * max(ref_n, 1e-6), (n, float(p.grad.norm()), ref_n)
+            e = rel_err(p.grad.flatten()[:64], fx['grad_sample'][n])
+            worst = max(worst, e)
+            assert e < 2e-2, (n, e)
+            if n in fx['grad_full']:
+                assert rel_err(p.grad, fx['grad_full'][n]) < 2e-2, n
+        print(f'sam_b_blocks_1024 fp32: worst gradient-sample error {worst:.2e}')
+    else:
+        a = torch.cat([p.grad.flatten()[:64].double().cpu() for _, p in m.named_parameters()])
+        b = torch.cat([fx['grad_sample'][n].double() for n, _ in m.named_parameters()])
+        cos = float(a @ b / (a.norm() * b.norm()))
+        assert cos > noise['bf16_grad_sample_cos'] - 0.1, cos
 
 
 def test_sam_encoder_gradient_checkpoint_equals_plain(monkeypatch):
