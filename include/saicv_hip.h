@@ -346,12 +346,23 @@ int saicv_attention_stream_bwd(int dtype, int D, const saicv_attn_desc* desc, vo
  * bytes to the other ranks out of band (the host mirror uses the torch.distributed store); every rank then calls
  * saicv_comm_create (collective).  All other calls only enqueue work; RCCL is resolved with dlopen at first use. */
 typedef struct saicv_comm saicv_comm;
+/* 0 when RCCL could be resolved in this process (no communicator, no collective involved): the ranks agree on this BEFORE
+ * anyone enters the collective saicv_comm_create, so that a rank-local failure sends everybody to the fallback instead of
+ * leaving the others blocked inside ncclCommInitRank. */
+int saicv_comm_available(void);
 int saicv_comm_unique_id(void* id128);
 int saicv_comm_create(const void* id128, int world, int rank, saicv_comm** out);
 /* grads[0..n) (device, fp32) <- sum or mean over the ranks, in place, ordered after everything enqueued on producer_stream
  * so far (the stream whose kernels wrote this bucket): on the library's communication stream while producer_stream is being
  * captured into a hipGraph (or with SAICV_COMM_MODE=events), on producer_stream itself otherwise. */
 int saicv_comm_allreduce_bucket(saicv_comm* c, float* grads, size_t n, int average, void* producer_stream);
+/* The two halves of an all-reduce as separate collectives (over the point-to-point xGMI mesh a direct
+ * reduce-scatter + all-gather keeps every link busy with 1/world of the bucket).  Stream choice and ordering as above.
+ *   reduce_scatter: shard[0..n_per_rank) <- sum or mean over the ranks of grads[rank * n_per_rank ..), grads holds
+ *                   world * n_per_rank floats; shard may alias grads + rank * n_per_rank (in place).
+ *   all_gather    : buf[r * n_per_rank ..) <- rank r's shard, for every r; shard may alias buf + rank * n_per_rank. */
+int saicv_comm_reduce_scatter(saicv_comm* c, const float* grads, float* shard, size_t n_per_rank, int average, void* producer_stream);
+int saicv_comm_all_gather(saicv_comm* c, const float* shard, float* buf, size_t n_per_rank, void* producer_stream);
 /* buf[0..bytes) <- root's copy (constructor-time parameter / per-forward buffer broadcast), ordered after what `stream` has
  * enqueued so far and before what it enqueues next (same stream choice as the all-reduce). */
 int saicv_comm_broadcast(saicv_comm* c, void* buf, size_t bytes, int root, void* stream);

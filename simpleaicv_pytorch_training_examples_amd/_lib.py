@@ -128,7 +128,10 @@ SIGNATURES = {
     'saicv_upsample4_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_mask_loss_stats_up4': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
     'saicv_mask_loss_grad_up4': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
+    'saicv_comm_available': (c_int, []),
     'saicv_comm_unique_id': (c_int, [_P]),
+    'saicv_comm_reduce_scatter': (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
+    'saicv_comm_all_gather': (c_int, [_P, _P, _P, c_size_t, _P]),
     'saicv_comm_create': (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
     'saicv_comm_allreduce_bucket': (c_int, [_P, _P, c_size_t, c_int, _P]),
     'saicv_comm_broadcast': (c_int, [_P, _P, c_size_t, c_int, _P]),

@@ -16,6 +16,7 @@
 // process must never hold two RCCL copies.  xGMI is point-to-point (7 links per GPU): the bucket size is the caller's
 // knob (engine.DistributedDataParallel: 48 MiB buckets, a small last bucket so the tail of backward is short).
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
 #include <rccl/rccl.h>
 
@@ -33,33 +34,42 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
 
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+char g_rccl_why[256] = "symbols missing";      // why loading failed (dlerror() may be read only once)
 
 void load_rccl() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);          // the copy the process already holds, if any
     for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return;
+    if (!h) {
+        const char* e = dlerror();              // one call: it clears the error it returns
+        snprintf(g_rccl_why, sizeof(g_rccl_why), "%s", e ? e : "dlopen failed");
+        return;
+    }
     g_rccl.handle = h;
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
     g_rccl.Broadcast = reinterpret_cast<decltype(g_rccl.Broadcast)>(dlsym(h, "ncclBroadcast"));
+    g_rccl.ReduceScatter = reinterpret_cast<decltype(g_rccl.ReduceScatter)>(dlsym(h, "ncclReduceScatter"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce &&
-                g_rccl.Broadcast && g_rccl.GetErrorString;
+                g_rccl.Broadcast && g_rccl.ReduceScatter && g_rccl.AllGather && g_rccl.GetErrorString;
 }
 
 const Rccl* rccl() {
     std::call_once(g_rccl_once, load_rccl);
     if (!g_rccl.ok) {
-        saicv::set_error("saicv_comm: RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+        saicv::set_error("saicv_comm: RCCL (librccl.so.1) could not be loaded: %s", g_rccl_why);
         return nullptr;
     }
     return &g_rccl;
@@ -114,6 +124,10 @@ bool on_side_stream(const saicv_comm* c, void* stream) {
 }  // namespace
 
 extern "C" {
+
+int saicv_comm_available(void) {
+    return rccl() ? 0 : -1;
+}
 
 int saicv_comm_unique_id(void* id128) {
     const Rccl* r = rccl();
@@ -176,6 +190,46 @@ int saicv_comm_allreduce_bucket(saicv_comm* c, float* grads, size_t n, int avera
     }
     c->buckets += 1;
     c->bytes += n * sizeof(float);
+    return 0;
+}
+
+// stream a collective of this communicator runs on, ordered after producer_stream's work so far (see on_side_stream)
+static int comm_stream_for(saicv_comm* c, void* producer_stream, hipStream_t* out, const char* what) {
+    if (on_side_stream(c, producer_stream)) {
+        COMM_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(producer_stream)), what);
+        COMM_HIP(hipStreamWaitEvent(c->side, c->ev_in, 0), what);
+        *out = c->side;
+    } else {
+        *out = static_cast<hipStream_t>(producer_stream);
+    }
+    return 0;
+}
+
+int saicv_comm_reduce_scatter(saicv_comm* c, const float* grads, float* shard, size_t n_per_rank, int average, void* producer_stream) {
+    if (!c || !c->nccl) { saicv::set_error("saicv_comm_reduce_scatter: no communicator"); return -1; }
+    if (n_per_rank == 0) return 0;
+    if (!grads || !shard) { saicv::set_error("saicv_comm_reduce_scatter: null buffer"); return -1; }
+    const Rccl* r = rccl();
+    if (!r) return -1;
+    hipStream_t s = nullptr;
+    if (int e = comm_stream_for(c, producer_stream, &s, "reduce_scatter (order)")) return e;
+    COMM_RCCL(r, r->ReduceScatter(grads, shard, n_per_rank, ncclFloat32, average ? ncclAvg : ncclSum, c->nccl, s), "reduce_scatter");
+    c->buckets += 1;
+    c->bytes += n_per_rank * (size_t)c->world * sizeof(float);
+    return 0;
+}
+
+int saicv_comm_all_gather(saicv_comm* c, const float* shard, float* buf, size_t n_per_rank, void* producer_stream) {
+    if (!c || !c->nccl) { saicv::set_error("saicv_comm_all_gather: no communicator"); return -1; }
+    if (n_per_rank == 0) return 0;
+    if (!shard || !buf) { saicv::set_error("saicv_comm_all_gather: null buffer"); return -1; }
+    const Rccl* r = rccl();
+    if (!r) return -1;
+    hipStream_t s = nullptr;
+    if (int e = comm_stream_for(c, producer_stream, &s, "all_gather (order)")) return e;
+    COMM_RCCL(r, r->AllGather(shard, buf, n_per_rank, ncclFloat32, c->nccl, s), "all_gather");
+    c->buckets += 1;
+    c->bytes += n_per_rank * (size_t)c->world * sizeof(float);
     return 0;
 }
 

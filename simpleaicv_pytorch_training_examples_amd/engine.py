@@ -84,6 +84,12 @@ class FlatArena:
         self.arrived = [False] * len(self.params)
         self.listeners = []             # callables(index), e.g. the DDP engine's bucket counter
         self._mask_cache = {}
+        self._flag_cache = {}
+        self._block_param = None
+        self.zero_listeners = []        # callables() run by zero_grad(): per-backward state of the DDP engine
+        # set by DistributedDataParallel(find_unused_parameters=True) after every gradient sync: fp32 [n params], > 0 where
+        # ANY rank produced a gradient for the parameter in the backward that was just reduced
+        self.global_flags = None
         for i, p in enumerate(self.params):
             if p.requires_grad:
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -96,13 +102,46 @@ class FlatArena:
                 cb(i)
         return hook
 
+    def missing(self):
+        """Indices of the trainable parameters without a gradient from THIS rank since the last zero_grad()."""
+        return tuple(i for i, p in enumerate(self.params) if p.requires_grad and not self.arrived[i])
+
+    def local_flags(self):
+        """fp32 [n params] device tensor: 1 where this rank produced a gradient (or the parameter is not trainable)."""
+        missing = self.missing()
+        f = self._flag_cache.get(missing)
+        if f is None:
+            t = torch.ones(len(self.params), dtype=torch.float32)
+            for i in missing:
+                t[i] = 0.0
+            f = t.to(self.device)
+            if len(self._flag_cache) > 64:
+                self._flag_cache.clear()
+            self._flag_cache[missing] = f
+        return f
+
+    def block_param(self):
+        """int64 [total/ALIGN] device table: index of the parameter each 1024-element block belongs to."""
+        if self._block_param is None:
+            t = torch.zeros(self.total // ALIGN, dtype=torch.int64)
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                t[o // ALIGN:o // ALIGN + (p.numel() + ALIGN - 1) // ALIGN] = i
+            self._block_param = t.to(self.device)
+        return self._block_param
+
     def has_grad_mask(self):
         """uint8 [total/ALIGN] device table, 1 for the blocks of parameters that received a gradient since
         the last zero_grad(); None when every trainable parameter did (the common case).  torch.optim
-        skips parameters whose .grad is None; the flat kernels skip the blocks this table zeroes."""
-        missing = tuple(i for i, p in enumerate(self.params) if p.requires_grad and not self.arrived[i])
+        skips parameters whose .grad is None; the flat kernels skip the blocks this table zeroes.
+        Under data parallelism with find_unused_parameters the table is GLOBAL: a parameter this rank did not use
+        still carries the averaged gradient of the ranks that did (nn.parallel.DistributedDataParallel sets its
+        .grad on every rank), so every rank must step it -- otherwise the replicas drift apart.  The per-parameter
+        flags were summed over the ranks with the gradients (device side, no host read)."""
+        missing = self.missing()
         if not missing:
-            return None
+            return None                 # used everywhere here => used somewhere: every block is stepped
+        if self.global_flags is not None:
+            return (self.global_flags > 0).to(torch.uint8)[self.block_param()]
         m = self._mask_cache.get(missing)
         if m is None:
             t = torch.ones(self.total // ALIGN, dtype=torch.uint8)
@@ -119,6 +158,8 @@ class FlatArena:
         ops.join_side_stream()
         self.flat_grad.zero_()
         self.arrived = [False] * len(self.params)
+        for cb in self.zero_listeners:
+            cb()
         # re-attach views in case someone set .grad = None (optimizer.zero_grad(set_to_none=True))
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
@@ -463,6 +504,7 @@ class StepGraph:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
+            ops._ZeroPool.zero_all()    # the statistics scratch starts a replay all-zero, whatever ran eagerly in between
             out = self.fn(*args)
             ops.join_side_stream()      # every forked stream rejoins before the capture ends
         self.graph, self.static_out = graph, out
@@ -588,6 +630,33 @@ class DistributedDataParallel(torch.nn.Module):
                     self._broadcast(b)
             ops.bump_weights_epoch()
         self.arena.listeners.append(self._on_grad_complete)
+        self.arena.zero_listeners.append(self._reset_backward_state)
+        # find_unused_parameters: which parameters got a gradient on ANY rank travels with the gradients (one more
+        # tiny all-reduce per step) -- see FlatArena.has_grad_mask
+        self._flags = None
+        if self._active and find_unused_parameters:
+            self._flags = torch.zeros(len(self.arena.params), dtype=torch.float32, device=self.arena.device)
+
+    def _reset_backward_state(self):
+        """A backward that raised (out of memory, a failing check in a criterion) never runs autograd's final callbacks:
+        `_callback_queued` would stay set and the bucket counters keep the aborted pass's arrivals, so that a loop which
+        catches the error and goes on would skip the gradient sync or launch buckets early.  zero_grad() -- which every
+        loop calls between two backward passes that are meant to be independent -- therefore starts from a clean slate.
+        Collectives already enqueued by the aborted pass stay matched across the ranks only if every rank aborted at the
+        same point; a rank-local failure remains fatal for the job, as it is with nn.parallel.DistributedDataParallel."""
+        if self._callback_queued or not self._done:
+            if self.comm is not None and self._works:
+                self.comm.join()
+            for w, _ in self._works:
+                if w is not None:
+                    w.wait()
+        self._callback_queued = False
+        self._done = True
+        self._works = []
+        self._next_bucket = 0
+        for b in self.buckets:
+            b['count'] = 0
+        self.arena.global_flags = None
 
     def _native_comm(self, process_group):
         """The library's own RCCL communicator when the job runs on RCCL over the default group; None (torch.distributed
@@ -601,6 +670,15 @@ class DistributedDataParallel(torch.nn.Module):
                 return comm if comm.self_check(self.arena.flat_grad.device) else None
             return None
         if dist.get_backend() != 'nccl':
+            return None
+        # rank-local preconditions first (RCCL resolvable in this process): agreed on BEFORE anyone enters the collective
+        # communicator creation, so a rank that cannot load RCCL sends every rank to the torch.distributed path instead of
+        # leaving the others blocked inside ncclCommInitRank / the store read of the unique id
+        pre = torch.tensor([int(lib().saicv_comm_available() == 0)], dtype=torch.int32, device=self.arena.flat_grad.device)
+        dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+        if int(pre.item()) != 1:
+            if dist.get_rank() == 0:
+                print('[saicv] RCCL not loadable on every rank; gradients go through torch.distributed')
             return None
         comm, ok = None, 1
         try:
@@ -719,6 +797,18 @@ class DistributedDataParallel(torch.nn.Module):
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
             self._works.append((w, view))
 
+    def _reduce_flags(self):
+        """Sum over the ranks of "this rank produced a gradient for parameter i": the last collective of the step."""
+        self._flags.copy_(self.arena.local_flags())
+        if self.comm is not None:
+            self.comm.allreduce_bucket(self._flags, torch.cuda.current_stream(), average=False)
+            self._works.append((None, None))
+        elif self.world > 1:
+            if dist.get_backend(self.process_group) != 'nccl':
+                ops.join_side_stream()
+            self._works.append((dist.all_reduce(self._flags, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True), None))
+        self.arena.global_flags = self._flags
+
     def finish_gradient_sync(self):
         """Makes the compute stream wait for every in-flight bucket of the backward that just ran, after
         reducing the buckets whose parameters produced no gradient (find_unused_parameters semantics).
@@ -727,6 +817,8 @@ class DistributedDataParallel(torch.nn.Module):
             return
         if self._active and self._sync:
             self._launch_ready_buckets(force=True)
+            if self._flags is not None:
+                self._reduce_flags()
         if self.comm is not None and self._works:
             self.comm.join()
         for w, view in self._works:

@@ -87,6 +87,14 @@ class _ZeroPool:
         return t[:want]
 
     @classmethod
+    def zero_all(cls):
+        """Zeroes every chunk in full (a few MB).  A captured step replays its BatchNorm atomics into fixed slices and
+        needs them zero whatever ran eagerly since the last step boundary (a train-mode forward without an optimizer step
+        takes the same slices and leaves its sums behind): engine.StepGraph captures this call in front of the step."""
+        for ch in cls.chunks:
+            ch[0].zero_()
+
+    @classmethod
     def reset(cls):
         for ch in cls.chunks:
             if ch[1]:

@@ -202,6 +202,79 @@ def test_gloo_world2_shared_and_rank_dependent_parameters_reference_loop_shape()
     assert [n for n, a in zip(names, a1) if not a] == ['rare.weight', 'rare.bias']   # rank 1 never touched `rare`
 
 
+def _worker_unused(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    m = _Shared()
+    m.never = nn.Linear(1100, 1100)            # used by no rank
+    ddp = engine.DistributedDataParallel(m, bucket_cap_mb=0.001, last_bucket_cap_mb=0.0005, find_unused_parameters=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 6, generator=g)
+    out = []
+    for step in range(2):
+        ddp.arena.zero_grad()
+        if step == 1:
+            # a backward that raises half-way (the skip-batch pattern): the next zero_grad() must restore a clean state
+            try:
+                # the failing node sits at the INPUT: it runs after every parameter reported (and every bucket was launched)
+                xin = _Boom.apply(x[rank * 4:(rank + 1) * 4].clone().requires_grad_(True))
+                ddp(xin, use_rare=True).sum().backward()
+            except RuntimeError:
+                pass
+            assert ddp._callback_queued                      # autograd did not run the end-of-backward callback
+            ddp.arena.zero_grad()
+            assert not ddp._callback_queued and ddp._next_bucket == 0 and all(b['count'] == 0 for b in ddp.buckets)
+        ddp(x[rank * 4:(rank + 1) * 4], use_rare=(rank == 0)).pow(2).mean().backward()
+        mask = ddp.arena.has_grad_mask()
+        out.append((ddp.arena.flat_grad.clone().numpy(), list(ddp.arena.arrived), None if mask is None else mask.numpy()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _Boom(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        raise RuntimeError('boom')
+
+
+@pytest.mark.timeout(300)
+def test_gloo_world2_unused_parameters_are_stepped_wherever_any_rank_used_them():
+    """with find_unused_parameters a parameter that THIS rank did not use still receives the averaged
+    gradient of the ranks that did, so the optimizer's skip mask must be global -- identical on every rank, 1 for `rare`
+    (rank 0 used it), 0 only for `never` (nobody did).  Also ADVICE r02 (medium): after a backward that raised, zero_grad()
+    restores the per-backward state and the next step synchronises as usual."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unused, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    m = _Shared()
+    m.never = nn.Linear(1100, 1100)
+    arena = engine.FlatArena(list(m.named_parameters()), torch.device('cpu'))
+    off = {n: o // engine.ALIGN for n, o in zip(arena.names, arena.offsets)}
+    for step in range(2):
+        (g0, a0, m0), (g1, a1, m1) = res[0][1][step], res[1][1][step]
+        assert torch.equal(torch.from_numpy(g0), torch.from_numpy(g1))
+        assert [n for n, a in zip(arena.names, a1) if not a] == ['rare.weight', 'rare.bias', 'never.weight', 'never.bias']
+        assert m0 is not None and m1 is not None and (m0 == m1).all()          # the SAME table on both ranks
+        assert m1[off['rare.weight']] == 1 and m1[off['rare.bias']] == 1       # rank 1 steps what rank 0 used
+        assert m1[off['never.weight']] == 0 and m1[off['never.bias']] == 0     # nobody used it: torch.optim skips it too
+        assert m1[off['shared.weight']] == 1 and m1[off['out.bias']] == 1
+    assert float(torch.from_numpy(res[0][1][0][0]).abs().sum()) > 0
+    assert torch.allclose(torch.from_numpy(res[0][1][0][0]), torch.from_numpy(res[0][1][1][0]), atol=1e-7)   # step 2 == step 1
+
+
 def test_arena_tracks_which_parameters_received_gradients():
     m = _Shared()
     arena = engine.FlatArena(list(m.named_parameters()), torch.device('cpu'))
