@@ -35,6 +35,15 @@ DEVINL uint32_t fdiv(uint32_t n, FastDiv d) {
 // LDS-DMA ring depth per geometry: 4 stages, except 256 x 128 where 3 stages (72 KiB) let TWO workgroups share
 // a CU so that one's epilogue overlaps the other's main loop
 constexpr int nt_stages(int bm, int bn) { return (bm == 256 && bn == 128) ? 3 : 4; }
+// resident workgroups per CU by LDS (the ring is all a workgroup holds: the epilogue stages through a vacated slot)
+// Which instantiations may run persistently (ticket draws hidden from the compiler, see draw_ticket): bf16 in and out,
+// and a register budget in which the compiler spills nothing -- a spilled ticket register would be saved before the atomic
+// has landed.  The 8-wavefront 256 x 128 geometry lives at 128 registers per lane (two workgroups per CU) and does spill
+// in its epilogue; it stays one tile per workgroup.  scripts/check_ticket_regs.py verifies the generated code of the rest.
+constexpr bool nt_can_persist(int elem_bytes, bool out_f32, int bm, int bn, int nwaves) {
+    return elem_bytes == 2 && !out_f32 && !(nwaves == 8 && bm * bn <= 256 * 128);
+}
+constexpr int nt_blocks_per_cu(int bm, int bn) { return 160 * 1024 / (nt_stages(bm, bn) * (bm + bn) * 64 + 16); }
 
 struct NTParams {
     const void* src;
@@ -62,7 +71,7 @@ struct NTParams {
     // rows (row = tile row mod count) of a zeroed buffer instead of written one row per tile row: few enough rows that the
     // consuming BatchNorm kernel finalises them itself (no partial-reduce / finalize launches)
     int stat_atomic_rows;
-    int nt_store;       // 1: the plain epilogue stores the output tile with non-temporal (streaming) stores
+    unsigned int* tickets;      // persistent launch: 8 per-XCD ticket counters (+ a departure counter at [32]), zero between launches
     uint32_t src_bytes, wgt_bytes;
     int H, W, C;        // gather-source spatial dims / channels
     int OH, OW;         // pixel grid that indexes the GEMM rows
@@ -86,11 +95,10 @@ DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
 }
 
-// Main loop = LDS-DMA ring: `buffer_load ... lds` writes global chunks straight into a 4-stage
-// LDS ring (no staging registers, no ds_write), three K tiles are in flight across the single
-// raw s_barrier of each tile, and the wait is a COUNTED s_waitcnt vmcnt(N) that only retires the
-// tile about to be consumed (guide section 5, T3/T4).  The DMA destination is wave-linear
-// (base + lane*16), so the XOR swizzle is applied to the SOURCE: lane l fetches the chunk that
+// Main loop = LDS-DMA ring: `buffer_load ... lds` writes global chunks straight into an NSTAGE-slot LDS ring (no staging
+// registers, no ds_write), NSTAGE-1 K tiles are in flight across the single raw s_barrier of each K step, and the wait is
+// a COUNTED s_waitcnt vmcnt(N) that only retires the tile about to be consumed (guide section 5, T3/T4).  The DMA
+// destination is wave-linear (base + lane*16), so the XOR swizzle is applied to the SOURCE: lane l fetches the chunk that
 // belongs in the slot it will fill.
 // The loop is bound by MFMA issue only if the integer work per K tile is tiny, so:
 //  * all gathers are raw buffer loads: an out-of-range lane (padding halo, M/N/K tails) gets
@@ -100,15 +108,31 @@ DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
 //  * LDS fragment addresses (with the XOR swizzle) are computed once.
 // PLAIN: 1x1 taps without padding (pointwise conv, nn.Linear and their data-gradients): the K
 // index IS the channel offset, no tap walker and no halo tests in the loop.
-// Tile geometry (BM_T x BN_T output tile, WM_ x WN_ wavefronts, each owning a
-// (BM_T/WM_) x (BN_T/WN_) sub-tile): 256x256 / 2x4, 256x128 / 4x2, 128x128 / 2x2, 128x64 / 2x2.
-// Wider tiles raise flop per LDS-fill byte and the MFMAs issued per barrier and per DMA.
+// Tile geometry (BM_T x BN_T output tile, WM_ x WN_ wavefronts, each owning a (BM_T/WM_) x (BN_T/WN_) sub-tile).
+//
+// r03 -- ONE OPERAND STREAM PER WORKGROUP, ACROSS TILES.  Round 2 measured a fixed cost of 10-12 us per output tile next
+// to ~1 us per K step (kernel exit, dispatch of the next workgroup, kernel-argument loads, index set-up, the first DMA's
+// HBM latency, a workgroup-wide LDS-staged epilogue): 30 % of a ViT-B K = 768 tile, 36 % of a 64-channel 3 x 3 one.  Now:
+//  * a launch with more tiles than resident workgroups is PERSISTENT: a workgroup draws its next tile from a per-XCD
+//    ticket counter (the tiles of one XCD stay a contiguous, L2-sharing range; late or slow workgroups simply draw fewer
+//    tickets, so nothing depends on all of them being resident -- RCCL kernels may hold CU slots);
+//  * the DMA stream does not drain at a tile boundary: the K steps of the NEXT tile are issued into the ring while the
+//    last steps of the current one are computed (the per-row gather state lives in the same registers -- it is
+//    recomputed at the switch, NSTAGE-1 steps before the compute side follows);
+//  * the epilogue is PER WAVEFRONT and needs no LDS of its own: a wavefront stages 16 rows of its sub-tile at a time
+//    through its share of the ring slot the last K step just vacated, reads them back as 16-byte row chunks (whole 128-byte
+//    lines per row in HBM) and stores them; no workgroup barrier, the next tile's operands are landing meanwhile;
+//  * BatchNorm statistics of bf16 outputs still come from the staged rows on the matrix cores (16x16x16: one transposed
+//    LDS read per 16 rows x 16 columns; sum = 1 . Y, sum of squares = diag(Y^T . Y)), per wavefront.
+// vmcnt accounting across the seam: gfx9 returns vector-memory operations in issue order (loads, stores and atomics share
+// the counter), so "at most LPT x min(2, steps issued after this one) operations outstanding" retires the K step about to
+// be consumed whatever epilogue stores or side loads were issued in between: they only make the wait conservative.
 template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
-__global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT_F32) ? 4 : 1) void igemm_nt_kernel(const NTParams p) {
+__global__ __launch_bounds__(64 * WM_ * WN_, nt_blocks_per_cu(BM_T, BN_T) * WM_ * WN_ / 4)
+void igemm_nt_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = 4 * EPC;                  // one 64-byte row per K tile
     constexpr int NWAVES = WM_ * WN_;
-    constexpr int NTHREADS = 64 * NWAVES;
     constexpr int WMR = BM_T / WM_;              // rows of the output tile owned by one wavefront
     constexpr int WN = BN_T / WN_;
     constexpr int NT_ = WN / 16;
@@ -120,7 +144,9 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     constexpr int A_BYTES = BM_T * 64;
     constexpr int W_BYTES = BN_T * 64;
     constexpr int STAGE = A_BYTES + W_BYTES;
-    constexpr uint32_t OOB = 0xfffffff0u;   // 16-byte aligned, beyond any operand (host checks sizes)
+    constexpr int MBOX = NSTAGE * STAGE;         // one dword behind the ring: the tile after the one being streamed
+    constexpr uint32_t OOB = 0xfffffff0u;        // 16-byte aligned, beyond any operand (host checks sizes)
+    static_assert(AROWS >= 1 && WROWS >= 1, "every wavefront issues at least one DMA row block per operand");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -153,34 +179,46 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
         Kc = Rc * Sc * p.C;
         nblk = ((Mc + BM_T - 1) / BM_T) * p.tiles_n;
     }
-    // ---- tile loop: one tile per workgroup by default (the hardware dispatcher balances the load); with
-    // SAICV_NT_PERSIST=1 the grid is one resident round of workgroups, each walking tiles tix, tix + grid, ...
-    // Spreading the workgroups' start times over a tile period -- so that epilogue write bursts and MFMA loops of
-    // different CUs interleave -- was measured and bought nothing: the ramp costs what the steady state gains.
-    for (int tix = blockIdx.x; tix < nblk; tix += gridDim.x) {
-    if (tix != (int)blockIdx.x) {                  // the previous tile's LDS reads are done (its stores may still drain)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    const int bid = xcd_remap(tix, nblk);
-    const int tile_n = bid % p.tiles_n;
-    const int tile_m = bid / p.tiles_n;
+    const int ohw = Hc * Wc;
+    const int nkt = (Kc + BK - 1) / BK;          // 0 for a class without taps: the output is zero
+
+    // ---- which tiles: block b runs on XCD b % 8 (observed dispatch order; speed only) and XCD x owns the contiguous tile
+    // range [xbase, xbase + xcount): its workgroups take the first gridDim.x / 8 of them by position, the rest by ticket
+    constexpr bool CAN_PERSIST = nt_can_persist((int)sizeof(T), OUT_F32, BM_T, BN_T, NWAVES);
+    const bool persistent = CAN_PERSIST && p.tickets != nullptr;      // host: only with more tiles than workgroups and nkt > NSTAGE
+    const int xcd = blockIdx.x & 7;
+    const int xq = nblk >> 3, xr = nblk & 7;
+    const int xbase = (xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int xcount = xq + (xcd < xr ? 1 : 0);
+    const int xwg = (int)(gridDim.x >> 3) + (((int)(gridDim.x & 7) > xcd) ? 1 : 0);     // workgroups of this launch on this XCD
+    unsigned int* const ticket = persistent ? p.tickets + blockIdx.y * 8 + xcd : nullptr;
+    const int pos0 = (int)(blockIdx.x >> 3);
+    const int first = pos0 < xcount ? xbase + pos0 : -1;
 
     const __amdgpu_buffer_rsrc_t src_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wgt_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
 
-    // ---- per-thread DMA state.  Wave w, instruction i, lane l fills LDS bytes
+    // ---- per-thread DMA state of the tile being streamed.  Wave w, instruction i, lane l fills LDS bytes
     // [(i*NWAVES + w)*1024 + l*16, +16) of the A region: row (i*NWAVES+w)*16 + (l>>2), slot l&3, i.e. the
     // logical chunk (l&3) ^ f((row>>2)&3) = (l&3) ^ f((l>>4)&3) -- one K-chunk column per thread.
     const int cc = (lane & 3) ^ lds_swz((lane >> 4) & 3);
     int rowc[AROWS], a0[AROWS], b0[AROWS];   // rowc = (image base + A0*W + B0) * C  [elements]
-    const int ohw = Hc * Wc;
+    int wrow[WROWS];                         // weight row base [elements], or -1
+    int kpos = 0, tc0 = 0, ttr = 0, tts = 0; // K-chunk walker: k = kt*BK + cc*EPC  ->  (tr, ts, c0), advanced by BK per tile
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-        const int m = tile_m * BM_T + (i * NWAVES + wave) * 16 + (lane >> 2);
-        if (m < Mc) {
+    for (int i = 0; i < AROWS; ++i) { rowc[i] = 0; a0[i] = 0; b0[i] = 0; }      // (defined on every path: the arrays stay in registers)
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) wrow[j] = -1;
+    auto stream_tile = [&](int bid) __attribute__((always_inline)) {        // point the DMA state at the first K step of tile `bid`
+        const int tile_n = bid % p.tiles_n;
+        const int tile_m = bid / p.tiles_n;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int mq = tile_m * BM_T + (i * NWAVES + wave) * 16 + (lane >> 2);
+            const bool in = mq < Mc;
+            const int m = in ? mq : 0;          // branch-free: rows past the end decompose row 0 and are then marked out of range
             int img, oh, ow;
             if (cs == 1) {
                 img = (int)fdiv((uint32_t)m, p.fd_ohw);
@@ -193,40 +231,27 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
                 oh = rem / Wc;
                 ow = rem - oh * Wc;
             }
-            if (MODE == 0) {
-                a0[i] = oh * p.stride - p.pad;
-                b0[i] = ow * p.stride - p.pad;
-            } else {
-                a0[i] = oh + q0h;
-                b0[i] = ow + q0w;
-            }
-            rowc[i] = ((img * p.H + a0[i]) * p.W + b0[i]) * p.C;
-        } else {
-            rowc[i] = 0;
-            a0[i] = -(1 << 24);
-            b0[i] = -(1 << 24);
+            const int av = MODE == 0 ? oh * p.stride - p.pad : oh + q0h;
+            const int bv = MODE == 0 ? ow * p.stride - p.pad : ow + q0w;
+            a0[i] = in ? av : -(1 << 24);
+            b0[i] = in ? bv : -(1 << 24);
+            rowc[i] = in ? ((img * p.H + av) * p.W + bv) * p.C : 0;
         }
-    }
-    int wrow[WROWS];                    // weight row base [elements], or -1
 #pragma unroll
-    for (int j = 0; j < WROWS; ++j) {
-        const int n = tile_n * BN_T + (j * NWAVES + wave) * 16 + (lane >> 2);
-        wrow[j] = n < p.Nn ? n * p.Kd : -1;
-    }
-
-    // K-chunk walker: k = kt*BK + cc*EPC  ->  (tr, ts, c0), advanced by BK per tile
-    int kpos = cc * EPC;
-    int tc0, ttr, tts;
-    {
+        for (int j = 0; j < WROWS; ++j) {
+            const int n = tile_n * BN_T + (j * NWAVES + wave) * 16 + (lane >> 2);
+            wrow[j] = n < p.Nn ? n * p.Kd : -1;
+        }
+        kpos = cc * EPC;
         const int tap = kpos / p.C;
         tc0 = kpos - tap * p.C;
         ttr = Sc > 0 ? tap / Sc : 0;
         tts = tap - ttr * Sc;
-    }
+    };
 
     typedef __attribute__((address_space(3))) void lds_void;
     // issue the DMA of the next K tile (walker position) into ring slot `stage`
-    auto issue_tile = [&](int stage) {
+    auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         char* base = smem + stage * STAGE + wave * 1024;
         const bool kvalid = kpos < Kc;
         int tapoff, kw;
@@ -283,13 +308,18 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
 
     const int l15 = lane & 15;
     const int lg = lane >> 4;
-    int fa[MT_], fw[NT_];               // LDS fragment offsets within a stage, hoisted out of the K loop
+    int fa[MT_], fw[NT_];               // LDS fragment offsets within a stage, hoisted out of the K loop (not out of the tile
+                                        // loop: they are recomputed per tile so that they are not live across the epilogue)
+    auto fragment_offsets = [&]() __attribute__((always_inline)) {
+        int l15o = l15, lgo = lg;
+        asm volatile("" : "+v"(l15o), "+v"(lgo));       // opaque: keeps the compiler from hoisting the offsets over the epilogue
 #pragma unroll
-    for (int mi = 0; mi < MT_; ++mi) fa[mi] = lds_off(wm * WMR + mi * 16 + l15, lg);
+        for (int mi = 0; mi < MT_; ++mi) fa[mi] = lds_off(wm * WMR + mi * 16 + l15o, lgo);
 #pragma unroll
-    for (int ni = 0; ni < NT_; ++ni) fw[ni] = A_BYTES + lds_off(wn * WN + ni * 16 + l15, lg);
+        for (int ni = 0; ni < NT_; ++ni) fw[ni] = A_BYTES + lds_off(wn * WN + ni * 16 + l15o, lgo);
+    };
 
-    auto compute = [&](int stage) {
+    auto compute = [&](int stage) __attribute__((always_inline)) {
         const char* base = smem + stage * STAGE;
         u32x4 af[MT_], wf[NT_];
 #pragma unroll
@@ -302,384 +332,435 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
             for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
     };
 
-    const int nkt = (Kc + BK - 1) / BK;        // 0 for a class without taps: the output is zero
-    // prologue: NSTAGE-1 tiles in flight
-    int issued = 0;
-    for (; issued < NSTAGE - 1 && issued < nkt; ++issued) issue_tile(issued);
-    int st_c = 0;                              // ring slot of the tile being consumed
-    int st_i = issued % NSTAGE;                // ring slot the next DMA fills
-    for (int kt = 0; kt < nkt; ++kt) {
-        // retire tile kt only: the tiles issued after it stay in flight across the barrier
-        const int ahead = issued - kt - 1;     // wave-uniform
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // everyone's part of tile kt landed; tile kt-1 fully consumed
-        if (issued < nkt) {                    // refill the slot tile kt-1 just vacated
-            issue_tile(st_i);
-            ++issued;
-            st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+    // ---- the operand stream.  bid_i / ki: tile and K step the DMA side is at; the mailbox holds the tile after bid_i
+    // (written by wavefront 0 two K steps after it drew the ticket, read by everyone at the switch, >= 1 barrier later).
+    int bid_c = first;                 // tile being computed
+    int bid_i = first, ki = 0;
+    int issued = 0, consumed = 0;      // K steps issued / retired by this workgroup, over all its tiles
+    int st_i = 0, st_c = 0;            // ring slots of the next DMA / the step being consumed
+    unsigned int tk = 0u;              // wavefront 0, lane 0: the ticket in flight
+    bool mb_pending = false;
+    int mb_wait = 0;
+    // The ticket is drawn ASYNCHRONOUSLY: a returning atomic hidden from the compiler (atomicAdd() is followed by an
+    // immediate s_waitcnt vmcnt(0) -- the whole DMA ring plus an L2 round trip, once per tile), whose result lands in `tk`
+    // some time later.  It is read two K steps on, behind the counted vmcnt wait of that step: vector-memory operations
+    // return in issue order and that wait leaves at most 2 x LPT of them outstanding, all issued after the atomic.
+    // The compiler does not know `tk` is in flight: tests/test_kernel_asm.py checks in the generated code of every
+    // instantiation that nothing reads or copies the destination register before the mailbox write.
+    const uint32_t mbox_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + MBOX);
+    auto draw_ticket = [&]() __attribute__((always_inline)) {
+        if constexpr (CAN_PERSIST) {
+            if (wave == 0 && lane == 0) {
+                const unsigned int one = 1u;
+                asm volatile("global_atomic_add %0, %1, %2, off sc0 ; saicv ticket" : "=v"(tk) : "v"(ticket), "v"(one) : "memory");
+            }
+            mb_pending = true;
         }
-        compute(st_c);
-        st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
+    };
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (bid_i < 0) return;
+        if (ki == nkt) {               // the stream moves on to the next tile of this workgroup
+            int nb = -1;
+            if (CAN_PERSIST && persistent) {
+                int v;              // LDS access spelled out: a volatile generic access becomes a FLAT load behind vmcnt(0)
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(mbox_addr) : "memory");
+                nb = __builtin_amdgcn_readfirstlane(v);
+            }
+            bid_i = nb;
+            ki = 0;
+            if (bid_i < 0) return;
+            stream_tile(bid_i);
+            draw_ticket();
+            mb_wait = 1;
+        }
+        issue_tile(st_i);
+        ++ki;
+        ++issued;
+        st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+    };
+    if (bid_c >= 0) {
+        stream_tile(bid_i);
+        if (persistent) draw_ticket();
+        if (nkt > 0)
+            for (int s = 0; s < NSTAGE - 1; ++s) issue_next();
     }
-    __syncthreads();                           // LDS is reused by the epilogue
 
-    // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*16 + lg*4 + r ; m = m_base + mi*16 + l15
-    // BN statistics come straight from the accumulators; the output tile is staged through LDS
-    // so that HBM sees whole rows written 16 bytes per lane (a lane's fragment is only 4 values
-    // of one row: storing it directly gives 32- or 64-byte row segments and half the write bandwidth -- measured).
-    // CODE SIZE is what this section is tuned for: with one workgroup per CU nothing overlaps the epilogue, and a
-    // fully unrolled epilogue that carries every fused mode in every unrolled copy (6 k instructions, 48 KiB)
-    // spent most of its 6 us per tile waiting for instruction fetch.  So: the unrolled part (accumulator -> LDS)
-    // carries no alternatives, the common copy-out is 16 loads + 16 stores, and everything with a fused operand,
-    // a row remap, an N tail or an unaligned leading dimension runs in ROLLED loops (one copy of the mode code).
     typedef typename std::conditional<OUT_F32, float, T>::type TO;
-    constexpr int OPITCH = BN_T * (int)sizeof(TO) + 16;         // bytes; +16 staggers banks
-    constexpr int OCPR = BN_T * (int)sizeof(TO) / 16;           // 16-byte chunks per tile row
+    // ---- epilogue geometry (per wavefront): a "piece" = 16 rows x WNS columns of the sub-tile, staged in LDS with a
+    // padded pitch, read back as 16-byte row chunks: CPR chunks per row, CPL per lane, lane -> (row = j*RPJ + lane/CPR,
+    // chunk = lane % CPR) -- a lane's column chunk is the same for every row it touches
+    constexpr int SLOT_SHARE = STAGE / NWAVES;
+    constexpr int NSPLIT = (16 * (WN * (int)sizeof(TO) + 16) <= SLOT_SHARE) ? 1 : 2;     // column halves per piece (fp32 outputs)
+    constexpr int NTH = NT_ / NSPLIT;
+    constexpr int WNS = WN / NSPLIT;
+    constexpr int OPITCH = WNS * (int)sizeof(TO) + 16;          // bytes; +16 staggers banks
+    static_assert(16 * OPITCH <= SLOT_SHARE && NT_ % NSPLIT == 0, "the staged piece must fit this wavefront's share of a ring slot");
     constexpr int OEPC = 16 / (int)sizeof(TO);
-    const int m_base = tile_m * BM_T + wm * WMR;
-    const int n_base = tile_n * BN_T + wn * WN;
-    const bool do_stats = p.stat_sum != nullptr;
-    // bf16 outputs: the BN statistics are taken from the STAGED tile by the matrix cores (below), not here
-    constexpr bool MSTAT = !OUT_F32 && sizeof(T) == 2;
-    const bool valu_stats = do_stats && !MSTAT;
-#pragma unroll
-    for (int ni = 0; ni < NT_; ++ni) {
-        const int n0 = n_base + ni * 16 + lg * 4;
-        float bs[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n0 + r < p.Nn) bs[r] = p.bias[n0 + r];
-        }
-        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-        char* q0 = smem + (wm * WMR + l15) * OPITCH + (wn * WN + ni * 16 + lg * 4) * (int)sizeof(TO);
-#pragma unroll
-        for (int mi = 0; mi < MT_; ++mi) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bs[r];
-            if (valu_stats) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float vr = OUT_F32 ? v[r] : round_through<T>(v[r]);
-                    ssum[r] += vr;
-                    ssq[r] += vr * vr;
-                }
-            }
-            char* q = q0 + mi * 16 * OPITCH;
-            if (sizeof(TO) == 2) {
-                bf16x4 pk;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(q) = pk;
-            } else {
-                *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
-            }
-        }
-        if (valu_stats) {
-            // rows m >= M were gathered as zeros (no bias when stats are requested) -> add 0.
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {        // over the 16 pixel lanes: four DPP adds each
-                ssum[r] = row16_sum(ssum[r]);
-                ssq[r] = row16_sum(ssq[r]);
-            }
-            if (l15 == 0) {                      // per-wavefront column sums -> LDS [2][WM_][BN_T] behind the staged tile
-                float* ws = reinterpret_cast<float*>(smem + BM_T * OPITCH) + wm * BN_T + wn * WN + ni * 16 + lg * 4;
-                *reinterpret_cast<f32x4*>(ws) = f32x4{ssum[0], ssum[1], ssum[2], ssum[3]};
-                *reinterpret_cast<f32x4*>(ws + WM_ * BN_T) = f32x4{ssq[0], ssq[1], ssq[2], ssq[3]};
-            }
-        }
-    }
-    __syncthreads();
-    if constexpr (MSTAT) {
-        if (do_stats) {
-            // Column sums of the staged bf16 tile on the matrix cores: with Y the [32 rows][16 cols] block read
-            // TRANSPOSED from LDS (ds_read_b64_tr_b16: lane (col, k-group) gets 8 consecutive rows of its column),
-            //   sum_m y      = (1 . Y)[any row][col]          -- A = ones
-            //   sum_m y * y  = (Y^T . Y)[col][col]            -- A = B = the same fragment, the diagonal
-            // exact products, fp32 accumulation, and exactly the values the next kernel reads (bf16-rounded).
-            // One wavefront owns 16 columns over ALL rows of the tile: no cross-wave combine, and the 14 VALU
-            // operations per output element + 128 DPP adds of the accumulator version are gone from the epilogue.
-            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-            const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-            for (int cg = wave; cg < BN_T / 16; cg += NWAVES) {
-                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-                const char* q = smem + (lg * 8 + (l15 >> 2)) * OPITCH + (cg * 16 + (l15 & 3) * 4) * 2;
-#pragma unroll 4
-                for (int rb = 0; rb < BM_T / 32; ++rb, q += 32 * OPITCH) {
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * OPITCH));
-                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-                    const u32x4 y = {l2[0], l2[1], h2[0], h2[1]};
-                    Mma<T>::run(s1, ones, y);
-                    Mma<T>::run(s2, y, y);
-                }
-                const int n = tile_n * BN_T + cg * 16 + l15;          // D: row lg*4 + r, column l15
-                if (n < p.Nn) {
-                    const size_t srow = p.stat_atomic_rows ? (size_t)(tile_m % p.stat_atomic_rows) : (size_t)tile_m;
-                    if (lg == 0) {
-                        if (p.stat_atomic_rows) unsafeAtomicAdd(&p.stat_sum[srow * (size_t)p.Nn + n], s1[0]);
-                        else p.stat_sum[srow * (size_t)p.Nn + n] = s1[0];
-                    }
-                    if (lg == (l15 >> 2)) {
-                        const int r = l15 & 3;
-                        const float qv = r == 0 ? s2[0] : r == 1 ? s2[1] : r == 2 ? s2[2] : s2[3];
-                        if (p.stat_atomic_rows) unsafeAtomicAdd(&p.stat_sq[srow * (size_t)p.Nn + n], qv);
-                        else p.stat_sq[srow * (size_t)p.Nn + n] = qv;
-                    }
-                }
-            }
-        }
-    } else
-    if (do_stats) {
-        // one row of partial statistics per WORKGROUP (fixed summation order over its wavefront rows): four times
-        // fewer partial rows for the finalize kernels to read than one row per wavefront row
-        for (int c = tid; c < 2 * BN_T; c += NTHREADS) {
-            const int which = c / BN_T, col = c - which * BN_T;
-            const float* ws = reinterpret_cast<const float*>(smem + BM_T * OPITCH) + which * WM_ * BN_T + col;
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM_; ++w) a += ws[w * BN_T];
-            const int n = tile_n * BN_T + col;
-            if (n < p.Nn) {
-                float* dst = (which ? p.stat_sq : p.stat_sum) +
-                             (size_t)(p.stat_atomic_rows ? tile_m % p.stat_atomic_rows : tile_m) * (size_t)p.Nn + n;
-                if (p.stat_atomic_rows) unsafeAtomicAdd(dst, a); else *dst = a;
-            }
-        }
-    }
-    const int oc = tid % OCPR;               // chunk within the tile row
-    const int orow0 = tid / OCPR;
-    constexpr int RPP = NTHREADS / OCPR;     // tile rows per pass
-    constexpr int NIT = BM_T / RPP;
-    const int ncol = tile_n * BN_T + oc * OEPC;
+    constexpr int CPR = WNS / OEPC;
+    constexpr int CPL = (16 * CPR) / 64;
+    constexpr int RPJ = 64 / CPR;                               // rows covered by one chunk pass of the wavefront
+    static_assert(16 * CPR >= 64 && CPL * 64 == 16 * CPR, "a staged piece is a whole number of chunk passes of the wavefront");
+    constexpr bool MSTAT = !OUT_F32 && sizeof(T) == 2 && MODE == 0;      // BN statistics from the staged bf16 rows (matrix cores)
+    constexpr bool VSTAT = MODE == 0 && !MSTAT;                          // ... from the accumulators (fp32 outputs)
+    constexpr bool DGRAD_EXTRAS = MODE == 1 && sizeof(TO) == sizeof(T);  // gated shortcut / BatchNorm-backward sums: data gradient only
     TO* const outp = reinterpret_cast<TO*>(p.out);
     const bool aligned = ((p.ldo * (int)sizeof(TO)) & 15) == 0;
     const bool remap = MODE == 1 && cs > 1;
-    constexpr bool DGRAD_EXTRAS = MODE == 1 && sizeof(TO) == sizeof(T);       // gated shortcut / BatchNorm-backward sums: data gradient only
-    const bool bstats = DGRAD_EXTRAS && p.bs_y != nullptr;                                                        // uniform
-    const bool plain = aligned && !remap && p.act_mode == 0 && p.addend == nullptr && p.row_scale == nullptr && !bstats;   // uniform
-    float bag[OEPC], bax[OEPC];                                // this thread's sum g, sum g * y over its rows of the tile
+    const bool do_stats = MODE == 0 && p.stat_sum != nullptr;
+    const bool bstats = DGRAD_EXTRAS && p.bs_y != nullptr;
+    const bool addp = p.addend != nullptr, scalep = p.row_scale != nullptr;
+    const bool gatep = DGRAD_EXTRAS && p.addend_gate != nullptr, maskp = bstats && p.bs_mask != nullptr;
+    const bool fused = p.act_mode != 0 || addp || scalep || bstats;
+    const bool fast = aligned && !remap && !fused;             // plain copy-out of whole chunks (N tail checked per chunk)
+    const int crow = lane / CPR;                                    // row of this lane's chunk within a pass
+    const int ccol = lane % CPR;                                    // its chunk column
+
+    auto epilogue = [&](int bid, char* stg) __attribute__((always_inline)) {
+        const int tile_n = bid % p.tiles_n;
+        const int tile_m = bid / p.tiles_n;
+        const int m_base = tile_m * BM_T + wm * WMR;
+        const int n_base = tile_n * BN_T + wn * WN;
+        float ssum[NT_][4], ssq[NT_][4];                   // VSTAT: column sums from the accumulators
+        float msum[NT_], msq[NT_];                          // MSTAT: this lane's column (sum: lanes lg == 0; squares: lg == l15 >> 2)
+        float bag[NSPLIT][OEPC], bax[NSPLIT][OEPC];         // BatchNorm-backward sums of this lane's column chunk
 #pragma unroll
-    for (int j = 0; j < OEPC; ++j) { bag[j] = 0.f; bax[j] = 0.f; }
-    if (plain && ncol + OEPC <= p.Nn) {
-        // the common case: a branch-free copy, the LDS reads of eight rows in flight before the first store
-        constexpr int GRP = NIT < 8 ? NIT : 8;
-        const int mrow0 = tile_m * BM_T + orow0;
-        const char* ls = smem + orow0 * OPITCH + oc * 16;
-        TO* o = outp + (size_t)mrow0 * p.ldo + ncol;
-        const size_t ostep = (size_t)RPP * p.ldo;
-        const bool full = (tile_m + 1) * BM_T <= Mc;                                         // uniform
+        for (int ni = 0; ni < NT_; ++ni) {
+            msum[ni] = 0.f; msq[ni] = 0.f;
 #pragma unroll
-        for (int g = 0; g < NIT; g += GRP) {
-            u32x4 v[GRP];
+            for (int r = 0; r < 4; ++r) { ssum[ni][r] = 0.f; ssq[ni][r] = 0.f; }
+        }
 #pragma unroll
-            for (int j = 0; j < GRP; ++j) v[j] = ld_chunk(ls + (g + j) * RPP * OPITCH);
-            if (full && p.nt_store) {
+        for (int h = 0; h < NSPLIT; ++h)
 #pragma unroll
-                for (int j = 0; j < GRP; ++j) st_chunk_nt(o + (g + j) * ostep, v[j]);
-            } else if (full) {
+            for (int e = 0; e < OEPC; ++e) { bag[h][e] = 0.f; bax[h][e] = 0.f; }
+        if (MODE == 0 && p.bias != nullptr) {      // (uniform) the bias joins the accumulators before they are staged: no bias
+#pragma unroll                                     // registers live across the piece loop
+            for (int ni = 0; ni < NT_; ++ni) {
+                const int n = n_base + ni * 16 + lg * 4;
+                const f32x4 bv = {n < p.Nn ? p.bias[n] : 0.f, n + 1 < p.Nn ? p.bias[n + 1] : 0.f,
+                                  n + 2 < p.Nn ? p.bias[n + 2] : 0.f, n + 3 < p.Nn ? p.bias[n + 3] : 0.f};
 #pragma unroll
-                for (int j = 0; j < GRP; ++j) st_chunk(o + (g + j) * ostep, v[j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j)
-                    if (mrow0 + (g + j) * RPP < Mc) st_chunk(o + (g + j) * ostep, v[j]);
+                for (int mi = 0; mi < MT_; ++mi) acc[ni][mi] += bv;
             }
         }
-    } else if (aligned && !remap && p.act_mode == 0 && (p.Nn % OEPC) == 0) {   // uniform
-        // residual add / drop-path scale (forward and data gradient) and the data gradient's gated shortcut and
-        // BatchNorm-backward sums, on dense rows of whole chunks: four rows at a time, every global load of the group
-        // (addend, y, the two mask bytes) in flight before the first use
-        if (ncol < p.Nn) {
-            constexpr int GRP = NIT < 4 ? NIT : 4;
-            const int mrow0 = tile_m * BM_T + orow0;
-            const char* ls = smem + orow0 * OPITCH + oc * 16;
-            const bool addp = p.addend != nullptr, scalep = p.row_scale != nullptr;
-            const bool gatep = DGRAD_EXTRAS && p.addend_gate != nullptr, maskp = DGRAD_EXTRAS && p.bs_mask != nullptr;
-            const TO* const addend = reinterpret_cast<const TO*>(p.addend);
-            const TO* const ybn = reinterpret_cast<const TO*>(p.bs_y);
-#pragma unroll 1
-            for (int g = 0; g < NIT; g += GRP) {
-                u32x4 v[GRP], av[GRP], yv[GRP];
-                unsigned gb[GRP], mb[GRP];
-                float sc[GRP];
+        // accumulators of row block MI (static index) + bias -> this wavefront's staging rows, columns of half H
+        auto stage_rows = [&](auto MI, auto H) __attribute__((always_inline)) {
+            constexpr int mi = decltype(MI)::value, h = decltype(H)::value;
 #pragma unroll
-                for (int j = 0; j < GRP; ++j) {
-                    const int mrow = mrow0 + (g + j) * RPP;
-                    const bool ok = mrow < Mc;
-                    const size_t off = (size_t)mrow * p.ldo + ncol;
-                    v[j] = ld_chunk(ls + (g + j) * RPP * OPITCH);
-                    av[j] = u32x4{0u, 0u, 0u, 0u};
-                    yv[j] = u32x4{0u, 0u, 0u, 0u};
-                    gb[j] = 0xffu;
-                    mb[j] = 0xffu;
-                    sc[j] = 1.f;
-                    if (ok) {
-                        if (scalep) sc[j] = p.row_scale[mrow / p.rows_per_scale];
-                        if (addp) av[j] = ld_chunk(addend + off);
-                        if (bstats) yv[j] = ld_chunk(ybn + off);
-                        if (gatep) gb[j] = p.addend_gate[off / OEPC];
-                        if (bstats && maskp) mb[j] = p.bs_mask[off / OEPC];
+            for (int i = 0; i < NTH; ++i) {
+                const int ni = h * NTH + i;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+                if (VSTAT) {
+                    if (do_stats) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float vr = OUT_F32 ? v[r] : round_through<T>(v[r]);
+                            ssum[ni][r] += vr;
+                            ssq[ni][r] = fmaf(vr, vr, ssq[ni][r]);
+                        }
                     }
                 }
+                char* q = stg + l15 * OPITCH + (i * 16 + lg * 4) * (int)sizeof(TO);
+                if (sizeof(TO) == 2) {
+                    bf16x4 pk;
 #pragma unroll
-                for (int j = 0; j < GRP; ++j) {
-                    const int mrow = mrow0 + (g + j) * RPP;
-                    if (mrow < Mc) {
-                        float f[OEPC];
-                        Chunk<TO>::unpack(v[j], f);
-                        if (addp || scalep) {
-                            float a[OEPC];
-                            Chunk<TO>::unpack(av[j], a);
+                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4*>(q) = pk;
+                } else {
+                    *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        };
+        // The piece loop exists twice: FUSED = false is the plain copy-out (no global load anywhere in it, so the compiler has
+        // no load destinations to protect with s_waitcnt vmcnt(0) -- which, with stores in flight, would be a store round
+        // trip per piece: gfx9 returns loads and stores in issue order), FUSED = true carries every fused mode.
+        auto pieces = [&](auto FUSED_T) __attribute__((always_inline)) {
+            constexpr bool FUSED = decltype(FUSED_T)::value;
+#pragma unroll 1
+            for (int mi = 0; mi < MT_; ++mi) {
 #pragma unroll
-                            for (int e = 0; e < OEPC; ++e) f[e] = fmaf(sc[j], f[e], ((gb[j] >> e) & 1u) ? a[e] : 0.f);
-                            v[j] = Chunk<TO>::pack(f);
-                            if (bstats) Chunk<TO>::unpack(v[j], f);      // the sums are over what is stored
+                for (int h = 0; h < NSPLIT; ++h) {
+                    int mrow[CPL];
+                    u32x4 av[CPL], yv[CPL];
+                    unsigned gb[CPL], mb[CPL];
+                    float sc[CPL];
+                    const int ncol = n_base + h * WNS + ccol * OEPC;
+                    const bool col_in = ncol < p.Nn;
+                    const bool whole = aligned && ncol + OEPC <= p.Nn;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int mr = m_base + mi * 16 + j * RPJ + crow;           // row in tile-order (class-local) numbering
+                        int mo = (mr < Mc && col_in) ? mr : -1;
+                        if (FUSED && remap && mo >= 0) {
+                            const int img = mr / ohw;
+                            const int rem = mr - img * ohw;
+                            const int hc = rem / Wc;
+                            mo = (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
                         }
-                        if (bstats) {
-                            float yy[OEPC];
-                            Chunk<TO>::unpack(yv[j], yy);
-#pragma unroll
-                            for (int e = 0; e < OEPC; ++e) {
-                                const float ge = ((mb[j] >> e) & 1u) ? f[e] : 0.f;
-                                bag[e] += ge;
-                                bax[e] = fmaf(ge, yy[e], bax[e]);
+                        mrow[j] = mo;
+                        av[j] = u32x4{0u, 0u, 0u, 0u};
+                        yv[j] = u32x4{0u, 0u, 0u, 0u};
+                        gb[j] = 0xffu;
+                        mb[j] = 0xffu;
+                        sc[j] = 1.f;
+                        if constexpr (FUSED) {
+                            // side operands of this piece's chunks: every global load in flight before the staging round trip
+                            if (fused && mo >= 0) {
+                                const size_t off = (size_t)mo * p.ldo + ncol;
+                                if (scalep) sc[j] = p.row_scale[mo / p.rows_per_scale];
+                                if (addp && whole) av[j] = ld_chunk(reinterpret_cast<const TO*>(p.addend) + off);
+                                if (bstats) yv[j] = ld_chunk(reinterpret_cast<const TO*>(p.bs_y) + off);
+                                if (gatep) gb[j] = p.addend_gate[off / OEPC];
+                                if (maskp) mb[j] = p.bs_mask[off / OEPC];
                             }
                         }
-                        st_chunk(outp + (size_t)mrow * p.ldo + ncol, v[j]);
+                    }
+                    // ---- accumulators -> LDS (the only part that needs static register indices: one small case per row block)
+#define STAGE_CASE(K)                                                                                                       \
+                    if constexpr (MT_ > K) {                                                                                \
+                        if (mi == K) {                                                                                      \
+                            if (h == 0) stage_rows(std::integral_constant<int, K>{}, std::integral_constant<int, 0>{});     \
+                            if constexpr (NSPLIT == 2) {                                                                    \
+                                if (h == 1) stage_rows(std::integral_constant<int, K>{}, std::integral_constant<int, 1>{}); \
+                            }                                                                                               \
+                        }                                                                                                   \
+                    }
+                    STAGE_CASE(0) STAGE_CASE(1) STAGE_CASE(2) STAGE_CASE(3) STAGE_CASE(4) STAGE_CASE(5) STAGE_CASE(6) STAGE_CASE(7)
+#undef STAGE_CASE
+                    // ---- BatchNorm statistics of the staged bf16 rows on the matrix cores
+                    if constexpr (MSTAT) {
+                        if (do_stats) {
+                            typedef __attribute__((ext_vector_type(4))) short s16x4;
+                            const s16x4 ones = {(short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80};
+                            // lane (column t = l15, row group lg) of a 16-lane group supplies the address of row lg*4 + (t>>2),
+                            // columns (t&3)*4.. and receives rows lg*4 .. lg*4+3 of column t: the B fragment of a 16x16x16 MFMA.
+                            // Spelled as asm: behind the BUILTIN transposed read the compiler waits vmcnt(0) (an LDS access it
+                            // can see, while LDS-DMA writes are pending) -- with the previous piece's stores in flight that is a
+                            // store round trip per piece.  LDS operations of one wavefront execute in issue order, so the staged
+                            // rows written just above are what these reads return.
+                            const uint32_t qa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(
+                                stg + (lg * 4 + (l15 >> 2)) * OPITCH + (l15 & 3) * 8);
+                            s16x4 ys[NTH];
+                            static_assert(NTH == 4 || NTH == 2, "column groups of a staged piece");
+                            if constexpr (NTH == 4) {
+                                asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:32\n\t"
+                                             "ds_read_b64_tr_b16 %2, %4 offset:64\n\tds_read_b64_tr_b16 %3, %4 offset:96\n\t"
+                                             "s_waitcnt lgkmcnt(0)"
+                                             : "=&v"(ys[0]), "=&v"(ys[1]), "=&v"(ys[2]), "=&v"(ys[3]) : "v"(qa) : "memory");
+                            } else {
+                                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:32\n\t"
+                                             "s_waitcnt lgkmcnt(0)"
+                                             : "=&v"(ys[0]), "=&v"(ys[1]) : "v"(qa) : "memory");
+                            }
+#pragma unroll
+                            for (int i = 0; i < NTH; ++i) {
+                                const s16x4 y = ys[i];
+                                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                                const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones, y, z, 0, 0, 0);
+                                const f32x4 s2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y, y, z, 0, 0, 0);
+                                // the diagonal element of this lane's column: row l15 = lg*4 + r lives in lanes lg == l15 >> 2.
+                                // (opaque copies: a select chain on vector elements is otherwise turned into a dynamically
+                                // indexed extract, which the backend lowers through scratch memory)
+                                float e0 = s2[0], e1 = s2[1], e2 = s2[2], e3 = s2[3];
+                                asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+                                const int r = l15 & 3;
+                                msum[h * NTH + i] += s1[0];
+                                msq[h * NTH + i] += (r & 2) ? ((r & 1) ? e3 : e2) : ((r & 1) ? e1 : e0);
+                            }
+                        }
+                    }
+                    // ---- staged rows -> 16-byte row chunks -> (fused modes) -> HBM
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int mo = mrow[j];
+                        u32x4 v = ld_chunk(stg + (j * RPJ + crow) * OPITCH + ccol * 16);
+                        if (mo < 0) continue;
+                        TO* o = outp + (size_t)mo * p.ldo + ncol;
+                        if constexpr (!FUSED) {
+                            if (whole) {
+                                st_chunk(o, v);
+                            } else {
+                                float e[OEPC];
+                                Chunk<TO>::unpack(v, e);
+#pragma unroll
+                                for (int k = 0; k < OEPC; ++k)
+                                    if (ncol + k < p.Nn) o[k] = from_f32<TO>(e[k]);
+                            }
+                        } else {
+                            float f[OEPC];
+                            Chunk<TO>::unpack(v, f);
+                            if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
+                                float gl[OEPC];
+#pragma unroll
+                                for (int k = 0; k < OEPC; ++k) gl[k] = gelu_fwd_f(f[k]);
+                                st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)mo * p.ldo + ncol, Chunk<TO>::pack(gl));
+                            } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)   (rows are whole chunks)
+                                float a[OEPC];
+                                Chunk<TO>::unpack(av[j], a);
+#pragma unroll
+                                for (int k = 0; k < OEPC; ++k) f[k] *= gelu_grad_f(a[k]);
+                                v = Chunk<TO>::pack(f);
+                            } else if (addp || scalep) {
+                                float a[OEPC];
+                                if (whole) {
+                                    Chunk<TO>::unpack(av[j], a);
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < OEPC; ++k)
+                                        a[k] = (addp && ncol + k < p.Nn)
+                                                   ? to_f32(reinterpret_cast<const TO*>(p.addend)[(size_t)mo * p.ldo + ncol + k]) : 0.f;
+                                }
+#pragma unroll
+                                for (int k = 0; k < OEPC; ++k) f[k] = fmaf(sc[j], f[k], ((gb[j] >> k) & 1u) ? a[k] : 0.f);
+                                v = Chunk<TO>::pack(f);
+                            }
+                            if (bstats) {                     // BatchNorm-backward sums of what is stored (rounded to TO), behind its ReLU gate
+                                float yy[OEPC];
+                                Chunk<TO>::unpack(v, f);
+                                Chunk<TO>::unpack(yv[j], yy);
+#pragma unroll
+                                for (int k = 0; k < OEPC; ++k) {
+                                    const float ge = ((mb[j] >> k) & 1u) ? f[k] : 0.f;
+                                    bag[h][k] += ge;
+                                    bax[h][k] = fmaf(ge, yy[k], bax[h][k]);
+                                }
+                            }
+                            if (whole) {
+                                st_chunk(o, v);
+                            } else {                          // N tail, or a leading dimension without 16-byte alignment
+                                float e[OEPC];
+                                Chunk<TO>::unpack(v, e);
+#pragma unroll
+                                for (int k = 0; k < OEPC; ++k)
+                                    if (ncol + k < p.Nn) o[k] = from_f32<TO>(e[k]);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        if (fast) pieces(std::false_type{});
+        else pieces(std::true_type{});
+        // ---- statistics of this wavefront's rows: one partial row per (tile row, wavefront row), or atomics into a few rows
+        if (do_stats) {
+            const size_t srow = p.stat_atomic_rows ? (size_t)((tile_m * WM_ + wm) % p.stat_atomic_rows) : (size_t)(tile_m * WM_ + wm);
+            if constexpr (MSTAT) {
+#pragma unroll
+                for (int ni = 0; ni < NT_; ++ni) {
+                    const int n = n_base + ni * 16 + l15;              // D: row lg*4 + r, column l15
+                    if (n < p.Nn) {
+                        if (lg == 0) {
+                            if (p.stat_atomic_rows) unsafeAtomicAdd(&p.stat_sum[srow * (size_t)p.Nn + n], msum[ni]);
+                            else p.stat_sum[srow * (size_t)p.Nn + n] = msum[ni];
+                        }
+                        if (lg == (l15 >> 2)) {
+                            if (p.stat_atomic_rows) unsafeAtomicAdd(&p.stat_sq[srow * (size_t)p.Nn + n], msq[ni]);
+                            else p.stat_sq[srow * (size_t)p.Nn + n] = msq[ni];
+                        }
+                    }
+                }
+            }
+            if constexpr (VSTAT) {
+                // rows m >= M were gathered as zeros (no bias when stats are requested) -> add 0.
+#pragma unroll
+                for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {        // over the 16 pixel lanes: four DPP adds each
+                        const float a = row16_sum(ssum[ni][r]), b = row16_sum(ssq[ni][r]);
+                        const int n = n_base + ni * 16 + lg * 4 + r;
+                        if (l15 == 0 && n < p.Nn) {
+                            if (p.stat_atomic_rows) {
+                                unsafeAtomicAdd(&p.stat_sum[srow * (size_t)p.Nn + n], a);
+                                unsafeAtomicAdd(&p.stat_sq[srow * (size_t)p.Nn + n], b);
+                            } else {
+                                p.stat_sum[srow * (size_t)p.Nn + n] = a;
+                                p.stat_sq[srow * (size_t)p.Nn + n] = b;
+                            }
+                        }
+                    }
+            }
+        }
+        if (bstats) {
+            // sum g * (y - mean) * invstd = invstd * (sum g y - mean * sum g): the mean leaves after this lane's few rows,
+            // while the sums are still small -- not after the whole column.  Lanes sharing a chunk column differ in crow.
+            const size_t prow0 = (size_t)((MODE == 1 && cs > 1) ? blockIdx.y : 0) * p.bs_rows + tile_m;
+            const size_t prow = prow0 * WM_ + wm;
+            const size_t drow = p.stat_atomic_rows ? prow % p.stat_atomic_rows : prow;
+#pragma unroll
+            for (int h = 0; h < NSPLIT; ++h) {
+                const int ncol = n_base + h * WNS + ccol * OEPC;
+                const bool have = ncol + OEPC <= p.Nn;
+#pragma unroll
+                for (int e = 0; e < OEPC; ++e) {
+                    const float mu = have ? p.bs_mean[ncol + e] : 0.f, is = have ? p.bs_invstd[ncol + e] : 0.f;
+                    float g = bag[h][e];
+                    float gx = is * fmaf(-mu, bag[h][e], bax[h][e]);
+#pragma unroll
+                    for (int d = CPR; d < 64; d <<= 1) {
+                        g += __shfl_xor(g, d, 64);
+                        gx += __shfl_xor(gx, d, 64);
+                    }
+                    if (lane < CPR && have) {
+                        float* dg = p.bs_g + drow * (size_t)p.Nn + ncol + e;
+                        float* dx = p.bs_gx + drow * (size_t)p.Nn + ncol + e;
+                        if (p.stat_atomic_rows) { unsafeAtomicAdd(dg, g); unsafeAtomicAdd(dx, gx); }
+                        else { *dg = g; *dx = gx; }
                     }
                 }
             }
         }
-    } else if (ncol < p.Nn) {
-        // one copy of the fused-mode code in a ROLLED loop; the staged chunk and the addend chunk of the NEXT row are
-        // fetched before the current row is processed, so a row's global-load latency hides under its predecessor
-        const bool whole = aligned && ncol + OEPC <= p.Nn;
-        const bool pre_add = whole && p.addend != nullptr;
-        const bool gated = DGRAD_EXTRAS && pre_add && p.addend_gate != nullptr;   // host: the gate needs whole, aligned chunks
-        const bool bst = bstats && whole;
-        // per row: gate byte of the addend (bits 0-7) | ReLU-mask byte of the statistics (bits 8-15)
-        auto side_bits = [&](int mrow) -> unsigned {
-            const size_t ch = ((size_t)mrow * p.ldo + ncol) / OEPC;
-            unsigned b = 0xffffu;
-            if (gated) b = (b & 0xff00u) | p.addend_gate[ch];
-            if (bst && p.bs_mask != nullptr) b = (b & 0x00ffu) | ((unsigned)p.bs_mask[ch] << 8);
-            return b;
-        };
-        auto out_row = [&](int rr) -> int {                // output row of tile row rr, -1 past the end
-            const int mrow = tile_m * BM_T + rr;
-            if (rr >= BM_T || mrow >= Mc) return -1;
-            if (!remap) return mrow;
-            const int img = mrow / ohw;
-            const int rem = mrow - img * ohw;
-            const int hc = rem / Wc;
-            return (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
-        };
-        int rr = orow0;
-        int m = out_row(rr);
-        u32x4 v = {0u, 0u, 0u, 0u}, av = {0u, 0u, 0u, 0u}, yv = {0u, 0u, 0u, 0u};
-        unsigned sb = 0xffffu;
-        if (m >= 0) {
-            v = ld_chunk(smem + rr * OPITCH + oc * 16);
-            if (pre_add) av = ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol);
-            if (bst) yv = ld_chunk(reinterpret_cast<const TO*>(p.bs_y) + (size_t)m * p.ldo + ncol);
-            if (gated || bst) sb = side_bits(m);
-        }
-#pragma unroll 1
-        while (m >= 0) {
-            const int rn = rr + RPP;
-            const int mn = out_row(rn);
-            u32x4 vn = {0u, 0u, 0u, 0u}, an = {0u, 0u, 0u, 0u}, yn = {0u, 0u, 0u, 0u};
-            unsigned sbn = 0xffffu;
-            if (mn >= 0) {
-                vn = ld_chunk(smem + rn * OPITCH + oc * 16);
-                if (pre_add) an = ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)mn * p.ldo + ncol);
-                if (bst) yn = ld_chunk(reinterpret_cast<const TO*>(p.bs_y) + (size_t)mn * p.ldo + ncol);
-                if (gated || bst) sbn = side_bits(mn);
-            }
-            TO* o = outp + (size_t)m * p.ldo + ncol;
-            if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
-                float f[OEPC];
-                Chunk<TO>::unpack(v, f);
-#pragma unroll
-                for (int j = 0; j < OEPC; ++j) f[j] = gelu_fwd_f(f[j]);
-                st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(f));
-            } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)   (rows are whole chunks)
-                float f[OEPC], a[OEPC];
-                Chunk<TO>::unpack(v, f);
-                Chunk<TO>::unpack(av, a);
-#pragma unroll
-                for (int j = 0; j < OEPC; ++j) f[j] *= gelu_grad_f(a[j]);
-                v = Chunk<TO>::pack(f);
-            } else if (p.addend != nullptr || p.row_scale != nullptr) {
-                float f[OEPC], a[OEPC];
-                Chunk<TO>::unpack(v, f);
-                const float sc = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.f;
-                if (pre_add) {
-                    Chunk<TO>::unpack(av, a);
-                    if (gated) {
-#pragma unroll
-                        for (int j = 0; j < OEPC; ++j) a[j] = ((sb >> j) & 1u) ? a[j] : 0.f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wavefront's staging traffic is over: the slot may be refilled
+    };
+
+    while (bid_c >= 0) {
+        fragment_offsets();
+        for (int kc = 0; kc < nkt; ++kc) {
+            // retire step `consumed` only: the steps issued after it stay in flight across the barrier
+            const int ahead = issued - consumed - 1;      // wave-uniform
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // everyone's part of this step landed; the previous step is fully consumed
+            if (CAN_PERSIST && mb_pending) {       // the ticket drawn two steps ago names the tile after bid_i
+                if (mb_wait == 0) {
+                    if (wave == 0 && lane == 0) {
+                        const int pos = xwg + (int)tk;
+                        const int nb = pos < xcount ? xbase + pos : -1;
+                        asm volatile("ds_write_b32 %0, %1 ; saicv mailbox" :: "v"(mbox_addr), "v"(nb) : "memory");
                     }
+                    mb_pending = false;
                 } else {
-                    for (int j = 0; j < OEPC; ++j)
-                        a[j] = (p.addend != nullptr && ncol + j < p.Nn)
-                                   ? to_f32(reinterpret_cast<const TO*>(p.addend)[(size_t)m * p.ldo + ncol + j]) : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < OEPC; ++j) f[j] = fmaf(sc, f[j], a[j]);
-                v = Chunk<TO>::pack(f);
-            }
-            if (bst) {                        // BatchNorm-backward sums of what is stored (rounded to TO), behind its ReLU gate
-                float f[OEPC], yy[OEPC];
-                Chunk<TO>::unpack(v, f);
-                Chunk<TO>::unpack(yv, yy);
-#pragma unroll
-                for (int j = 0; j < OEPC; ++j) {
-                    const float gj = ((sb >> (8 + j)) & 1u) ? f[j] : 0.f;
-                    bag[j] += gj;
-                    bax[j] = fmaf(gj, yy[j], bax[j]);
+                    --mb_wait;
                 }
             }
-            if (whole) {
-                st_chunk(o, v);
-            } else {                          // N tail, or a leading dimension without 16-byte alignment
-                const TO* e = reinterpret_cast<const TO*>(&v);
-                for (int j = 0; j < OEPC; ++j)
-                    if (ncol + j < p.Nn) o[j] = e[j];
-            }
-            rr = rn; m = mn; v = vn; av = an; yv = yn; sb = sbn;
+            issue_next();                          // refill the slot the previous step just vacated
+            compute(st_c);
+            st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
+            ++consumed;
         }
-    }
-    if (bstats) {       // uniform: combine the row lanes of every column through the (now consumed) staging area
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);                      // [RPP][2][BN_T]
-        const bool have = ncol + OEPC <= p.Nn;
+        // ---- tile seam: the slot of the last K step is free once every wavefront has read its fragments; it is not
+        // refilled before the barrier of the NEXT tile's first step, which every wavefront reaches after its epilogue
+        const int st_last = st_c == 0 ? NSTAGE - 1 : st_c - 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        epilogue(bid_c, smem + st_last * STAGE + wave * SLOT_SHARE);
 #pragma unroll
-        for (int j = 0; j < OEPC; ++j) {
-            // sum g * (y - mean) * invstd = invstd * (sum g y - mean * sum g): the mean leaves after this thread's few
-            // rows (BM_T / RPP of them), while the sums are still small -- not after the whole column
-            const float mu = have ? p.bs_mean[ncol + j] : 0.f, is = have ? p.bs_invstd[ncol + j] : 0.f;
-            red[(orow0 * 2 + 0) * BN_T + oc * OEPC + j] = bag[j];
-            red[(orow0 * 2 + 1) * BN_T + oc * OEPC + j] = is * fmaf(-mu, bag[j], bax[j]);
-        }
-        __syncthreads();
-        const size_t prow = (size_t)((MODE == 1 && cs > 1) ? blockIdx.y : 0) * p.bs_rows + tile_m;
-        for (int c = tid; c < 2 * BN_T; c += NTHREADS) {
-            const int which = c / BN_T, col = c - which * BN_T;
-            float a = 0.f;
-            for (int r = 0; r < RPP; ++r) a += red[(r * 2 + which) * BN_T + col];
-            const int n = tile_n * BN_T + col;
-            if (n < p.Nn) {
-                float* dst = (which ? p.bs_gx : p.bs_g) + (p.stat_atomic_rows ? prow % p.stat_atomic_rows : prow) * (size_t)p.Nn + n;
-                if (p.stat_atomic_rows) unsafeAtomicAdd(dst, a); else *dst = a;
-            }
+        for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT_; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the DMA side switched tiles NSTAGE-1 steps ago (host: nkt > NSTAGE in persistent launches), or the stream ended
+        bid_c = persistent ? bid_i : -1;
+    }
+    // ---- persistent launches leave their ticket counters zeroed: the last workgroup to leave resets them
+    if (persistent && wave == 0 && lane == 0) {
+        unsigned int* const done = p.tickets + 32;
+        const unsigned int total = gridDim.x * gridDim.y;
+        if (atomicAdd(done, 1u) == total - 1u) {
+            for (int i = 0; i < 33; ++i) __hip_atomic_store(p.tickets + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------ TN
@@ -964,22 +1045,48 @@ void allow_lds(K k, size_t smem) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
+// Ticket counters of persistent launches: a ring of 64 sets (64 dwords each) per device, zero whenever no kernel is using
+// them (the last workgroup of a launch to leave resets its set).  Successive launches take successive sets, so two launches
+// overlapping on different streams do not share one; a captured launch keeps the set it was captured with.
+unsigned int* nt_ticket_set() {
+    static unsigned int* base[16] = {nullptr};
+    static unsigned int seq[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!base[dev]) {
+        void* q = nullptr;
+        if (hipMalloc(&q, 64 * 64 * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(q, 0, 64 * 64 * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(q); return nullptr; }
+        base[dev] = static_cast<unsigned int*>(q);
+    }
+    return base[dev] + (size_t)(seq[dev]++ % 64u) * 64;
+}
+
 template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
 void launch_nt_inst(const NTParams& p, size_t smem, hipStream_t st) {
     auto k = igemm_nt_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN>;
     static bool once = (allow_lds(k, 160 * 1024), true);
     (void)once;
-    dim3 grid(p.nblk < p.grid_x ? p.nblk : p.grid_x, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
+    dim3 grid(p.grid_x, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
 }
 
 template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE>
-int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
-    constexpr size_t smem_full = nt_stages(BM_T, BN_T) * (size_t)(BM_T * 64 + BN_T * 64);      // DMA ring
-    const size_t epi = BM_T * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16) +
-                       2 * WM_ * BN_T * sizeof(float);      // staged output tile + per-wavefront BN column sums
-    size_t smem = smem_full;
-    if (smem < epi) smem = epi;
+int launch_nt(NTParams& p, bool out_f32, int nkt, hipStream_t st) {
+    constexpr size_t smem = nt_stages(BM_T, BN_T) * (size_t)(BM_T * 64 + BN_T * 64) + 16;      // DMA ring + ticket mailbox
+    // persistent when there are more tiles than resident workgroups and a tile's K loop is long enough for the ticket of
+    // the tile after next to travel through the mailbox (kernel: written 2 steps after the switch, read at the next one);
+    // the parity classes of a stride > 1 data gradient have unequal (possibly empty) K loops and stay one tile per workgroup
+    const char* pe = getenv("SAICV_NT_PERSIST");                       // (read per call: a tuning sweep flips it in-process)
+    const int persist_env = pe ? atoi(pe) : 1;
+    const int slots = 256 * nt_blocks_per_cu(BM_T, BN_T);
+    p.tickets = nullptr;
+    p.grid_x = p.nblk;
+    if (persist_env && nt_can_persist((int)sizeof(T), out_f32, BM_T, BN_T, WM_ * WN_) && p.nblk > slots &&
+        nkt > nt_stages(BM_T, BN_T) && !(MODE == 1 && p.stride > 1)) {
+        p.tickets = nt_ticket_set();
+        if (p.tickets) p.grid_x = slots;
+    }
     // pointwise taps without padding: the source pixel of a row never leaves the image
     const bool plain = p.R == 1 && p.S == 1 && p.pad == 0 && (MODE == 0 || p.stride == 1);
     if (out_f32) {
@@ -999,18 +1106,18 @@ int launch_nt(const NTParams& p, bool out_f32, hipStream_t st) {
 // 64 K outputs per CU whatever the geometry), which beats one 256 x 256 workgroup until the K loop is long enough
 // (~100 K tiles) for its lower LDS traffic per flop to matter.
 struct NTTile { int bm, bn, wm, blocks_per_cu; float speed; float fixed_us, step_us; };   // tile time = fixed + K tiles x step (fit)
-const NTTile kTiles[4] = {{256, 256, 2, 1, 0.80f, 11.8f, 0.905f}, {256, 128, 4, 2, 1.00f, 9.95f, 0.97f},
-                           {128, 128, 2, 2, 0.60f, 6.1f, 0.60f}, {128, 64, 2, 3, 0.50f, 4.55f, 0.685f}};
+const NTTile kTiles[5] = {{256, 256, 2, 1, 0.80f, 11.8f, 0.905f}, {256, 128, 4, 2, 1.00f, 9.95f, 0.97f},
+                           {128, 128, 2, 2, 0.60f, 6.1f, 0.60f}, {128, 64, 2, 3, 0.50f, 4.55f, 0.685f},
+                           {256, 128, 2, 2, 0.00f, 9.95f, 0.97f}};      // [4]: 256 x 128 on FOUR wavefronts of 128 x 64 (SAICV_NT_TILE=4)
 
 int pick_tile(int M, int Nn, int nkt, bool f32_out_big) {
     if (const char* force = getenv("SAICV_NT_TILE")) {      // tuning aid: force a geometry
         const int t = atoi(force);
-        if (t >= 0 && t < 4 && !(f32_out_big && kTiles[t].bm * kTiles[t].bn * 4 > 150 * 1024)) return t;
+        if (t >= 0 && t < 5) return t;
     }
     int best = 2;
     float best_score = -1.f;
     for (int t = 0; t < 4; ++t) {
-        if (f32_out_big && kTiles[t].bm * kTiles[t].bn * 4 > 150 * 1024) continue;   // fp32 epilogue tile must fit LDS
         const NTTile& g = kTiles[t];
         const long tm = (M + g.bm - 1) / g.bm, tn = (Nn + g.bn - 1) / g.bn;
         const float blocks = (float)(tm * tn);
@@ -1047,7 +1154,7 @@ namespace saicv {
 int conv_stat_rows(int M, int Nn, int Kd, int dtype) {
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
     const NTTile& g = kTiles[pick_tile(M, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32)];
-    return (M + g.bm - 1) / g.bm;
+    return ((M + g.bm - 1) / g.bm) * g.wm;          // one partial row per (tile row, wavefront row)
 }
 
 // partial rows the data gradient writes with EpiExtra::bs_*: (rows of tiles of the largest parity class) x classes
@@ -1056,7 +1163,7 @@ int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dt
     int M_tile = M;
     if (stride > 1) M_tile = (M / (OH * OW)) * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);
     const NTTile& g = kTiles[pick_tile(M_tile, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32)];
-    return ((M_tile + g.bm - 1) / g.bm) * stride * stride;
+    return ((M_tile + g.bm - 1) / g.bm) * stride * stride * g.wm;
 }
 
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
@@ -1084,8 +1191,7 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.bs_gx = ex ? ex->bs_gx : nullptr;
     p.bs_rows = 0;
     p.stat_atomic_rows = ex ? ex->stat_atomic_rows : 0;
-    static const int nt_store_env = getenv("SAICV_NT_STORE") ? atoi(getenv("SAICV_NT_STORE")) : 0;
-    p.nt_store = nt_store_env;
+    p.tickets = nullptr;
     SAICV_REQUIRE(p.stat_atomic_rows >= 0 && p.stat_atomic_rows <= 64, "igemm_nt: stat_atomic_rows=%d outside [0, 64]", p.stat_atomic_rows);
     if (p.addend_gate || p.bs_y) {
         const int osz1 = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
@@ -1131,20 +1237,13 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
     p.bs_rows = (M_tile + g.bm - 1) / g.bm;
-    {
-        // One workgroup per tile by default.  The persistent form (one resident round of workgroups walking all tiles,
-        // SAICV_NT_PERSIST=1) measured the same on one GPU, but its static tile partition doubles a kernel's time as
-        // soon as some of its workgroups cannot be resident from the start -- which is what happens under
-        // data-parallel training while RCCL's all-reduce kernels hold CU slots during backward.
-        static const int persist = getenv("SAICV_NT_PERSIST") ? atoi(getenv("SAICV_NT_PERSIST")) : 0;
-        p.grid_x = persist ? 256 * g.blocks_per_cu : 0x7fffffff;
-    }
 #define NT_DISPATCH(TT, MODE_)                                                              \
     switch (t) {                                                                            \
-        case 0: return launch_nt<TT, 256, 256, 2, 4, MODE_>(p, f32o, st);                   \
-        case 1: return launch_nt<TT, 256, 128, 4, 2, MODE_>(p, f32o, st);                   \
-        case 2: return launch_nt<TT, 128, 128, 2, 2, MODE_>(p, f32o, st);                   \
-        default: return launch_nt<TT, 128, 64, 2, 2, MODE_>(p, f32o, st);                   \
+        case 0: return launch_nt<TT, 256, 256, 2, 4, MODE_>(p, f32o, nkt_host, st);         \
+        case 1: return launch_nt<TT, 256, 128, 4, 2, MODE_>(p, f32o, nkt_host, st);         \
+        case 2: return launch_nt<TT, 128, 128, 2, 2, MODE_>(p, f32o, nkt_host, st);         \
+        case 4: return launch_nt<TT, 256, 128, 2, 2, MODE_>(p, f32o, nkt_host, st);         \
+        default: return launch_nt<TT, 128, 64, 2, 2, MODE_>(p, f32o, nkt_host, st);         \
     }
     if (dtype == SAICV_DTYPE_BF16) {
         if (mode == 0) { NT_DISPATCH(bf16_t, 0) } else { NT_DISPATCH(bf16_t, 1) }

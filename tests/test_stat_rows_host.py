@@ -1,6 +1,7 @@
 """Host-side contract of the BN partial-statistics buffer (no GPU): `saicv_conv2d_stat_rows` is what the Python
 wrapper sizes the [2, rows, K] buffer with BEFORE the convolution launch picks its tile geometry, so it must be a
-pure function of the descriptor and agree with one row per row of workgroups of one of the four geometries."""
+pure function of the descriptor and agree with one row per (row of workgroups, row of wavefronts) of one of the
+geometries: since r03 every WAVEFRONT writes (or atomically adds) the column sums of its own rows of the tile."""
 import ctypes
 
 import pytest
@@ -17,10 +18,11 @@ SHAPES = [(8, 64, 7, 2, 224), (64, 64, 1, 1, 56), (64, 256, 1, 1, 56), (256, 128
 @pytest.mark.parametrize('batch', [2, 256])
 @pytest.mark.parametrize('ci,co,k,s,h', SHAPES)
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
-def test_stat_rows_is_one_row_per_workgroup_row(ci, co, k, s, h, batch, dt):
+def test_stat_rows_is_one_row_per_wavefront_row(ci, co, k, s, h, batch, dt):
     d = ops._desc(batch, h, h, ci, co, k, k, s, k // 2, dt)
     L = lib()
     rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
     m = batch * d.OH * d.OW
-    assert rows in {-(-m // 256), -(-m // 128)}, (rows, m)
+    # 256 x 256 (2 wavefront rows), 256 x 128 (4), 128 x 128 (2), 128 x 64 (2)
+    assert rows in {-(-m // 256) * 2, -(-m // 256) * 4, -(-m // 128) * 2}, (rows, m)
     assert rows == L.saicv_conv2d_stat_rows(ctypes.byref(d))          # pure function of the descriptor
