@@ -135,7 +135,15 @@ def detr_stem_layer1(name='detr_r50_stem_layer1_1333', model_seed=0, data_seed=1
     for n, p in m2.named_parameters():
         if p.grad is not None and norms[n] > 1e-7:
             worst = max(worst, _rel(p.grad.flatten()[:64], samples[n]))
-    noise = {'fp32_reorder_output': _rel(out2.detach(), out.detach()), 'fp32_reorder_grad_sample': worst}
+    # ... and its own bf16 autocast deviation (the gate of the bf16 test)
+    m3 = build()
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        out3 = run(m3, x)
+    (out3.float() * probe).sum().backward()
+    a = torch.cat([p.grad.flatten()[:64].double() for n, p in m3.named_parameters() if p.grad is not None])
+    b = torch.cat([samples[n].double() for n, p in m3.named_parameters() if p.grad is not None])
+    noise = {'fp32_reorder_output': _rel(out2.detach(), out.detach()), 'fp32_reorder_grad_sample': worst,
+             'bf16_output': _rel(out3.detach().float(), out.detach()), 'bf16_grad_sample_cos': float(a @ b / (a.norm() * b.norm()))}
     fx = {'name': name, 'h': h, 'w': w, 'model_seed': model_seed, 'data_seed': data_seed,
           'input_checksum': float(x.double().sum()), 'output_shape': list(out.shape), 'output_norm': float(out.norm()),
           'output_sub': out.detach()[:, :, ::8, ::8].clone(), 'output_row': out.detach()[:, :, 101, :].clone(),

@@ -17,16 +17,19 @@ from simpleaicv_pytorch_training_examples_amd import _lib, ops  # noqa: E402
 from simpleaicv_pytorch_training_examples_amd._lib import check, lib, ptr  # noqa: E402
 from kernel_bench import R50, timeit  # noqa: E402
 
-CONFIGS = [('auto', None, '1'), ('auto_np', None, '0'), ('t0', '0', '1'), ('t0_np', '0', '0'), ('t1', '1', '1'),
-           ('t4', '4', '1'), ('t4_np', '4', '0'), ('t2', '2', '1'), ('t3', '3', '1')]
+# (name, SAICV_NT_TILE, SAICV_NT_PERSIST, SAICV_NT_STAGGER)
+CONFIGS = [('auto_np', None, '0', '0'), ('auto', None, '1', '4'), ('t0_np', '0', '0', '0'), ('t0_s0', '0', '1', '0'), ('t0_s2', '0', '1', '2'),
+           ('t0_s4', '0', '1', '4'), ('t0_s8', '0', '1', '8'), ('t4_s0', '4', '1', '0'), ('t4_s2', '4', '1', '2'), ('t4_s4', '4', '1', '4'),
+           ('t4_s8', '4', '1', '8'), ('t2_s4', '2', '1', '4')]
 
 
-def setcfg(tile, persist):
+def setcfg(tile, persist, stagger='0'):
     if tile is None:
         os.environ.pop('SAICV_NT_TILE', None)
     else:
         os.environ['SAICV_NT_TILE'] = tile
     os.environ['SAICV_NT_PERSIST'] = persist
+    os.environ['SAICV_NT_STAGGER'] = stagger
 
 
 def main():
@@ -44,8 +47,8 @@ def main():
             fl = 2.0 * M * K * N
             ref = None
             rec = {'gemm': f'{M}x{K}x{N}'}
-            for name, tile, persist in CONFIGS:
-                setcfg(tile, persist)
+            for name, tile, persist, stag in CONFIGS:
+                setcfg(tile, persist, stag)
                 y = torch.empty(M, N, device='cuda', dtype=dt)
                 dx = torch.empty(M, K, device='cuda', dtype=dt)
                 tf = timeit(lambda: check(L.saicv_linear_fwd(0, ptr(x), ptr(wf), ptr(bias), ptr(y), M, K, N, 0, 0, 0, 1, st)))
@@ -71,8 +74,8 @@ def main():
             fl = 2.0 * batch * d.OH * d.OW * co * k * k * ci
             rec = {'conv': f'{ci}->{co} k{k} s{s} {h}'}
             ref = None
-            for name, tile, persist in CONFIGS:
-                setcfg(tile, persist)
+            for name, tile, persist, stag in CONFIGS:
+                setcfg(tile, persist, stag)
                 y = torch.empty(batch, d.OH, d.OW, co, device='cuda', dtype=dt)
                 dx = torch.empty_like(x)
                 rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))

@@ -72,6 +72,8 @@ struct NTParams {
     // consuming BatchNorm kernel finalises them itself (no partial-reduce / finalize launches)
     int stat_atomic_rows;
     unsigned int* tickets;      // persistent launch: 8 per-XCD ticket counters (+ a departure counter at [32]), zero between launches
+    int stagger_phases;         // persistent launch: workgroups start in this many phase groups ...
+    int stagger_sleeps;         // ... `s_sleep 16` periods (~0.5 us each) apart, so that their epilogue store bursts interleave
     uint32_t src_bytes, wgt_bytes;
     int H, W, C;        // gather-source spatial dims / channels
     int OH, OW;         // pixel grid that indexes the GEMM rows
@@ -127,7 +129,11 @@ DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
 // vmcnt accounting across the seam: gfx9 returns vector-memory operations in issue order (loads, stores and atomics share
 // the counter), so "at most LPT x min(2, steps issued after this one) operations outstanding" retires the K step about to
 // be consumed whatever epilogue stores or side loads were issued in between: they only make the wait conservative.
-template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
+// FUSEDK: the instantiation carries the fused epilogue modes (residual / drop-path / GELU / gated shortcut / BatchNorm-backward
+// sums, unaligned rows) -- or only the plain copy-out with BN statistics and bias.  Two kernels instead of two paths in one:
+// the plain one stays clear of the register cap (no spill reloads, i.e. no compiler vmcnt(0), around the tile seam) and can
+// count its own stores exactly.
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, bool FUSEDK>
 __global__ __launch_bounds__(64 * WM_ * WN_, nt_blocks_per_cu(BM_T, BN_T) * WM_ * WN_ / 4)
 void igemm_nt_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
@@ -378,6 +384,17 @@ void igemm_nt_kernel(const NTParams p) {
         ++issued;
         st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
     };
+    // ---- staggered start.  Tiles of one launch take the same time, so workgroups that start together reach their epilogues
+    // together: 256 x 128 KiB of output stores hit HBM at once (33 MB, ~7 us at 4.7 TB/s) while every matrix core idles --
+    // and gfx9 returns vector-memory operations in issue order, so a wavefront cannot confirm the operand loads it issued
+    // BEHIND its stores before those stores are acknowledged (r03 measurement: a ViT-B K = 768 tile computes in ~22 us and
+    // then waits ~7 us).  A persistent workgroup keeps the phase it starts with; spreading the starts over a tile period in
+    // a few groups turns the bursts into a steady write stream that the next tile's first K steps cover.
+    if (persistent && p.stagger_phases > 1) {
+        const int slot = (int)(blockIdx.x >> 3) + (int)(blockIdx.x >> 8) * (p.stagger_phases >> 1);   // b and b + 256 share a CU
+        const int naps = (slot % p.stagger_phases) * p.stagger_sleeps;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     if (bid_c >= 0) {
         stream_tile(bid_i);
         if (persistent) draw_ticket();
@@ -412,10 +429,16 @@ void igemm_nt_kernel(const NTParams p) {
     const bool gatep = DGRAD_EXTRAS && p.addend_gate != nullptr, maskp = bstats && p.bs_mask != nullptr;
     const bool fused = p.act_mode != 0 || addp || scalep || bstats;
     const bool fast = aligned && !remap && !fused;             // plain copy-out of whole chunks (N tail checked per chunk)
-    const int crow = lane / CPR;                                    // row of this lane's chunk within a pass
-    const int ccol = lane % CPR;                                    // its chunk column
 
     auto epilogue = [&](int bid, char* stg) __attribute__((always_inline)) {
+        // lane-derived indices of the epilogue are recomputed per tile from an opaque copy of the lane id: hoisted out of the
+        // tile loop they would sit in registers all through the main loop (the 256-wide geometries run at the 256-register cap)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int l15 = lane_o & 15;
+        const int lg = lane_o >> 4;
+        const int crow = lane_o / CPR;                                  // row of this lane's chunk within a pass
+        const int ccol = lane_o % CPR;                                  // its chunk column
         const int tile_n = bid % p.tiles_n;
         const int tile_m = bid / p.tiles_n;
         const int m_base = tile_m * BM_T + wm * WMR;
@@ -641,8 +664,8 @@ void igemm_nt_kernel(const NTParams p) {
                 }
             }
         };
-        if (fast) pieces(std::false_type{});
-        else pieces(std::true_type{});
+        if constexpr (FUSEDK) pieces(std::true_type{});
+        else pieces(std::false_type{});           // host: launched only when `fast` holds
         // ---- statistics of this wavefront's rows: one partial row per (tile row, wavefront row), or atomics into a few rows
         if (do_stats) {
             const size_t srow = p.stat_atomic_rows ? (size_t)((tile_m * WM_ + wm) % p.stat_atomic_rows) : (size_t)(tile_m * WM_ + wm);
@@ -682,7 +705,7 @@ void igemm_nt_kernel(const NTParams p) {
                     }
             }
         }
-        if (bstats) {
+        if (FUSEDK && bstats) {
             // sum g * (y - mean) * invstd = invstd * (sum g y - mean * sum g): the mean leaves after this lane's few rows,
             // while the sums are still small -- not after the whole column.  Lanes sharing a chunk column differ in crow.
             const size_t prow0 = (size_t)((MODE == 1 && cs > 1) ? blockIdx.y : 0) * p.bs_rows + tile_m;
@@ -702,7 +725,7 @@ void igemm_nt_kernel(const NTParams p) {
                         g += __shfl_xor(g, d, 64);
                         gx += __shfl_xor(gx, d, 64);
                     }
-                    if (lane < CPR && have) {
+                    if (lane_o < CPR && have) {
                         float* dg = p.bs_g + drow * (size_t)p.Nn + ncol + e;
                         float* dx = p.bs_gx + drow * (size_t)p.Nn + ncol + e;
                         if (p.stat_atomic_rows) { unsafeAtomicAdd(dg, g); unsafeAtomicAdd(dx, gx); }
@@ -714,13 +737,28 @@ void igemm_nt_kernel(const NTParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wavefront's staging traffic is over: the slot may be refilled
     };
 
+    // Stores a plain epilogue of a full tile issues per wavefront (one per chunk pass, every pass taken): known exactly, so
+    // the first NSTAGE-1 K steps behind the seam -- whose DMAs were issued BEFORE those stores -- wait with the stores
+    // allowed to stay in flight.  (vmcnt is a 6-bit count.)
+    constexpr int S_PLAIN = MT_ * NSPLIT * CPL;
+    static_assert(2 * LPT + S_PLAIN <= 63, "vmcnt immediate");
+    int seam_steps = 0;                // first K steps of this tile whose DMA precedes S_PLAIN in-flight stores of the last epilogue
     while (bid_c >= 0) {
         fragment_offsets();
+#pragma clang loop unroll(disable)
         for (int kc = 0; kc < nkt; ++kc) {
             // retire step `consumed` only: the steps issued after it stay in flight across the barrier
             const int ahead = issued - consumed - 1;      // wave-uniform
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            // (the choice between the two counts lives INSIDE one asm statement: as separate statements behind a C++ branch
+            // the same logic costs the 256-wide geometries 12-50 spilled registers -- another block structure for the
+            // scheduler -- and a spilled register is what the asynchronous ticket cannot afford)
+            const int behind_seam = __builtin_amdgcn_readfirstlane(seam_steps > kc ? 1 : 0);
+            if (ahead >= 2)
+                asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%2)\n\ts_branch 2f\n"
+                             "1:\n\ts_waitcnt vmcnt(%1)\n2:" ::"s"(behind_seam), "n"(2 * LPT), "n"(2 * LPT + S_PLAIN) : "memory", "scc");
+            else if (ahead == 1)
+                asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%2)\n\ts_branch 2f\n"
+                             "1:\n\ts_waitcnt vmcnt(%1)\n2:" ::"s"(behind_seam), "n"(LPT), "n"(LPT + S_PLAIN) : "memory", "scc");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // everyone's part of this step landed; the previous step is fully consumed
             if (CAN_PERSIST && mb_pending) {       // the ticket drawn two steps ago names the tile after bid_i
@@ -745,7 +783,18 @@ void igemm_nt_kernel(const NTParams p) {
         const int st_last = st_c == 0 ? NSTAGE - 1 : st_c - 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        epilogue(bid_c, smem + st_last * STAGE + wave * SLOT_SHARE);
+        {
+            // exact store count: plain path, no statistics traffic, the tile entirely inside the output (every lane of
+            // every chunk pass stores, so every store instruction is issued)
+            const int tm = bid_c / p.tiles_n, tn = bid_c - tm * p.tiles_n;
+            // (bias loads of the epilogue are waited for by the compiler before the stores are issued: more operations behind
+            // the DMAs than counted, never fewer)
+            const bool exact = !FUSEDK && !do_stats && (tm + 1) * BM_T <= Mc && (tn + 1) * BN_T <= p.Nn;
+            int ex = __builtin_amdgcn_readfirstlane(exact ? NSTAGE - 1 : 0);
+            asm volatile("" : "+s"(ex));       // opaque: keeps the optimiser from specialising the K loop per epilogue path
+            epilogue(bid_c, smem + st_last * STAGE + wave * SLOT_SHARE);
+            seam_steps = ex;
+        }
 #pragma unroll
         for (int ni = 0; ni < NT_; ++ni)
 #pragma unroll
@@ -762,6 +811,605 @@ void igemm_nt_kernel(const NTParams p) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------ NT, one tile per workgroup
+// The r02 kernel, kept for every launch that is NOT persistent (at most one round of resident workgroups, short K loops,
+// stride > 1 data-gradient classes, fp32 parity mode, fp32 outputs): its workgroup-wide epilogue (whole tile staged in LDS,
+// statistics over all rows of the tile, eight independent row chunks per thread in flight) is the faster one when nothing
+// follows the tile in the same workgroup, and it writes ONE partial-statistics row per tile row.
+// Main loop = LDS-DMA ring: `buffer_load ... lds` writes global chunks straight into a 4-stage
+// LDS ring (no staging registers, no ds_write), three K tiles are in flight across the single
+// raw s_barrier of each tile, and the wait is a COUNTED s_waitcnt vmcnt(N) that only retires the
+// tile about to be consumed (guide section 5, T3/T4).  The DMA destination is wave-linear
+// (base + lane*16), so the XOR swizzle is applied to the SOURCE: lane l fetches the chunk that
+// belongs in the slot it will fill.
+// The loop is bound by MFMA issue only if the integer work per K tile is tiny, so:
+//  * all gathers are raw buffer loads: an out-of-range lane (padding halo, M/N/K tails) gets
+//    an offset beyond the buffer and the hardware writes zeros -- no branches, no exec masking;
+//  * the (r, s, c) position of a thread's K chunk advances incrementally (no divisions);
+//  * per-row constants fold image base and top-left corner, so a gather address is one add;
+//  * LDS fragment addresses (with the XOR swizzle) are computed once.
+// PLAIN: 1x1 taps without padding (pointwise conv, nn.Linear and their data-gradients): the K
+// index IS the channel offset, no tap walker and no halo tests in the loop.
+// Tile geometry (BM_T x BN_T output tile, WM_ x WN_ wavefronts, each owning a
+// (BM_T/WM_) x (BN_T/WN_) sub-tile): 256x256 / 2x4, 256x128 / 4x2, 128x128 / 2x2, 128x64 / 2x2.
+// Wider tiles raise flop per LDS-fill byte and the MFMAs issued per barrier and per DMA.
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
+__global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT_F32) ? 4 : 1) void igemm_nt1_kernel(const NTParams p) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = 4 * EPC;                  // one 64-byte row per K tile
+    constexpr int NWAVES = WM_ * WN_;
+    constexpr int NTHREADS = 64 * NWAVES;
+    constexpr int WMR = BM_T / WM_;              // rows of the output tile owned by one wavefront
+    constexpr int WN = BN_T / WN_;
+    constexpr int NT_ = WN / 16;
+    constexpr int MT_ = WMR / 16;
+    constexpr int AROWS = BM_T / 16 / NWAVES;    // A-tile DMA instructions per thread
+    constexpr int WROWS = BN_T / 16 / NWAVES;    // weight-tile DMA instructions per thread
+    constexpr int LPT = AROWS + WROWS;           // loads per thread per K tile
+    constexpr int NSTAGE = nt_stages(BM_T, BN_T);
+    constexpr int A_BYTES = BM_T * 64;
+    constexpr int W_BYTES = BN_T * 64;
+    constexpr int STAGE = A_BYTES + W_BYTES;
+    constexpr uint32_t OOB = 0xfffffff0u;   // 16-byte aligned, beyond any operand (host checks sizes)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base)
+    const int wm = wave % WM_;
+    const int wn = wave / WM_;
+
+    // ---- data-gradient with stride s > 1: the input pixels split into s*s parity classes
+    // (h % s, w % s); a class only ever meets the taps r == (h + pad) mod s, so each class is a
+    // dense GEMM over its own tap subset (no multiply-by-zero work).  blockIdx.y = class.
+    // In class-local terms the source pixel of (row, tap) is (A0 - tr, B0 - ts).
+    int cs = 1, ph = 0, pw = 0, r0 = 0, s0 = 0, q0h = p.pad, q0w = p.pad;
+    int Sc = p.S, Hc = p.OH, Wc = p.OW, Mc = p.M, Kc = p.Kd;
+    int nblk = p.nblk;
+    if (MODE == 1 && p.stride > 1) {
+        cs = p.stride;
+        ph = blockIdx.y / cs;
+        pw = blockIdx.y - ph * cs;
+        Hc = (p.OH - ph + cs - 1) / cs;
+        Wc = (p.OW - pw + cs - 1) / cs;
+        Mc = (p.M / (p.OH * p.OW)) * Hc * Wc;
+        r0 = (ph + p.pad) % cs;
+        s0 = (pw + p.pad) % cs;
+        q0h = (ph + p.pad - r0) / cs;
+        q0w = (pw + p.pad - s0) / cs;
+        const int Rc = r0 < p.R ? (p.R - r0 + cs - 1) / cs : 0;
+        Sc = s0 < p.S ? (p.S - s0 + cs - 1) / cs : 0;
+        Kc = Rc * Sc * p.C;
+        nblk = ((Mc + BM_T - 1) / BM_T) * p.tiles_n;
+    }
+    // ---- tile loop: one tile per workgroup by default (the hardware dispatcher balances the load); with
+    // SAICV_NT_PERSIST=1 the grid is one resident round of workgroups, each walking tiles tix, tix + grid, ...
+    // Spreading the workgroups' start times over a tile period -- so that epilogue write bursts and MFMA loops of
+    // different CUs interleave -- was measured and bought nothing: the ramp costs what the steady state gains.
+    for (int tix = blockIdx.x; tix < nblk; tix += gridDim.x) {
+    if (tix != (int)blockIdx.x) {                  // the previous tile's LDS reads are done (its stores may still drain)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    const int bid = xcd_remap(tix, nblk);
+    const int tile_n = bid % p.tiles_n;
+    const int tile_m = bid / p.tiles_n;
+
+    const __amdgpu_buffer_rsrc_t src_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+
+    // ---- per-thread DMA state.  Wave w, instruction i, lane l fills LDS bytes
+    // [(i*NWAVES + w)*1024 + l*16, +16) of the A region: row (i*NWAVES+w)*16 + (l>>2), slot l&3, i.e. the
+    // logical chunk (l&3) ^ f((row>>2)&3) = (l&3) ^ f((l>>4)&3) -- one K-chunk column per thread.
+    const int cc = (lane & 3) ^ lds_swz((lane >> 4) & 3);
+    int rowc[AROWS], a0[AROWS], b0[AROWS];   // rowc = (image base + A0*W + B0) * C  [elements]
+    const int ohw = Hc * Wc;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = tile_m * BM_T + (i * NWAVES + wave) * 16 + (lane >> 2);
+        if (m < Mc) {
+            int img, oh, ow;
+            if (cs == 1) {
+                img = (int)fdiv((uint32_t)m, p.fd_ohw);
+                const int rem = m - img * ohw;
+                oh = (int)fdiv((uint32_t)rem, p.fd_ow);
+                ow = rem - oh * Wc;
+            } else {
+                img = m / ohw;
+                const int rem = m - img * ohw;
+                oh = rem / Wc;
+                ow = rem - oh * Wc;
+            }
+            if (MODE == 0) {
+                a0[i] = oh * p.stride - p.pad;
+                b0[i] = ow * p.stride - p.pad;
+            } else {
+                a0[i] = oh + q0h;
+                b0[i] = ow + q0w;
+            }
+            rowc[i] = ((img * p.H + a0[i]) * p.W + b0[i]) * p.C;
+        } else {
+            rowc[i] = 0;
+            a0[i] = -(1 << 24);
+            b0[i] = -(1 << 24);
+        }
+    }
+    int wrow[WROWS];                    // weight row base [elements], or -1
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) {
+        const int n = tile_n * BN_T + (j * NWAVES + wave) * 16 + (lane >> 2);
+        wrow[j] = n < p.Nn ? n * p.Kd : -1;
+    }
+
+    // K-chunk walker: k = kt*BK + cc*EPC  ->  (tr, ts, c0), advanced by BK per tile
+    int kpos = cc * EPC;
+    int tc0, ttr, tts;
+    {
+        const int tap = kpos / p.C;
+        tc0 = kpos - tap * p.C;
+        ttr = Sc > 0 ? tap / Sc : 0;
+        tts = tap - ttr * Sc;
+    }
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    // issue the DMA of the next K tile (walker position) into ring slot `stage`
+    auto issue_tile = [&](int stage) {
+        char* base = smem + stage * STAGE + wave * 1024;
+        const bool kvalid = kpos < Kc;
+        int tapoff, kw;
+        if (PLAIN) {
+            tapoff = kpos;
+            kw = kpos;
+        } else if (MODE == 0) {
+            tapoff = (ttr * p.W + tts) * p.C + tc0;
+            kw = kpos;
+        } else {
+            tapoff = tc0 - (ttr * p.W + tts) * p.C;
+            kw = ((r0 + ttr * cs) * p.S + (s0 + tts * cs)) * p.C + tc0;
+        }
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int ih = PLAIN ? a0[i] : (MODE == 0) ? a0[i] + ttr : a0[i] - ttr;
+            const int iw = PLAIN ? b0[i] : (MODE == 0) ? b0[i] + tts : b0[i] - tts;
+            // bitwise (not short-circuit) logic keeps this branch-free
+            const bool ok = PLAIN ? (kvalid & (a0[i] >= 0))
+                                  : (kvalid & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W));
+            const uint32_t off = ok ? (uint32_t)(rowc[i] + tapoff) * (uint32_t)sizeof(T) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + i * NWAVES * 1024), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < WROWS; ++j) {
+            const bool ok = kvalid & (wrow[j] >= 0);
+            const uint32_t off = ok ? (uint32_t)(wrow[j] + kw) * (uint32_t)sizeof(T) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rs, (lds_void*)(base + A_BYTES + j * NWAVES * 1024), 16, (int)off, 0, 0, 0);
+        }
+        // advance to the next K tile
+        kpos += BK;
+        if (PLAIN) return;
+        tc0 += BK;
+        if (p.C >= BK) {                 // at most one tap boundary per tile (uniform branch)
+            const bool wrap = tc0 >= p.C;
+            tc0 -= wrap ? p.C : 0;
+            tts += wrap ? 1 : 0;
+            const bool wrap2 = tts == Sc;
+            tts = wrap2 ? 0 : tts;
+            ttr += wrap2 ? 1 : 0;
+        } else {
+            while (tc0 >= p.C) {
+                tc0 -= p.C;
+                if (++tts == Sc) { tts = 0; ++ttr; }
+            }
+        }
+    };
+
+    f32x4 acc[NT_][MT_];
+#pragma unroll
+    for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MT_; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    int fa[MT_], fw[NT_];               // LDS fragment offsets within a stage, hoisted out of the K loop
+#pragma unroll
+    for (int mi = 0; mi < MT_; ++mi) fa[mi] = lds_off(wm * WMR + mi * 16 + l15, lg);
+#pragma unroll
+    for (int ni = 0; ni < NT_; ++ni) fw[ni] = A_BYTES + lds_off(wn * WN + ni * 16 + l15, lg);
+
+    auto compute = [&](int stage) {
+        const char* base = smem + stage * STAGE;
+        u32x4 af[MT_], wf[NT_];
+#pragma unroll
+        for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(base + fa[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(base + fw[ni]);
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
+    };
+
+    const int nkt = (Kc + BK - 1) / BK;        // 0 for a class without taps: the output is zero
+    // prologue: NSTAGE-1 tiles in flight
+    int issued = 0;
+    for (; issued < NSTAGE - 1 && issued < nkt; ++issued) issue_tile(issued);
+    int st_c = 0;                              // ring slot of the tile being consumed
+    int st_i = issued % NSTAGE;                // ring slot the next DMA fills
+    for (int kt = 0; kt < nkt; ++kt) {
+        // retire tile kt only: the tiles issued after it stay in flight across the barrier
+        const int ahead = issued - kt - 1;     // wave-uniform
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everyone's part of tile kt landed; tile kt-1 fully consumed
+        if (issued < nkt) {                    // refill the slot tile kt-1 just vacated
+            issue_tile(st_i);
+            ++issued;
+            st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+        }
+        compute(st_c);
+        st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
+    }
+    __syncthreads();                           // LDS is reused by the epilogue
+
+    // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*16 + lg*4 + r ; m = m_base + mi*16 + l15
+    // BN statistics come straight from the accumulators; the output tile is staged through LDS
+    // so that HBM sees whole rows written 16 bytes per lane (a lane's fragment is only 4 values
+    // of one row: storing it directly gives 32- or 64-byte row segments and half the write bandwidth -- measured).
+    // CODE SIZE is what this section is tuned for: with one workgroup per CU nothing overlaps the epilogue, and a
+    // fully unrolled epilogue that carries every fused mode in every unrolled copy (6 k instructions, 48 KiB)
+    // spent most of its 6 us per tile waiting for instruction fetch.  So: the unrolled part (accumulator -> LDS)
+    // carries no alternatives, the common copy-out is 16 loads + 16 stores, and everything with a fused operand,
+    // a row remap, an N tail or an unaligned leading dimension runs in ROLLED loops (one copy of the mode code).
+    typedef typename std::conditional<OUT_F32, float, T>::type TO;
+    constexpr int OPITCH = BN_T * (int)sizeof(TO) + 16;         // bytes; +16 staggers banks
+    constexpr int OCPR = BN_T * (int)sizeof(TO) / 16;           // 16-byte chunks per tile row
+    constexpr int OEPC = 16 / (int)sizeof(TO);
+    const int m_base = tile_m * BM_T + wm * WMR;
+    const int n_base = tile_n * BN_T + wn * WN;
+    const bool do_stats = p.stat_sum != nullptr;
+    // bf16 outputs: the BN statistics are taken from the STAGED tile by the matrix cores (below), not here
+    constexpr bool MSTAT = !OUT_F32 && sizeof(T) == 2;
+    const bool valu_stats = do_stats && !MSTAT;
+#pragma unroll
+    for (int ni = 0; ni < NT_; ++ni) {
+        const int n0 = n_base + ni * 16 + lg * 4;
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.Nn) bs[r] = p.bias[n0 + r];
+        }
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+        char* q0 = smem + (wm * WMR + l15) * OPITCH + (wn * WN + ni * 16 + lg * 4) * (int)sizeof(TO);
+#pragma unroll
+        for (int mi = 0; mi < MT_; ++mi) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bs[r];
+            if (valu_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vr = OUT_F32 ? v[r] : round_through<T>(v[r]);
+                    ssum[r] += vr;
+                    ssq[r] += vr * vr;
+                }
+            }
+            char* q = q0 + mi * 16 * OPITCH;
+            if (sizeof(TO) == 2) {
+                bf16x4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(q) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        if (valu_stats) {
+            // rows m >= M were gathered as zeros (no bias when stats are requested) -> add 0.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {        // over the 16 pixel lanes: four DPP adds each
+                ssum[r] = row16_sum(ssum[r]);
+                ssq[r] = row16_sum(ssq[r]);
+            }
+            if (l15 == 0) {                      // per-wavefront column sums -> LDS [2][WM_][BN_T] behind the staged tile
+                float* ws = reinterpret_cast<float*>(smem + BM_T * OPITCH) + wm * BN_T + wn * WN + ni * 16 + lg * 4;
+                *reinterpret_cast<f32x4*>(ws) = f32x4{ssum[0], ssum[1], ssum[2], ssum[3]};
+                *reinterpret_cast<f32x4*>(ws + WM_ * BN_T) = f32x4{ssq[0], ssq[1], ssq[2], ssq[3]};
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (MSTAT) {
+        if (do_stats) {
+            // Column sums of the staged bf16 tile on the matrix cores: with Y the [32 rows][16 cols] block read
+            // TRANSPOSED from LDS (ds_read_b64_tr_b16: lane (col, k-group) gets 8 consecutive rows of its column),
+            //   sum_m y      = (1 . Y)[any row][col]          -- A = ones
+            //   sum_m y * y  = (Y^T . Y)[col][col]            -- A = B = the same fragment, the diagonal
+            // exact products, fp32 accumulation, and exactly the values the next kernel reads (bf16-rounded).
+            // One wavefront owns 16 columns over ALL rows of the tile: no cross-wave combine, and the 14 VALU
+            // operations per output element + 128 DPP adds of the accumulator version are gone from the epilogue.
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            for (int cg = wave; cg < BN_T / 16; cg += NWAVES) {
+                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+                const char* q = smem + (lg * 8 + (l15 >> 2)) * OPITCH + (cg * 16 + (l15 & 3) * 4) * 2;
+#pragma unroll 4
+                for (int rb = 0; rb < BM_T / 32; ++rb, q += 32 * OPITCH) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * OPITCH));
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    const u32x4 y = {l2[0], l2[1], h2[0], h2[1]};
+                    Mma<T>::run(s1, ones, y);
+                    Mma<T>::run(s2, y, y);
+                }
+                const int n = tile_n * BN_T + cg * 16 + l15;          // D: row lg*4 + r, column l15
+                if (n < p.Nn) {
+                    const size_t srow = p.stat_atomic_rows ? (size_t)(tile_m % p.stat_atomic_rows) : (size_t)tile_m;
+                    if (lg == 0) {
+                        if (p.stat_atomic_rows) unsafeAtomicAdd(&p.stat_sum[srow * (size_t)p.Nn + n], s1[0]);
+                        else p.stat_sum[srow * (size_t)p.Nn + n] = s1[0];
+                    }
+                    if (lg == (l15 >> 2)) {
+                        const int r = l15 & 3;
+                        const float qv = r == 0 ? s2[0] : r == 1 ? s2[1] : r == 2 ? s2[2] : s2[3];
+                        if (p.stat_atomic_rows) unsafeAtomicAdd(&p.stat_sq[srow * (size_t)p.Nn + n], qv);
+                        else p.stat_sq[srow * (size_t)p.Nn + n] = qv;
+                    }
+                }
+            }
+        }
+    } else
+    if (do_stats) {
+        // one row of partial statistics per WORKGROUP (fixed summation order over its wavefront rows): four times
+        // fewer partial rows for the finalize kernels to read than one row per wavefront row
+        for (int c = tid; c < 2 * BN_T; c += NTHREADS) {
+            const int which = c / BN_T, col = c - which * BN_T;
+            const float* ws = reinterpret_cast<const float*>(smem + BM_T * OPITCH) + which * WM_ * BN_T + col;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM_; ++w) a += ws[w * BN_T];
+            const int n = tile_n * BN_T + col;
+            if (n < p.Nn) {
+                float* dst = (which ? p.stat_sq : p.stat_sum) +
+                             (size_t)(p.stat_atomic_rows ? tile_m % p.stat_atomic_rows : tile_m) * (size_t)p.Nn + n;
+                if (p.stat_atomic_rows) unsafeAtomicAdd(dst, a); else *dst = a;
+            }
+        }
+    }
+    const int oc = tid % OCPR;               // chunk within the tile row
+    const int orow0 = tid / OCPR;
+    constexpr int RPP = NTHREADS / OCPR;     // tile rows per pass
+    constexpr int NIT = BM_T / RPP;
+    const int ncol = tile_n * BN_T + oc * OEPC;
+    TO* const outp = reinterpret_cast<TO*>(p.out);
+    const bool aligned = ((p.ldo * (int)sizeof(TO)) & 15) == 0;
+    const bool remap = MODE == 1 && cs > 1;
+    constexpr bool DGRAD_EXTRAS = MODE == 1 && sizeof(TO) == sizeof(T);       // gated shortcut / BatchNorm-backward sums: data gradient only
+    const bool bstats = DGRAD_EXTRAS && p.bs_y != nullptr;                                                        // uniform
+    const bool plain = aligned && !remap && p.act_mode == 0 && p.addend == nullptr && p.row_scale == nullptr && !bstats;   // uniform
+    float bag[OEPC], bax[OEPC];                                // this thread's sum g, sum g * y over its rows of the tile
+#pragma unroll
+    for (int j = 0; j < OEPC; ++j) { bag[j] = 0.f; bax[j] = 0.f; }
+    if (plain && ncol + OEPC <= p.Nn) {
+        // the common case: a branch-free copy, the LDS reads of eight rows in flight before the first store
+        constexpr int GRP = NIT < 8 ? NIT : 8;
+        const int mrow0 = tile_m * BM_T + orow0;
+        const char* ls = smem + orow0 * OPITCH + oc * 16;
+        TO* o = outp + (size_t)mrow0 * p.ldo + ncol;
+        const size_t ostep = (size_t)RPP * p.ldo;
+        const bool full = (tile_m + 1) * BM_T <= Mc;                                         // uniform
+#pragma unroll
+        for (int g = 0; g < NIT; g += GRP) {
+            u32x4 v[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) v[j] = ld_chunk(ls + (g + j) * RPP * OPITCH);
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) st_chunk(o + (g + j) * ostep, v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j)
+                    if (mrow0 + (g + j) * RPP < Mc) st_chunk(o + (g + j) * ostep, v[j]);
+            }
+        }
+    } else if (aligned && !remap && p.act_mode == 0 && (p.Nn % OEPC) == 0) {   // uniform
+        // residual add / drop-path scale (forward and data gradient) and the data gradient's gated shortcut and
+        // BatchNorm-backward sums, on dense rows of whole chunks: four rows at a time, every global load of the group
+        // (addend, y, the two mask bytes) in flight before the first use
+        if (ncol < p.Nn) {
+            constexpr int GRP = NIT < 4 ? NIT : 4;
+            const int mrow0 = tile_m * BM_T + orow0;
+            const char* ls = smem + orow0 * OPITCH + oc * 16;
+            const bool addp = p.addend != nullptr, scalep = p.row_scale != nullptr;
+            const bool gatep = DGRAD_EXTRAS && p.addend_gate != nullptr, maskp = DGRAD_EXTRAS && p.bs_mask != nullptr;
+            const TO* const addend = reinterpret_cast<const TO*>(p.addend);
+            const TO* const ybn = reinterpret_cast<const TO*>(p.bs_y);
+#pragma unroll 1
+            for (int g = 0; g < NIT; g += GRP) {
+                u32x4 v[GRP], av[GRP], yv[GRP];
+                unsigned gb[GRP], mb[GRP];
+                float sc[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int mrow = mrow0 + (g + j) * RPP;
+                    const bool ok = mrow < Mc;
+                    const size_t off = (size_t)mrow * p.ldo + ncol;
+                    v[j] = ld_chunk(ls + (g + j) * RPP * OPITCH);
+                    av[j] = u32x4{0u, 0u, 0u, 0u};
+                    yv[j] = u32x4{0u, 0u, 0u, 0u};
+                    gb[j] = 0xffu;
+                    mb[j] = 0xffu;
+                    sc[j] = 1.f;
+                    if (ok) {
+                        if (scalep) sc[j] = p.row_scale[mrow / p.rows_per_scale];
+                        if (addp) av[j] = ld_chunk(addend + off);
+                        if (bstats) yv[j] = ld_chunk(ybn + off);
+                        if (gatep) gb[j] = p.addend_gate[off / OEPC];
+                        if (bstats && maskp) mb[j] = p.bs_mask[off / OEPC];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int mrow = mrow0 + (g + j) * RPP;
+                    if (mrow < Mc) {
+                        float f[OEPC];
+                        Chunk<TO>::unpack(v[j], f);
+                        if (addp || scalep) {
+                            float a[OEPC];
+                            Chunk<TO>::unpack(av[j], a);
+#pragma unroll
+                            for (int e = 0; e < OEPC; ++e) f[e] = fmaf(sc[j], f[e], ((gb[j] >> e) & 1u) ? a[e] : 0.f);
+                            v[j] = Chunk<TO>::pack(f);
+                            if (bstats) Chunk<TO>::unpack(v[j], f);      // the sums are over what is stored
+                        }
+                        if (bstats) {
+                            float yy[OEPC];
+                            Chunk<TO>::unpack(yv[j], yy);
+#pragma unroll
+                            for (int e = 0; e < OEPC; ++e) {
+                                const float ge = ((mb[j] >> e) & 1u) ? f[e] : 0.f;
+                                bag[e] += ge;
+                                bax[e] = fmaf(ge, yy[e], bax[e]);
+                            }
+                        }
+                        st_chunk(outp + (size_t)mrow * p.ldo + ncol, v[j]);
+                    }
+                }
+            }
+        }
+    } else if (ncol < p.Nn) {
+        // one copy of the fused-mode code in a ROLLED loop; the staged chunk and the addend chunk of the NEXT row are
+        // fetched before the current row is processed, so a row's global-load latency hides under its predecessor
+        const bool whole = aligned && ncol + OEPC <= p.Nn;
+        const bool pre_add = whole && p.addend != nullptr;
+        const bool gated = DGRAD_EXTRAS && pre_add && p.addend_gate != nullptr;   // host: the gate needs whole, aligned chunks
+        const bool bst = bstats && whole;
+        // per row: gate byte of the addend (bits 0-7) | ReLU-mask byte of the statistics (bits 8-15)
+        auto side_bits = [&](int mrow) -> unsigned {
+            const size_t ch = ((size_t)mrow * p.ldo + ncol) / OEPC;
+            unsigned b = 0xffffu;
+            if (gated) b = (b & 0xff00u) | p.addend_gate[ch];
+            if (bst && p.bs_mask != nullptr) b = (b & 0x00ffu) | ((unsigned)p.bs_mask[ch] << 8);
+            return b;
+        };
+        auto out_row = [&](int rr) -> int {                // output row of tile row rr, -1 past the end
+            const int mrow = tile_m * BM_T + rr;
+            if (rr >= BM_T || mrow >= Mc) return -1;
+            if (!remap) return mrow;
+            const int img = mrow / ohw;
+            const int rem = mrow - img * ohw;
+            const int hc = rem / Wc;
+            return (img * p.OH + hc * cs + ph) * p.OW + (rem - hc * Wc) * cs + pw;
+        };
+        int rr = orow0;
+        int m = out_row(rr);
+        u32x4 v = {0u, 0u, 0u, 0u}, av = {0u, 0u, 0u, 0u}, yv = {0u, 0u, 0u, 0u};
+        unsigned sb = 0xffffu;
+        if (m >= 0) {
+            v = ld_chunk(smem + rr * OPITCH + oc * 16);
+            if (pre_add) av = ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)m * p.ldo + ncol);
+            if (bst) yv = ld_chunk(reinterpret_cast<const TO*>(p.bs_y) + (size_t)m * p.ldo + ncol);
+            if (gated || bst) sb = side_bits(m);
+        }
+#pragma unroll 1
+        while (m >= 0) {
+            const int rn = rr + RPP;
+            const int mn = out_row(rn);
+            u32x4 vn = {0u, 0u, 0u, 0u}, an = {0u, 0u, 0u, 0u}, yn = {0u, 0u, 0u, 0u};
+            unsigned sbn = 0xffffu;
+            if (mn >= 0) {
+                vn = ld_chunk(smem + rn * OPITCH + oc * 16);
+                if (pre_add) an = ld_chunk(reinterpret_cast<const TO*>(p.addend) + (size_t)mn * p.ldo + ncol);
+                if (bst) yn = ld_chunk(reinterpret_cast<const TO*>(p.bs_y) + (size_t)mn * p.ldo + ncol);
+                if (gated || bst) sbn = side_bits(mn);
+            }
+            TO* o = outp + (size_t)m * p.ldo + ncol;
+            if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
+                float f[OEPC];
+                Chunk<TO>::unpack(v, f);
+#pragma unroll
+                for (int j = 0; j < OEPC; ++j) f[j] = gelu_fwd_f(f[j]);
+                st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(f));
+            } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)   (rows are whole chunks)
+                float f[OEPC], a[OEPC];
+                Chunk<TO>::unpack(v, f);
+                Chunk<TO>::unpack(av, a);
+#pragma unroll
+                for (int j = 0; j < OEPC; ++j) f[j] *= gelu_grad_f(a[j]);
+                v = Chunk<TO>::pack(f);
+            } else if (p.addend != nullptr || p.row_scale != nullptr) {
+                float f[OEPC], a[OEPC];
+                Chunk<TO>::unpack(v, f);
+                const float sc = p.row_scale ? p.row_scale[m / p.rows_per_scale] : 1.f;
+                if (pre_add) {
+                    Chunk<TO>::unpack(av, a);
+                    if (gated) {
+#pragma unroll
+                        for (int j = 0; j < OEPC; ++j) a[j] = ((sb >> j) & 1u) ? a[j] : 0.f;
+                    }
+                } else {
+                    for (int j = 0; j < OEPC; ++j)
+                        a[j] = (p.addend != nullptr && ncol + j < p.Nn)
+                                   ? to_f32(reinterpret_cast<const TO*>(p.addend)[(size_t)m * p.ldo + ncol + j]) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < OEPC; ++j) f[j] = fmaf(sc, f[j], a[j]);
+                v = Chunk<TO>::pack(f);
+            }
+            if (bst) {                        // BatchNorm-backward sums of what is stored (rounded to TO), behind its ReLU gate
+                float f[OEPC], yy[OEPC];
+                Chunk<TO>::unpack(v, f);
+                Chunk<TO>::unpack(yv, yy);
+#pragma unroll
+                for (int j = 0; j < OEPC; ++j) {
+                    const float gj = ((sb >> (8 + j)) & 1u) ? f[j] : 0.f;
+                    bag[j] += gj;
+                    bax[j] = fmaf(gj, yy[j], bax[j]);
+                }
+            }
+            if (whole) {
+                st_chunk(o, v);
+            } else {                          // N tail, or a leading dimension without 16-byte alignment
+                const TO* e = reinterpret_cast<const TO*>(&v);
+                for (int j = 0; j < OEPC; ++j)
+                    if (ncol + j < p.Nn) o[j] = e[j];
+            }
+            rr = rn; m = mn; v = vn; av = an; yv = yn; sb = sbn;
+        }
+    }
+    if (bstats) {       // uniform: combine the row lanes of every column through the (now consumed) staging area
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);                      // [RPP][2][BN_T]
+        const bool have = ncol + OEPC <= p.Nn;
+#pragma unroll
+        for (int j = 0; j < OEPC; ++j) {
+            // sum g * (y - mean) * invstd = invstd * (sum g y - mean * sum g): the mean leaves after this thread's few
+            // rows (BM_T / RPP of them), while the sums are still small -- not after the whole column
+            const float mu = have ? p.bs_mean[ncol + j] : 0.f, is = have ? p.bs_invstd[ncol + j] : 0.f;
+            red[(orow0 * 2 + 0) * BN_T + oc * OEPC + j] = bag[j];
+            red[(orow0 * 2 + 1) * BN_T + oc * OEPC + j] = is * fmaf(-mu, bag[j], bax[j]);
+        }
+        __syncthreads();
+        const size_t prow = (size_t)((MODE == 1 && cs > 1) ? blockIdx.y : 0) * p.bs_rows + tile_m;
+        for (int c = tid; c < 2 * BN_T; c += NTHREADS) {
+            const int which = c / BN_T, col = c - which * BN_T;
+            float a = 0.f;
+            for (int r = 0; r < RPP; ++r) a += red[(r * 2 + which) * BN_T + col];
+            const int n = tile_n * BN_T + col;
+            if (n < p.Nn) {
+                float* dst = (which ? p.bs_gx : p.bs_g) + (p.stat_atomic_rows ? prow % p.stat_atomic_rows : prow) * (size_t)p.Nn + n;
+                if (p.stat_atomic_rows) unsafeAtomicAdd(dst, a); else *dst = a;
+            }
+        }
+    }
+    }   // tile loop
+}
+
 
 // ------------------------------------------------------------------------------------ TN
 struct TNParams {
@@ -1062,39 +1710,60 @@ unsigned int* nt_ticket_set() {
     return base[dev] + (size_t)(seq[dev]++ % 64u) * 64;
 }
 
+// ---- launches.  Streaming kernel: persistent launches only (bf16 in and out); everything else: one tile per workgroup.
+template <int BM_T, int BN_T, int WM_, int WN_, int MODE>
+int launch_nt_stream(NTParams& p, hipStream_t st) {
+    constexpr size_t smem = nt_stages(BM_T, BN_T) * (size_t)(BM_T * 64 + BN_T * 64) + 16;      // DMA ring + ticket mailbox
+    static_assert(nt_can_persist(2, false, BM_T, BN_T, WM_ * WN_), "geometry without a persistent instantiation");
+    p.tickets = nt_ticket_set();
+    SAICV_REQUIRE(p.tickets != nullptr, "igemm_nt: no device memory for the ticket counters");
+    p.grid_x = 256 * nt_blocks_per_cu(BM_T, BN_T);
+    const bool plain = p.R == 1 && p.S == 1 && p.pad == 0 && (MODE == 0 || p.stride == 1);
+    // the plain-epilogue kernel: no fused operand, rows of whole 16-byte chunks at a 16-byte aligned pitch
+    const bool fusedk = p.act_mode != 0 || p.addend != nullptr || p.row_scale != nullptr || p.bs_y != nullptr ||
+                        ((p.ldo * 2) & 15) != 0 || (p.Nn & 7) != 0;
+    dim3 grid(p.grid_x, 1), block(64 * WM_ * WN_);
+#define NT_STREAM_LAUNCH(PL, FK)                                                                   \
+    {                                                                                              \
+        auto k = igemm_nt_kernel<bf16_t, BM_T, BN_T, WM_, WN_, MODE, false, PL, FK>;               \
+        static bool once = (allow_lds(k, 160 * 1024), true);                                       \
+        (void)once;                                                                                \
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);                                           \
+    }
+    if (plain && fusedk) NT_STREAM_LAUNCH(true, true)
+    else if (plain) NT_STREAM_LAUNCH(true, false)
+    else if (fusedk) NT_STREAM_LAUNCH(false, true)
+    else NT_STREAM_LAUNCH(false, false)
+#undef NT_STREAM_LAUNCH
+    return saicv::check_launch("igemm_nt (persistent)");
+}
+
 template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
-void launch_nt_inst(const NTParams& p, size_t smem, hipStream_t st) {
-    auto k = igemm_nt_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN>;
+void launch_nt1_inst(const NTParams& p, size_t smem, hipStream_t st) {
+    auto k = igemm_nt1_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN>;
     static bool once = (allow_lds(k, 160 * 1024), true);
     (void)once;
-    dim3 grid(p.grid_x, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
+    dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
 }
 
 template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE>
-int launch_nt(NTParams& p, bool out_f32, int nkt, hipStream_t st) {
-    constexpr size_t smem = nt_stages(BM_T, BN_T) * (size_t)(BM_T * 64 + BN_T * 64) + 16;      // DMA ring + ticket mailbox
-    // persistent when there are more tiles than resident workgroups and a tile's K loop is long enough for the ticket of
-    // the tile after next to travel through the mailbox (kernel: written 2 steps after the switch, read at the next one);
-    // the parity classes of a stride > 1 data gradient have unequal (possibly empty) K loops and stay one tile per workgroup
-    const char* pe = getenv("SAICV_NT_PERSIST");                       // (read per call: a tuning sweep flips it in-process)
-    const int persist_env = pe ? atoi(pe) : 1;
-    const int slots = 256 * nt_blocks_per_cu(BM_T, BN_T);
+int launch_nt1(NTParams& p, bool out_f32, hipStream_t st) {
+    constexpr size_t smem_full = nt_stages(BM_T, BN_T) * (size_t)(BM_T * 64 + BN_T * 64);      // DMA ring
+    const size_t epi = BM_T * (size_t)(BN_T * ((out_f32 || sizeof(T) == 4) ? 4 : 2) + 16) +
+                       2 * WM_ * BN_T * sizeof(float);      // staged output tile + per-wavefront BN column sums
+    size_t smem = smem_full;
+    if (smem < epi) smem = epi;
     p.tickets = nullptr;
     p.grid_x = p.nblk;
-    if (persist_env && nt_can_persist((int)sizeof(T), out_f32, BM_T, BN_T, WM_ * WN_) && p.nblk > slots &&
-        nkt > nt_stages(BM_T, BN_T) && !(MODE == 1 && p.stride > 1)) {
-        p.tickets = nt_ticket_set();
-        if (p.tickets) p.grid_x = slots;
-    }
     // pointwise taps without padding: the source pixel of a row never leaves the image
     const bool plain = p.R == 1 && p.S == 1 && p.pad == 0 && (MODE == 0 || p.stride == 1);
     if (out_f32) {
-        if (plain) launch_nt_inst<T, BM_T, BN_T, WM_, WN_, MODE, true, true>(p, smem, st);
-        else launch_nt_inst<T, BM_T, BN_T, WM_, WN_, MODE, true, false>(p, smem, st);
+        if (plain) launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, true, true>(p, smem, st);
+        else launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, true, false>(p, smem, st);
     } else {
-        if (plain) launch_nt_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, true>(p, smem, st);
-        else launch_nt_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, false>(p, smem, st);
+        if (plain) launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, true>(p, smem, st);
+        else launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, false>(p, smem, st);
     }
     return saicv::check_launch("igemm_nt");
 }
@@ -1113,11 +1782,12 @@ const NTTile kTiles[5] = {{256, 256, 2, 1, 0.80f, 11.8f, 0.905f}, {256, 128, 4, 
 int pick_tile(int M, int Nn, int nkt, bool f32_out_big) {
     if (const char* force = getenv("SAICV_NT_TILE")) {      // tuning aid: force a geometry
         const int t = atoi(force);
-        if (t >= 0 && t < 5) return t;
+        if (t >= 0 && t < 5 && !(f32_out_big && kTiles[t].bm * kTiles[t].bn * 4 > 150 * 1024)) return t;
     }
     int best = 2;
     float best_score = -1.f;
     for (int t = 0; t < 4; ++t) {
+        if (f32_out_big && kTiles[t].bm * kTiles[t].bn * 4 > 150 * 1024) continue;   // fp32 epilogue tile must fit LDS
         const NTTile& g = kTiles[t];
         const long tm = (M + g.bm - 1) / g.bm, tn = (Nn + g.bn - 1) / g.bn;
         const float blocks = (float)(tm * tn);
@@ -1131,6 +1801,26 @@ int pick_tile(int M, int Nn, int nkt, bool f32_out_big) {
         if (score > best_score) { best_score = score; best = t; }
     }
     return best;
+}
+
+// What a launch will do, as a pure function of the problem (conv_stat_rows() must size the statistics buffer before the
+// launch): geometry, and whether the launch is PERSISTENT -- the streaming kernel, one partial-statistics row per (tile row,
+// wavefront row) -- or one tile per workgroup (one row per tile row).  Persistent: bf16 in and out, a geometry with a
+// persistent instantiation, more tiles than resident workgroups, a K loop longer than the DMA ring, not a stride > 1 data
+// gradient (its parity classes have unequal, possibly empty K loops).  SAICV_NT_PERSIST=0 turns it off.
+struct NTPlan { int tile; bool persist; };
+NTPlan nt_plan(int dtype, int mode, int stride, int M_tile, int Nn, int nkt, bool f32o) {
+    NTPlan pl;
+    pl.tile = pick_tile(M_tile, Nn, nkt, f32o);
+    const NTTile& g = kTiles[pl.tile];
+    const char* pe = getenv("SAICV_NT_PERSIST");                       // (read per call: a tuning sweep flips it in-process)
+    const int persist_env = pe ? atoi(pe) : 1;
+    const long nblk = (long)((Nn + g.bn - 1) / g.bn) * ((M_tile + g.bm - 1) / g.bm);
+    const int nwaves = g.wm * (pl.tile == 0 ? 4 : 2);
+    pl.persist = persist_env && dtype == SAICV_DTYPE_BF16 && !f32o && nt_can_persist(2, false, g.bm, g.bn, nwaves) &&
+                 nblk > 256L * nt_blocks_per_cu(g.bm, g.bn) && nkt > nt_stages(g.bm, g.bn) && !(mode == 1 && stride > 1);
+    if (pl.tile == 4 && !pl.persist) pl.tile = 1;      // the four-wavefront 256 x 128 geometry exists in the streaming kernel only
+    return pl;
 }
 
 template <typename T, int BA, int BB, int NWA = 2, int NWB = 2>
@@ -1150,11 +1840,13 @@ int launch_tn(const TNParams& p, int splits, hipStream_t st) {
 
 namespace saicv {
 
-// rows of BN partial statistics written by the forward kernel: one per row of workgroups
+// rows of BN partial statistics written by the forward kernel: one per row of workgroups (per row of wavefronts when the
+// launch is persistent)
 int conv_stat_rows(int M, int Nn, int Kd, int dtype) {
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
-    const NTTile& g = kTiles[pick_tile(M, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32)];
-    return ((M + g.bm - 1) / g.bm) * g.wm;          // one partial row per (tile row, wavefront row)
+    const NTPlan pl = nt_plan(dtype, 0, 1, M, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32);
+    const NTTile& g = kTiles[pl.tile];
+    return ((M + g.bm - 1) / g.bm) * (pl.persist ? g.wm : 1);
 }
 
 // partial rows the data gradient writes with EpiExtra::bs_*: (rows of tiles of the largest parity class) x classes
@@ -1162,8 +1854,9 @@ int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dt
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
     int M_tile = M;
     if (stride > 1) M_tile = (M / (OH * OW)) * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);
-    const NTTile& g = kTiles[pick_tile(M_tile, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32)];
-    return ((M_tile + g.bm - 1) / g.bm) * stride * stride * g.wm;
+    const NTPlan pl = nt_plan(dtype, 1, stride, M_tile, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32);
+    const NTTile& g = kTiles[pl.tile];
+    return ((M_tile + g.bm - 1) / g.bm) * stride * stride * (pl.persist ? g.wm : 1);
 }
 
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
@@ -1232,18 +1925,47 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
         M_tile = nimg * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);   // largest parity class
     }
     const int nkt_host = (Kd + 4 * epc - 1) / (4 * epc);      // K tiles (stride > 1 data-gradient classes run fewer)
-    const int t = (stat_sum != nullptr) ? pick_tile(M, Nn, nkt_host, f32o) : pick_tile(M_tile, Nn, nkt_host, f32o);
+    const NTPlan pl = nt_plan(dtype, mode, stride, M_tile, Nn, nkt_host, f32o);
+    const int t = pl.tile;
     const NTTile& g = kTiles[t];
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
     p.bs_rows = (M_tile + g.bm - 1) / g.bm;
+    p.stagger_phases = 0;
+    p.stagger_sleeps = 0;
+    if (pl.persist) {
+        // start phases: SAICV_NT_STAGGER = number of phase groups (default 4; 0 or 1 = none), spread over one tile period
+        // (estimated from the fitted step time of the geometry; SAICV_NT_STAGGER_US overrides the period)
+        const char* sp = getenv("SAICV_NT_STAGGER");
+        const char* su = getenv("SAICV_NT_STAGGER_US");
+        const int phases = sp ? atoi(sp) : 4;
+        if (phases > 1) {
+            const float period_us = su ? (float)atof(su) : (float)nkt_host * g.step_us * (g.blocks_per_cu > 1 ? 1.f : 1.f);
+            p.stagger_phases = phases;
+            p.stagger_sleeps = (int)(period_us / (float)phases / 0.5f + 0.5f);
+        }
+        if (mode == 0) {
+            switch (t) {
+                case 0: return launch_nt_stream<256, 256, 2, 4, 0>(p, st);
+                case 2: return launch_nt_stream<128, 128, 2, 2, 0>(p, st);
+                case 3: return launch_nt_stream<128, 64, 2, 2, 0>(p, st);
+                default: return launch_nt_stream<256, 128, 2, 2, 0>(p, st);
+            }
+        } else {
+            switch (t) {
+                case 0: return launch_nt_stream<256, 256, 2, 4, 1>(p, st);
+                case 2: return launch_nt_stream<128, 128, 2, 2, 1>(p, st);
+                case 3: return launch_nt_stream<128, 64, 2, 2, 1>(p, st);
+                default: return launch_nt_stream<256, 128, 2, 2, 1>(p, st);
+            }
+        }
+    }
 #define NT_DISPATCH(TT, MODE_)                                                              \
     switch (t) {                                                                            \
-        case 0: return launch_nt<TT, 256, 256, 2, 4, MODE_>(p, f32o, nkt_host, st);         \
-        case 1: return launch_nt<TT, 256, 128, 4, 2, MODE_>(p, f32o, nkt_host, st);         \
-        case 2: return launch_nt<TT, 128, 128, 2, 2, MODE_>(p, f32o, nkt_host, st);         \
-        case 4: return launch_nt<TT, 256, 128, 2, 2, MODE_>(p, f32o, nkt_host, st);         \
-        default: return launch_nt<TT, 128, 64, 2, 2, MODE_>(p, f32o, nkt_host, st);         \
+        case 0: return launch_nt1<TT, 256, 256, 2, 4, MODE_>(p, f32o, st);                  \
+        case 1: return launch_nt1<TT, 256, 128, 4, 2, MODE_>(p, f32o, st);                  \
+        case 2: return launch_nt1<TT, 128, 128, 2, 2, MODE_>(p, f32o, st);                  \
+        default: return launch_nt1<TT, 128, 64, 2, 2, MODE_>(p, f32o, st);                  \
     }
     if (dtype == SAICV_DTYPE_BF16) {
         if (mode == 0) { NT_DISPATCH(bf16_t, 0) } else { NT_DISPATCH(bf16_t, 1) }

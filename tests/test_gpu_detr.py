@@ -181,7 +181,7 @@ def test_detr_backbone_stem_and_layer1_at_800x1333_match_reference(dtype):
     detr_resnet50backbone on one 3 x 800 x 1333 image (odd width: 667 / 334 columns after the two stride-2 stages), forward
     and backward -- fixture produced by the reference's DetrResNetBackbone on the CPU (oracle/make_golden_r03.py; reference
     detr_resnet.py:256-340).  fp32: output 1e-3, BN running statistics 1e-3, gradient norms 1e-2, samples
-    max(2e-2, 2 x the reference's own reorder noise); bf16: output 3e-2 of its scale, gradient-sample cosine > 0.98."""
+    max(2e-2, 2 x the reference's own reorder noise); bf16: against the reference's own bf16-autocast deviation (stored)."""
     from simpleaicv_pytorch_training_examples_amd import ops
     from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models.backbones import detr_resnet
     fx = load_golden('detr_r50_stem_layer1_1333')
@@ -199,7 +199,7 @@ def test_detr_backbone_stem_and_layer1_at_800x1333_match_reference(dtype):
     assert list(out.shape) == fx['output_shape']
     (out.float() * probe.cuda()).sum().backward()
     torch.cuda.synchronize()
-    otol = 1e-3 if dtype == torch.float32 else 3e-2
+    otol = 1e-3 if dtype == torch.float32 else 1.5 * fx['reference_noise']['bf16_output'] + 2e-2
     assert rel_err(out.float()[:, :, ::8, ::8], fx['output_sub']) < otol
     assert rel_err(out.float()[:, :, 101, :], fx['output_row']) < otol * float(fx['output_sub'].abs().max() / fx['output_row'].abs().max())
     assert abs(float(out.float().norm()) - fx['output_norm']) < (1e-3 if dtype == torch.float32 else 1e-2) * fx['output_norm']
@@ -224,4 +224,7 @@ def test_detr_backbone_stem_and_layer1_at_800x1333_match_reference(dtype):
     else:
         a = torch.cat([params[n].grad.flatten()[:64].double().cpu() for n in fx['used_params']])
         b = torch.cat([fx['grad_sample'][n].double() for n in fx['used_params']])
-        assert float(a @ b / (a.norm() * b.norm())) > 0.98
+        cos = float(a @ b / (a.norm() * b.norm()))
+        noise = fx['reference_noise']
+        print(f'detr_r50_stem_layer1_1333 bf16: gradient-sample cosine {cos:.4f} (reference bf16 autocast {noise["bf16_grad_sample_cos"]:.4f})')
+        assert cos > noise['bf16_grad_sample_cos'] - 0.1

@@ -18,6 +18,6 @@ sys.path.insert(0, os.path.join(ROOT, 'scripts'))
 def test_ticket_register_of_persistent_kernels_is_untouched_between_draw_and_use():
     import check_ticket_regs as C
     report = C.check(C.assembly())
-    assert len(report) >= 16                                  # 4 persistent geometries x fwd / dgrad x plain / gather
+    assert len(report) == 32                                  # 4 geometries x fwd / dgrad x pointwise / gather x plain / fused epilogue
     for name, reg, draws, boxes in report:
         assert draws >= 2 and boxes == 1, (name, reg, draws, boxes)
