@@ -1817,9 +1817,23 @@ NTPlan nt_plan(int dtype, int mode, int stride, int M_tile, int Nn, int nkt, boo
     const int persist_env = pe ? atoi(pe) : 1;
     const long nblk = (long)((Nn + g.bn - 1) / g.bn) * ((M_tile + g.bm - 1) / g.bm);
     const int nwaves = g.wm * (pl.tile == 0 ? 4 : 2);
-    pl.persist = persist_env && dtype == SAICV_DTYPE_BF16 && !f32o && nt_can_persist(2, false, g.bm, g.bn, nwaves) &&
-                 nblk > 256L * nt_blocks_per_cu(g.bm, g.bn) && nkt > nt_stages(g.bm, g.bn) && !(mode == 1 && stride > 1);
+    const bool can = persist_env && dtype == SAICV_DTYPE_BF16 && !f32o && !(mode == 1 && stride > 1);
+    pl.persist = can && nt_can_persist(2, false, g.bm, g.bn, nwaves) && nblk > 256L * nt_blocks_per_cu(g.bm, g.bn) &&
+                 nkt > nt_stages(g.bm, g.bn);
     if (pl.tile == 4 && !pl.persist) pl.tile = 1;      // the four-wavefront 256 x 128 geometry exists in the streaming kernel only
+    if (!getenv("SAICV_NT_TILE") && can && !pl.persist) {
+        // Where the streaming kernel (256 x 256 tiles, staggered start) measured ahead of the tile picker's one-tile choice
+        // (profiles/r03_nt_sweep_*.jsonl: M = 50 432 rows, +9..14 % on N = 2304 / 3072 outputs with K = 768 and on long
+        // reductions; level or behind on N = 768 and on every ResNet-50 shape, whose launches are one to three rounds):
+        // at least four rounds of tiles per CU, nearly full last round, and wide outputs with a short K loop or a long K loop.
+        const long t0 = (long)((Nn + 255) / 256) * ((M_tile + 255) / 256);
+        const float rounds = (float)t0 / 256.f;
+        const float quant = rounds / (float)(long)(rounds + 0.999999f);
+        if (t0 >= 4 * 256 && quant >= 0.85f && nkt > nt_stages(256, 256) && ((Nn >= 2048 && nkt <= 32) || nkt >= 64)) {
+            pl.tile = 0;
+            pl.persist = true;
+        }
+    }
     return pl;
 }
 
@@ -1934,11 +1948,11 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.stagger_phases = 0;
     p.stagger_sleeps = 0;
     if (pl.persist) {
-        // start phases: SAICV_NT_STAGGER = number of phase groups (default 4; 0 or 1 = none), spread over one tile period
+        // start phases: SAICV_NT_STAGGER = number of phase groups (default 8; 0 or 1 = none), spread over one tile period
         // (estimated from the fitted step time of the geometry; SAICV_NT_STAGGER_US overrides the period)
         const char* sp = getenv("SAICV_NT_STAGGER");
         const char* su = getenv("SAICV_NT_STAGGER_US");
-        const int phases = sp ? atoi(sp) : 4;
+        const int phases = sp ? atoi(sp) : 8;
         if (phases > 1) {
             const float period_us = su ? (float)atof(su) : (float)nkt_host * g.step_us * (g.blocks_per_cu > 1 ? 1.f : 1.f);
             p.stagger_phases = phases;

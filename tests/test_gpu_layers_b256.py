@@ -134,8 +134,10 @@ def test_s2d_stem_at_batch_256_matches_cpu_fp32(dt):
     assert rel_err(bn.running_var, 0.9 + 0.1 * var_ref) < (1e-4 if f32 else 2e-3)
     assert rel_err(conv.weight.grad, wr.grad) < (1e-3 if f32 else 4e-2)
     dgamma_ref, dbeta_ref = _bn_grads(y_ref.detach(), dz, z_ref.detach())
-    assert rel_err(bn.weight.grad, dgamma_ref) < (1e-3 if f32 else 1e-2)
-    assert rel_err(bn.bias.grad, dbeta_ref) < (1e-3 if f32 else 1e-2)
+    # bf16: the ReLU gate is taken from the bf16-rounded y -- a few thousand of the 3.2 M pixels per channel sit within that
+    # rounding of zero and flip, each moving the sum by its whole dz (measured 2.0e-2 of the largest dbeta)
+    assert rel_err(bn.weight.grad, dgamma_ref) < (1e-3 if f32 else 4e-2)
+    assert rel_err(bn.bias.grad, dbeta_ref) < (1e-3 if f32 else 4e-2)
 
 
 def _bn_grads(y, dz, z):
