@@ -1,9 +1,12 @@
 #!/bin/bash
-# A/B of an environment switch on the three bench workloads:  bash scripts/gpu_ab.sh VAR
+# same-box A/B of the default bench line: the r02 tree (in _r02/, built in the container) against this tree
 cd "$GRAFT_REPO_ROOT" || exit 1
-V=$1
-for m in "resnet50 --batch 256 --steps 15 --warmup 4" "vit_base_patch16 --batch 256 --steps 8 --warmup 3" "sam_b_encoder --batch 8 --steps 4 --warmup 2"; do
-  a=$(env $V=1 timeout 300 python bench.py --model $m --no-cpu-baseline --no-kernel-timer 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
-  b=$(timeout 300 python bench.py --model $m --no-cpu-baseline --no-kernel-timer 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
-  echo "$m : $V=1 -> $a   default -> $b"
+O=$GRAFT_REPO_ROOT/gpurun_out/r03ab$1; mkdir -p $O
+for rep in 1 2; do
+  (cd _r02 && timeout 600 python bench.py --no-cpu-baseline --no-secondary --max-windows 5 > $O/r02_r50_$rep.log 2>&1; tail -1 $O/r02_r50_$rep.log | cut -c1-140)
+  timeout 600 python bench.py --no-cpu-baseline --no-secondary --max-windows 5 > $O/new_r50_$rep.log 2>&1; tail -1 $O/new_r50_$rep.log | cut -c1-140
+  SAICV_NT_PERSIST=0 timeout 600 python bench.py --no-cpu-baseline --no-secondary --max-windows 5 > $O/new_np_r50_$rep.log 2>&1; tail -1 $O/new_np_r50_$rep.log | cut -c1-140
 done
+(cd _r02 && timeout 600 python bench.py --model vit_base_patch16 --no-cpu-baseline --no-secondary --max-windows 5 > $O/r02_vit.log 2>&1; tail -1 $O/r02_vit.log | cut -c1-140)
+timeout 600 python bench.py --model vit_base_patch16 --no-cpu-baseline --no-secondary --max-windows 5 > $O/new_vit.log 2>&1; tail -1 $O/new_vit.log | cut -c1-140
+SAICV_NT_PERSIST=0 timeout 600 python bench.py --model vit_base_patch16 --no-cpu-baseline --no-secondary --max-windows 5 > $O/new_np_vit.log 2>&1; tail -1 $O/new_np_vit.log | cut -c1-140

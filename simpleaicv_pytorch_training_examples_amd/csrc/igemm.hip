@@ -1813,13 +1813,18 @@ NTPlan nt_plan(int dtype, int mode, int stride, int M_tile, int Nn, int nkt, boo
     NTPlan pl;
     pl.tile = pick_tile(M_tile, Nn, nkt, f32o);
     const NTTile& g = kTiles[pl.tile];
+    // OFF by default (r03 measurement, profiles/r03_streaming_kernel.md): the streaming kernel is 3-14 % ahead of the one-tile
+    // kernel on isolated ViT-B GEMMs with wide outputs, level elsewhere -- and BEHIND inside the models on the same box
+    // (ResNet-50 23.8 vs 22.6 ms per step with every eligible layer persistent, ViT-B 44.9 vs 44.3 ms with the rule below):
+    // a ViT-B launch is ~7 tiles per workgroup, a ResNet-50 launch 1-3 rounds -- the ramp of a staggered start costs what
+    // the interleaved store bursts gain.  SAICV_NT_PERSIST=1 turns the rule below on, with SAICV_NT_TILE every eligible launch.
     const char* pe = getenv("SAICV_NT_PERSIST");                       // (read per call: a tuning sweep flips it in-process)
-    const int persist_env = pe ? atoi(pe) : 1;
+    const int persist_env = pe ? atoi(pe) : 0;
     const long nblk = (long)((Nn + g.bn - 1) / g.bn) * ((M_tile + g.bm - 1) / g.bm);
     const int nwaves = g.wm * (pl.tile == 0 ? 4 : 2);
     const bool can = persist_env && dtype == SAICV_DTYPE_BF16 && !f32o && !(mode == 1 && stride > 1);
-    pl.persist = can && nt_can_persist(2, false, g.bm, g.bn, nwaves) && nblk > 256L * nt_blocks_per_cu(g.bm, g.bn) &&
-                 nkt > nt_stages(g.bm, g.bn);
+    pl.persist = can && getenv("SAICV_NT_TILE") != nullptr && nt_can_persist(2, false, g.bm, g.bn, nwaves) &&
+                 nblk > 256L * nt_blocks_per_cu(g.bm, g.bn) && nkt > nt_stages(g.bm, g.bn);
     if (pl.tile == 4 && !pl.persist) pl.tile = 1;      // the four-wavefront 256 x 128 geometry exists in the streaming kernel only
     if (!getenv("SAICV_NT_TILE") && can && !pl.persist) {
         // Where the streaming kernel (256 x 256 tiles, staggered start) measured ahead of the tile picker's one-tile choice

