@@ -348,6 +348,9 @@ def measure(name, args, world, rank, device, use_graph, primary):
         'rccl_ranks': dist.get_world_size() if world > 1 else 1,
         'gradient_allreduce': ('saicv_comm (library RCCL communicator)' if getattr(model, 'comm', None) is not None
                                else 'torch.distributed') if world > 1 else None,
+        # True: the bucketed all-reduces run on the communication stream under the rest of backward (captured step);
+        # False: serialised on the compute stream (eager launches)
+        'overlap': bool(use_graph) if world > 1 else None,
         'allreduce_bytes_per_step': int(sum(b['end'] - b['start'] for b in model.buckets) * 4) if (world > 1 and hasattr(model, 'buckets')) else 0,
         'gradient_bytes': int(arena.total * 4) if arena is not None else None,
     }
@@ -392,6 +395,38 @@ def measure(name, args, world, rank, device, use_graph, primary):
                     res.setdefault('hbm_kernels', {})[t] = {'GB/s': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
                                                             'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 8e12, 4)}
     return res
+
+
+def want_step_graph(eager, force_graph, world, env):
+    """Whether the training step runs as one replayed hipGraph.  One GPU: yes unless --eager.  Several ranks (the driver's
+    `--gpus N`): ALSO yes by default -- inside a captured step the bucketed all-reduces run on the library's communication
+    stream behind event edges and overlap the rest of backward (csrc/comm.hip), which is what nn.parallel.DistributedDataParallel
+    gives the reference loop (reference tools/utils.py:193-197); launched eagerly they are serialised on the compute stream
+    (profiles/r02_ddp_eager_path.md).  SAICV_STEP_GRAPH=0 / --eager select the eager path, and it is the fallback when the
+    capture raises or (watchdog) the first replays do not come back."""
+    if eager or env == '0':
+        return False
+    return True if world == 1 else (force_graph or env in (None, '', '1'))
+
+
+def _arm_watchdog(seconds):
+    """N > 1 only: if warm-up + capture + the first timed windows of the captured step have not finished after `seconds`
+    (an RCCL collective that never completes inside a replay cannot raise), EVERY rank re-executes itself with --eager: same
+    PID (the launcher keeps its children), a fresh HIP / RCCL state, the same rendezvous variables.  Returns the event that
+    disarms it."""
+    import threading
+    done = threading.Event()
+
+    def run():
+        if not done.wait(seconds):
+            sys.stderr.write(f'[bench] captured N-rank step did not finish within {seconds:.0f} s: re-executing with --eager\n')
+            sys.stderr.flush()
+            os.environ['SAICV_BENCH_REEXEC'] = '1'
+            argv = [a for a in sys.argv if a != '--graph'] + ['--eager']
+            os.execv(sys.executable, [sys.executable] + argv)
+
+    threading.Thread(target=run, daemon=True).start()
+    return done
 
 
 _CONFIGS = {}
@@ -532,9 +567,10 @@ def worker(args):
         probe = torch.ones(1, device=device)
         dist.all_reduce(probe)                         # RCCL really connects `world` ranks before anything is timed
         assert int(probe) == world, f'RCCL all-reduce over {world} ranks returned {float(probe)}'
-    # the step graph: default with one GPU.  With several ranks the bucketed RCCL all-reduces would have to be captured
-    # too; that path cannot be exercised on the 1-GPU development boxes, so it is opt-in (--graph / SAICV_STEP_GRAPH=1)
-    want_graph = not args.eager and (world == 1 or args.graph or os.environ.get('SAICV_STEP_GRAPH') == '1')
+    want_graph = want_step_graph(args.eager, args.graph, world, os.environ.get('SAICV_STEP_GRAPH'))
+    watchdog = None
+    if world > 1 and want_graph and os.environ.get('SAICV_BENCH_REEXEC') != '1':
+        watchdog = _arm_watchdog(float(os.environ.get('SAICV_BENCH_WATCHDOG_S', '420')))
 
     def guarded(name, primary):
         try:
@@ -547,6 +583,8 @@ def worker(args):
             return measure(name, args, world, rank, device, False, primary)
 
     primary = guarded(args.model, True)
+    if watchdog is not None:
+        watchdog.set()                  # the captured N-rank step replayed and was timed: the watchdog stands down
     secondary = None
     if args.model == 'resnet50' and not args.no_secondary:
         import gc

@@ -558,6 +558,20 @@ class NativeComm:
         check(lib().saicv_comm_allreduce_bucket(self.handle, ptr(view), view.numel(), int(average),
                                                 producer_stream.cuda_stream), 'comm_allreduce_bucket')
 
+    def reduce_scatter_all_gather(self, view, producer_stream, average=True):
+        """The same result as allreduce_bucket as its two halves, in place: every rank reduces the 1/world slice it owns
+        (saicv_comm_reduce_scatter), then the slices are gathered (saicv_comm_all_gather).  Over the point-to-point xGMI mesh
+        each half keeps every link busy with 1/world of the bucket; which form is faster for which
+        bucket size can only be measured on a multi-GPU node -- DistributedDataParallel takes it for buckets of at least
+        SAICV_DDP_RSAG_MIB MiB when that variable is set."""
+        n = view.numel()
+        assert n % self.world == 0, 'bucket length must be a multiple of the world size'
+        per = n // self.world
+        shard = view[self.rank * per:(self.rank + 1) * per]
+        s = producer_stream.cuda_stream
+        check(lib().saicv_comm_reduce_scatter(self.handle, ptr(view), ptr(shard), per, int(average), s), 'comm_reduce_scatter')
+        check(lib().saicv_comm_all_gather(self.handle, ptr(shard), ptr(view), per, s), 'comm_all_gather')
+
     def allreduce_now(self, t, average=False):
         """Small fp32 tensor written on the current stream: reduced on the communication stream (behind every bucket
         already enqueued there), and the current stream waits for it."""
@@ -774,7 +788,11 @@ class DistributedDataParallel(torch.nn.Module):
             if side is not None:
                 side.wait_stream(producer)
                 producer = side
-            self.comm.allreduce_bucket(view, producer)
+            rsag = os.environ.get('SAICV_DDP_RSAG_MIB')
+            if rsag and view.numel() * 4 >= float(rsag) * 2 ** 20 and view.numel() % self.comm.world == 0:
+                self.comm.reduce_scatter_all_gather(view, producer)
+            else:
+                self.comm.allreduce_bucket(view, producer)
             self._works.append((None, None))
             return
         if self.world == 1:

@@ -215,6 +215,14 @@ def _worker_native(port, q):
     u = t + 1.0
     torch.cuda.synchronize()
     out['raw_ok'] = out['raw_ok'] and bool(torch.equal(u, torch.arange(8, dtype=torch.float32, device='cuda') * 2.0 + 1.0))
+    # the two halves of the all-reduce as separate collectives (saicv_comm_reduce_scatter + saicv_comm_all_gather), in place
+    v = torch.randn(1 << 16, device='cuda')
+    w = v * 2.0
+    comm.reduce_scatter_all_gather(w, torch.cuda.current_stream(), average=True)
+    comm.join()
+    z = w - 1.0
+    torch.cuda.synchronize()
+    out['raw_ok'] = out['raw_ok'] and bool(torch.equal(z, v * 2.0 - 1.0))
     comm.close()
 
     def train(wrap):
@@ -267,7 +275,7 @@ def test_native_rccl_communicator_in_a_world_of_one():
     out = q.get(timeout=500)
     p.join(120)
     assert p.exitcode == 0
-    assert out['raw_ok'] and out['raw_stats']['buckets'] == 1 and out['raw_stats']['bytes'] == 4 << 20
+    assert out['raw_ok'] and out['raw_stats']['buckets'] == 1 and out['raw_stats']['bytes'] == 4 << 20      # (stats read before the later collectives)
     assert out['native'], 'the DDP wrapper did not pick the native communicator on an RCCL process group'
     assert out['buckets'] >= 3
     assert out['stats']['buckets'] == 1 + 4 * out['buckets']          # self-check + every bucket of every step

@@ -286,3 +286,23 @@ def test_bench_spawn_gives_every_rank_the_torchrun_environment(monkeypatch):
         assert p.env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and p.env['SAICV_BENCH_SPAWNED'] == '1'
         assert (p.stdout is None) == (r == 0)
     assert all(p.terminated for p in started if p.rank not in (1,))
+
+
+def test_bench_runs_the_captured_overlapped_step_by_default_with_several_ranks():
+    """the path `bench.py --gpus N` takes must be the one whose gradient all-reduces overlap backward --
+    the captured step (collectives on the communication stream behind graph edges), not eager launches with the collectives
+    serialised on the compute stream.  bench.want_step_graph is the selection; eager stays reachable explicitly."""
+    import importlib
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    for world in (2, 4, 8):
+        assert bench.want_step_graph(False, False, world, None) is True          # the driver's launch: no flags, no env
+        assert bench.want_step_graph(False, True, world, None) is True
+        assert bench.want_step_graph(True, False, world, None) is False          # --eager
+        assert bench.want_step_graph(False, False, world, '0') is False          # SAICV_STEP_GRAPH=0
+    assert bench.want_step_graph(False, False, 1, None) is True
+    assert bench.want_step_graph(True, False, 1, None) is False
+    src = open(bench.__file__).read()
+    assert "'overlap': bool(use_graph) if world > 1 else None" in src            # ... and the JSON line says which one ran
