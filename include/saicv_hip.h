@@ -60,14 +60,15 @@ int saicv_unpack_wgrad(const float* dw, int O, int I, int R, int S, int Ip, floa
 /* ---- convolution / linear (implicit GEMM on MFMA) ------------------------------------- */
 /* All weights of a model repacked in one launch (after the optimizer step): `descs` is a DEVICE array of n descriptors,
  * each as for saicv_pack_weight plus its first tile index; tiles of one weight = tiles_i * tiles_o * R * S with
- * tiles_i = ceil(Ip / 32), tiles_o = ceil(Op / 32); total_tiles = the sum.  wd may be NULL per weight. */
+ * tiles_i = ceil(Ip / T), tiles_o = ceil(Op / T), T = `tile` (32, or 64 for the vectorised form: requires sI == 1, sO / sR /
+ * sS / I / Ip / Op multiples of 4 and 16-byte aligned w / wf / wd); total_tiles = the sum.  wd may be NULL per weight. */
 typedef struct saicv_pack_desc {
     const float* w;
     long sO, sI, sR, sS;
     int O, I, R, S, Ip, Op;
     void* wf;
     void* wd;
-    int tile_begin, tiles_i, tiles_o, reserved;
+    int tile_begin, tiles_i, tiles_o, tile;      /* tile: 0 / 32 or 64 */
 } saicv_pack_desc;
 int saicv_pack_weight_batched(int dtype, const saicv_pack_desc* descs, int n, int total_tiles, void* stream);
 
@@ -337,6 +338,33 @@ typedef struct saicv_attn_desc {
 int saicv_attention_stream_fwd(int dtype, int D, const saicv_attn_desc* desc, void* stream);
 /* backward = dQ pass (also writes dsum and d_rel_*) followed by the dK/dV pass */
 int saicv_attention_stream_bwd(int dtype, int D, const saicv_attn_desc* desc, void* stream);
+
+/* ---- on-device batch preparation ---------------------------------
+ * Mixup / CutMix of sample i with sample B-1-i (reference SimpleAICV/classification/mixupcutmixclassificationcollator.py:
+ * 140-284) from a plan the HOST draws with the reference's numpy calls (one entry per sample), on an NHWC batch in device
+ * memory: fp32, or uint8 with the dataset's per-channel normalisation v * scale[c] + shift[c] folded in.  mode 0: copy,
+ * 1: x * lam + x' * one_minus_lam (two products and a sum, each rounded: bit-identical to the reference's tensor expression),
+ * 2: the box rows [yl, yh) x columns [xl, xh) come from x'.  dst: fp32 [B][H][W][C], not aliasing src. */
+typedef struct saicv_mix_plan {
+    int mode, yl, yh, xl, xh;
+    float lam, one_minus_lam;              /* image mixing weights */
+    float label_lam, label_one_minus_lam;  /* label mixing weights (the box-corrected lambda for CutMix) */
+} saicv_mix_plan;
+int saicv_mixup_cutmix(int src_is_u8, const void* src, const saicv_mix_plan* plan, const float* scale, const float* shift,
+                       float* dst, int B, int H, int W, int C, void* stream);
+/* out[b][c] = y[b][c] * label_lam + y[B-1-b][c] * label_one_minus_lam, y = on_value at the label's class, off_value elsewhere
+ * (the smoothed one-hot of the same collater, :262-284) */
+int saicv_soft_labels(const long long* labels, const saicv_mix_plan* plan, float off_value, float on_value, float* out, int B,
+                      int num_classes, void* stream);
+/* One click per sample, uniform over the error region of a mask prediction (reference tools/interactive_segmentation_scripts.py:
+ * 202-228): label 1 on a false-negative pixel, label 0 on a false-positive one -- or on a background pixel when the
+ * prediction is exact.  gt: fp32 [B][H][W], a pixel is foreground where gt > gt_threshold; pred: [B][pred_channels][H][W]
+ * logits (dtype 0 bf16 / 1 fp32; NULL = nothing predicted), channel pred_index[b] (NULL = 0), foreground where
+ * > pred_threshold.  keys_ws: B * 4 u64 of scratch; points: fp32 [B][3] = (x, y, label).  The draw of every (pixel, label)
+ * slot is a counter-based function of (seed, sample, slot): no noise tensor exists. */
+int saicv_sam_sample_point(int pred_dtype, const float* gt, const void* pred, long pred_plane_stride, const long long* pred_index,
+                           int pred_channels, float gt_threshold, float pred_threshold, unsigned int seed,
+                           unsigned long long* keys_ws, float* points, int B, int H, int W, void* stream);
 
 /* ---- gradient all-reduce over RCCL / xGMI ------------------------------------------------
  * The reducer of nn.parallel.DistributedDataParallel (reference tools/train_classification_model.py:217-227 wraps the

@@ -6,7 +6,12 @@ Same constructor arguments, same output contract ({'image': float32 [B,3,H,W] as
 float32 [B, num_classes]}) and the same numpy random-draw ORDER as the reference, so a seeded run mixes the same pairs
 with the same lambdas and boxes (pinned by tests/golden/mixup_cutmix.pt, produced by the reference collater).
 Structure differs: the random plan (who mixes with whom, lambda, box) is drawn first as plain numbers, then applied
-with whole-batch tensor operations instead of per-sample python loops."""
+with whole-batch tensor operations instead of per-sample python loops.
+
+r03: `plan()` + `apply_on_device()` run the same collater on a batch that is ALREADY in device memory
+(fp32 NHWC, or uint8 NHWC with the dataset's normalisation folded in): the numpy draws stay on the host in the reference's
+order, the pixels and the soft labels are produced by two HBM-bound HIP kernels (csrc/input.hip) whose arithmetic is
+bit-identical to the tensor expressions of `__call__`."""
 import numpy as np
 import torch
 
@@ -99,6 +104,72 @@ class MixupCutmixClassificationCollater:
                 if mirror:
                     x[j] = src[j] * lam[k] + src[i] * (1 - lam[k])
         return lam
+
+    # ---- the same plan as plain numbers (one entry per sample), for the device path ---------------------------------
+    def plan(self, b, h, w):
+        """-> list of b tuples (mode, yl, yh, xl, xh, lam, one_minus_lam, label_lam, label_one_minus_lam): mode 0 copy,
+        1 mixup, 2 cutmix box; sample i always mixes with sample b-1-i.  Consumes the numpy generator exactly as
+        __call__ does for a batch of this size (same draws in the same order), and the float32 / float64 roundings of the
+        weights are the ones the tensor expressions of __call__ apply."""
+        f32 = np.float32
+        keep = (0, 0, 0, 0, 0, f32(1), f32(0), f32(1), f32(0))
+        if not self.use_mixup:
+            return [keep] * b
+        assert b % 2 == 0, 'Batch size should be even when using this'
+        if self.mode == 'batch':
+            lam, cut = self._draw_batch()
+            if lam == 1.:
+                return [keep] * b
+            if cut:
+                yl, yh, xl, xh, lam = _box_for(lam, h, w, self.cutmix_minmax, self.correct_lam)
+                return [(2, yl, yh, xl, xh, f32(1), f32(0), f32(lam), f32(1. - lam))] * b
+            return [(1, 0, 0, 0, 0, f32(lam), f32(1. - lam), f32(lam), f32(1. - lam))] * b
+        out = [keep] * b
+        if self.mode == 'elem':
+            lam, cut = self._draw(b)
+            slots, mirror = range(b), False
+        else:
+            lam, cut = self._draw(b // 2)
+            slots, mirror = range(b // 2), True
+        lam = lam.copy()                                   # float32, as in _apply
+        for k, i in enumerate(slots):
+            if lam[k] == 1.:
+                continue
+            if cut[k]:
+                yl, yh, xl, xh, lam[k] = _box_for(lam[k], h, w, self.cutmix_minmax, self.correct_lam)
+                e = (2, yl, yh, xl, xh, f32(1), f32(0), lam[k], f32(1) - lam[k])
+            else:
+                e = (1, 0, 0, 0, 0, lam[k], f32(1) - lam[k], lam[k], f32(1) - lam[k])
+            out[i] = e
+            if mirror:
+                out[b - 1 - i] = e
+        return out                     # (pair mode: both members of a pair carry the same entry, as concat(half, half[::-1]) does)
+
+    def apply_on_device(self, images, labels, scale=None, shift=None):
+        """images: [B, H, W, C] on the device, fp32 or uint8 (then `scale` / `shift`: per-channel fp32 device tensors of the
+        dataset normalisation v * scale + shift); labels: int64 [B] on the device.  -> the dict __call__ returns, with
+        tensors on the device.  No host synchronisation: the plan is uploaded with the launch."""
+        import ctypes
+        from ..._lib import MixPlan, check, lib, ptr, require_gpu, stream
+        require_gpu(images)
+        assert images.dim() == 4 and images.is_contiguous() and images.dtype in (torch.float32, torch.uint8)
+        b, h, w, c = images.shape
+        entries = self.plan(b, h, w)
+        arr = (MixPlan * b)()
+        for i, e in enumerate(entries):
+            (arr[i].mode, arr[i].yl, arr[i].yh, arr[i].xl, arr[i].xh) = (int(v) for v in e[:5])
+            (arr[i].lam, arr[i].one_minus_lam, arr[i].label_lam, arr[i].label_one_minus_lam) = (float(v) for v in e[5:])
+        plan_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(images.device, non_blocking=True)
+        out = torch.empty((b, h, w, c), dtype=torch.float32, device=images.device)
+        check(lib().saicv_mixup_cutmix(int(images.dtype == torch.uint8), ptr(images), ptr(plan_dev), ptr(scale), ptr(shift),
+                                       ptr(out), b, h, w, c, stream()), 'mixup_cutmix')
+        if not self.use_mixup:
+            return {'image': out.permute(0, 3, 1, 2), 'label': labels}
+        off = self.label_smoothing / self.num_classes
+        y = torch.empty((b, self.num_classes), dtype=torch.float32, device=images.device)
+        check(lib().saicv_soft_labels(ptr(labels), ptr(plan_dev), ctypes.c_float(off), ctypes.c_float(1. - self.label_smoothing + off),
+                                      ptr(y), b, self.num_classes, stream()), 'soft_labels')
+        return {'image': out.permute(0, 3, 1, 2), 'label': y}
 
     def __call__(self, data):
         images = torch.from_numpy(np.array([s['image'] for s in data]).astype(np.float32)).permute(0, 3, 1, 2)

@@ -56,7 +56,13 @@ class PackDesc(Structure):
     _fields_ = [('w', c_void_p), ('sO', c_long), ('sI', c_long), ('sR', c_long), ('sS', c_long),
                 ('O', c_int), ('I', c_int), ('R', c_int), ('S', c_int), ('Ip', c_int), ('Op', c_int),
                 ('wf', c_void_p), ('wd', c_void_p), ('tile_begin', c_int), ('tiles_i', c_int), ('tiles_o', c_int),
-                ('reserved', c_int)]
+                ('tile', c_int)]
+
+class MixPlan(Structure):
+    """saicv_mix_plan (include/saicv_hip.h)"""
+    _fields_ = [('mode', c_int), ('yl', c_int), ('yh', c_int), ('xl', c_int), ('xh', c_int), ('lam', ctypes.c_float),
+                ('one_minus_lam', ctypes.c_float), ('label_lam', ctypes.c_float), ('label_one_minus_lam', ctypes.c_float)]
+
 
 # name -> (restype, argtypes); mirrors include/saicv_hip.h one to one
 SIGNATURES = {
@@ -128,6 +134,10 @@ SIGNATURES = {
     'saicv_upsample4_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_mask_loss_stats_up4': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
     'saicv_mask_loss_grad_up4': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
+    'saicv_mixup_cutmix': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'saicv_soft_labels': (c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, c_int, c_int, _P]),
+    'saicv_sam_sample_point': (c_int, [c_int, _P, _P, c_long, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _P, _P,
+                                       c_int, c_int, c_int, _P]),
     'saicv_comm_available': (c_int, []),
     'saicv_comm_unique_id': (c_int, [_P]),
     'saicv_comm_reduce_scatter': (c_int, [_P, _P, _P, c_size_t, c_int, _P]),

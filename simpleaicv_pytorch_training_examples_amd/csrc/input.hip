@@ -1,0 +1,193 @@
+// On-device batch preparation: what the reference does per sample on CPU workers and per batch in
+// its collaters, as HBM-bound streaming kernels on the batch that is already in device memory.
+//
+//   saicv_mixup_cutmix     reference SimpleAICV/classification/mixupcutmixclassificationcollator.py:140-284 -- batch / pair /
+//                          elem Mixup and CutMix of sample i with sample B-1-i from a HOST-drawn plan (lambda, box: the numpy
+//                          draws stay on the host, in the reference's order, so a seeded run mixes the same pairs), with the
+//                          per-channel affine normalisation of the dataset transform folded in for uint8 inputs.
+//   saicv_soft_labels      the smoothed, mixed one-hot labels of the same collater (:262-284).
+//   saicv_sam_sample_point reference tools/interactive_segmentation_scripts.py:202-228 -- one click per sample, uniformly over the
+//                          error region of the current mask prediction, WITHOUT the [B, 1, H, W, 2] noise tensor the reference
+//                          materialises (168 MB at batch 20, four times per step): a counter-based generator gives every
+//                          (pixel, label) slot its own 32-bit draw and the arg-max travels as a packed 64-bit key.
+//
+// Arithmetic of the first two is written to be BIT-IDENTICAL to the reference's fp32 tensor expressions (separately rounded
+// products and sum, no fused multiply-add): tests compare with the fixture the reference collater produced.
+#include "common.h"
+#include "saicv_internal.h"
+#include "../../include/saicv_hip.h"
+
+namespace {
+
+// one thread per (pixel, all channels); C <= 4
+template <typename TIN>
+__global__ __launch_bounds__(256) void mixup_cutmix_kernel(const TIN* __restrict__ src, const saicv_mix_plan* __restrict__ plan,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ dst, int B, int H, int W, int C) {
+    const size_t npix = (size_t)B * H * W;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gstride) {
+        size_t t = i;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const saicv_mix_plan pl = plan[b];
+        const size_t own = i * C;
+        const size_t other = ((((size_t)(B - 1 - b)) * H + y) * W + x) * C;
+        const bool in_box = y >= pl.yl && y < pl.yh && x >= pl.xl && x < pl.xh;
+        for (int c = 0; c < C; ++c) {
+            float a = (float)src[own + c], o = (float)src[other + c];
+            if (scale != nullptr) {                          // dataset normalisation: v * scale[c] + shift[c], rounded as torch does
+                a = __fadd_rn(__fmul_rn(a, scale[c]), shift[c]);
+                o = __fadd_rn(__fmul_rn(o, scale[c]), shift[c]);
+            }
+            float v = a;
+            if (pl.mode == 1) v = __fadd_rn(__fmul_rn(a, pl.lam), __fmul_rn(o, pl.one_minus_lam));
+            else if (pl.mode == 2 && in_box) v = o;
+            dst[own + c] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void soft_labels_kernel(const int64_t* __restrict__ labels, const saicv_mix_plan* __restrict__ plan,
+                                                          float off, float on, float* __restrict__ out, int B, int NC) {
+    const size_t total = (size_t)B * NC;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        const int b = (int)(i / NC), c = (int)(i - (size_t)b * NC);
+        const float ya = labels[b] == c ? on : off;
+        const float yb = labels[B - 1 - b] == c ? on : off;
+        // y * lam + y.flip(0) * (1 - lam) with the LABEL lambda of the plan (the box-corrected one for CutMix)
+        out[i] = __fadd_rn(__fmul_rn(ya, plan[b].label_lam), __fmul_rn(yb, plan[b].label_one_minus_lam));
+    }
+}
+
+// ---- SAM click sampling
+DEVINL uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {        // counter-based draw: three rounds of a 32-bit mixer over (seed, sample, slot)
+    uint32_t h = a ^ 0x9e3779b9u;
+    h = (h ^ b) * 0x85ebca6bu; h ^= h >> 13;
+    h = (h ^ c) * 0xc2b2ae35u; h ^= h >> 16;
+    h *= 0x27d4eb2fu; h ^= h >> 15;
+    h *= 0x165667b1u; h ^= h >> 13;
+    return h;
+}
+
+DEVINL unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// keys[b][0]: best false-positive slot (label 0), [1]: best false-negative slot (label 1), [2]: best background slot (label 0,
+// used when the prediction is exact).  key = (draw + 1) << 32 | pixel index; 0 = no candidate.
+template <typename TP>
+__global__ __launch_bounds__(256) void sample_point_scan_kernel(const float* __restrict__ gt, const TP* __restrict__ pred, long pred_stride,
+                                                                const int64_t* __restrict__ pred_index, int pred_channels,
+                                                                float gt_threshold, float pred_threshold, uint32_t seed,
+                                                                unsigned long long* __restrict__ keys, int B, int HW) {
+    const int b = blockIdx.y;
+    const float* g = gt + (size_t)b * HW;
+    const TP* p = nullptr;
+    if (pred != nullptr) {
+        const long ch = pred_index ? (long)pred_index[b] : 0;
+        p = pred + (size_t)b * pred_stride * pred_channels + (size_t)ch * pred_stride;
+    }
+    unsigned long long kfp = 0ull, kfn = 0ull, kbg = 0ull;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        const bool gm = g[i] > gt_threshold;
+        const bool pm = p != nullptr && (float)p[i] > pred_threshold;
+        const uint32_t d0 = mix32(seed, (uint32_t)b, 2u * (uint32_t)i), d1 = mix32(seed, (uint32_t)b, 2u * (uint32_t)i + 1u);
+        const unsigned long long k0 = (((unsigned long long)d0 + 1ull) << 32) | (unsigned)i;
+        const unsigned long long k1 = (((unsigned long long)d1 + 1ull) << 32) | (unsigned)i;
+        if (!gm && pm && k0 > kfp) kfp = k0;
+        if (gm && !pm && k1 > kfn) kfn = k1;
+        if (!gm && !pm && k0 > kbg) kbg = k0;
+    }
+    kfp = wave_max_u64(kfp); kfn = wave_max_u64(kfn); kbg = wave_max_u64(kbg);
+    if ((threadIdx.x & 63) == 0) {
+        if (kfp) atomicMax(&keys[(size_t)b * 4 + 0], kfp);
+        if (kfn) atomicMax(&keys[(size_t)b * 4 + 1], kfn);
+        if (kbg) atomicMax(&keys[(size_t)b * 4 + 2], kbg);
+    }
+}
+
+__global__ void sample_point_pick_kernel(const unsigned long long* __restrict__ keys, float* __restrict__ points, int B, int W) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long kfp = keys[(size_t)b * 4 + 0], kfn = keys[(size_t)b * 4 + 1], kbg = keys[(size_t)b * 4 + 2];
+    unsigned long long k;
+    float label;
+    if (kfp | kfn) {                               // an error region exists: the largest draw over both label slots wins
+        const bool take_fn = kfp == 0ull ? true : (kfn == 0ull ? false : (kfn >> 32) > (kfp >> 32));
+        k = take_fn ? kfn : kfp;
+        label = take_fn ? 1.f : 0.f;
+    } else {                                       // exact prediction: a background pixel, label 0; nothing at all: pixel 0
+        k = kbg;
+        label = 0.f;
+    }
+    const unsigned idx = (unsigned)k;
+    points[b * 3 + 0] = (float)(idx % (unsigned)W);
+    points[b * 3 + 1] = (float)(idx / (unsigned)W);
+    points[b * 3 + 2] = label;
+}
+
+int sgrid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int saicv_mixup_cutmix(int src_is_u8, const void* src, const saicv_mix_plan* plan, const float* scale, const float* shift,
+                       float* dst, int B, int H, int W, int C, void* stream) {
+    SAICV_REQUIRE(src && plan && dst && B > 0 && H > 0 && W > 0 && C > 0 && C <= 4, "saicv_mixup_cutmix: bad arguments (C=%d)", C);
+    SAICV_REQUIRE((scale == nullptr) == (shift == nullptr), "saicv_mixup_cutmix: scale and shift come together");
+    SAICV_REQUIRE((const void*)src != (const void*)dst, "saicv_mixup_cutmix: not in place (sample B-1-i is read while sample i is written)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t npix = (size_t)B * H * W;
+    if (src_is_u8)
+        hipLaunchKernelGGL(mixup_cutmix_kernel<uint8_t>, dim3(sgrid(npix)), dim3(256), 0, st, (const uint8_t*)src, plan, scale, shift, dst, B, H, W, C);
+    else
+        hipLaunchKernelGGL(mixup_cutmix_kernel<float>, dim3(sgrid(npix)), dim3(256), 0, st, (const float*)src, plan, scale, shift, dst, B, H, W, C);
+    return saicv::check_launch("mixup_cutmix");
+}
+
+int saicv_soft_labels(const long long* labels, const saicv_mix_plan* plan, float off_value, float on_value, float* out, int B,
+                      int num_classes, void* stream) {
+    SAICV_REQUIRE(labels && plan && out && B > 0 && num_classes > 0, "saicv_soft_labels: bad arguments");
+    hipLaunchKernelGGL(soft_labels_kernel, dim3(sgrid((size_t)B * num_classes)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const int64_t*)labels, plan, off_value, on_value, out, B, num_classes);
+    return saicv::check_launch("soft_labels");
+}
+
+int saicv_sam_sample_point(int pred_dtype, const float* gt, const void* pred, long pred_plane_stride, const long long* pred_index,
+                           int pred_channels, float gt_threshold, float pred_threshold, unsigned int seed,
+                           unsigned long long* keys_ws, float* points, int B, int H, int W, void* stream) {
+    SAICV_REQUIRE(gt && keys_ws && points && B > 0 && H > 0 && W > 0, "saicv_sam_sample_point: bad arguments");
+    SAICV_REQUIRE((size_t)H * W < (1ull << 31), "saicv_sam_sample_point: mask too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(keys_ws, 0, (size_t)B * 4 * sizeof(unsigned long long), st) != hipSuccess) {
+        saicv::set_error("saicv_sam_sample_point: memset failed");
+        return -2;
+    }
+    const int HW = H * W;
+    int gx = (HW + 256 * 16 - 1) / (256 * 16);
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, B);
+    if (pred_dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(sample_point_scan_kernel<bf16_t>, grid, dim3(256), 0, st, gt, (const bf16_t*)pred, pred_plane_stride,
+                           (const int64_t*)pred_index, pred_channels, gt_threshold, pred_threshold, seed, keys_ws, B, HW);
+    else
+        hipLaunchKernelGGL(sample_point_scan_kernel<float>, grid, dim3(256), 0, st, gt, (const float*)pred, pred_plane_stride,
+                           (const int64_t*)pred_index, pred_channels, gt_threshold, pred_threshold, seed, keys_ws, B, HW);
+    hipLaunchKernelGGL(sample_point_pick_kernel, dim3((B + 63) / 64), dim3(64), 0, st, keys_ws, points, B, W);
+    return saicv::check_launch("sam_sample_point");
+}
+
+}  // extern "C"

@@ -401,7 +401,11 @@ class _PackRegistry:
                     d.w, d.sO, d.sI, d.sR, d.sS = wv.data_ptr(), so, si, sr, ss
                     d.O, d.I, d.R, d.S, d.Ip, d.Op = o, i, r, s, e['ip'], e['op']
                     d.wf, d.wd = ptr(e['wf']), ptr(e['wd'])
-                    d.tiles_i, d.tiles_o = (e['ip'] + 31) // 32, (e['op'] + 31) // 32
+                    # 64 x 64 tiles with 16-byte reads / 8-byte writes where the input-channel axis is contiguous and aligned
+                    vec = (si == 1 and all(v % 4 == 0 for v in (so, sr, ss, i, e['ip'], e['op'])) and wv.data_ptr() % 16 == 0)
+                    ts = 64 if vec else 32
+                    d.tile = ts
+                    d.tiles_i, d.tiles_o = (e['ip'] + ts - 1) // ts, (e['op'] + ts - 1) // ts
                     d.tile_begin = t0
                     t0 += d.tiles_i * d.tiles_o * r * s
                 dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][1].device)

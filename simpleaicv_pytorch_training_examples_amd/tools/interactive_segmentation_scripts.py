@@ -1,7 +1,7 @@
 """Per-iteration SAM training loop of the reference tools/interactive_segmentation_scripts.py on the
 MI355X engine.
 
-  sample_random_point                                 (reference :202-228)
+  sample_error_click                                  (reference sample_random_point, :202-228; one HIP kernel)
   get_decoder_iters_prompt_points_and_prompt_mask     (reference :231-271)
   train_sam_segmentation                              (reference :274-533)
 
@@ -26,47 +26,56 @@ from ..SimpleAICV.classification.common import AverageMeter, get_amp_type
 from .scripts import _device_of, _dist_on, all_reduce_sum_packed
 
 
-def sample_random_point(gt_masks, pred_masks, num_pt=1):
-    """One click per sample in the error region: label 1 on a false negative, 0 on a false positive
-    (or on background when the prediction is already exact)."""
-    gt_masks = gt_masks.bool()
-    if pred_masks is None:
-        pred_masks = torch.zeros_like(gt_masks)
-    pred_masks = pred_masks.bool()
-    B, _, H_im, W_im = gt_masks.shape
-    device = gt_masks.device
-    fp_masks = ~gt_masks & pred_masks
-    fn_masks = gt_masks & ~pred_masks
-    all_correct = torch.all((gt_masks == pred_masks).flatten(2), dim=2)[..., None, None]
-    pts_noise = torch.rand(B, num_pt, H_im, W_im, 2, device=device)
-    pts_noise[..., 0] *= fp_masks | (all_correct & ~gt_masks)
-    pts_noise[..., 1] *= fn_masks
-    pts_idx = pts_noise.flatten(2).argmax(dim=2)
-    labels = (pts_idx % 2).to(torch.int32)
-    pts_idx = pts_idx // 2
-    pts_x = pts_idx % W_im
-    pts_y = pts_idx // W_im
-    points = torch.stack([pts_x, pts_y], dim=2).float()
-    return torch.cat([points, labels.unsqueeze(dim=-1)], dim=-1)
+_click_serial = [0]
+
+
+def sample_error_click(gt_masks, mask_logits=None, channel=None, gt_threshold=0.5, pred_threshold=0.0, seed=None):
+    """[B, 1, 3] (x, y, label): one click per sample drawn uniformly from the error region of the current prediction --
+    label 1 on a missed foreground pixel, label 0 on a falsely predicted one, and on a background pixel when the
+    prediction is already exact (what reference tools/interactive_segmentation_scripts.py:202-228 samples through an
+    arg-max over a [B, 1, H, W, 2] noise tensor).  Here: saicv_sam_sample_point -- one pass over the masks, a counter-based
+    draw per (pixel, label) slot, no noise tensor, no gather of the best mask (the kernel reads channel `channel[b]` of the
+    [B, M, H, W] logits in place).  gt_masks: [B, 1, H, W] fp32; mask_logits: [B, M, H, W] bf16 / fp32 or None."""
+    from .._lib import check, dtype_code, lib, ptr, require_gpu, stream
+    require_gpu(gt_masks)
+    b, _, h, w = gt_masks.shape
+    gt = gt_masks.float().contiguous()
+    if mask_logits is not None:
+        mask_logits = mask_logits.contiguous()
+        if mask_logits.dtype not in (torch.float32, torch.bfloat16):
+            mask_logits = mask_logits.float()
+        assert mask_logits.shape[0] == b and tuple(mask_logits.shape[-2:]) == (h, w)
+        if channel is not None:
+            channel = channel.to(torch.int64).contiguous()
+    if seed is None:
+        _click_serial[0] += 1
+        seed = (torch.initial_seed() * 2654435761 + _click_serial[0]) & 0xffffffff
+    keys = torch.empty(b * 4, dtype=torch.int64, device=gt.device)
+    points = torch.empty((b, 1, 3), dtype=torch.float32, device=gt.device)
+    m = mask_logits.shape[1] if mask_logits is not None else 1
+    check(lib().saicv_sam_sample_point(dtype_code(mask_logits.dtype) if mask_logits is not None else 1, ptr(gt), ptr(mask_logits),
+                                       h * w, ptr(channel), m, float(gt_threshold), float(pred_threshold), int(seed), ptr(keys),
+                                       ptr(points), b, h, w, stream()), 'sam_sample_point')
+    return points
 
 
 def get_decoder_iters_prompt_points_and_prompt_mask(mask_preds, iou_preds, gt_masks, prompts, config):
+    """Prompts of the next decoder pass (reference :231-271): the click above against the best-IoU mask of this pass, appended
+    to the point prompts, and that mask at 1/4 resolution as the mask prompt."""
     with torch.no_grad():
-        if len(mask_preds.shape) == 5:
-            mask_preds = torch.squeeze(mask_preds, dim=2)
-        batch_size, mask_out_idx_num = iou_preds.shape[0], iou_preds.shape[1]
-        device = iou_preds.device
-        best_iou_masks = mask_preds
-        if mask_out_idx_num > 1:
-            best_iou_idxs = torch.argmax(iou_preds, dim=-1)
-            best_iou_masks = mask_preds[torch.arange(batch_size, device=device), best_iou_idxs].unsqueeze(1)
-        new_prompt_points = sample_random_point((gt_masks > 0.5), (best_iou_masks > config.mask_threshold), num_pt=1)
-        prompt_points = prompts['prompt_point']
-        prompts['prompt_point'] = (torch.cat([prompt_points, new_prompt_points], dim=1)
-                                   if prompt_points is not None else new_prompt_points)
-        prompts['prompt_mask'] = F.interpolate(best_iou_masks.float(),
-                                               size=(config.input_image_size // 4, config.input_image_size // 4),
-                                               mode='bilinear')
+        if mask_preds.dim() == 5:
+            mask_preds = mask_preds.squeeze(2)
+        n_out = iou_preds.shape[1]
+        best = torch.argmax(iou_preds, dim=-1) if n_out > 1 else None
+        click = sample_error_click(gt_masks, mask_preds, best, 0.5, config.mask_threshold)
+        if best is not None:
+            best_mask = mask_preds[torch.arange(mask_preds.shape[0], device=mask_preds.device), best].unsqueeze(1)
+        else:
+            best_mask = mask_preds
+        old = prompts['prompt_point']
+        prompts['prompt_point'] = click if old is None else torch.cat([old, click], dim=1)
+        q = config.input_image_size // 4
+        prompts['prompt_mask'] = F.interpolate(best_mask.float(), size=(q, q), mode='bilinear')
     return prompts
 
 

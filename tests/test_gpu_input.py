@@ -1,0 +1,119 @@
+"""On-device batch preparation (csrc/input.hip) on a real MI355X.
+
+saicv_mixup_cutmix / saicv_soft_labels : MixupCutmixClassificationCollater.apply_on_device against the fixture the REFERENCE
+    collater produced (tests/golden/mixup_cutmix.pt, oracle/make_golden_mixup.py): same numpy seed -> bit-identical images and
+    soft labels in all three modes; the uint8 + normalisation form against the same expressions in torch.
+saicv_sam_sample_point : the click of reference tools/interactive_segmentation_scripts.py:202-228 -- always inside the error
+    region with the label of its kind, a background pixel when the prediction is exact, uniform over the candidate
+    (pixel, label) slots (chi-square over 6000 draws)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle.make_golden_mixup import batch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_mixup_cutmix_is_bit_identical_to_the_reference_collater():
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.common import MixupCutmixClassificationCollater
+    for case in load_golden('mixup_cutmix'):
+        np.random.seed(case['np_seed'])
+        data = batch(case['data_seed'])
+        images = torch.from_numpy(np.array([s['image'] for s in data]).astype(np.float32)).cuda()          # [B, H, W, C]
+        labels = torch.tensor([s['label'] for s in data], dtype=torch.int64).cuda()
+        got = MixupCutmixClassificationCollater(num_classes=10, **case['kwargs']).apply_on_device(images, labels)
+        torch.cuda.synchronize()
+        assert got['image'].shape == case['image'].shape and got['image'].stride()[1] == 1      # NHWC-strided NCHW view
+        assert torch.equal(got['image'].cpu(), case['image']), case['kwargs']
+        assert float((got['label'].cpu() - case['label']).abs().max()) == 0.0, case['kwargs']
+
+
+def test_device_mixup_cutmix_from_uint8_with_normalisation():
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.common import MixupCutmixClassificationCollater
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (8, 20, 24, 3), generator=g, dtype=torch.uint8)
+    labels = torch.randint(0, 10, (8,), generator=g)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    scale, shift = 1.0 / (255.0 * std), -mean / std
+    for mode in ('batch', 'pair', 'elem'):
+        for seed in (0, 1, 2):
+            col = MixupCutmixClassificationCollater(num_classes=10, mode=mode)
+            np.random.seed(seed)
+            got = col.apply_on_device(u8.cuda(), labels.cuda(), scale.cuda(), shift.cuda())
+            np.random.seed(seed)
+            plan = col.plan(8, 20, 24)
+            x = u8.float() * scale + shift                      # two rounded operations, as the kernel does them
+            ref = x.clone()
+            for i, (m, yl, yh, xl, xh, lam, oml, _, _) in enumerate(plan):
+                j = 7 - i
+                if m == 1:
+                    ref[i] = x[i] * torch.tensor(lam) + x[j] * torch.tensor(oml)
+                elif m == 2:
+                    ref[i, yl:yh, xl:xh] = x[j, yl:yh, xl:xh]
+            torch.cuda.synchronize()
+            assert torch.equal(got['image'].permute(0, 2, 3, 1).cpu(), ref), (mode, seed)
+            assert abs(float(got['label'].sum()) - 8.0) < 1e-4
+
+
+def _click(gt, logits=None, channel=None, seed=0, thr=0.0):
+    from simpleaicv_pytorch_training_examples_amd.tools.interactive_segmentation_scripts import sample_error_click
+    return sample_error_click(gt, logits, channel, 0.5, thr, seed=seed)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_sam_click_lies_in_the_error_region_with_the_label_of_its_kind(dtype):
+    g = torch.Generator().manual_seed(11)
+    b, m, h, w = 5, 3, 40, 56
+    gt = (torch.rand(b, 1, h, w, generator=g) > 0.6).float().cuda()
+    logits = torch.randn(b, m, h, w, generator=g).cuda().to(dtype)
+    ch = torch.randint(0, m, (b,), generator=g).cuda()
+    pred = logits[torch.arange(b), ch].float() > 0.0
+    gtb = gt[:, 0] > 0.5
+    for seed in range(40):
+        pts = _click(gt, logits, ch, seed)
+        torch.cuda.synchronize()
+        assert pts.shape == (b, 1, 3)
+        for i in range(b):
+            x, y, lab = int(pts[i, 0, 0]), int(pts[i, 0, 1]), int(pts[i, 0, 2])
+            assert 0 <= x < w and 0 <= y < h
+            if lab == 1:
+                assert bool(gtb[i, y, x]) and not bool(pred[i, y, x])        # a missed foreground pixel
+            else:
+                assert not bool(gtb[i, y, x]) and bool(pred[i, y, x])        # a falsely predicted one
+    # exact prediction: a background pixel with label 0; nothing predicted at all (pred None): only misses can be clicked
+    exact = torch.where(gt[:, :1] > 0.5, 5.0, -5.0).to(dtype)
+    pts = _click(gt, exact, None, 3)
+    for i in range(b):
+        x, y, lab = int(pts[i, 0, 0]), int(pts[i, 0, 1]), int(pts[i, 0, 2])
+        assert lab == 0 and not bool(gtb[i, y, x])
+    pts = _click(gt, None, None, 4)
+    for i in range(b):
+        x, y, lab = int(pts[i, 0, 0]), int(pts[i, 0, 1]), int(pts[i, 0, 2])
+        assert lab == 1 and bool(gtb[i, y, x])
+    full = torch.ones(2, 1, 8, 8).cuda()
+    pts = _click(full, torch.full((2, 1, 8, 8), 3.0).cuda(), None, 5)          # everything foreground and predicted: pixel 0, label 0
+    assert torch.equal(pts.cpu(), torch.zeros(2, 1, 3))
+
+
+def test_sam_click_is_uniform_over_the_candidate_slots():
+    # 3 false-positive pixels (label 0) and 5 false-negative ones (label 1) in a 16 x 16 mask: 8 slots, 6000 seeded draws
+    gt = torch.zeros(1, 1, 16, 16)
+    logit = torch.full((1, 1, 16, 16), -1.0)
+    fp = [(2, 3), (9, 9), (15, 0)]
+    fn = [(0, 0), (4, 7), (8, 8), (12, 1), (13, 14)]
+    for y, x in fp:
+        logit[0, 0, y, x] = 1.0
+    for y, x in fn:
+        gt[0, 0, y, x] = 1.0
+    gt, logit = gt.cuda(), logit.cuda()
+    n = 6000
+    pts = torch.cat([_click(gt, logit, None, seed) for seed in range(n)], 0).cpu()
+    counts = {}
+    for x, y, lab in pts[:, 0].tolist():
+        counts[(int(y), int(x), int(lab))] = counts.get((int(y), int(x), int(lab)), 0) + 1
+    assert set(counts) == {(y, x, 0) for y, x in fp} | {(y, x, 1) for y, x in fn}
+    exp = n / 8
+    chi2 = sum((c - exp) ** 2 / exp for c in counts.values())
+    assert chi2 < 29.9, (chi2, counts)            # chi-square, 7 degrees of freedom: p = 1e-4
