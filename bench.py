@@ -65,6 +65,8 @@ def parse():
     ap.add_argument('--max-windows', type=int, default=15)
     ap.add_argument('--eager', action='store_true', help='no step graph (one kernel launch per kernel from Python)')
     ap.add_argument('--graph', action='store_true', help='force the step graph also with several ranks')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='fixed-order BatchNorm statistics, as the entry scripts run after set_seed() (default: fp32 atomics)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
@@ -340,7 +342,9 @@ def measure(name, args, world, rank, device, use_graph, primary):
         'config': {'workload': f'{name} 3x{size}x{size} synthetic training step (fwd+loss+bwd+all-reduce+optimizer), per-GPU batch {batch}',
                    'model': name, 'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}',
                    'final_loss': round(float(state['loss']), 4), 'loss_scale': scaler.get_scale() if scaler is not None else None,
-                   'step_graph': bool(use_graph), 'host_ms_per_step': round(statistics.median(host) / args.steps * 1e3, 3),
+                   'step_graph': bool(use_graph),
+                   'bn_statistics': 'fp32 atomics into pooled rows (SAICV_BN_INLINE=1)' if ops.BN_INLINE else 'fixed-order partial rows',
+                   'host_ms_per_step': round(statistics.median(host) / args.steps * 1e3, 3),
                    # host time spent ISSUING a step when it is a graph replay (input copies, hyper-parameter refresh,
                    # hipGraphLaunch); host_ms_per_step above also contains the loop's lagged read of the loss, i.e. waiting
                    'host_enqueue_ms_per_step': _replay_host_ms(state), **info},
@@ -546,6 +550,11 @@ def cpu_reference_child(threads):
 
 # ------------------------------------------------------------------------------------------ worker
 def worker(args):
+    # BatchNorm statistics: the entry scripts' set_seed() selects the fixed-order (bit-reproducible) sums, as the reference's
+    # set_seed asks for deterministic kernels; the benchmark opts into the atomically accumulated ones (0.35-0.4 ms per
+    # ResNet-50 step) unless --deterministic, and says so in its JSON line (config.bn_statistics)
+    if not args.deterministic:
+        os.environ.setdefault('SAICV_BN_INLINE', '1')
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))

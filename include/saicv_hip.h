@@ -241,6 +241,9 @@ int saicv_adamw_flat(float* p, const float* g, float* m, float* v, const int32_t
 int saicv_grad_stats(const float* g, size_t n, float* found_inf, float* sumsq, void* stream);
 int saicv_grad_clip_scale(float* g, size_t n, const float* sumsq, const float* inv_scale,
                           double max_norm, void* stream);
+/* torch.nn.utils.clip_grad_value_ on the flat gradient arena with the GradScaler unscale folded in:
+ * g = clamp(g * inv_scale, -value, value)  (reference tools/scripts.py:211-218). */
+int saicv_grad_clip_value(float* g, size_t n, const float* inv_scale, double value, void* stream);
 int saicv_scaler_update(float* state, const float* found_inf, double growth, double backoff,
                         int interval, void* stream);
 

@@ -110,6 +110,7 @@ SIGNATURES = {
     'saicv_adamw_flat': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'saicv_grad_stats': (c_int, [_P, c_size_t, _P, _P, _P]),
     'saicv_grad_clip_scale': (c_int, [_P, c_size_t, _P, _P, c_double, _P]),
+    'saicv_grad_clip_value': (c_int, [_P, c_size_t, _P, c_double, _P]),
     'saicv_scaler_update': (c_int, [_P, _P, c_double, c_double, c_int, _P]),
     # transformer kernels (tfm.hip)
     'saicv_layernorm_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),

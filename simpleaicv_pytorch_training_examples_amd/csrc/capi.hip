@@ -63,6 +63,7 @@ int sgd_flat(float*, const float*, float*, const int32_t*, const float*, const f
 int adamw_flat(float*, const float*, float*, float*, const int32_t*, const float*, const float*, const float*, const uint8_t*, float*, size_t, hipStream_t);
 int grad_stats(const float*, size_t, float*, float*, hipStream_t);
 int grad_clip_scale(float*, size_t, const float*, const float*, double, hipStream_t);
+int grad_clip_value(float*, size_t, const float*, double, hipStream_t);
 int scaler_update(float*, const float*, double, double, int, hipStream_t);
 int layernorm_fwd(int, const void*, const float*, const float*, void*, float*, float*, int, int, double, hipStream_t);
 size_t layernorm_bwd_ws_floats(int, int);
@@ -338,6 +339,9 @@ int saicv_grad_stats(const float* g, size_t n, float* found_inf, float* sumsq, v
 int saicv_grad_clip_scale(float* g, size_t n, const float* sumsq, const float* inv_scale,
                           double max_norm, void* stream) {
     return grad_clip_scale(g, n, sumsq, inv_scale, max_norm, S(stream));
+}
+int saicv_grad_clip_value(float* g, size_t n, const float* inv_scale, double value, void* stream) {
+    return grad_clip_value(g, n, inv_scale, value, S(stream));
 }
 int saicv_scaler_update(float* state, const float* found_inf, double growth, double backoff,
                         int interval, void* stream) {

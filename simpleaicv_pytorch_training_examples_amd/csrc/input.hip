@@ -17,6 +17,11 @@
 #include "saicv_internal.h"
 #include "../../include/saicv_hip.h"
 
+// No fused multiply-add anywhere in this file (plain operators under contract(off); HIP's __fmul_rn / __fadd_rn are inline
+// functions of a header compiled with contraction ALLOWED, and keep that flag when inlined): a contracted product is not
+// rounded, while the reference's tensor expressions round every step.
+#pragma clang fp contract(off)
+
 namespace {
 
 // one thread per (pixel, all channels); C <= 4
@@ -38,11 +43,11 @@ __global__ __launch_bounds__(256) void mixup_cutmix_kernel(const TIN* __restrict
         for (int c = 0; c < C; ++c) {
             float a = (float)src[own + c], o = (float)src[other + c];
             if (scale != nullptr) {                          // dataset normalisation: v * scale[c] + shift[c], rounded as torch does
-                a = __fadd_rn(__fmul_rn(a, scale[c]), shift[c]);
-                o = __fadd_rn(__fmul_rn(o, scale[c]), shift[c]);
+                a = a * scale[c] + shift[c];
+                o = o * scale[c] + shift[c];
             }
             float v = a;
-            if (pl.mode == 1) v = __fadd_rn(__fmul_rn(a, pl.lam), __fmul_rn(o, pl.one_minus_lam));
+            if (pl.mode == 1) v = a * pl.lam + o * pl.one_minus_lam;
             else if (pl.mode == 2 && in_box) v = o;
             dst[own + c] = v;
         }
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void soft_labels_kernel(const int64_t* __restr
         const float ya = labels[b] == c ? on : off;
         const float yb = labels[B - 1 - b] == c ? on : off;
         // y * lam + y.flip(0) * (1 - lam) with the LABEL lambda of the plan (the box-corrected one for CutMix)
-        out[i] = __fadd_rn(__fmul_rn(ya, plan[b].label_lam), __fmul_rn(yb, plan[b].label_one_minus_lam));
+        out[i] = ya * plan[b].label_lam + yb * plan[b].label_one_minus_lam;
     }
 }
 

@@ -138,6 +138,23 @@ __global__ __launch_bounds__(256) void grad_clip_scale_kernel(float* __restrict_
     }
 }
 
+// torch.nn.utils.clip_grad_value_ over the whole arena, with the GradScaler unscale folded in: g = clamp(g * inv_scale, -v, v)
+// (reference tools/scripts.py:211-218 unscales, then clamps).  NaN stays NaN (the step is skipped by the found-inf flag anyway).
+__global__ __launch_bounds__(256) void grad_clip_value_kernel(float* __restrict__ g, size_t n, const float* __restrict__ inv_scale,
+                                                              float value) {
+    const float is = inv_scale ? inv_scale[0] : 1.f;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += gstride) {
+        f32x4 gv = *reinterpret_cast<f32x4*>(g + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float u = gv[k] * is;
+            gv[k] = u != u ? u : fminf(fmaxf(u, -value), value);
+        }
+        *reinterpret_cast<f32x4*>(g + i) = gv;
+    }
+}
+
 // GradScaler.update(): state = {scale, growth_tracker}
 __global__ void scaler_update_kernel(float* __restrict__ state, const float* __restrict__ found_inf,
                                      float growth, float backoff, int interval) {
@@ -194,6 +211,15 @@ int grad_clip_scale(float* g, size_t n, const float* sumsq, const float* inv_sca
     if (b < 1) b = 1;
     hipLaunchKernelGGL(grad_clip_scale_kernel, dim3((unsigned)b), dim3(256), 0, st, g, n, sumsq, inv_scale, (float)max_norm);
     return check_launch("grad_clip_scale");
+}
+
+int grad_clip_value(float* g, size_t n, const float* inv_scale, double value, hipStream_t st) {
+    SAICV_REQUIRE(n % 4 == 0 && value > 0, "grad_clip_value: length %zu must be a multiple of 4, the bound positive", n);
+    size_t b = (n / 4 + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(grad_clip_value_kernel, dim3((unsigned)b), dim3(256), 0, st, g, n, inv_scale, (float)value);
+    return check_launch("grad_clip_value");
 }
 
 int scaler_update(float* state, const float* found_inf, double growth, double backoff, int interval,

@@ -245,6 +245,12 @@ class _FlatOptimizer:
         check(lib().saicv_grad_clip_scale(ptr(self.arena.flat_grad), self.arena.total, ptr(self.sumsq),
                                           ptr(inv_scale), float(max_norm), _lib.stream()), 'grad_clip_scale')
 
+    def clip_grad_value_(self, clip_value, inv_scale=None):
+        """torch.nn.utils.clip_grad_value_ over the whole arena, fused with the unscale (the reference unscales first)."""
+        ops.join_side_stream()
+        check(lib().saicv_grad_clip_value(ptr(self.arena.flat_grad), self.arena.total, ptr(inv_scale), float(clip_value),
+                                          _lib.stream()), 'grad_clip_value')
+
     def step(self, inv_scale=None, found_inf=None):
         mask = self.arena.has_grad_mask() if self.track_missing_grads else None
         ops.join_side_stream()

@@ -135,8 +135,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
     lag = getattr(config, 'host_sync_lag', 2)
     scaler = getattr(config, 'scaler', None) if config.use_amp else None
     clip_norm = getattr(config, 'clip_max_norm', 0) or 0
-    if (getattr(config, 'clip_grad_value', 0) or 0) > 0:
-        raise NotImplementedError('clip_grad_value is not used by the hot-path configs')
+    clip_value = getattr(config, 'clip_grad_value', 0) or 0
     pending = collections.deque()
     carried_bad = None
     net = model.module
@@ -207,6 +206,9 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
                 optimizer.check_finite()
                 skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
             inv_scale = scaler.state[2:3] if scaler is not None else None
+            if clip_value > 0:
+                optimizer.clip_grad_value_(clip_value, inv_scale)
+                inv_scale = None
             if clip_norm > 0:
                 optimizer.clip_grad_norm_(clip_norm, inv_scale)
                 inv_scale = None

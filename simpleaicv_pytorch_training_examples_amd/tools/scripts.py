@@ -170,8 +170,9 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
             optimizer.check_finite()
             skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
         inv_scale = scaler.state[2:3] if scaler is not None else None
-        if clip_value > 0:
-            raise NotImplementedError('clip_grad_value is not used by the hot-path configs')
+        if clip_value > 0:             # reference :211-218: unscale, clamp every gradient element, then the norm clip
+            optimizer.clip_grad_value_(clip_value, inv_scale)
+            inv_scale = None
         if clip_norm > 0:
             optimizer.clip_grad_norm_(clip_norm, inv_scale)
             inv_scale = None
@@ -251,8 +252,7 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
     lag = getattr(config, 'host_sync_lag', 2)
     scaler = getattr(config, 'scaler', None) if config.use_amp else None
     clip_norm = getattr(config, 'clip_max_norm', 0) or 0
-    if (getattr(config, 'clip_grad_value', 0) or 0) > 0:
-        raise NotImplementedError('clip_grad_value is not used by the hot-path configs')
+    clip_value = getattr(config, 'clip_grad_value', 0) or 0
     pending = collections.deque()
     carried_bad = None
     keys = None
@@ -303,6 +303,9 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
                 optimizer.check_finite()
                 skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
             inv_scale = scaler.state[2:3] if scaler is not None else None
+            if clip_value > 0:
+                optimizer.clip_grad_value_(clip_value, inv_scale)
+                inv_scale = None
             if clip_norm > 0:
                 optimizer.clip_grad_norm_(clip_norm, inv_scale)
                 inv_scale = None

@@ -47,8 +47,14 @@ def set_seed(seed):
     if torch.cuda.is_available():
         torch.cuda.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
-    # the saicv kernels are deterministic except for the fp32-atomic weight-gradient reduction;
-    # there is no cuDNN/MIOpen autotuning to pin (reference sets cudnn.deterministic here)
+    # The reference asks for deterministic kernels here (cudnn.deterministic = True, tools/utils.py:106-107).  This engine's
+    # counterpart: BatchNorm statistics are summed in a FIXED order (one partial row per tile row + the finalize kernels)
+    # instead of being added with fp32 atomics into a few pooled rows (ops.BN_INLINE, the 0.35-0.4 ms faster default of the
+    # benchmark) -- unless SAICV_BN_INLINE=1 asks for the fast path explicitly.  What stays order-dependent: the fp32-atomic
+    # split reduction of the weight gradients ("Deviations").  There is no autotuning to pin.
+    from .. import ops
+    if os.environ.get('SAICV_BN_INLINE') is None:
+        ops.BN_INLINE = False
 
 
 def worker_seed_init_fn(worker_id, num_workers, local_rank, seed):

@@ -201,6 +201,28 @@ def test_clip_grad_norm_and_unscale_match_torch():
             assert rel_err(a.grad, b.grad) < 5e-6, (max_norm, scale, n)
 
 
+def test_clip_grad_value_and_unscale_match_torch():
+    """clip_grad_value of the loops (reference tools/scripts.py:211-218: GradScaler.unscale_, then
+    torch.nn.utils.clip_grad_value_, then -- if configured -- the norm clip)."""
+    from simpleaicv_pytorch_training_examples_amd import engine
+    gpu, cpu = _pair()
+    opt = engine.SGD(gpu, [{'params': list(gpu.parameters())}], lr=0.1, momentum=0.0)
+    arena = opt.arena
+    for value, scale in ((0.05, 1.0), (1e9, 1.0), (0.3, 65536.0)):
+        _set_grads(gpu, cpu, arena, 600, scale=scale)
+        inv = torch.tensor([1.0 / scale], device='cuda')
+        opt.clip_grad_value_(value, inv if scale != 1.0 else None)
+        for p in cpu.parameters():
+            p.grad.mul_(1.0 / scale)
+        torch.nn.utils.clip_grad_value_(list(cpu.parameters()), value)
+        torch.cuda.synchronize()
+        clipped = 0
+        for (n, a), b in zip(gpu.named_parameters(), cpu.parameters()):
+            assert torch.equal(a.grad.cpu(), b.grad), (value, scale, n)          # a product and a clamp: bit-identical
+            clipped += int((b.grad.abs() == value).sum())
+        assert (clipped > 0) == (value < 1e9)
+
+
 def test_grad_scaler_follows_torch_amp_grad_scaler():
     """Same sequence of clean / overflowing steps through torch.amp.GradScaler (on plain GPU tensors and
     torch.optim.SGD) and through engine.GradScaler + the flat SGD: identical scale after every update, identical

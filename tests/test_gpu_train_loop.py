@@ -375,3 +375,141 @@ def test_step_graph_replays_the_same_training_as_eager_launches():
     for i, (a, b, c) in enumerate(zip(eager, graph, eager2)):
         assert abs(a - b) < max(3 * abs(a - c), 3 * spread, 0.1 * max(abs(a), 0.1)), (i, a, b, c)
     assert eager[-1] < eager[0] * 0.7 and graph[-1] < graph[0] * 0.7               # both learn
+
+
+def _gate_trajectory(got, fx, first_tol, floor):
+    ref, noise = fx['losses'], fx['reference_noise']['loss_rel']
+    assert len(got) == len(ref)
+    report, worst = [], 0.0
+    for i, (a, b) in enumerate(zip(got, ref)):
+        err = abs(a - b) / abs(b)
+        gate = first_tol if i == 0 else max(floor, 4 * max(noise[:i + 1]))
+        report.append(f'{i}:{err:.1e}/{gate:.1e}')
+        assert err < gate, (i, a, b, report)
+        worst = max(worst, err)
+    return worst
+
+
+def _spy_average_meter():
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import common
+    got, orig = [], common.AverageMeter.update
+
+    def spy(self, val, n=1):
+        got.append(float(val))
+        return orig(self, val, n)
+
+    common.AverageMeter.update = spy
+    return got, lambda: setattr(common.AverageMeter, 'update', orig)
+
+
+def test_detection_loop_follows_the_reference_loop():
+    """8 fp32 iterations of resnet18_detr (dropout 0) through THIS package's train_detection / AdamW / Scheduler / norm clip
+    against the per-iteration total losses the reference's own tools/scripts.py:900-1092 produced on CPU for the same weights
+    and batches (oracle/make_golden_traj_det_sam.py).  Gate: 1e-3 on the first iteration (north_star), afterwards
+    max(2e-3, 4 x how far the reference moved from ITSELF by then under another thread count -- the Hungarian assignment
+    makes the trajectory chaotic: 6.6e-3 by iteration 7)."""
+    from conftest import load_golden
+    from oracle.make_golden_detr import detr_inputs, zero_dropout
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import detr
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts, utils
+    fx = load_golden('traj_detr_r18_tiny')
+    steps, batch = fx['config']['steps'], fx['config']['batch']
+
+    class config:
+        pass
+    config.network = 'resnet18_detr'
+    config.optimizer = ('AdamW', {'lr': 1e-4, 'global_weight_decay': False, 'weight_decay': 1e-4, 'no_weight_decay_layer_name_list': []})
+    config.scheduler = ('MultiStepLR', {'warm_up_epochs': 0, 'gamma': 0.1, 'milestones': [100]})
+    config.epochs, config.batch_size, config.accumulation_steps, config.print_interval = 1, batch, 1, 1
+    config.use_amp, config.use_ema_model, config.local_rank, config.gpus_num, config.group = False, False, 0, 1, None
+    config.clip_max_norm, config.sync_bn, config.host_sync_lag = 0.1, False, 2
+    torch.manual_seed(0)
+    model = detr.resnet18_detr(hidden_inplanes=256, query_nums=20, num_classes=20)
+    zero_dropout(model)
+    model = model.cuda()
+    optimizer, _ = utils.build_optimizer(config, model)
+    scheduler = utils.Scheduler(config, optimizer)
+    model, config.ema_model, config.scaler = utils.build_training_mode(config, model)
+    batches = []
+    for s in range(steps):
+        images, masks, annots = detr_inputs(batch, 1000 + s)
+        batches.append({'image': images, 'annots': annots, 'scaled_annots': annots, 'mask': masks})
+
+    class Loader(list):
+        dataset = [None] * (steps * batch)
+
+    got, restore = _spy_average_meter()
+    try:
+        avg = scripts.train_detection(Loader(batches), model, DETRLoss(num_classes=20), optimizer, scheduler, 1,
+                                      logging.getLogger('saicv_traj_detr'), config)
+    finally:
+        restore()
+    worst = _gate_trajectory(got, fx, 1e-3, 2e-3)
+    print(f'[detection trajectory] worst relative loss error {worst:.2e}; reference self-noise up to '
+          f'{max(fx["reference_noise"]["loss_rel"]):.2e}')
+    assert abs(avg - fx['avg_loss']) / fx['avg_loss'] < max(2e-3, 4 * max(fx['reference_noise']['loss_rel']))
+    assert abs(scheduler.current_lr - fx['lr']) < 1e-12
+
+
+@pytest.mark.parametrize('regime', ['all', 'iters'])
+def test_sam_loop_follows_the_reference_loop(regime, monkeypatch):
+    """6 fp32 iterations of the tiny SAM through THIS package's train_sam_segmentation against the reference's own loop
+    (tools/interactive_segmentation_scripts.py:274-564; oracle/make_golden_traj_det_sam.py).  'all': point + box + mask prompts,
+    one decoder pass.  'iters': point + box, then two more decoder passes; the click of those passes is random in both
+    implementations (different generators), so fixture and test both use the deterministic `first_error_click` rule -- the
+    sampler itself is tested in tests/test_gpu_input.py.  The reference's two runs agree to 1e-7: the gate is 2e-3."""
+    import numpy as np
+    from conftest import load_golden
+    from oracle.make_golden_sam import SAM_TINY, sam_inputs
+    from oracle.make_golden_traj_det_sam import first_error_click, sam_config
+    from oracle.torch_oracle import sam_randomize_zero_init
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation import losses
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.models.segment_anything import sam
+    from simpleaicv_pytorch_training_examples_amd.tools import interactive_segmentation_scripts as iss, utils
+    fx = load_golden('traj_sam_tiny')[regime]
+    steps, batch = fx['config']['steps'], fx['config']['batch']
+    ref_cfg = sam_config(regime)
+
+    class config:
+        pass
+    for k, v in vars(ref_cfg).items():
+        setattr(config, k, v)
+    config.network, config.sync_bn, config.find_unused_parameters, config.host_sync_lag = 'sam_tiny', False, True, 2
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = sam.SAM(**SAM_TINY)
+    sam_randomize_zero_init(net.named_parameters(), 100)
+    net = net.cuda()
+    optimizer, _ = utils.build_optimizer(config, net)
+    scheduler = utils.Scheduler(config, optimizer)
+    model, _, config.scaler = utils.build_training_mode(config, net)
+
+    def click(gt_masks, mask_logits=None, channel=None, gt_threshold=0.5, pred_threshold=0.0, seed=None):
+        pred = None
+        if mask_logits is not None:
+            idx = channel if channel is not None else torch.zeros(mask_logits.shape[0], dtype=torch.long, device=mask_logits.device)
+            pred = (mask_logits[torch.arange(mask_logits.shape[0], device=mask_logits.device), idx].unsqueeze(1).float() > pred_threshold)
+        return first_error_click(gt_masks > gt_threshold, pred)
+
+    monkeypatch.setattr(iss, 'sample_error_click', click)
+    batches = []
+    q = SAM_TINY['image_size'] // 4
+    for s in range(steps):
+        images, masks, points, boxes = sam_inputs(SAM_TINY, batch, 2000 + s)
+        batches.append({'image': images, 'mask': masks, 'prompt_point': points, 'prompt_box': boxes,
+                        'prompt_mask': torch.nn.functional.interpolate(masks, size=(q, q), mode='nearest')})
+
+    class Loader(list):
+        dataset = [None] * (steps * batch)
+
+    got, restore = _spy_average_meter()
+    try:
+        avg = iss.train_sam_segmentation(Loader(batches), model, losses.SAMLoss(alpha=0.25, gamma=2, focal_loss_weight=20,
+                                         dice_loss_weight=1, iou_predict_loss_weight=1, supervise_all_iou=True,
+                                         mask_threshold=0.0), optimizer, scheduler, 1, logging.getLogger('saicv_traj_sam'), config)
+    finally:
+        restore()
+    worst = _gate_trajectory(got, fx, 1e-3, 2e-3)
+    print(f'[sam trajectory {regime}] worst relative loss error {worst:.2e}')
+    assert abs(avg - fx['avg_loss']) / fx['avg_loss'] < 2e-3
