@@ -283,7 +283,9 @@ def test_native_rccl_communicator_in_a_world_of_one():
     assert out['param_err'] <= max(3 * out['noise'], 1e-6), out
     # (atomically accumulated BatchNorm statistics: two runs of the SAME code differ by `loss_noise`; 3 x that held in five of
     # six driver runs, 3.5 x showed up once -- the gate is 5 x)
-    assert max(abs(a - b) for a, b in zip(out['loss_ddp'], out['loss_ref'])) <= max(5 * out['loss_noise'], 1e-5), out
+    # ... and the noise estimate itself comes from ONE pair of runs (5.9e-4 to 2.0e-3 from box to box): a relative floor of
+    # 5e-3 of the loss (four steps of bf16 training at lr 0.05 on the atomically reduced weight gradients)
+    assert all(abs(a - b) <= max(5 * out['loss_noise'], 5e-3 * abs(b), 1e-5) for a, b in zip(out['loss_ddp'], out['loss_ref'])), out
 
 
 def test_bench_spawns_the_ranks_it_is_asked_for():
