@@ -1677,6 +1677,254 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_kernel(const TNParams
     }
 }
 
+// ------------------------------------------------------------------------------------ TN, LDS-DMA ring (bf16)
+// The weight-gradient product with the operand stream of the forward kernel: `buffer_load ... lds` writes the dY and
+// gather-source rows of a 32-row reduction step straight into a 4-slot LDS ring (no staging registers, no ds_write),
+// three steps stay in flight across the single raw s_barrier of a step and the wait is a counted s_waitcnt vmcnt(N).
+// The register-staged kernel above keeps ONE step (64 rows) in flight: at one resident 256 x 256 workgroup per CU its
+// 0.85 us of MFMA work per step is shorter than a loaded L2/HBM round trip, so its loop runs at the latency, not at the
+// matrix cores (620-700 TFLOP/s on the ViT shapes where the forward kernel reaches 800-900).
+// LDS image of a step: [32 rows][BA] then [32 rows][BB], rows unpadded (the DMA destination is wave-linear, 1 KiB per
+// instruction).  ds_read_b64_tr_b16 is served in 32-lane groups that read rows {R..R+3, R+8..R+11}, 32 bytes each, at
+// one column offset: the 32-byte PAIR p of row r lives at pair slot p ^ g(r), g = (r & 3) | ((r >> 3) & 1) << 2 (halved
+// for 128-byte rows, where two rows share a 256-byte bank window), so the eight rows hit eight distinct bank groups.
+// As everywhere, the swizzle is applied on the SOURCE side: lane l fetches the chunk that belongs in the slot it fills.
+// Bias gradient: the workgroups of the first kk tile multiply their dY fragments with a ones operand (AT / NWB extra
+// MFMAs per wavefront and step) instead of summing staged registers.
+DEVINL int tn_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+template <int CPR> DEVINL int tn_g(int r) { return CPR >= 16 ? tn_key(r) : (tn_key(r) >> 1); }
+
+template <int BA, int BB, int NWA, int NWB, bool PLAIN>
+__global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNParams p) {
+    typedef bf16_t T;
+    constexpr int NWAVES = NWA * NWB;
+    constexpr int BR = 32;                                 // reduction rows per step: one MFMA k-step
+    constexpr int CPR_A = BA / 8, CPR_B = BB / 8;           // 16-byte chunks per row
+    constexpr int RPI_A = 64 / CPR_A, RPI_B = 64 / CPR_B;   // rows filled by one DMA wave-instruction
+    constexpr int NIA = (BR / RPI_A) / NWAVES, NIB = (BR / RPI_B) / NWAVES;
+    static_assert(NIA >= 1 && NIB >= 1 && NIA * NWAVES * RPI_A == BR && NIB * NWAVES * RPI_B == BR, "tile / wavefront split");
+    constexpr int LPT = NIA + NIB;                          // loads per thread per step
+    constexpr int PITCH_A = BA * 2, PITCH_B = BB * 2;
+    constexpr int A_BYTES = BR * PITCH_A, B_BYTES = BR * PITCH_B;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NSTAGE = 4;
+    constexpr int WA = BA / NWA, WB = BB / NWB;
+    constexpr int AT = WA / 16, BT = WB / 16;
+    static_assert(AT % NWB == 0, "bias-gradient tiles per wavefront");
+    constexpr int ABT = AT / NWB;
+    constexpr uint32_t OOB = 0xfffffff0u;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave % NWA, wb = wave / NWA;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int ntile = gridDim.x;
+    const int lid = xcd_remap(blockIdx.y * ntile + blockIdx.x, ntile * gridDim.y);
+    const int split = lid / ntile;
+    const int tile = lid - split * ntile;
+    const int tile_a = tile % p.tiles_a;
+    const int tile_b = tile / p.tiles_a;
+    const int m_begin = split * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+    if (m_begin >= m_end) return;
+
+    const __amdgpu_buffer_rsrc_t dy_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t src_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
+
+    // ---- per-thread DMA state.  Instruction i of wavefront w fills bytes [(i*NWAVES + w)*1024 + lane*16, +16) of a
+    // region: row (i*NWAVES + w)*RPI + lane/CPR, slot lane%CPR, i.e. the logical chunk slot ^ (g(row) << 1)
+    uint32_t a_off[NIA];
+    int a_m[NIA];
+    bool a_ok[NIA];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int row = (i * NWAVES + wave) * RPI_A + lane / CPR_A;
+        const int chunk = (lane % CPR_A) ^ (tn_g<CPR_A>(row) << 1);
+        const int n = tile_a * BA + chunk * 8;
+        a_ok[i] = n < p.Cout;
+        a_m[i] = m_begin + row;
+        a_off[i] = (uint32_t)((m_begin + row) * p.Cout + n) * 2u;
+    }
+    const uint32_t a_step = (uint32_t)(BR * p.Cout) * 2u;
+    uint32_t b_off[NIB];                 // PLAIN: byte offset, advanced per step
+    int b_m[NIB], g_img[NIB], g_oh[NIB], g_ow[NIB], b_fr[NIB], b_fs[NIB], b_c0[NIB];
+    bool b_ok[NIB];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < NIB; ++j) {
+        const int row = (j * NWAVES + wave) * RPI_B + lane / CPR_B;
+        const int chunk = (lane % CPR_B) ^ (tn_g<CPR_B>(row) << 1);
+        const int kk = tile_b * BB + chunk * 8;
+        b_ok[j] = kk < p.Kd;
+        const int m = m_begin + row;
+        b_m[j] = m;
+        if (PLAIN) {
+            b_off[j] = (uint32_t)(m * p.C + kk) * 2u;
+            g_img[j] = g_oh[j] = g_ow[j] = b_fr[j] = b_fs[j] = b_c0[j] = 0;
+        } else {
+            const int tap = kk / p.C;
+            b_c0[j] = kk - tap * p.C;
+            b_fr[j] = tap / p.S - p.pad;
+            b_fs[j] = tap - (tap / p.S) * p.S - p.pad;
+            const int img = (int)fdiv((uint32_t)m, p.fd_ohw);
+            const int rem = m - img * ohw;
+            g_img[j] = img;
+            g_oh[j] = (int)fdiv((uint32_t)rem, p.fd_ow);
+            g_ow[j] = rem - g_oh[j] * p.OW;
+            b_off[j] = 0;
+        }
+    }
+    const uint32_t b_step = (uint32_t)(BR * p.C) * 2u;
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue_step = [&](int stage) __attribute__((always_inline)) {
+        char* base = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const bool ok = a_ok[i] & (a_m[i] < m_end);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rs, (lds_void*)(base + i * NWAVES * 1024), 16, (int)(ok ? a_off[i] : OOB), 0, 0, 0);
+            a_off[i] += a_step;
+            a_m[i] += BR;
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            if (PLAIN) {
+                const bool ok = b_ok[j] & (b_m[j] < m_end);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + A_BYTES + j * NWAVES * 1024), 16, (int)(ok ? b_off[j] : OOB), 0, 0, 0);
+                b_off[j] += b_step;
+            } else {
+                const int ih = g_oh[j] * p.stride + b_fr[j];
+                const int iw = g_ow[j] * p.stride + b_fs[j];
+                const bool ok = b_ok[j] & (b_m[j] < m_end) & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+                const uint32_t off = (uint32_t)(((g_img[j] * p.H + ih) * p.W + iw) * p.C + b_c0[j]) * 2u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + A_BYTES + j * NWAVES * 1024), 16, (int)(ok ? off : OOB), 0, 0, 0);
+                int ow = g_ow[j] + p.d_ow;            // advance this row by BR pixels (mixed-radix add with carries)
+                int cy = ow >= p.OW;
+                ow -= cy ? p.OW : 0;
+                int oh = g_oh[j] + p.d_oh + cy;
+                cy = oh >= p.OH;
+                oh -= cy ? p.OH : 0;
+                g_ow[j] = ow;
+                g_oh[j] = oh;
+                g_img[j] += p.d_img + cy;
+            }
+            b_m[j] += BR;
+        }
+    };
+
+    f32x4 acc[AT][BT];
+#pragma unroll
+    for (int ai = 0; ai < AT; ++ai)
+#pragma unroll
+        for (int bi = 0; bi < BT; ++bi) acc[ai][bi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (p.dbias != nullptr) && (tile_b == 0);
+    f32x4 bacc[ABT];
+#pragma unroll
+    for (int t = 0; t < ABT; ++t) bacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment offsets within a step: rows row0 .. row0+3 (and +4), 16 columns = one 32-byte pair
+    const int row0 = lg * 8 + (l15 >> 2);
+    int fa_off[AT], fb_off[BT];
+#pragma unroll
+    for (int ai = 0; ai < AT; ++ai)
+        fa_off[ai] = row0 * PITCH_A + (((wa * AT + ai) ^ tn_g<CPR_A>(row0)) << 5) + (l15 & 3) * 8;
+#pragma unroll
+    for (int bi = 0; bi < BT; ++bi)
+        fb_off[bi] = A_BYTES + row0 * PITCH_B + (((wb * BT + bi) ^ tn_g<CPR_B>(row0)) << 5) + (l15 & 3) * 8;
+
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    // The transposed fragment reads are spelled as asm: behind the BUILTIN the compiler waits vmcnt(0) (an LDS access it can
+    // see while LDS-DMA writes are pending), which would drain the whole ring every step.  All reads of a step are issued at
+    // once; a counted lgkmcnt wait tied to the B fragment of column bi releases that column's MFMAs (LDS returns in order,
+    // and the A fragments were issued first).
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + stage * STAGE);
+        u32x2 alo[AT], ahi[AT], blo[BT], bhi[BT];
+#pragma unroll
+        for (int ai = 0; ai < AT; ++ai) {
+            const uint32_t q = base + (uint32_t)fa_off[ai];
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                         : "=&v"(alo[ai]), "=&v"(ahi[ai]) : "v"(q), "n"(4 * PITCH_A) : "memory");
+        }
+#pragma unroll
+        for (int bi = 0; bi < BT; ++bi) {
+            const uint32_t q = base + (uint32_t)fb_off[bi];
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                         : "=&v"(blo[bi]), "=&v"(bhi[bi]) : "v"(q), "n"(4 * PITCH_B) : "memory");
+        }
+        u32x4 af[AT];
+#pragma unroll
+        for (int bi = 0; bi < BT; ++bi) {
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blo[bi]), "+v"(bhi[bi]) : "n"(2 * (BT - 1 - bi)) : "memory");
+            if (bi == 0) {
+#pragma unroll
+                for (int ai = 0; ai < AT; ++ai) af[ai] = u32x4{alo[ai][0], alo[ai][1], ahi[ai][0], ahi[ai][1]};
+            }
+            const u32x4 bf = {blo[bi][0], blo[bi][1], bhi[bi][0], bhi[bi][1]};
+#pragma unroll
+            for (int ai = 0; ai < AT; ++ai)
+                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[ai]),
+                                                                      __builtin_bit_cast(bf16x8, bf), acc[ai][bi], 0, 0, 0);
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int t = 0; t < ABT; ++t)
+                bacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[wb * ABT + t]),
+                                                                  __builtin_bit_cast(bf16x8, ones), bacc[t], 0, 0, 0);
+        }
+    };
+
+    const int nt = (m_end - m_begin + BR - 1) / BR;
+    int issued = 0;
+    for (; issued < NSTAGE - 1 && issued < nt; ++issued) issue_step(issued);
+    int st_c = 0;
+    int st_i = issued % NSTAGE;
+    for (int t = 0; t < nt; ++t) {
+        const int ahead = issued - t - 1;          // wave-uniform
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // everyone's part of step t landed; step t-1 is fully consumed
+        if (issued < nt) {
+            issue_step(st_i);
+            ++issued;
+            st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+        }
+        compute(st_c);
+        st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
+    }
+
+    if (do_bias && l15 == 0) {      // every column of bacc holds the row sums: D row -> n = .. + lg*4 + r
+#pragma unroll
+        for (int t = 0; t < ABT; ++t) {
+            const int n0 = tile_a * BA + wa * WA + (wb * ABT + t) * 16 + lg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.Cout) unsafeAtomicAdd(p.dbias + n0 + r, bacc[t][r]);
+        }
+    }
+    // epilogue: D row -> n = .. + lg*4 + r ; D col -> kk = .. + l15
+#pragma unroll
+    for (int ai = 0; ai < AT; ++ai) {
+        const int n0 = tile_a * BA + wa * WA + ai * 16 + lg * 4;
+#pragma unroll
+        for (int bi = 0; bi < BT; ++bi) {
+            const int kk = tile_b * BB + wb * WB + bi * 16 + l15;
+            if (kk < p.Kd) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < p.Cout)
+                        unsafeAtomicAdd(p.dw + (size_t)(n0 + r) * (size_t)p.Kd + kk, acc[ai][bi][r]);
+            }
+        }
+    }
+}
+
 FastDiv make_fastdiv(uint32_t d) {
     FastDiv f;
     uint32_t l = 0;
@@ -1852,6 +2100,24 @@ int launch_tn(const TNParams& p, int splits, hipStream_t st) {
     static bool once = (allow_lds(k, smem), true);
     (void)once;
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    return saicv::check_launch("igemm_tn");
+}
+
+template <int BA, int BB, int NWA = 2, int NWB = 2>
+int launch_tn_dma(const TNParams& p, int splits, bool plain, hipStream_t st) {
+    constexpr size_t smem = 4 * (size_t)32 * (BA + BB) * 2;
+    dim3 grid(p.tiles_a * p.tiles_b, splits), block(64 * NWA * NWB);
+    if (plain) {
+        auto k = igemm_tn_dma_kernel<BA, BB, NWA, NWB, true>;
+        static bool once = (allow_lds(k, smem), true);
+        (void)once;
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    } else {
+        auto k = igemm_tn_dma_kernel<BA, BB, NWA, NWB, false>;
+        static bool once = (allow_lds(k, smem), true);
+        (void)once;
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    }
     return saicv::check_launch("igemm_tn");
 }
 
@@ -2046,6 +2312,21 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     const int rem = BR - p.d_img * ohw;
     p.d_oh = rem / OW;
     p.d_ow = rem - p.d_oh * OW;
+    // bf16: the LDS-DMA ring kernel (32-row steps; SAICV_TN_DMA=0 selects the register-staged kernel for A/B runs)
+    static const int use_dma = getenv("SAICV_TN_DMA") ? atoi(getenv("SAICV_TN_DMA")) : 1;
+    if (use_dma && dtype == SAICV_DTYPE_BF16) {
+        const int br = 32;
+        p.d_img = br / ohw;
+        const int rem32 = br - p.d_img * ohw;
+        p.d_oh = rem32 / OW;
+        p.d_ow = rem32 - p.d_oh * OW;
+        const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0 && H == OH && W == OW;
+        if (big) return launch_tn_dma<256, 256, 2, 4>(p, splits, plain, st);
+        if (ba == 64 && bb == 64) return launch_tn_dma<64, 64>(p, splits, plain, st);
+        if (ba == 64) return launch_tn_dma<64, 128>(p, splits, plain, st);
+        if (bb == 64) return launch_tn_dma<128, 64>(p, splits, plain, st);
+        return launch_tn_dma<128, 128>(p, splits, plain, st);
+    }
     if (big) {
         if (dtype == SAICV_DTYPE_BF16) return launch_tn<bf16_t, 256, 256, 2, 4>(p, splits, st);
         return launch_tn<float, 256, 256, 2, 4>(p, splits, st);
