@@ -569,6 +569,240 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(const T* __r
     }
 }
 
+// ------------------------------------------------------------------------ backward, bf16, two tiles per wavefront
+// Same three phases as above with the instruction mix turned around: the one-tile kernel issues ~104 VALU and 16 LDS
+// instructions per 12 MFMAs (address swizzles, masks, scalar stores) and runs at the VALU / LDS rate.  Here
+//  * a wavefront owns TWO 16-row tiles (32 queries in phase A, 32 keys in phase B) that share every LDS fragment read;
+//  * every LDS address is a lane constant plus a block offset (a 32-row block is 4096 bytes and the swizzle only looks
+//    at row bits below that);
+//  * no masks: padded K / V / Q / dO rows are zero in LDS, so whatever the softmax recomputation produces for them
+//    multiplies zeros (their own output rows are never stored);
+//  * the 1/sqrt(d) factor is applied once to the finished dQ / dK tiles;
+//  * outputs are computed TRANSPOSED (A = operand^T fragment, B = probabilities), so a lane ends up with four consecutive
+//    d of one row and stores 8 bytes instead of four scattered 2-byte elements.
+// 4 wavefronts per workgroup, two workgroups per CU (LDS), pairs of tiles dealt round-robin to the wavefronts.
+constexpr int ATT2_THREADS = 256;
+
+DEVINL u32x4 tr_pair(const char* q) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 2048));
+    const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+    return u32x4{a[0], a[1], b[0], b[1]};
+}
+DEVINL f32x4 mma2(const u32x4 (&a)[2], const u32x4 (&b)[2]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    Mma<bf16_t>::run(acc, a[0], b[0]);
+    Mma<bf16_t>::run(acc, a[1], b[1]);
+    return acc;
+}
+DEVINL void st_bf16x4(bf16_t* dst, const f32x4& v, float mul) {
+    bf16x4 pk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(v[r] * mul);
+    *reinterpret_cast<bf16x4*>(dst) = pk;
+}
+
+__global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                         const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                         bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H;
+    const int C = H * 64, RS = 3 * C;
+    const int Np = (N + 31) & ~31;
+    const int nblk = Np / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    char* M0 = smem;
+    char* M1 = smem + Np * 128;
+    float* Dq = reinterpret_cast<float*>(smem + 2 * Np * 128);
+    float* Ls = Dq + Np;
+    const T* qb = qkv + (size_t)b * N * RS + h * 64;
+    const T* ob = out + (size_t)b * N * C + h * 64;
+    const T* dob = dout + (size_t)b * N * C + h * 64;
+    T* dqb = dqkv + (size_t)b * N * RS + h * 64;
+    constexpr int NW = ATT2_THREADS / 64;
+
+    // ---- phase 0: D[q] = dO[q] . O[q], two threads per query row; log-sum-exp in log2 units
+    for (int i = threadIdx.x; i < Np * 2; i += ATT2_THREADS) {
+        const int q = i >> 1, hf = i & 1;
+        float d = 0.f;
+        if (q < N) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a[8], o[8];
+                Chunk<T>::unpack(ld_chunk(dob + (size_t)q * C + (hf * 4 + c) * 8), a);
+                Chunk<T>::unpack(ld_chunk(ob + (size_t)q * C + (hf * 4 + c) * 8), o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d += a[k] * o[k];
+            }
+        }
+        d += __shfl_xor(d, 1, 64);
+        if (hf == 0) {
+            Dq[q] = d;
+            Ls[q] = q < N ? lse[((size_t)b * H + h) * N + q] * 1.4426950408889634f : 0.f;
+        }
+    }
+    attn_stage<T>(M0, qb + C, RS, N, Np);          // K
+    attn_stage<T>(M1, qb + 2 * C, RS, N, Np);      // V
+    __syncthreads();
+
+    // lane constants: row-fragment chunk (row l15 of a tile, chunks s*4 + lg) and transposed-read address (rows
+    // lg*4 + (l15>>2) and +16 of a 32-row block, 16 columns dt*16..)
+    int rf[2], tro[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) rf[s] = l15 * 128 + ((((s * 4 + lg) ^ (l15 >> 1)) & 7) << 4);
+    {
+        const int trow = lg * 4 + (l15 >> 2);
+        const int tsw = (trow >> 1) & 7;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) tro[dt] = trow * 128 + ((((dt * 2 + ((l15 & 3) >> 1)) ^ tsw) & 7) << 4) + ((l15 & 1) << 3);
+    }
+    const float c2 = scale * 1.4426950408889634f;
+    const int npair = nblk;                        // pairs of 16-row tiles = 32-row blocks
+
+    // ---- phase A: dQ for the 32 queries of a pair; S^T tiles (rows keys, column = this lane's query)
+    for (int pr = wave; pr < npair; pr += NW) {
+        u32x4 qf[2][2], dof[2][2];
+        float lq[2], dqv[2];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int row = pr * 32 + qi * 16 + l15;
+            const bool ok = row < N;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qf[qi][s] = ok ? ld_chunk(qb + (size_t)row * RS + (s * 4 + lg) * 8) : zero_chunk();
+                dof[qi][s] = ok ? ld_chunk(dob + (size_t)row * C + (s * 4 + lg) * 8) : zero_chunk();
+            }
+            lq[qi] = Ls[row];
+            dqv[qi] = Dq[row];
+        }
+        f32x4 o[2][4];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[qi][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int blk = 0; blk < nblk; ++blk) {
+            const char* kb = M0 + blk * 4096;
+            const char* vb = M1 + blk * 4096;
+            u32x4 kf[2][2], vf[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    kf[t][s] = ld_chunk(kb + t * 2048 + rf[s]);
+                    vf[t][s] = ld_chunk(vb + t * 2048 + rf[s]);
+                }
+            u32x4 kT[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) kT[dt] = tr_pair(kb + tro[dt]);
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+                f32x4 ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 sv = mma2(kf[t], qf[qi]);
+                    const f32x4 dp = mma2(vf[t], dof[qi]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[t][r] = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq[qi])) * (dp[r] - dqv[qi]);
+                }
+                const u32x4 pa = pack_p(ds[0], ds[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) Mma<T>::run(o[qi][dt], kT[dt], pa);      // dQ^T: rows d, column query
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int row = pr * 32 + qi * 16 + l15;
+            if (row < N) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) st_bf16x4(dqb + (size_t)row * RS + dt * 16 + lg * 4, o[qi][dt], scale);
+            }
+        }
+    }
+    __syncthreads();
+    attn_stage<T>(M0, qb, RS, N, Np);              // Q
+    attn_stage<T>(M1, dob, C, N, Np);              // dO
+    __syncthreads();
+
+    // ---- phase B: dK, dV for the 32 keys of a pair; tiles with rows = queries, column = this lane's key
+    for (int pr = wave; pr < npair; pr += NW) {
+        u32x4 kf[2][2], vf[2][2];
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+            const int row = pr * 32 + ki * 16 + l15;
+            const bool ok = row < N;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kf[ki][s] = ok ? ld_chunk(qb + C + (size_t)row * RS + (s * 4 + lg) * 8) : zero_chunk();
+                vf[ki][s] = ok ? ld_chunk(qb + 2 * C + (size_t)row * RS + (s * 4 + lg) * 8) : zero_chunk();
+            }
+        }
+        f32x4 dv[2][4], dk[2][4];
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dv[ki][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[ki][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int blk = 0; blk < nblk; ++blk) {
+            const char* qp = M0 + blk * 4096;
+            const char* dp_ = M1 + blk * 4096;
+            u32x4 qf[2][2], dof[2][2];
+            f32x4 Lv[2], Dv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    qf[t][s] = ld_chunk(qp + t * 2048 + rf[s]);
+                    dof[t][s] = ld_chunk(dp_ + t * 2048 + rf[s]);
+                }
+                Lv[t] = *reinterpret_cast<const f32x4*>(Ls + blk * 32 + t * 16 + lg * 4);
+                Dv[t] = *reinterpret_cast<const f32x4*>(Dq + blk * 32 + t * 16 + lg * 4);
+            }
+            u32x4 doT[4], qT[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                doT[dt] = tr_pair(dp_ + tro[dt]);
+                qT[dt] = tr_pair(qp + tro[dt]);
+            }
+#pragma unroll
+            for (int ki = 0; ki < 2; ++ki) {
+                f32x4 pt[2], dst_[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 sv = mma2(qf[t], kf[ki]);
+                    const f32x4 dpp = mma2(dof[t], vf[ki]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -Lv[t][r]));
+                        pt[t][r] = p;
+                        dst_[t][r] = p * (dpp[r] - Dv[t][r]);
+                    }
+                }
+                const u32x4 pa = pack_p(pt[0], pt[1]);
+                const u32x4 da = pack_p(dst_[0], dst_[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    Mma<T>::run(dv[ki][dt], doT[dt], pa);      // dV^T: rows d, column key
+                    Mma<T>::run(dk[ki][dt], qT[dt], da);       // dK^T
+                }
+            }
+        }
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+            const int row = pr * 32 + ki * 16 + l15;
+            if (row < N) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    st_bf16x4(dqb + (size_t)row * RS + C + dt * 16 + lg * 4, dk[ki][dt], scale);
+                    st_bf16x4(dqb + (size_t)row * RS + 2 * C + dt * 16 + lg * 4, dv[ki][dt], 1.f);
+                }
+            }
+        }
+    }
+}
+
 inline int sgrid(size_t n) {
     size_t b = (n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -707,6 +941,18 @@ int attention_bwd(int dtype, const void* qkv, const void* out, const void* dout,
                   int B, int N, int H, int D, double scale, hipStream_t st) {
     if (attn_check("attention_bwd", B, N, H, D)) return -1;
     const int Np = (N + 31) & ~31;
+    // bf16: SAICV_ATTN_BWD2=1 selects the two-tiles-per-wavefront kernel.  Measured equal on the ViT-B step (42.58 vs 42.64 ms,
+    // profiles/r03_tn_dma_and_attention.md): half the VALU / LDS instructions per MFMA, but 221 registers leave two
+    // wavefronts per SIMD to hide the three staging round trips of a workgroup, where the one-tile kernel has four.
+    static const int two = getenv("SAICV_ATTN_BWD2") ? atoi(getenv("SAICV_ATTN_BWD2")) : 0;
+    if (dtype == SAICV_DTYPE_BF16 && two) {
+        const size_t smem = (size_t)2 * Np * 128 + 2 * Np * sizeof(float);
+        auto k = attention_bwd2_kernel;
+        static bool once = (allow_lds(k, 2 * 256 * 128 + 2048), true);
+        (void)once;
+        hipLaunchKernelGGL(k, dim3(B * H), dim3(ATT2_THREADS), smem, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, (float)scale);
+        return check_launch("attention_bwd");
+    }
     if (dtype == SAICV_DTYPE_BF16) {
         const size_t smem = (size_t)2 * Np * 128 + 2 * Np * sizeof(float);
         auto k = attention_bwd_kernel<bf16_t>;
