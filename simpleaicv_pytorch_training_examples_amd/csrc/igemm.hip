@@ -35,6 +35,7 @@ DEVINL uint32_t fdiv(uint32_t n, FastDiv d) {
 // LDS-DMA ring depth per geometry: 4 stages, except 256 x 128 where 3 stages (72 KiB) let TWO workgroups share
 // a CU so that one's epilogue overlaps the other's main loop
 constexpr int nt_stages(int bm, int bn) { return (bm == 256 && bn == 128) ? 3 : 4; }
+constexpr int nt_stages_kc8(int bm, int bn) { return (bm + bn) * 128 * 3 <= 150 * 1024 ? 3 : 2; }      // 128-byte K slices
 // resident workgroups per CU by LDS (the ring is all a workgroup holds: the epilogue stages through a vacated slot)
 // Which instantiations may run persistently (ticket draws hidden from the compiler, see draw_ticket): bf16 in and out,
 // and a register budget in which the compiler spills nothing -- a spilled ticket register would be saved before the atomic
@@ -83,6 +84,7 @@ struct NTParams {
     int tiles_n;
     int nblk;
     int grid_x;         // resident workgroups (256 CUs x workgroups per CU)
+    int kc8;            // host: launch the 128-byte-K-slice instantiation (pointwise bf16, 256-row tiles)
     FastDiv fd_ohw, fd_ow;   // for OH*OW and OW (unit-stride row decomposition)
 };
 
@@ -92,6 +94,10 @@ struct NTParams {
 // the 16 lanes of every group hit 16 distinct 16-byte bank groups.
 DEVINL int lds_swz(int q) { return ((q & 1) << 1) ^ ((q >> 1) * 3); }
 DEVINL int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ lds_swz((row >> 2) & 3)) << 4); }
+// 128-byte rows (KC = 8): chunk c of row r at slot c ^ ((r >> 1) & 7).  Two rows share a 256-byte bank window, and the 16-lane
+// groups of ds_read_b128 mix rows {0-3, 12-15} of chunk c with rows {4-11} of chunk c + 1: per row parity that is eight (row,
+// chunk) pairs whose slots c ^ {0, 1, 6, 7} and (c + 1) ^ {2, 3, 4, 5} are all different.
+DEVINL int lds_off128(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
 
 DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
@@ -834,22 +840,30 @@ void igemm_nt_kernel(const NTParams p) {
 // Tile geometry (BM_T x BN_T output tile, WM_ x WN_ wavefronts, each owning a
 // (BM_T/WM_) x (BN_T/WN_) sub-tile): 256x256 / 2x4, 256x128 / 4x2, 128x128 / 2x2, 128x64 / 2x2.
 // Wider tiles raise flop per LDS-fill byte and the MFMAs issued per barrier and per DMA.
-template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
-__global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT_F32) ? 4 : 1) void igemm_nt1_kernel(const NTParams p) {
+// KC = 16-byte chunks per LDS row = width of the K slice a step loads: 4 (64 bytes, 32 bf16) or 8 (128 bytes).  With 64-byte
+// slices every DMA request is half a cache line; scripts/probes/fill_probe.hip measures what that costs on the fill path
+// alone (profiles/r03_lds_fill_probe.jsonl: 8.7-10 TB/s against 11.5-12.3 TB/s for whole lines when four workgroups share
+// a stream) and the 64-byte kernels sit exactly at that figure.  KC = 8 rows take twice the LDS per step: 3 slots of
+// 48 KiB for the 256 x 128 tile, one workgroup per CU.
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4>
+__global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT_F32 && KC == 4) ? 4 : 1) void igemm_nt1_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
-    constexpr int BK = 4 * EPC;                  // one 64-byte row per K tile
+    constexpr int BK = KC * EPC;                 // one 64- or 128-byte row per K tile
+    constexpr int ROWB = KC * 16;                // bytes of an LDS row
+    constexpr int RPI = 1024 / ROWB;             // tile rows filled by one DMA wave-instruction
     constexpr int NWAVES = WM_ * WN_;
     constexpr int NTHREADS = 64 * NWAVES;
     constexpr int WMR = BM_T / WM_;              // rows of the output tile owned by one wavefront
     constexpr int WN = BN_T / WN_;
     constexpr int NT_ = WN / 16;
     constexpr int MT_ = WMR / 16;
-    constexpr int AROWS = BM_T / 16 / NWAVES;    // A-tile DMA instructions per thread
-    constexpr int WROWS = BN_T / 16 / NWAVES;    // weight-tile DMA instructions per thread
+    constexpr int AROWS = BM_T / RPI / NWAVES;   // A-tile DMA instructions per thread
+    constexpr int WROWS = BN_T / RPI / NWAVES;   // weight-tile DMA instructions per thread
     constexpr int LPT = AROWS + WROWS;           // loads per thread per K tile
-    constexpr int NSTAGE = nt_stages(BM_T, BN_T);
-    constexpr int A_BYTES = BM_T * 64;
-    constexpr int W_BYTES = BN_T * 64;
+    constexpr int NSTAGE = KC == 8 ? nt_stages_kc8(BM_T, BN_T) : nt_stages(BM_T, BN_T);
+    constexpr int A_BYTES = BM_T * ROWB;
+    constexpr int W_BYTES = BN_T * ROWB;
+    static_assert(KC == 4 || (KC == 8 && NWAVES % 2 == 0 && sizeof(T) == 2), "128-byte K slices: bf16, even wavefront count");
     constexpr int STAGE = A_BYTES + W_BYTES;
     constexpr uint32_t OOB = 0xfffffff0u;   // 16-byte aligned, beyond any operand (host checks sizes)
 
@@ -905,12 +919,14 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     // ---- per-thread DMA state.  Wave w, instruction i, lane l fills LDS bytes
     // [(i*NWAVES + w)*1024 + l*16, +16) of the A region: row (i*NWAVES+w)*16 + (l>>2), slot l&3, i.e. the
     // logical chunk (l&3) ^ f((row>>2)&3) = (l&3) ^ f((l>>4)&3) -- one K-chunk column per thread.
-    const int cc = (lane & 3) ^ lds_swz((lane >> 4) & 3);
+    // KC = 8: row (i*NWAVES + wave)*8 + (lane>>3), slot lane&7, logical chunk slot ^ ((row >> 1) & 7); (row >> 1) & 7 =
+    // ((lane >> 4) + 4 * (wave & 1)) & 7 because NWAVES is even -- still one K-chunk column per thread
+    const int cc = KC == 4 ? ((lane & 3) ^ lds_swz((lane >> 4) & 3)) : ((lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7));
     int rowc[AROWS], a0[AROWS], b0[AROWS];   // rowc = (image base + A0*W + B0) * C  [elements]
     const int ohw = Hc * Wc;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-        const int m = tile_m * BM_T + (i * NWAVES + wave) * 16 + (lane >> 2);
+        const int m = tile_m * BM_T + (i * NWAVES + wave) * RPI + lane / KC;
         if (m < Mc) {
             int img, oh, ow;
             if (cs == 1) {
@@ -941,7 +957,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     int wrow[WROWS];                    // weight row base [elements], or -1
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
-        const int n = tile_n * BN_T + (j * NWAVES + wave) * 16 + (lane >> 2);
+        const int n = tile_n * BN_T + (j * NWAVES + wave) * RPI + lane / KC;
         wrow[j] = n < p.Nn ? n * p.Kd : -1;
     }
 
@@ -1016,21 +1032,24 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     const int lg = lane >> 4;
     int fa[MT_], fw[NT_];               // LDS fragment offsets within a stage, hoisted out of the K loop
 #pragma unroll
-    for (int mi = 0; mi < MT_; ++mi) fa[mi] = lds_off(wm * WMR + mi * 16 + l15, lg);
+    for (int mi = 0; mi < MT_; ++mi) fa[mi] = KC == 4 ? lds_off(wm * WMR + mi * 16 + l15, lg) : lds_off128(wm * WMR + mi * 16 + l15, lg);
 #pragma unroll
-    for (int ni = 0; ni < NT_; ++ni) fw[ni] = A_BYTES + lds_off(wn * WN + ni * 16 + l15, lg);
+    for (int ni = 0; ni < NT_; ++ni) fw[ni] = A_BYTES + (KC == 4 ? lds_off(wn * WN + ni * 16 + l15, lg) : lds_off128(wn * WN + ni * 16 + l15, lg));
 
     auto compute = [&](int stage) {
         const char* base = smem + stage * STAGE;
-        u32x4 af[MT_], wf[NT_];
 #pragma unroll
-        for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(base + fa[mi]);
+        for (int ks = 0; ks < KC / 4; ++ks) {        // chunk ks*4 + lg: the swizzle is an XOR, so the second half is offset ^ 64
+            u32x4 af[MT_], wf[NT_];
 #pragma unroll
-        for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(base + fw[ni]);
+            for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(base + (fa[mi] ^ (ks * 64)));
 #pragma unroll
-        for (int ni = 0; ni < NT_; ++ni)
+            for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(base + (fw[ni] ^ (ks * 64)));
 #pragma unroll
-            for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
+            for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
+        }
     };
 
     const int nkt = (Kc + BK - 1) / BK;        // 0 for a class without taps: the output is zero
@@ -1986,9 +2005,9 @@ int launch_nt_stream(NTParams& p, hipStream_t st) {
     return saicv::check_launch("igemm_nt (persistent)");
 }
 
-template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN>
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4>
 void launch_nt1_inst(const NTParams& p, size_t smem, hipStream_t st) {
-    auto k = igemm_nt1_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN>;
+    auto k = igemm_nt1_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN, KC>;
     static bool once = (allow_lds(k, 160 * 1024), true);
     (void)once;
     dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
@@ -2006,6 +2025,14 @@ int launch_nt1(NTParams& p, bool out_f32, hipStream_t st) {
     p.grid_x = p.nblk;
     // pointwise taps without padding: the source pixel of a row never leaves the image
     const bool plain = p.R == 1 && p.S == 1 && p.pad == 0 && (MODE == 0 || p.stride == 1);
+    // 128-byte K slices: chosen by igemm_nt (p.kc8)
+    if constexpr (sizeof(T) == 2 && BM_T == 256) {
+        if (p.kc8 && plain && !out_f32) {
+            constexpr size_t ring = nt_stages_kc8(BM_T, BN_T) * (size_t)(BM_T + BN_T) * 128;
+            launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, true, 8>(p, ring < epi ? epi : ring, st);
+            return saicv::check_launch("igemm_nt");
+        }
+    }
     if (out_f32) {
         if (plain) launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, true, true>(p, smem, st);
         else launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, true, false>(p, smem, st);
@@ -2211,7 +2238,22 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     }
     const int nkt_host = (Kd + 4 * epc - 1) / (4 * epc);      // K tiles (stride > 1 data-gradient classes run fewer)
     const NTPlan pl = nt_plan(dtype, mode, stride, M_tile, Nn, nkt_host, f32o);
-    const int t = pl.tile;
+    int t = pl.tile;
+    // 128-byte K slices (igemm_nt1_kernel, KC = 8) on the 256 x 256 tile: one workgroup per CU, so only where the main loop is
+    // long against the exposed prologue / epilogue and the launch fills the CUs several times.  SAICV_NT_KC8: 0 never,
+    // 1 every eligible launch of a 256-row tile, 2 (default) wide pointwise GEMMs -- measured on the ViT-B shapes
+    // (profiles/r03_lds_fill_and_kc8.md): +10...13 % for N >= 2048, K = 768; -8 % for N = K = 768.
+    static const int kc8_mode = getenv("SAICV_NT_KC8") ? atoi(getenv("SAICV_NT_KC8")) : 2;
+    p.kc8 = 0;
+    {
+        const bool pointwise = R == 1 && S == 1 && pad == 0 && (mode == 0 || stride == 1);
+        const bool ok = dtype == SAICV_DTYPE_BF16 && !f32o && pointwise && !pl.persist && kTiles[t].bm == 256 && Kd >= 256;
+        if (ok && kc8_mode == 1) p.kc8 = 1;
+        if (ok && kc8_mode == 2 && Nn >= 2048 && Nn % 256 == 0 && Kd >= 512 && (long)((M_tile + 255) / 256) * (Nn / 256) >= 4 * 256) {
+            p.kc8 = 1;
+            t = 0;
+        }
+    }
     const NTTile& g = kTiles[t];
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
