@@ -51,7 +51,7 @@ CONFIG_DIR = {'resnet50': '00.classification_training/imagenet/resnet50',
 LOOP_MODELS = {'resnet50_detr_config': ('tools.scripts.train_detection', 8, 1024, 3 * 189.1 * (768 * 1024) / (800 * 1344)),
                # full SAM step: one encoder pass (972.1 GFLOP fwd) + 1 + decoder_iters light decoder passes
                'sam_b': ('tools.interactive_segmentation_scripts.train_sam_segmentation', 8, 1024, 3 * 972.1)}
-PMC_FILE = 'profiles/r02_pmc_hbm_traffic.json'
+PMC_FILE = 'profiles/r03_pmc_hbm_traffic.json'
 
 
 def parse():
@@ -446,7 +446,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
     same command, corrected as MI355X_MICROARCH.md prescribes); None when the summary is absent.  Counters cannot be
     collected inside the timed run itself."""
-    for f in (PMC_FILE, 'profiles/r01e_pmc_hbm_traffic.json'):
+    for f in (PMC_FILE, 'profiles/r02_pmc_hbm_traffic.json', 'profiles/r01e_pmc_hbm_traffic.json'):
         try:
             return json.load(open(os.path.join(ROOT, f)))['kernels'][kernel]['bytes_per_launch']
         except (OSError, KeyError, ValueError):
