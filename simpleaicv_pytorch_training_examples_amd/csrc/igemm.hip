@@ -2241,15 +2241,18 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     int t = pl.tile;
     // 128-byte K slices (igemm_nt1_kernel, KC = 8) on the 256 x 256 tile: one workgroup per CU, so only where the main loop is
     // long against the exposed prologue / epilogue and the launch fills the CUs several times.  SAICV_NT_KC8: 0 never,
-    // 1 every eligible launch of a 256-row tile, 2 (default) wide pointwise GEMMs -- measured on the ViT-B shapes
-    // (profiles/r03_lds_fill_and_kc8.md): +10...13 % for N >= 2048, K = 768; -8 % for N = K = 768.
+    // 1 every eligible launch of a 256-row tile, 2 (default) wide pointwise GEMMs without a fused activation, 3 the same with
+    // them -- measured on the ViT-B shapes (profiles/r03_lds_fill_and_kc8.md): +10...13 % for N >= 2048, K = 768; -8 % for
+    // N = K = 768; the GELU-fused launches (two output tensors / one more input in the epilogue) lose 10 % with one workgroup
+    // per CU: ViT-B step 42.57 ms off, 42.95 with them, 42.31 without.
     static const int kc8_mode = getenv("SAICV_NT_KC8") ? atoi(getenv("SAICV_NT_KC8")) : 2;
     p.kc8 = 0;
     {
         const bool pointwise = R == 1 && S == 1 && pad == 0 && (mode == 0 || stride == 1);
         const bool ok = dtype == SAICV_DTYPE_BF16 && !f32o && pointwise && !pl.persist && kTiles[t].bm == 256 && Kd >= 256;
         if (ok && kc8_mode == 1) p.kc8 = 1;
-        if (ok && kc8_mode == 2 && Nn >= 2048 && Nn % 256 == 0 && Kd >= 512 && (long)((M_tile + 255) / 256) * (Nn / 256) >= 4 * 256) {
+        const bool rule_ok = (kc8_mode == 2 && p.act_mode == 0) || kc8_mode == 3;
+        if (ok && rule_ok && Nn >= 2048 && Nn % 256 == 0 && Kd >= 512 && (long)((M_tile + 255) / 256) * (Nn / 256) >= 4 * 256) {
             p.kc8 = 1;
             t = 0;
         }
