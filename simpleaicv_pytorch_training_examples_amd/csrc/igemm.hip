@@ -2237,7 +2237,18 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
         M_tile = nimg * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);   // largest parity class
     }
     const int nkt_host = (Kd + 4 * epc - 1) / (4 * epc);      // K tiles (stride > 1 data-gradient classes run fewer)
-    const NTPlan pl = nt_plan(dtype, mode, stride, M_tile, Nn, nkt_host, f32o);
+    NTPlan pl = nt_plan(dtype, mode, stride, M_tile, Nn, nkt_host, f32o);
+    {
+        // SAICV_NT_PERSIST=2: the streaming kernel only for launches with a plain epilogue (bias at most) -- the fused modes run
+        // in its rolled per-wavefront loops.  Statistics launches keep the plan conv_stat_rows() sized their buffers with.
+        const char* pe = getenv("SAICV_NT_PERSIST");
+        const bool fused = p.act_mode || p.addend || p.row_scale || p.out2 || p.addend_gate || p.bs_y;
+        if (pl.persist && pe && atoi(pe) == 2 && fused && !stat_sum) {
+            pl.persist = false;
+            pl.tile = pick_tile(M_tile, Nn, nkt_host, f32o);
+            if (pl.tile == 4) pl.tile = 1;
+        }
+    }
     int t = pl.tile;
     // 128-byte K slices (igemm_nt1_kernel, KC = 8) on the 256 x 256 tile: one workgroup per CU, so only where the main loop is
     // long against the exposed prologue / epilogue and the launch fills the CUs several times.  SAICV_NT_KC8: 0 never,
