@@ -35,6 +35,7 @@ DEVINL uint32_t fdiv(uint32_t n, FastDiv d) {
 // LDS-DMA ring depth per geometry: 4 stages, except 256 x 128 where 3 stages (72 KiB) let TWO workgroups share
 // a CU so that one's epilogue overlaps the other's main loop
 constexpr int nt_stages(int bm, int bn) { return (bm == 256 && bn == 128) ? 3 : 4; }
+constexpr int HALO_ROWS = 384;      // staged input pixels per channel slice of the 3 x 3 halo path: 258 + 2 W <= 384 -> W <= 63
 constexpr int nt_stages_kc8(int bm, int bn) { return (bm + bn) * 128 * 3 <= 150 * 1024 ? 3 : 2; }      // 128-byte K slices
 // resident workgroups per CU by LDS (the ring is all a workgroup holds: the epilogue stages through a vacated slot)
 // Which instantiations may run persistently (ticket draws hidden from the compiler, see draw_ticket): bf16 in and out,
@@ -85,6 +86,7 @@ struct NTParams {
     int nblk;
     int grid_x;         // resident workgroups (256 CUs x workgroups per CU)
     int kc8;            // host: launch the 128-byte-K-slice instantiation (pointwise bf16, 256-row tiles)
+    int halo;           // host: launch the 3 x 3 staged-range instantiation (stride 1, pad 1, bf16, 256 x 128 tiles)
     FastDiv fd_ohw, fd_ow;   // for OH*OW and OW (unit-stride row decomposition)
 };
 
@@ -845,8 +847,8 @@ void igemm_nt_kernel(const NTParams p) {
 // alone (profiles/r03_lds_fill_probe.jsonl: 8.7-10 TB/s against 11.5-12.3 TB/s for whole lines when four workgroups share
 // a stream) and the 64-byte kernels sit exactly at that figure.  KC = 8 rows take twice the LDS per step: 3 slots of
 // 48 KiB for the 256 x 128 tile, one workgroup per CU.
-template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4>
-__global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT_F32 && KC == 4) ? 4 : 1) void igemm_nt1_kernel(const NTParams p) {
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4, bool HALO = false>
+__global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 128 && !OUT_F32 && KC == 4) ? 4 : 1) void igemm_nt1_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = KC * EPC;                 // one 64- or 128-byte row per K tile
     constexpr int ROWB = KC * 16;                // bytes of an LDS row
@@ -916,6 +918,146 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     const __amdgpu_buffer_rsrc_t wgt_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
 
+    f32x4 acc[NT_][MT_];
+#pragma unroll
+    for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MT_; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ohw = Hc * Wc;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    if constexpr (HALO) {
+    // ================================================================ 3 x 3, stride 1, pad 1: one staged input range for all nine taps
+    // The gather kernel streams the input pixels of a tile NINE times from L2 into LDS (once per tap); with the fill path as
+    // the bound that is 9/9 + ... of the traffic for 1/9 of the information.  The 256 output pixels of a
+    // tile are consecutive in the flattened (image, row, column) order, so every input pixel any tap needs lies in ONE contiguous
+    // range of 258 + 2W pixels: it is staged once per 32-channel slice (HALO_ROWS x 64 bytes, two slots) and the taps read it at
+    // row offsets r*W + s.  Weights keep their ring (one 64-byte K slice per tap and channel slice, four slots).  What the
+    // flattening gets wrong -- a tap that leaves the image lands on a neighbouring row's pixel instead of on padding -- is
+    // repaired in registers: a 9-bit tap mask per output row zeroes the A fragment of an invalid (row, tap).
+    // The halo slots are NOT swizzled (a tap's row offset is arbitrary, so no row-indexed XOR survives it): fragment addresses
+    // are a per-row base plus an immediate, at the price of 2-way bank conflicts on the A reads.
+    // K order: channel slice outer, tap inner (the gather kernel runs tap outer): same sums, different fp32 order.
+    static_assert(!HALO || (KC == 4 && sizeof(T) == 2 && !PLAIN), "halo path: bf16, 64-byte slices");
+    constexpr int HROWS = HALO_ROWS;                       // staged pixels per slice (multiple of 16 * NWAVES)
+    constexpr int AI = HROWS / 16 / NWAVES;                // A DMA instructions per thread and slice
+    constexpr int A_SLOT = HROWS * 64;
+    constexpr int B_BASE = 2 * A_SLOT;
+    constexpr int NB = 4;                                  // weight ring slots
+    constexpr int BI = WROWS;                              // weight DMA instructions per thread and step
+    const int Wd_ = p.W;
+    const int range0 = tile_m * BM_T - Wd_ - 1;            // first staged pixel (may be negative: hardware zero fill)
+    const int ncs = p.C / 32;
+    const int nt = ncs * 9;
+    // register diet (128 VGPRs at four wavefronts per SIMD): one base per thread for the range loads, the A fragments and the
+    // weight fragments -- the other instructions / tiles are immediates (16 rows = 1 KiB) or a scalar stride away
+    // No validity logic on the loads: a pixel before the first image gives a "negative" (huge unsigned) offset, a pixel behind
+    // the last one or a weight row >= N an offset beyond the descriptor's size -- the hardware returns zeros for both, and the
+    // zero-fill steps behind the last slice may read whatever lies there (they are never consumed).
+    const uint32_t a_off0 = (uint32_t)((range0 + wave * 16 + (lane >> 2)) * p.C + (lane & 3) * EPC) * (uint32_t)sizeof(T);
+    const uint32_t a_stride = (uint32_t)(NWAVES * 16 * p.C) * (uint32_t)sizeof(T);
+    const int ccw = (lane & 3) ^ lds_swz((lane >> 4) & 3);     // weight ring keeps the swizzled layout
+    const uint32_t w_off0 = (uint32_t)((tile_n * BN_T + wave * 16 + (lane >> 2)) * p.Kd + ccw * EPC) * (uint32_t)sizeof(T);
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue_a = [&](int slot, int csl) __attribute__((always_inline)) {
+        char* base = smem + slot * A_SLOT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + i * NWAVES * 1024), 16,
+                                                     (int)(a_off0 + (uint32_t)i * a_stride + (uint32_t)csl * 64u), 0, 0, 0);
+    };
+    const uint32_t w_stride = (uint32_t)(NWAVES * 16 * p.Kd) * (uint32_t)sizeof(T);
+    auto issue_b = [&](int slot, int csl, int tap) __attribute__((always_inline)) {
+        char* base = smem + B_BASE + slot * W_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < BI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rs, (lds_void*)(base + j * NWAVES * 1024), 16,
+                                                     (int)(w_off0 + (uint32_t)j * w_stride + (uint32_t)(tap * p.C + csl * 32) * (uint32_t)sizeof(T)), 0, 0, 0);
+    };
+    // per output row of this lane's fragments: which taps stay inside the image (bit tap = r*3 + s), 9 bits per fragment packed
+    // three to a register
+    constexpr int NTM = (MT_ + 2) / 3;
+    int tapmask[NTM];
+#pragma unroll
+    for (int q = 0; q < NTM; ++q) tapmask[q] = 0;
+#pragma unroll
+    for (int mi = 0; mi < MT_; ++mi) {
+        const int m = tile_m * BM_T + wm * WMR + mi * 16 + l15;
+        int bits = 0;
+        if (m < Mc) {
+            const int img = (int)fdiv((uint32_t)m, p.fd_ohw);
+            const int rem = m - img * ohw;
+            const int oh = (int)fdiv((uint32_t)rem, p.fd_ow);
+            const int ow = rem - oh * Wc;
+            // forward: tap (r, s) reads pixel (oh + r - 1, ow + s - 1); data gradient: (oh + 1 - r, ow + 1 - s)
+            const bool up = MODE == 0 ? oh == 0 : oh == Hc - 1;          // taps with r == 0 leave the image
+            const bool dn = MODE == 0 ? oh == Hc - 1 : oh == 0;          // r == 2
+            const bool lf = MODE == 0 ? ow == 0 : ow == Wc - 1;          // s == 0
+            const bool rt = MODE == 0 ? ow == Wc - 1 : ow == 0;          // s == 2
+            bits = 0x1ff;
+            bits &= up ? ~0x007 : ~0;
+            bits &= dn ? ~0x1c0 : ~0;
+            bits &= lf ? ~0x049 : ~0;
+            bits &= rt ? ~0x124 : ~0;
+        }
+        tapmask[mi / 3] |= bits << (9 * (mi % 3));
+    }
+    const int abase0 = (wm * WMR + l15) * 64 + lg * 16;                          // fragment mi: + mi * 1024
+    const int fwh0 = B_BASE + lds_off(wn * WN + l15, lg);                         // fragment ni: + ni * 1024 (same swizzle class)
+
+    // prologue: slice 0 of the range, three weight steps
+    issue_a(0, 0);
+    issue_b(0, 0, 0);
+    issue_b(1, 0, 1);
+    issue_b(2, 0, 2);
+    int bslot = 0;                                         // ring slot of the weight step being consumed
+    for (int csl = 0; csl < ncs; ++csl) {
+        int ab = abase0 + (csl & 1) * A_SLOT;
+        int tm[NTM];
+        // keeps the nine tap addresses and the keep-masks from being hoisted out of this loop (they would be spilled)
+        asm volatile("" : "+v"(ab));
+#pragma unroll
+        for (int q = 0; q < NTM; ++q) { tm[q] = tapmask[q]; asm volatile("" : "+v"(tm[q])); }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // this step's weights (and, at tap 0, this slice's range) have landed.  Outstanding behind them, in issue order:
+            // the next two weight steps, plus at taps 1 and 2 the AI range loads and the weight step issued at tap 0.
+            if (tap == 1 || tap == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + 2 * BI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BI) : "memory");
+            __builtin_amdgcn_s_barrier();                  // everyone's part landed; the previous step is fully consumed
+            if (tap == 0) issue_a((csl + 1) & 1, csl + 1);                 // beyond the last slice: zero-fill loads keep the counts uniform
+            {
+                const int t3 = tap + 3;
+                const int slot3 = (bslot + 3) & (NB - 1);
+                issue_b(slot3, t3 >= 9 ? csl + 1 : csl, t3 >= 9 ? t3 - 9 : t3);
+            }
+            const int r = tap / 3, sx = tap - r * 3;
+            const int drow = MODE == 0 ? r * Wd_ + sx : (2 - r) * Wd_ + (2 - sx);
+            const char* ap = smem + (ab + drow * 64);
+            const char* wb = smem + (fwh0 + bslot * W_BYTES);
+            u32x4 af[MT_], wf[NT_];
+#pragma unroll
+            for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(ap + mi * 1024);
+#pragma unroll
+            for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(wb + ni * 1024);
+#pragma unroll
+            for (int mi = 0; mi < MT_; ++mi) {
+                const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe(tm[mi / 3], tap + 9 * (mi % 3), 1);      // 0 or ~0
+                af[mi] = u32x4{af[mi][0] & keep, af[mi][1] & keep, af[mi][2] & keep, af[mi][3] & keep};
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
+            // nothing crosses into the next tap: left alone, the scheduler sinks this tap's MFMAs below the next barrier (they
+            // touch no memory), keeps two taps' fragments alive and spills -- and a spill reload inside the loop is a vmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+            bslot = (bslot + 1) & (NB - 1);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero-fill loads of the tail have landed before LDS is reused
+    } else {
     // ---- per-thread DMA state.  Wave w, instruction i, lane l fills LDS bytes
     // [(i*NWAVES + w)*1024 + l*16, +16) of the A region: row (i*NWAVES+w)*16 + (l>>2), slot l&3, i.e. the
     // logical chunk (l&3) ^ f((row>>2)&3) = (l&3) ^ f((l>>4)&3) -- one K-chunk column per thread.
@@ -923,7 +1065,6 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     // ((lane >> 4) + 4 * (wave & 1)) & 7 because NWAVES is even -- still one K-chunk column per thread
     const int cc = KC == 4 ? ((lane & 3) ^ lds_swz((lane >> 4) & 3)) : ((lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7));
     int rowc[AROWS], a0[AROWS], b0[AROWS];   // rowc = (image base + A0*W + B0) * C  [elements]
-    const int ohw = Hc * Wc;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
         const int m = tile_m * BM_T + (i * NWAVES + wave) * RPI + lane / KC;
@@ -1022,14 +1163,6 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
         }
     };
 
-    f32x4 acc[NT_][MT_];
-#pragma unroll
-    for (int ni = 0; ni < NT_; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MT_; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int l15 = lane & 15;
-    const int lg = lane >> 4;
     int fa[MT_], fw[NT_];               // LDS fragment offsets within a stage, hoisted out of the K loop
 #pragma unroll
     for (int mi = 0; mi < MT_; ++mi) fa[mi] = KC == 4 ? lds_off(wm * WMR + mi * 16 + l15, lg) : lds_off128(wm * WMR + mi * 16 + l15, lg);
@@ -1073,6 +1206,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
         compute(st_c);
         st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
     }
+    }   // !HALO
     __syncthreads();                           // LDS is reused by the epilogue
 
     // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*16 + lg*4 + r ; m = m_base + mi*16 + l15
@@ -2005,9 +2139,9 @@ int launch_nt_stream(NTParams& p, hipStream_t st) {
     return saicv::check_launch("igemm_nt (persistent)");
 }
 
-template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4>
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4, bool HALO = false>
 void launch_nt1_inst(const NTParams& p, size_t smem, hipStream_t st) {
-    auto k = igemm_nt1_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN, KC>;
+    auto k = igemm_nt1_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN, KC, HALO>;
     static bool once = (allow_lds(k, 160 * 1024), true);
     (void)once;
     dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
@@ -2030,6 +2164,15 @@ int launch_nt1(NTParams& p, bool out_f32, hipStream_t st) {
         if (p.kc8 && plain && !out_f32) {
             constexpr size_t ring = nt_stages_kc8(BM_T, BN_T) * (size_t)(BM_T + BN_T) * 128;
             launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, true, 8>(p, ring < epi ? epi : ring, st);
+            return saicv::check_launch("igemm_nt");
+        }
+    }
+    if constexpr (sizeof(T) == 2 && BM_T == 256 && BN_T == 128) {
+        if (p.halo && !plain && !out_f32) {
+            // four wavefronts of 128 x 64 (256 registers each at two workgroups per CU): the eight-wavefront form spills
+            constexpr size_t ring = 2 * (size_t)HALO_ROWS * 64 + 4 * (size_t)BN_T * 64;
+            const size_t epi4 = BM_T * (size_t)(BN_T * 2 + 16) + 2 * 2 * BN_T * sizeof(float);
+            launch_nt1_inst<T, BM_T, BN_T, 2, 2, MODE, false, false, 4, true>(p, ring < epi4 ? epi4 : ring, st);
             return saicv::check_launch("igemm_nt");
         }
     }
@@ -2268,6 +2411,14 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
             t = 0;
         }
     }
+    // 3 x 3 / stride 1 / pad 1 on the 256 x 128 tile: SAICV_NT_HALO=1 selects the staged-range main loop.  OFF by default: it
+    // cuts the LDS-fill traffic of these layers 2.3x and measured level with the nine-stream gather (ResNet-50 b256, us forward /
+    // data gradient: 64 ch @56 117 / 121 vs 115 / 119, 128 ch @28 87 / 78 vs 78 / 79, 256 ch @14 72 / 67 vs 69 / 70; step 22.83 vs
+    // 22.74 ms) -- at 760-870 TFLOP/s these layers are not fill-bound but at ~2/3 of what a barrier-per-step MFMA loop sustains
+    // (profiles/r03_lds_fill_and_kc8.md section 7).
+    static const int halo_on = getenv("SAICV_NT_HALO") ? atoi(getenv("SAICV_NT_HALO")) : 0;
+    p.halo = (halo_on && dtype == SAICV_DTYPE_BF16 && !f32o && !pl.persist && t == 1 && R == 3 && S == 3 && stride == 1 && pad == 1 &&
+              H == OH && W == OW && C % 32 == 0 && 258 + 2 * W <= HALO_ROWS) ? 1 : 0;
     const NTTile& g = kTiles[t];
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
