@@ -2399,7 +2399,8 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     // them -- measured on the ViT-B shapes (profiles/r03_lds_fill_and_kc8.md): +10...13 % for N >= 2048, K = 768; -8 % for
     // N = K = 768; the GELU-fused launches (two output tensors / one more input in the epilogue) lose 10 % with one workgroup
     // per CU: ViT-B step 42.57 ms off, 42.95 with them, 42.31 without.
-    static const int kc8_mode = getenv("SAICV_NT_KC8") ? atoi(getenv("SAICV_NT_KC8")) : 2;
+    const char* ke = getenv("SAICV_NT_KC8");             // read per call
+    const int kc8_mode = ke ? atoi(ke) : 2;
     p.kc8 = 0;
     {
         const bool pointwise = R == 1 && S == 1 && pad == 0 && (mode == 0 || stride == 1);
@@ -2416,7 +2417,8 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     // data gradient: 64 ch @56 117 / 121 vs 115 / 119, 128 ch @28 87 / 78 vs 78 / 79, 256 ch @14 72 / 67 vs 69 / 70; step 22.83 vs
     // 22.74 ms) -- at 760-870 TFLOP/s these layers are not fill-bound but at ~2/3 of what a barrier-per-step MFMA loop sustains
     // (profiles/r03_lds_fill_and_kc8.md section 7).
-    static const int halo_on = getenv("SAICV_NT_HALO") ? atoi(getenv("SAICV_NT_HALO")) : 0;
+    const char* he = getenv("SAICV_NT_HALO");            // read per call (like SAICV_NT_PERSIST): tests and sweeps flip it in-process
+    const int halo_on = he ? atoi(he) : 0;
     p.halo = (halo_on && dtype == SAICV_DTYPE_BF16 && !f32o && !pl.persist && t == 1 && R == 3 && S == 3 && stride == 1 && pad == 1 &&
               H == OH && W == OW && C % 32 == 0 && 258 + 2 * W <= HALO_ROWS) ? 1 : 0;
     const NTTile& g = kTiles[t];
@@ -2520,7 +2522,8 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     p.d_oh = rem / OW;
     p.d_ow = rem - p.d_oh * OW;
     // bf16: the LDS-DMA ring kernel (32-row steps; SAICV_TN_DMA=0 selects the register-staged kernel for A/B runs)
-    static const int use_dma = getenv("SAICV_TN_DMA") ? atoi(getenv("SAICV_TN_DMA")) : 1;
+    const char* de = getenv("SAICV_TN_DMA");             // read per call
+    const int use_dma = de ? atoi(de) : 1;
     if (use_dma && dtype == SAICV_DTYPE_BF16) {
         const int br = 32;
         p.d_img = br / ohw;
