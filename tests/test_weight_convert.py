@@ -1,0 +1,68 @@
+"""f4: official-weight converters (reference SimpleAICV/classification/weight_convert/).  CPU only.
+* torchvision ResNet -> this package: the key mapping must equal the reference converter's own (tests/golden/
+  convert_resnet_keys.json, produced from the reference's tables by oracle/make_golden_convert.py), and a converted
+  checkpoint must load with strict=True and reproduce every tensor;
+* official MAE checkpoint -> ViT encoder: keep what the target has, drop the decoder, report the rest."""
+import json
+import os
+
+import pytest
+import torch
+
+from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones
+from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.weight_convert import (
+    convert_official_mae_state_dict, convert_torchvision_resnet_state_dict)
+from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.weight_convert.convert_resnet_weight_from_pytorch_offical_weight import \
+    check_against_model
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'convert_resnet_keys.json')
+
+
+@pytest.mark.parametrize('network', ['resnet18', 'resnet50'])
+def test_torchvision_resnet_keys_convert_like_the_reference(network):
+    pairs = json.load(open(GOLDEN))[network]
+    model = backbones.__dict__[network](**{'num_classes': 1000})
+    target = model.state_dict()
+    # a torchvision-style checkpoint: the reference's mapping tells which of OUR tensors each torchvision key holds
+    g = torch.Generator().manual_seed(7)
+    source = {}
+    for tv_key, ref_key in pairs:
+        assert ref_key in target, (tv_key, ref_key)
+        t = target[ref_key]
+        source[tv_key] = torch.randn(t.shape, generator=g).to(t.dtype) if t.dtype.is_floating_point else torch.tensor(3, dtype=t.dtype)
+    converted, unknown = convert_torchvision_resnet_state_dict(source)
+    assert unknown == []
+    assert list(converted) == [ref_key for _, ref_key in pairs]                    # same mapping, same order
+    extra, missing, shapes = check_against_model(converted, model)
+    assert (extra, missing, shapes) == ([], [], [])
+    model.load_state_dict(converted, strict=True)
+    for tv_key, ref_key in pairs:
+        assert torch.equal(model.state_dict()[ref_key], source[tv_key])
+
+
+def test_torchvision_converter_reports_foreign_keys():
+    converted, unknown = convert_torchvision_resnet_state_dict({'conv1.weight': torch.zeros(1), 'layer1.0.se.fc1.weight': torch.zeros(1),
+                                                               'fc.bias': torch.zeros(1)})
+    assert list(converted) == ['conv1.layer.0.weight', 'fc.bias'] and unknown == ['layer1.0.se.fc1.weight']
+
+
+def test_official_mae_checkpoint_keeps_the_encoder_only():
+    model = backbones.__dict__['vit_base_patch16'](**{'image_size': 224, 'global_pool': True, 'num_classes': 1000})
+    target = model.state_dict()
+    g = torch.Generator().manual_seed(11)
+    official = {k: torch.randn(v.shape, generator=g) for k, v in target.items() if not k.startswith('fc.')}
+    official.update({'mask_token': torch.zeros(1, 1, 512), 'decoder_pos_embed': torch.zeros(1, 197, 512),
+                     'decoder_embed.weight': torch.zeros(512, 768), 'decoder_blocks.0.norm1.weight': torch.zeros(512),
+                     'decoder_pred.bias': torch.zeros(768)})
+    official['pos_embed_wrong_shape'] = torch.zeros(3)
+    kept, dropped, uninit = convert_official_mae_state_dict({'model': official}, model)
+    assert sorted(dropped) == sorted(['mask_token', 'decoder_pos_embed', 'decoder_embed.weight', 'decoder_blocks.0.norm1.weight',
+                                      'decoder_pred.bias', 'pos_embed_wrong_shape'])
+    assert uninit == ['fc.weight', 'fc.bias']
+    missing, unexpected = model.load_state_dict(kept, strict=False)
+    assert sorted(missing) == ['fc.bias', 'fc.weight'] and unexpected == []
+    assert torch.equal(model.state_dict()['blocks.11.mlp.fc2.weight'], official['blocks.11.mlp.fc2.weight'])
+    # a tensor of the right name but another shape (e.g. a 14-patch pos_embed) is dropped, not loaded
+    official['pos_embed'] = torch.zeros(1, 257, 768)
+    kept2, dropped2, uninit2 = convert_official_mae_state_dict(official, model)
+    assert 'pos_embed' in dropped2 and 'pos_embed' in uninit2
