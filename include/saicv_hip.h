@@ -369,6 +369,19 @@ int saicv_sam_sample_point(int pred_dtype, const float* gt, const void* pred, lo
                            int pred_channels, float gt_threshold, float pred_threshold, unsigned int seed,
                            unsigned long long* keys_ws, float* points, int B, int H, int W, void* stream);
 
+/* ---- depthwise convolution ---------------------------------
+ * nn.Conv2d(C, C, K, stride, padding, dilation, groups=C) and its backward: reference
+ * SimpleAICV/classification/backbones/van.py:30,68,75 (3x3 / 5x5 / dilated 7x7 of the LKA block) and convformer.py (7x7 of the
+ * SepConv mixer).  NHWC activations; weights tap-major wt[K*K][C] in the compute dtype (the [C,1,K,K] parameter transposed),
+ * weight gradient dwt[K*K][C] fp32.  dtype 0 bf16 / 1 fp32, fp32 accumulation, C a multiple of 8 (bf16) / 4 (fp32), K <= 8. */
+int saicv_dwconv2d_fwd(int dtype, const void* x, const void* wt, const float* bias, void* y, int N, int H, int W, int C, int OH,
+                       int OW, int K, int stride, int pad, int dil, void* stream);
+int saicv_dwconv2d_dgrad(int dtype, const void* dy, const void* wt, void* dx, int N, int H, int W, int C, int OH, int OW, int K,
+                         int stride, int pad, int dil, void* stream);
+/* ACCUMULATES into dwt / dbias (fp32 atomics; dbias may be NULL) */
+int saicv_dwconv2d_wgrad(int dtype, const void* dy, const void* x, float* dwt, float* dbias, int N, int H, int W, int C, int OH,
+                         int OW, int K, int stride, int pad, int dil, void* stream);
+
 /* ---- gradient all-reduce over RCCL / xGMI ------------------------------------------------
  * The reducer of nn.parallel.DistributedDataParallel (reference tools/train_classification_model.py:217-227 wraps the
  * model; tools/scripts.py:183-226 relies on gradients being averaged when backward() returns): contiguous ranges of the

@@ -137,6 +137,9 @@ SIGNATURES = {
     'saicv_mask_loss_grad_up4': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
     'saicv_mixup_cutmix': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'saicv_soft_labels': (c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, c_int, c_int, _P]),
+    'saicv_dwconv2d_fwd': (c_int, [c_int, _P, _P, _P, _P] + [c_int] * 10 + [_P]),
+    'saicv_dwconv2d_dgrad': (c_int, [c_int, _P, _P, _P] + [c_int] * 10 + [_P]),
+    'saicv_dwconv2d_wgrad': (c_int, [c_int, _P, _P, _P, _P] + [c_int] * 10 + [_P]),
     'saicv_sam_sample_point': (c_int, [c_int, _P, _P, c_long, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _P, _P,
                                        c_int, c_int, c_int, _P]),
     'saicv_comm_available': (c_int, []),

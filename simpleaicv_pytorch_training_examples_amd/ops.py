@@ -825,6 +825,60 @@ def conv2d(x, weight, bias=None, stride=1, pad=0):
     return ConvFn.apply(x, weight, bias, stride, pad)
 
 
+class DepthwiseConvFn(torch.autograd.Function):
+    """nn.Conv2d(C, C, k, stride, padding, dilation, groups=C) on NHWC data (csrc/dwconv.hip): the depthwise layers of
+    reference classification/backbones/van.py:30,68,75 and convformer.py.  weight [C, 1, k, k]; HBM-bound streaming kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dilation):
+        require_gpu(x, weight)
+        x = _nhwc(x)
+        dt = x.dtype
+        n, c, h, w = x.shape
+        if weight.shape[0] != c or weight.shape[1] != 1 or weight.shape[2] != weight.shape[3]:
+            raise ValueError(f'depthwise weight {tuple(weight.shape)} for {c} channels')
+        k = weight.shape[2]
+        oh = (h + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+        ow = (w + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+        wt = weight.detach().reshape(c, k * k).t().contiguous().to(dt)        # tap-major [k*k][C]
+        y = _empty_nhwc(n, c, oh, ow, dt, x.device)
+        bf = bias.detach().float() if bias is not None else None
+        check(lib().saicv_dwconv2d_fwd(dtype_code(dt), ptr(x), ptr(wt), ptr(bf), ptr(y), n, h, w, c, oh, ow, k, stride, pad, dilation,
+                                       stream()), 'dwconv2d_fwd')
+        ctx.save_for_backward(x, weight, bias, wt)
+        ctx.cfg = (n, h, w, c, oh, ow, k, stride, pad, dilation)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, wt = ctx.saved_tensors
+        n, h, w, c, oh, ow, k, stride, pad, dilation = ctx.cfg
+        L, st = lib(), stream()
+        dt = x.dtype
+        dy = _nhwc(dy)
+        if dy.dtype != dt:
+            dy = dy.to(dt)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty_nhwc(n, c, h, w, dt, x.device)
+            check(L.saicv_dwconv2d_dgrad(dtype_code(dt), ptr(dy), ptr(wt), ptr(dx), n, h, w, c, oh, ow, k, stride, pad, dilation, st),
+                  'dwconv2d_dgrad')
+        want_b = bias is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dwt = torch.zeros((k * k, c), dtype=torch.float32, device=x.device)
+            tb = torch.zeros(c, dtype=torch.float32, device=x.device) if want_b else None
+            check(L.saicv_dwconv2d_wgrad(dtype_code(dt), ptr(dy), ptr(x), ptr(dwt), ptr(tb), n, h, w, c, oh, ow, k, stride, pad, dilation,
+                                         st), 'dwconv2d_wgrad')
+            if ctx.needs_input_grad[1]:
+                dw = dwt.t().reshape(c, 1, k, k).to(weight.dtype)
+            db = tb.to(bias.dtype) if want_b else None
+        return dx, dw, db, None, None, None
+
+
+def depthwise_conv2d(x, weight, bias=None, stride=1, pad=0, dilation=1):
+    return DepthwiseConvFn.apply(x, weight, bias, stride, pad, dilation)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b on the implicit-GEMM kernel (1x1 geometry).  nn.Linear of resnet.py:204."""
 
