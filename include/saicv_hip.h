@@ -114,6 +114,14 @@ int saicv_linear_gelu_fwd(int dtype, const void* x, const void* wf, const float*
                           int K, int N, void* stream);
 int saicv_linear_dgrad_gelu(int dtype, const void* dy, const void* wd, const void* pre, void* dx, int M, int K, int N,
                             void* stream);
+/* The same pair with the activation's DERIVATIVE stored instead of the pre-activation (which nothing else reads): the forward
+ * computes gelu(y) and gelu'(y) from one exp / one rcp anyway, and the backward epilogue becomes one multiply per element instead
+ * of ~14 vector operations -- what a one-workgroup-per-CU GEMM cannot hide (profiles/r03_lds_fill_and_kc8.md, section 6).
+ * y_dact = gelu'(x W^T + b) in the compute dtype; dx = (dy W) * factor. */
+int saicv_linear_gelu_fwd_aux(int dtype, const void* x, const void* wf, const float* bias, void* y_dact, void* y_act, int M,
+                              int K, int N, void* stream);
+int saicv_linear_dgrad_mul(int dtype, const void* dy, const void* wd, const void* factor, void* dx, int M, int K, int N,
+                           void* stream);
 int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int M, int K, int N,
                        void* stream);
 /* conv data-gradient that adds an existing gradient (residual branch) in its epilogue */

@@ -122,6 +122,8 @@ SIGNATURES = {
     'saicv_attention_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
     'saicv_linear_gelu_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_linear_dgrad_gelu': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_linear_gelu_fwd_aux': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_linear_dgrad_mul': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_window_partition': (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_window_unpartition': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_relpos_fwd': (c_int, [c_int, _P, c_long, c_long, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -187,6 +187,18 @@ int saicv_linear_dgrad_gelu(int dtype, const void* dy, const void* wd, const voi
     ex.act_mode = 2; ex.addend = pre;
     return igemm_nt(dtype, 1, dy, wd, dx, nullptr, nullptr, nullptr, 1, 1, N, 1, 1, 1, 1, 1, 0, M, K, N, K, 0, S(stream), &ex);
 }
+int saicv_linear_gelu_fwd_aux(int dtype, const void* x, const void* wf, const float* bias, void* y_dact, void* y_act, int M,
+                              int K, int N, void* stream) {
+    EpiExtra ex;
+    ex.act_mode = 3; ex.out2 = y_act;
+    return igemm_nt(dtype, 0, x, wf, y_dact, bias, nullptr, nullptr, 1, 1, K, 1, 1, 1, 1, 1, 0, M, N, K, N, 0, S(stream), &ex);
+}
+int saicv_linear_dgrad_mul(int dtype, const void* dy, const void* wd, const void* factor, void* dx, int M, int K, int N,
+                           void* stream) {
+    EpiExtra ex;
+    ex.act_mode = 4; ex.addend = factor;
+    return igemm_nt(dtype, 1, dy, wd, dx, nullptr, nullptr, nullptr, 1, 1, N, 1, 1, 1, 1, 1, 0, M, K, N, K, 0, S(stream), &ex);
+}
 int saicv_linear_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int M, int K, int N,
                        void* stream) {
     return igemm_tn(dtype, dy, x, dw, 1, 1, K, 1, 1, 1, 1, 1, 0, M, N, K, S(stream), dbias);

@@ -56,7 +56,7 @@ struct NTParams {
     float* stat_sq;
     const void* addend;         // epilogue: out = addend + row_scale * (acc + bias)   (act_mode 2: the GELU pre-activation)
     void* out2;                 // act_mode 1: second output, gelu(out)
-    int act_mode;               // 0 none | 1 out2 = gelu(out) | 2 out = (acc + bias) * gelu'(addend)
+    int act_mode;               // 0 none | 1 out2 = gelu(out) | 2 out = (acc + bias) * gelu'(addend) | 3 out = gelu'(pre), out2 = gelu(pre) | 4 out = (acc + bias) * addend
     const float* row_scale;
     int rows_per_scale;
     // data-gradient epilogue extras of a residual network (all tensors share out's [M][ldo] coordinates):
@@ -622,16 +622,27 @@ void igemm_nt_kernel(const NTParams p) {
                         } else {
                             float f[OEPC];
                             Chunk<TO>::unpack(v, f);
-                            if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
-                                float gl[OEPC];
+                            if (p.act_mode == 1 || p.act_mode == 3) {   // fc1 of an MLP: emit gelu() beside the pre-activation (1) or gelu'() (3)
+                                float gl[OEPC], gr[OEPC];
 #pragma unroll
-                                for (int k = 0; k < OEPC; ++k) gl[k] = gelu_fwd_f(f[k]);
+                                for (int k = 0; k < OEPC; ++k) {
+                                    float c, d;
+                                    gelu_cdf_pdf(f[k], c, d);
+                                    gl[k] = f[k] * c;
+                                    gr[k] = fmaf(f[k], d, c);
+                                }
                                 st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)mo * p.ldo + ncol, Chunk<TO>::pack(gl));
-                            } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)   (rows are whole chunks)
+                                if (p.act_mode == 3) v = Chunk<TO>::pack(gr);
+                            } else if (p.act_mode == 2 || p.act_mode == 4) {     // dgrad of fc2: times gelu'(pre) (2) or times the stored derivative (4)
                                 float a[OEPC];
                                 Chunk<TO>::unpack(av[j], a);
+                                if (p.act_mode == 2) {
 #pragma unroll
-                                for (int k = 0; k < OEPC; ++k) f[k] *= gelu_grad_f(a[k]);
+                                    for (int k = 0; k < OEPC; ++k) f[k] *= gelu_grad_f(a[k]);
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < OEPC; ++k) f[k] *= a[k];
+                                }
                                 v = Chunk<TO>::pack(f);
                             } else if (addp || scalep) {
                                 float a[OEPC];
@@ -1482,18 +1493,29 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
                 if (gated || bst) sbn = side_bits(mn);
             }
             TO* o = outp + (size_t)m * p.ldo + ncol;
-            if (p.act_mode == 1) {            // fc1 of an MLP: keep the pre-activation, emit gelu() beside it
-                float f[OEPC];
+            if (p.act_mode == 1 || p.act_mode == 3) {   // fc1 of an MLP: emit gelu() beside the pre-activation (1) or beside gelu'() (3)
+                float f[OEPC], gr[OEPC];
                 Chunk<TO>::unpack(v, f);
 #pragma unroll
-                for (int j = 0; j < OEPC; ++j) f[j] = gelu_fwd_f(f[j]);
+                for (int j = 0; j < OEPC; ++j) {
+                    float c, d;
+                    gelu_cdf_pdf(f[j], c, d);
+                    gr[j] = fmaf(f[j], d, c);
+                    f[j] *= c;
+                }
                 st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(f));
-            } else if (p.act_mode == 2) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre)   (rows are whole chunks)
+                if (p.act_mode == 3) v = Chunk<TO>::pack(gr);
+            } else if (p.act_mode == 2 || p.act_mode == 4) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre) (2) or * the stored derivative (4)
                 float f[OEPC], a[OEPC];
                 Chunk<TO>::unpack(v, f);
                 Chunk<TO>::unpack(av, a);
+                if (p.act_mode == 2) {
 #pragma unroll
-                for (int j = 0; j < OEPC; ++j) f[j] *= gelu_grad_f(a[j]);
+                    for (int j = 0; j < OEPC; ++j) f[j] *= gelu_grad_f(a[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < OEPC; ++j) f[j] *= a[j];
+                }
                 v = Chunk<TO>::pack(f);
             } else if (p.addend != nullptr || p.row_scale != nullptr) {
                 float f[OEPC], a[OEPC];
@@ -2354,7 +2376,8 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
         const int osz0 = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
         SAICV_REQUIRE((ldo * osz0) % 16 == 0 && Nn % (16 / osz0) == 0,
                       "igemm_nt: the fused GELU epilogues need 16-byte aligned rows (N=%d)", Nn);
-        SAICV_REQUIRE(p.act_mode == 1 ? p.out2 != nullptr : p.addend != nullptr, "igemm_nt: fused GELU operand missing");
+        SAICV_REQUIRE(p.act_mode >= 1 && p.act_mode <= 4, "igemm_nt: act_mode %d", p.act_mode);
+        SAICV_REQUIRE((p.act_mode & 1) ? p.out2 != nullptr : p.addend != nullptr, "igemm_nt: fused GELU operand missing");
         SAICV_REQUIRE(stat_sum == nullptr && p.row_scale == nullptr, "igemm_nt: fused GELU excludes BN statistics / row scale");
     }
     if (p.addend || p.row_scale) {

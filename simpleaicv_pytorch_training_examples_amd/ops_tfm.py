@@ -6,6 +6,8 @@ is ONE autograd node whose forward fuses the residual add and the drop-path scal
 GEMM's epilogue and whose backward lets the residual-stream gradient join inside the LayerNorm
 backward kernel -- no stand-alone add / mul / permute / contiguous kernels remain.
 """
+import os as _os
+
 import torch
 
 from . import _lib, ops
@@ -43,31 +45,40 @@ def lin_fwd(x2, weight, bias, out_f32=False, addend=None, row_scale=None, rows_p
     return y if op == o else y[:, :o]
 
 
-def lin_gelu_fwd(x2, weight, bias):
+GELU_AUX = _os.environ.get('SAICV_GELU_AUX', '1') != '0'
+
+
+def lin_gelu_fwd(x2, weight, bias, aux=False):
     """(pre, act) = (x2 W^T + b, gelu(pre)) from one GEMM; falls back to two kernels when the output
-    width is not a whole number of 16-byte chunks."""
+    width is not a whole number of 16-byte chunks.  aux=True: the first result is gelu'(pre) instead of pre -- the only
+    consumer of pre is the activation's backward, which then is one multiply in the next data gradient's epilogue
+    (`lin_bwd(..., gelu_dact=...)`).  Returns (first, act, first_is_derivative)."""
     dt = x2.dtype
     m, k = x2.shape
     o = weight.shape[0]
     e = _lib.epc(dt)
     if o % e or k % e:
         pre = lin_fwd(x2, weight, bias)
-        return pre, gelu_fwd(pre)
+        return (pre, gelu_fwd(pre), False) if aux else (pre, gelu_fwd(pre))
     wf, _ = packed_weight(weight, dt, k, True, o)
     pre = torch.empty((m, o), dtype=dt, device=x2.device)
     act = torch.empty((m, o), dtype=dt, device=x2.device)
     t0 = KernelTimer.begin('igemm_nt')
-    check(lib().saicv_linear_gelu_fwd(dtype_code(dt), ptr(x2), ptr(wf), ptr(bias), ptr(pre), ptr(act), m, k, o, stream()),
-          'linear_gelu_fwd')
+    if aux and GELU_AUX:
+        check(lib().saicv_linear_gelu_fwd_aux(dtype_code(dt), ptr(x2), ptr(wf), ptr(bias), ptr(pre), ptr(act), m, k, o, stream()),
+              'linear_gelu_fwd_aux')
+    else:
+        check(lib().saicv_linear_gelu_fwd(dtype_code(dt), ptr(x2), ptr(wf), ptr(bias), ptr(pre), ptr(act), m, k, o, stream()),
+              'linear_gelu_fwd')
     KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, 0)
-    return pre, act
+    return (pre, act, GELU_AUX) if aux else (pre, act)
 
 
 _AUTO = object()
 
 
 def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None, grad_w=_AUTO, grad_b=_AUTO, want_w=None,
-            want_bias=None):
+            want_bias=None, gelu_dact=None):
     """-> (dx or None, dw or None, db or None); a None dw/db means it was accumulated in place
     into the parameter's arena gradient.  gelu_pre: x2 = gelu(gelu_pre) and the caller wants the gradient
     with respect to gelu_pre -- the activation's backward is applied in the dgrad epilogue.
@@ -92,7 +103,11 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None, grad
         _, wd = packed_weight(weight, dt, k, True, op)
         dx = torch.empty((m, k), dtype=dt, device=x2.device)
         t0 = KernelTimer.begin('igemm_nt')
-        if gelu_pre is not None:
+        if gelu_dact is not None:                  # x2 = gelu(pre) and gelu_dact = gelu'(pre), stored by the forward
+            if addend is not None or k % e:
+                raise ValueError('fused GELU backward: no addend, 16-byte aligned rows')
+            check(L.saicv_linear_dgrad_mul(dtype_code(dt), ptr(dy), ptr(wd), ptr(gelu_dact), ptr(dx), m, k, op, st), 'linear_dgrad_mul')
+        elif gelu_pre is not None:
             if addend is not None or k % e:
                 raise ValueError('fused GELU backward: no addend, 16-byte aligned rows')
             check(L.saicv_linear_dgrad_gelu(dtype_code(dt), ptr(dy), ptr(wd), ptr(gelu_pre), ptr(dx), m, k, op, st),
@@ -489,10 +504,11 @@ class MlpSubLayerFn(torch.autograd.Function):
         b, n, c = x.shape
         x2 = _as2d(x)
         h, mean, rstd = ln_fwd(x2, ln_w, ln_b, eps)
-        f1, g = lin_gelu_fwd(h, fc1_w, fc1_b)
+        f1, g, f1_is_dact = lin_gelu_fwd(h, fc1_w, fc1_b, aux=True)      # f1 = gelu'(pre) when the aux form ran, else pre
         out = lin_fwd(g, fc2_w, fc2_b, addend=x2, row_scale=drop_scale, rows_per_scale=n)
         ctx.save_for_backward(x2, ln_w, ln_b, mean, rstd, h, fc1_w, fc1_b, f1, g, fc2_w, fc2_b, drop_scale)
         ctx.cfg = (b, n, c)
+        ctx.f1_is_dact = f1_is_dact
         return out.view(b, n, c)
 
     @staticmethod
@@ -503,7 +519,7 @@ class MlpSubLayerFn(torch.autograd.Function):
         if dy.dtype != x2.dtype:
             dy = dy.to(x2.dtype)
         dys = row_scale(dy, drop_scale, n) if drop_scale is not None else dy
-        df1, d2w, d2b = lin_bwd(g, fc2_w, fc2_b, dys, gelu_pre=f1)      # dgrad epilogue applies gelu'(f1)
+        df1, d2w, d2b = lin_bwd(g, fc2_w, fc2_b, dys, **({'gelu_dact': f1} if ctx.f1_is_dact else {'gelu_pre': f1}))      # dgrad epilogue applies gelu'
         dh, d1w, d1b = lin_bwd(h, fc1_w, fc1_b, df1)
         dx, dlw, dlb = ln_bwd(dh, x2, ln_w, ln_b, mean, rstd, addend=dy)
         return dx.view(b, n, c), dlw, dlb, d1w, d1b, d2w, d2b, None, None

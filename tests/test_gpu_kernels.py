@@ -387,6 +387,34 @@ def test_fused_gelu_linear_epilogues_equal_the_unfused_kernels(dtype):
     assert torch.equal(dpre, ops_tfm.gelu_bwd(dact, pre))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_stored_gelu_derivative_form_matches_the_recomputing_form(dtype):
+    """saicv_linear_gelu_fwd_aux stores gelu'(pre) where saicv_linear_gelu_fwd stores pre; saicv_linear_dgrad_mul multiplies by
+    it where saicv_linear_dgrad_gelu recomputes gelu'(pre).  Same activation output bit for bit; the stored derivative equals
+    gelu'(pre) of the rounded pre-activation rounded once more to the compute dtype (fp32: identical; bf16: 2^-9), and so does
+    the data gradient."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    if not ops_tfm.GELU_AUX:
+        pytest.skip('SAICV_GELU_AUX=0')
+    g = torch.Generator().manual_seed(12)
+    m, k, o = 300, 96, 256
+    x = torch.randn(m, k, generator=g).cuda().to(dtype)
+    w = (torch.randn(o, k, generator=g) * 0.2).cuda().requires_grad_(True)
+    b = torch.randn(o, generator=g).cuda().requires_grad_(True)
+    pre, act = ops_tfm.lin_gelu_fwd(x, w, b)
+    dact_, act2, is_dact = ops_tfm.lin_gelu_fwd(x, w, b, aux=True)
+    assert is_dact and torch.equal(act, act2)
+    pf = pre.float().cpu().double()
+    cdf = 0.5 * (1 + torch.erf(pf / 2 ** 0.5))
+    pdf = torch.exp(-pf * pf / 2) / (2 * torch.pi) ** 0.5
+    assert rel_err(dact_.float().cpu(), (cdf + pf * pdf).float()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    w2 = (torch.randn(64, o, generator=g) * 0.2).cuda().requires_grad_(True)
+    dy = torch.randn(m, 64, generator=g).cuda().to(dtype)
+    d_rec, _, _ = ops_tfm.lin_bwd(act, w2, None, dy, gelu_pre=pre)
+    d_mul, _, _ = ops_tfm.lin_bwd(act, w2, None, dy, gelu_dact=dact_)
+    assert rel_err(d_mul.float(), d_rec.float()) < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
 FUSED_DGRAD_CASES = [
     # N, C, H, W, K, R, stride, pad   (C = channels of dx = the previous BatchNorm's channels)
     (2, 64, 14, 14, 64, 3, 1, 1),
