@@ -123,9 +123,12 @@ class TransformerEncoderLayer(nn.Module):
             return self.drop_path.sample_scale(x.shape[0], x.device)
         return None
 
-    def forward(self, x):
-        x = ops_tfm.attn_sublayer(x, self.norm1, self.attn, self._scale(x))
-        x = ops_tfm.mlp_sublayer(x, self.norm2, self.mlp, self._scale(x))
+    def forward(self, x, scales=None):
+        """scales: the two per-sample drop-path factors of this layer, drawn by the caller for all layers at once (ViT.forward);
+        None = draw them here (one bernoulli_ + one div_ per sub-layer)."""
+        s1, s2 = scales if scales is not None else (self._scale(x), self._scale(x))
+        x = ops_tfm.attn_sublayer(x, self.norm1, self.attn, s1)
+        x = ops_tfm.mlp_sublayer(x, self.norm2, self.mlp, s2)
         return x
 
 
@@ -174,13 +177,37 @@ class ViT(nn.Module):
         nn.init.trunc_normal_(self.fc.weight, std=2e-5)
         nn.init.zeros_(self.fc.bias)
 
+    def _drop_path_scales(self, batch, device):
+        """All stochastic-depth factors of a forward pass from ONE uniform draw: row 2i / 2i+1 = the per-sample factor (0 or
+        1 / keep) of layer i's attention / MLP sub-layer (reference vit.py:102-133 draws one bernoulli per DropPathBlock call;
+        the masks are not RNG-identical to the reference either way).  Three launches instead of 4 per layer."""
+        if not self.training or self.use_gradient_checkpoint:
+            return None
+        keeps = [blk.drop_path.keep_path_prob if isinstance(blk.drop_path, DropPathBlock) else 1.0 for blk in self.blocks]
+        if all(k >= 1.0 for k in keeps):
+            return None
+        cache = getattr(self, '_keep_cache', None)
+        if cache is None or cache[0].device != device:
+            keep = torch.tensor([k for k in keeps for _ in (0, 1)], dtype=torch.float32, device=device).view(-1, 1)
+            scale_by = torch.tensor([(1.0 / k if (k > 0. and blk.drop_path.scale_by_keep) else 1.0) if isinstance(blk.drop_path, DropPathBlock) else 1.0
+                                     for k, blk in zip(keeps, self.blocks) for _ in (0, 1)], dtype=torch.float32, device=device).view(-1, 1)
+            cache = self._keep_cache = (keep, scale_by)
+        keep, scale_by = cache
+        u = torch.rand(keep.shape[0], batch, dtype=torch.float32, device=device)
+        return (u < keep).to(torch.float32).mul_(scale_by)
+
     def forward(self, x):
         x = self.patch_embed(x)                                             # [B, N, C], compute dtype
         # token assembly (cls concat + position embedding): two small elementwise ops on [B, N+1, C]
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1).to(x.dtype), x), dim=1)
         x = x + self.pos_embed.to(x.dtype)
-        for block in self.blocks:
-            x = checkpoint(block, x, use_reentrant=False) if self.use_gradient_checkpoint else block(x)
+        scales = self._drop_path_scales(x.shape[0], x.device)
+        for i, block in enumerate(self.blocks):
+            if self.use_gradient_checkpoint:
+                x = checkpoint(block, x, use_reentrant=False)
+            else:
+                dropped = scales is not None and isinstance(block.drop_path, DropPathBlock) and block.drop_path.drop_path_prob > 0.
+                x = block(x, (scales[2 * i], scales[2 * i + 1]) if dropped else (None, None) if scales is not None else None)
         if self.global_pool:
             x = x[:, 1:, :].float().mean(dim=1).to(x.dtype)                # global pool without cls token
             x = ops_tfm.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
