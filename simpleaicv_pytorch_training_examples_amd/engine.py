@@ -463,6 +463,25 @@ class GradScaler:
 
 
 # ------------------------------------------------------------------------------ step graph
+def any_nonfinite(*tensors):
+    """bool 0-d device tensor: some element of the given tensors is inf / nan -- the device-side form of the reference loops'
+    `torch.isinf / isnan` host branches on the batch (tools/scripts.py:147-151).  Dense fp32 tensors (the image batch: 154 MB at
+    256 x 3 x 224 x 224) go through ONE pass of the gradient-statistics kernel; ATen's isfinite().all() is abs + two compares + an
+    and + a reduction, two extra passes over the batch and ~8 launches (0.25 ms per step)."""
+    dev = tensors[0].device
+    flag = torch.zeros(1, dtype=torch.float32, device=dev)
+    other = None
+    for t in tensors:
+        if (t.is_cuda and t.dtype == torch.float32 and t.numel() % 4 == 0 and t.numel() > 0 and t.data_ptr() % 16 == 0
+                and (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)))):
+            check(lib().saicv_grad_stats(ptr(t), t.numel(), ptr(flag), 0, _lib.stream()), 'grad_stats')
+        else:
+            b = ~torch.isfinite(t).all()
+            other = b if other is None else (other | b)
+    bad = flag[0] != 0
+    return bad if other is None else (bad | other)
+
+
 class StepGraph:
     """One training step as a hipGraph: `fn(*tensors) -> tensor | tuple of tensors` runs eagerly `warmup` times,
     is then captured once (torch.cuda.CUDAGraph on a side stream; every saicv kernel is launched on torch's current

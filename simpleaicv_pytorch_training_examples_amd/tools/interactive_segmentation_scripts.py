@@ -22,6 +22,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch.amp.autocast_mode import autocast
 
+from ..engine import any_nonfinite
 from ..SimpleAICV.classification.common import AverageMeter, get_amp_type
 from .scripts import _device_of, _dist_on, all_reduce_sum_packed
 
@@ -166,7 +167,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
         images, masks = data['image'].to(device, non_blocking=True), data['mask'].to(device, non_blocking=True)
         prompts, decoder_iters = _choose_prompts(config, data['prompt_point'], data['prompt_box'], data['prompt_mask'],
                                                  device)
-        bad = ~torch.isfinite(images).all()
+        bad = any_nonfinite(images)
         with amp():
             batch_image_embeddings = net.forward_image_encoder(images)
             mask_preds, iou_preds = net.forward_prompt_encoder_mask_decoder(batch_image_embeddings, prompts,

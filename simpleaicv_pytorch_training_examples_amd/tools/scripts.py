@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 from torch.amp.autocast_mode import autocast
 
+from ..engine import any_nonfinite
 from ..SimpleAICV.classification.common import AccMeter, AverageMeter, get_amp_type
 
 
@@ -138,9 +139,7 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
     def forward_backward(images, labels, boundary):
         """forward, loss, (scaled) backward; -> packed [skip flag, loss / acc_steps] of this rank"""
         # device-side replacement of the reference's isinf/isnan python branches (:147-151)
-        bad = ~torch.isfinite(images).all()
-        if labels.dtype.is_floating_point:
-            bad = bad | ~torch.isfinite(labels).all()
+        bad = any_nonfinite(images, labels) if labels.dtype.is_floating_point else any_nonfinite(images)
         if config.use_amp:
             with autocast(device_type=device.type, dtype=amp_type):
                 outputs = model(images)
@@ -345,7 +344,7 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
         targets = host_targets.to(device, non_blocking=True)
         if is_detr and not host_targets.is_cuda:
             targets._saicv_host = host_targets           # DETRLoss selects the valid rows on the host (no per-image device sync)
-        bad = ~torch.isfinite(images).all() | ~torch.isfinite(targets).all()
+        bad = any_nonfinite(images, targets)
         with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
             outs = model(images, data['mask'].to(device, non_blocking=True)) if is_detr else model(images)
             loss_value = criterion(outs, targets)
