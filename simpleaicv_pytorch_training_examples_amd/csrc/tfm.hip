@@ -181,9 +181,12 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* 
     }
 }
 
-// out[c] (=|+=) sum_p part[p][c]
-__global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ part, int P, int C,
-                                                         float* __restrict__ out, int accumulate) {
+// out[c] (=|+=) sum_p part[p][c]; blockIdx.y selects one of two (partials, output) pairs, so dgamma and dbeta of a LayerNorm
+// backward leave in ONE launch (ViT-B: 25 launches of ~7 us per step less)
+__global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int P, int C,
+                                                         float* __restrict__ out0, float* __restrict__ out1, int accumulate) {
+    const float* __restrict__ part = blockIdx.y ? part1 : part0;
+    float* __restrict__ out = blockIdx.y ? out1 : out0;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ty = threadIdx.x >> 6;              // 16 row lanes
     float s = 0.f;
@@ -875,8 +878,7 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
     else if (nch <= 4) LN_LAUNCH(4);
     else { set_error("layernorm_bwd: C=%d too wide", C); return -1; }
 #undef LN_LAUNCH
-    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, pg, nb, C, dgamma, accumulate);
-    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, pb, nb, C, dbeta, accumulate);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64, 2), dim3(1024), 0, st, pg, pb, nb, C, dgamma, dbeta, accumulate);
     return check_launch("layernorm_bwd");
 }
 
