@@ -1,1 +1,2 @@
 from .detr import *
+from .retinanet import *

@@ -787,6 +787,26 @@ class ConvFn(torch.autograd.Function):
             dy = dy.to(dt)
         n, c, h, w = x.shape
         k = weight.shape[0]
+        e = _lib.epc(dt)
+        if k % e:
+            # output channels that are not whole 16-byte chunks (RetinaNet's 9 x 4 box offsets, FCOS's 4 + 1 outputs): the
+            # backward kernels gather dY by chunks, so dY travels zero-padded to kp channels and the gradients are sliced back
+            kp = (k + e - 1) // e * e
+            dyp = torch.zeros((n, kp, d.OH, d.OW), dtype=dt, device=dy.device).contiguous(memory_format=torch.channels_last)
+            dyp[:, :k] = dy
+            dp = _desc(n, h, w, c, kp, d.R, d.S, d.stride, d.pad, dt)
+            dx = dwt = db = None
+            if ctx.needs_input_grad[0]:
+                _, wdp = packed_weight(weight, dt, c, True, kp)
+                dx = _empty_nhwc(n, c, h, w, dt, x.device)
+                check(L.saicv_conv2d_dgrad(ctypes.byref(dp), ptr(dyp), ptr(wdp), ptr(dx), st), 'conv2d_dgrad')
+            if ctx.needs_input_grad[1]:
+                dwp = torch.zeros((kp, d.R, d.S, c), dtype=torch.float32, device=x.device)
+                check(L.saicv_conv2d_wgrad(ctypes.byref(dp), ptr(dyp), ptr(x), ptr(dwp), st), 'conv2d_wgrad')
+                dwt = dwp[:k].permute(0, 3, 1, 2).to(weight.dtype)
+            if bias is not None and ctx.needs_input_grad[2]:
+                db = dy.float().sum((0, 2, 3)).to(bias.dtype)
+            return dx, dwt, db, None, None
         M = n * d.OH * d.OW
         flops = 2.0 * M * k * d.R * d.S * c
         dx = dwt = db = None
