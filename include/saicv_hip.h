@@ -377,6 +377,16 @@ int saicv_sam_sample_point(int pred_dtype, const float* gt, const void* pred, lo
                            int pred_channels, float gt_threshold, float pred_threshold, unsigned int seed,
                            unsigned long long* keys_ws, float* points, int B, int H, int W, void* stream);
 
+/* SAM sparse prompt tokens in one launch (reference segment_anything/prompt_encoder.py:150-190 embed_points / embed_boxes over
+ * :28-49 PositionEmbeddingRandom): points fp32 [B][Np][3] = (x, y, label) or NULL, `pad` = 1 appends the reference's padding
+ * click, boxes fp32 [B][4] or NULL, gauss fp32 [2][F], table fp32 [5][2F] = rows {negative click, positive click, box corner 1,
+ * box corner 2, not-a-point}; tokens fp32 [B][T][2F], kinds int32 [B][T] (kept for the backward), T = Np + pad + 2 [boxes].
+ * _bwd ACCUMULATES d table[5][C] from d tokens.  saicv_sam_grid_pe: the same encoding on the S x S grid centres, out [2F][S][S]. */
+int saicv_sam_prompt_tokens(const float* points, int Np, int pad, const float* boxes, const float* gauss, int F, const float* table,
+                            float image_size, float* tokens, int* kinds, int B, void* stream);
+int saicv_sam_prompt_tokens_bwd(const float* dtokens, const int* kinds, float* dtable, int BT, int C, void* stream);
+int saicv_sam_grid_pe(const float* gauss, int F, int S, float* out, void* stream);
+
 /* ---- depthwise convolution ---------------------------------
  * nn.Conv2d(C, C, K, stride, padding, dilation, groups=C) and its backward: reference
  * SimpleAICV/classification/backbones/van.py:30,68,75 (3x3 / 5x5 / dilated 7x7 of the LKA block) and convformer.py (7x7 of the

@@ -1,52 +1,68 @@
-"""SAM prompt encoder -- drop-in for the reference module.
+"""SAM prompt encoder -- drop-in for the reference module, built on the engine's kernels.
 
 Interface contract (reference SimpleAICV/interactive_segmentation/models/segment_anything/prompt_encoder.py):
 PositionEmbeddingRandom (:7), LayerNorm2d (:51), PromptEncoder (:69); same constructor arguments, parameter /
 buffer names (`pe_layer.positional_encoding_gaussian_matrix`, `point_embeddings.N.weight`,
 `not_a_point_embed.weight`, `no_mask_embed.weight`, `mask_downscaling.{0,1,3,4,6}.*`) and draw order.
 
-The sparse path (random-Fourier encoding of <= a dozen points / box corners per sample) is host-scale
-tensor glue and stays in plain tensor ops.  In the dense path the two 2x2 stride-2 convs run on 1 and 4
-channels -- below the 16-byte chunk the implicit-GEMM kernels stream -- so they, their LayerNorm2d and GELU
-stay as tensor ops on [B, <=16, <=128, <=128]; the 16 -> 256 projection onto the 64x64 grid is the HIP linear.
+Sparse path: ONE kernel (`saicv_sam_prompt_tokens`, csrc/input.hip) turns the clicks / box corners of a batch into their
+tokens -- random-Fourier encoding of the pixel centre plus the learned row its kind selects, "not a point" rows replacing the
+encoding -- and records each token's kind; its backward (`saicv_sam_prompt_tokens_bwd`) scatters the token gradients into
+the five learned rows, the only trainable inputs of the path.  The dense position encoding of the 64 x 64 grid is the same
+formula on the grid centres (`saicv_sam_grid_pe`).  Dense path: see `embed_masks`.
 """
-import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from ..... import ops_tfm
+from ..... import _lib, ops_tfm
+from ....._lib import check, lib, ptr, require_gpu, stream
+
+
+class PromptTokensFn(torch.autograd.Function):
+    """tokens[B, T, C] = encoding(points | padding click | box corners) + table[kind]; gradient only to the table rows."""
+
+    @staticmethod
+    def forward(ctx, table, gauss, points, boxes, pad, image_size):
+        require_gpu(table, gauss)
+        src = points if points is not None else boxes
+        b = src.shape[0]
+        npts = points.shape[1] if points is not None else 0
+        f = gauss.shape[1]
+        t = (npts + (1 if (points is not None and pad) else 0)) + (2 if boxes is not None else 0)
+        pts = points.detach().float().contiguous() if points is not None else None
+        bxs = boxes.detach().float().reshape(b, 4).contiguous() if boxes is not None else None
+        tokens = torch.empty((b, t, 2 * f), dtype=torch.float32, device=table.device)
+        kinds = torch.empty((b, t), dtype=torch.int32, device=table.device)
+        check(lib().saicv_sam_prompt_tokens(ptr(pts), npts, int(bool(pad and points is not None)), ptr(bxs), ptr(gauss), f,
+                                            ptr(table), float(image_size), ptr(tokens), ptr(kinds), b, stream()), 'sam_prompt_tokens')
+        ctx.save_for_backward(kinds)
+        ctx.rows = table.shape[0]
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtokens):
+        kinds, = ctx.saved_tensors
+        d = dtokens.float().contiguous()
+        dtable = torch.zeros((ctx.rows, d.shape[-1]), dtype=torch.float32, device=d.device)
+        check(lib().saicv_sam_prompt_tokens_bwd(ptr(d), ptr(kinds), ptr(dtable), kinds.numel(), d.shape[-1], stream()),
+              'sam_prompt_tokens_bwd')
+        return dtable, None, None, None, None, None
 
 
 class PositionEmbeddingRandom(nn.Module):
+    """Random-Fourier features of a 2-D position: [sin, cos](2 pi (2 p - 1) G), G ~ N(0, 1)^{2 x F} drawn at construction."""
 
     def __init__(self, num_pos_feats=64):
         super(PositionEmbeddingRandom, self).__init__()
         self.register_buffer("positional_encoding_gaussian_matrix", torch.randn((2, num_pos_feats)))
 
     def forward(self, size):
-        """Positional encoding of a size x size grid: C x H x W."""
-        h, w = size, size
-        device = self.positional_encoding_gaussian_matrix.device
-        grid = torch.ones((h, w), device=device, dtype=torch.float32)
-        y_embed = (grid.cumsum(dim=0) - 0.5) / h
-        x_embed = (grid.cumsum(dim=1) - 0.5) / w
-        pe = self.pe_encoding(torch.stack([x_embed, y_embed], dim=-1))
-        return pe.permute(2, 0, 1)
-
-    def forward_with_coords(self, coords_input, image_size):
-        """Positionally encode points that are not normalized to [0,1]."""
-        coords = coords_input.clone()
-        coords[:, :, 0] = coords[:, :, 0] / image_size
-        coords[:, :, 1] = coords[:, :, 1] / image_size
-        return self.pe_encoding(coords.to(torch.float))
-
-    def pe_encoding(self, coords):
-        coords = 2 * coords - 1
-        with torch.autocast(coords.device.type, enabled=False):      # tiny K=2 product, keep fp32 phases
-            coords = coords.float() @ self.positional_encoding_gaussian_matrix.float()
-        coords = 2 * np.pi * coords
-        return torch.cat([torch.sin(coords), torch.cos(coords)], dim=-1)
+        """Encoding of the size x size grid centres: [2F, size, size] (fp32)."""
+        g = self.positional_encoding_gaussian_matrix.float().contiguous()
+        require_gpu(g)
+        out = torch.empty((2 * g.shape[1], size, size), dtype=torch.float32, device=g.device)
+        check(lib().saicv_sam_grid_pe(ptr(g), g.shape[1], size, ptr(out), stream()), 'sam_grid_pe')
+        return out
 
 
 class LayerNorm2d(nn.Module):
@@ -58,10 +74,9 @@ class LayerNorm2d(nn.Module):
         self.eps = eps
 
     def forward(self, x):
-        u = x.mean(1, keepdim=True)
-        s = (x - u).pow(2).mean(1, keepdim=True)
-        x = (x - u) / torch.sqrt(s + self.eps)
-        return self.weight[:, None, None] * x + self.bias[:, None, None]
+        # channel-axis LayerNorm of an NCHW tensor on the HIP kernel (rows = pixels)
+        y = ops_tfm.layer_norm(x.permute(0, 2, 3, 1), self.weight, self.bias, self.eps)
+        return y.permute(0, 3, 1, 2)
 
 
 class PromptEncoder(nn.Module):
@@ -72,8 +87,7 @@ class PromptEncoder(nn.Module):
         self.embedding_planes = embedding_planes
         self.image_embedding_size = image_size // patch_size
         self.pe_layer = PositionEmbeddingRandom(embedding_planes // 2)
-        # pos/neg point + 2 box corners
-        self.num_point_embeddings = 4
+        self.num_point_embeddings = 4            # negative / positive click, two box corners
         self.point_embeddings = nn.ModuleList(
             [nn.Embedding(1, embedding_planes) for _ in range(self.num_point_embeddings)])
         self.not_a_point_embed = nn.Embedding(1, embedding_planes)
@@ -85,52 +99,31 @@ class PromptEncoder(nn.Module):
             LayerNorm2d(mask_inter_planes), nn.GELU(),
             nn.Conv2d(mask_inter_planes, embedding_planes, kernel_size=1, stride=1, padding=0))
 
+    def _token_table(self):
+        """[5, C]: the learned rows in the kernel's kind order (clicks 0 / 1, box corners, not-a-point)."""
+        return torch.cat([e.weight for e in self.point_embeddings] + [self.not_a_point_embed.weight], dim=0).float()
+
+    def sparse_tokens(self, points, boxes):
+        """[B, T, C] tokens of the clicks (+ the padding click when no box comes with them) followed by the box corners."""
+        gauss = self.pe_layer.positional_encoding_gaussian_matrix.float().contiguous()
+        return PromptTokensFn.apply(self._token_table(), gauss, points, boxes, boxes is None, self.image_size)
+
     def forward(self, points, boxes, masks):
-        if points is not None:
-            batch_size = points.shape[0]
-        elif boxes is not None:
-            batch_size = boxes.shape[0]
-        elif masks is not None:
-            batch_size = masks.shape[0]
+        given = [t for t in (points, boxes, masks) if t is not None]
+        batch_size = given[0].shape[0] if given else 1
+        if points is None and boxes is None:
+            sparse = torch.empty((batch_size, 0, self.embedding_planes), device=self.no_mask_embed.weight.device)
         else:
-            batch_size = 1
-        device = self.point_embeddings[0].weight.device
-        sparse_embeddings = torch.empty((batch_size, 0, self.embedding_planes), device=device)
-        if points is not None:
-            coords, labels = points[:, :, 0:2], points[:, :, 2]
-            point_embeddings = self.embed_points(coords, labels, pad=(boxes is None))
-            sparse_embeddings = torch.cat([sparse_embeddings, point_embeddings], dim=1)
-        if boxes is not None:
-            sparse_embeddings = torch.cat([sparse_embeddings, self.embed_boxes(boxes)], dim=1)
-        if masks is not None:
-            dense_embeddings = self.embed_masks(masks)
+            sparse = self.sparse_tokens(points, boxes)
+        if masks is None:
+            g = self.image_embedding_size
+            dense = self.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(batch_size, -1, g, g)
         else:
-            dense_embeddings = self.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(
-                batch_size, -1, self.image_embedding_size, self.image_embedding_size)
-        return sparse_embeddings, dense_embeddings
+            dense = self.embed_masks(masks)
+        return sparse, dense
 
     def get_dense_pe_layer(self):
         return self.pe_layer(self.image_embedding_size).unsqueeze(0)
-
-    def embed_points(self, points, labels, pad):
-        points = points + 0.5                                   # shift to the pixel centre
-        if pad:
-            points = torch.cat([points, torch.zeros((points.shape[0], 1, 2), device=points.device)], dim=1)
-            labels = torch.cat([labels, -torch.ones((labels.shape[0], 1), device=labels.device)], dim=1)
-        point_embedding = self.pe_layer.forward_with_coords(points, self.image_size)
-        point_embedding[labels == -1] = 0.0
-        point_embedding[labels == -1] += self.not_a_point_embed.weight
-        point_embedding[labels == 0] += self.point_embeddings[0].weight
-        point_embedding[labels == 1] += self.point_embeddings[1].weight
-        return point_embedding
-
-    def embed_boxes(self, boxes):
-        boxes = boxes + 0.5
-        coords = boxes.reshape(-1, 2, 2)
-        corner_embedding = self.pe_layer.forward_with_coords(coords, self.image_size)
-        corner_embedding[:, 0, :] += self.point_embeddings[2].weight
-        corner_embedding[:, 1, :] += self.point_embeddings[3].weight
-        return corner_embedding
 
     def embed_masks(self, masks):
         """mask_downscaling (reference prompt_encoder.py:93-109): two 2 x 2 stride-2 convolutions, each followed by

@@ -144,6 +144,76 @@ int sgrid(size_t n) {
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+
+// ---- SAM prompt tokens (f3 c): reference segment_anything/prompt_encoder.py:150-190 (embed_points / embed_boxes) and :28-49
+// (random-Fourier position encoding) as ONE launch.  Token t of sample b is a click (x, y, label), the padding click the
+// reference appends when no box is given, or a box corner; its 2F features are [sin(phase), cos(phase)],
+// phase_f = 2 pi ((2 u - 1) G[0][f] + (2 v - 1) G[1][f]), (u, v) = (x + 0.5, y + 0.5) / image_size, plus the row of the learned table
+// its kind selects: 0 / 1 = negative / positive click, 2 / 3 = box corners, 4 = "not a point" (label -1: the encoding is
+// REPLACED by the table row), 5 = other labels (encoding only).  kinds[b][t] is kept for the backward.
+__global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restrict__ points, int Np, int pad, const float* __restrict__ boxes,
+                                                            const float* __restrict__ gauss, int F, const float* __restrict__ table,
+                                                            float inv_size, float* __restrict__ tokens, int* __restrict__ kinds, int B, int T) {
+    const int bt = blockIdx.x;
+    const int b = bt / T, t = bt - b * T;
+    const int npts = points ? Np + pad : 0;
+    float x, y;
+    int kind;
+    if (t < npts) {
+        if (t < Np) {
+            const float* p = points + ((size_t)b * Np + t) * 3;
+            x = p[0] + 0.5f; y = p[1] + 0.5f;
+            const float lab = p[2];
+            kind = lab == -1.f ? 4 : lab == 0.f ? 0 : lab == 1.f ? 1 : 5;
+        } else {                                   // the padding click: coordinates (0, 0) unshifted, label -1
+            x = 0.f; y = 0.f; kind = 4;
+        }
+    } else {
+        const int c = t - npts;                    // corner 0 = (x1, y1), corner 1 = (x2, y2)
+        const float* q = boxes + (size_t)b * 4 + c * 2;
+        x = q[0] + 0.5f; y = q[1] + 0.5f;
+        kind = 2 + c;
+    }
+    if (threadIdx.x == 0) kinds[bt] = kind;
+    const float u = 2.f * (x * inv_size) - 1.f, v = 2.f * (y * inv_size) - 1.f;
+    float* out = tokens + (size_t)bt * 2 * F;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const float ph = 6.283185307179586f * (u * gauss[f] + v * gauss[F + f]);
+        float sn = sinf(ph), cs = cosf(ph);
+        if (kind == 4) { sn = 0.f; cs = 0.f; }
+        if (kind < 5) { sn += table[(size_t)kind * 2 * F + f]; cs += table[(size_t)kind * 2 * F + F + f]; }
+        out[f] = sn;
+        out[F + f] = cs;
+    }
+}
+
+// d table[kind][c] += sum over the tokens of that kind of d tokens[b][t][c]   (the only trainable inputs of the sparse path)
+__global__ __launch_bounds__(256) void prompt_tokens_bwd_kernel(const float* __restrict__ dtokens, const int* __restrict__ kinds,
+                                                                float* __restrict__ dtable, int BT, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < BT; ++i) {
+        const int k = kinds[i];
+        const float g = dtokens[(size_t)i * C + c];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[j] += (k == j) ? g : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dtable[(size_t)j * C + c] += acc[j];
+}
+
+// the same encoding on the centres of an S x S grid (get_dense_pe: reference prompt_encoder.py:28-38): out[c][i][j], c < 2F
+__global__ __launch_bounds__(256) void grid_pe_kernel(const float* __restrict__ gauss, int F, int S, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= F * S * S) return;
+    const int f = idx / (S * S), r = idx - f * S * S, i = r / S, j = r - i * S;
+    const float u = 2.f * (((float)j + 0.5f) / (float)S) - 1.f, v = 2.f * (((float)i + 0.5f) / (float)S) - 1.f;
+    const float ph = 6.283185307179586f * (u * gauss[f] + v * gauss[F + f]);
+    out[(size_t)f * S * S + r] = sinf(ph);
+    out[(size_t)(F + f) * S * S + r] = cosf(ph);
+}
+
 }  // namespace
 
 extern "C" {
@@ -193,6 +263,31 @@ int saicv_sam_sample_point(int pred_dtype, const float* gt, const void* pred, lo
                            (const int64_t*)pred_index, pred_channels, gt_threshold, pred_threshold, seed, keys_ws, B, HW);
     hipLaunchKernelGGL(sample_point_pick_kernel, dim3((B + 63) / 64), dim3(64), 0, st, keys_ws, points, B, W);
     return saicv::check_launch("sam_sample_point");
+}
+
+int saicv_sam_prompt_tokens(const float* points, int Np, int pad, const float* boxes, const float* gauss, int F, const float* table,
+                            float image_size, float* tokens, int* kinds, int B, void* stream) {
+    SAICV_REQUIRE((points || boxes) && gauss && table && tokens && kinds && B > 0 && F > 0 && image_size > 0.f,
+                  "saicv_sam_prompt_tokens: bad arguments");
+    SAICV_REQUIRE(points || (Np == 0 && pad == 0), "saicv_sam_prompt_tokens: point count without points");
+    const int T = (points ? Np + pad : 0) + (boxes ? 2 : 0);
+    SAICV_REQUIRE(T > 0, "saicv_sam_prompt_tokens: no tokens");
+    hipLaunchKernelGGL(prompt_tokens_kernel, dim3(B * T), dim3(F < 256 ? ((F + 63) / 64) * 64 : 256), 0, static_cast<hipStream_t>(stream),
+                       points, Np, pad, boxes, gauss, F, table, 1.f / image_size, tokens, kinds, B, T);
+    return saicv::check_launch("sam_prompt_tokens");
+}
+
+int saicv_sam_prompt_tokens_bwd(const float* dtokens, const int* kinds, float* dtable, int BT, int C, void* stream) {
+    SAICV_REQUIRE(dtokens && kinds && dtable && BT > 0 && C > 0, "saicv_sam_prompt_tokens_bwd: bad arguments");
+    hipLaunchKernelGGL(prompt_tokens_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), dtokens, kinds,
+                       dtable, BT, C);
+    return saicv::check_launch("sam_prompt_tokens_bwd");
+}
+
+int saicv_sam_grid_pe(const float* gauss, int F, int S, float* out, void* stream) {
+    SAICV_REQUIRE(gauss && out && F > 0 && S > 0, "saicv_sam_grid_pe: bad arguments");
+    hipLaunchKernelGGL(grid_pe_kernel, dim3((F * S * S + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gauss, F, S, out);
+    return saicv::check_launch("sam_grid_pe");
 }
 
 }  // extern "C"
