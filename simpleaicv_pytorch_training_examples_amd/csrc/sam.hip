@@ -9,6 +9,7 @@
 //    gradient into q and into the two tables.  0.8 % of the attention flops: plain fp32 FMA kernels with the
 //    table rows in LDS, replacing four strided batched GEMM dispatches, two gathers and two index_adds.
 // All are HBM / latency bound; activations are bf16 (perf mode) or fp32 (parity mode).
+#include <stdlib.h>
 #include "common.h"
 #include "saicv_internal.h"
 
@@ -161,6 +162,79 @@ __global__ __launch_bounds__(RP_THREADS) void relpos_fwd_kernel(const RelPosPara
             }
         } else {
             for (int kw = 0; kw < p.Sw; ++kw) ow[kw] = dot(tw + (qw - kw + p.Sw - 1) * RP_PITCH);
+        }
+    }
+}
+
+// The same logits on the matrix cores (bf16 q): for one query row qh the Sw queries x 64 channels of a head times
+//   Th^T  (Sh table rows qh - kh + Sh - 1, kh = 0..Sh-1)            -> rel_h[q][kh]
+//   Tw'^T (ALL 2 Sw - 1 rows, stored REVERSED: Tw'[j] = Tw[2 Sw - 2 - j])  -> P[q][j],  rel_w[q][kw] = P[q][kw + Sw - 1 - qw]
+// are two small GEMMs (K = 64): 96 MFMAs per head at Sh = Sw = 64, against 8 192 fp32 FMAs per query in the kernel above
+// (which runs at the vector-ALU rate: 1.05 ms per 4096-token block where its 0.63 GB of traffic would take 0.13).  Tables are
+// rounded to bf16 in LDS (what the reference's autocast einsum does), fp32 accumulation, fp32 outputs.  Work items are (head,
+// 16-query tile) pairs dealt to the four wavefronts; a D tile (rows = queries lg*4 + r, column = l15) is stored as 16 consecutive
+// floats of four query rows per instruction.
+DEVINL int rpm_off(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
+
+__global__ __launch_bounds__(RP_THREADS) void relpos_fwd_mfma_kernel(const RelPosParams p) {
+    extern __shared__ __attribute__((aligned(16))) char rpm_smem[];
+    const int qh = blockIdx.x, b = blockIdx.y;
+    const int Sh = p.Sh, Sw = p.Sw, J = 2 * Sw - 1;
+    const int ShP = (Sh + 15) & ~15, JP = (J + 15) & ~15;
+    char* th = rpm_smem;                         // [ShP][64] bf16, swizzled rows of 128 bytes
+    char* tw = rpm_smem + ShP * 128;             // [JP][64] bf16
+    for (int i = threadIdx.x; i < (ShP + JP) * 8; i += RP_THREADS) {
+        const int row = i >> 3, c = i & 7;
+        const bool ish = row < ShP;
+        const int r = ish ? row : row - ShP;
+        const bool ok = ish ? r < Sh : r < J;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        if (ok) {
+            const float* src = ish ? p.tab_h + (size_t)(qh - r + Sh - 1) * RP_D : p.tab_w + (size_t)(J - 1 - r) * RP_D;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + c * 8), bq = *reinterpret_cast<const f32x4*>(src + c * 8 + 4);
+            f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = bq[0]; f[5] = bq[1]; f[6] = bq[2]; f[7] = bq[3];
+        }
+        st_chunk((ish ? th : tw) + rpm_off(r, c), Chunk<bf16_t>::pack(f));
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int MT = (Sw + 15) >> 4, NTH = ShP >> 4, NTW = JP >> 4;
+    const int N = Sh * Sw;
+    for (int item = wave; item < p.heads * MT; item += RP_THREADS / 64) {
+        const int head = item / MT, mt = item - head * MT;
+        const int qw_a = mt * 16 + l15;                                  // the query this lane feeds as an A row
+        u32x4 a[2];
+        {
+            const bf16_t* qrow = (const bf16_t*)p.q + (size_t)b * p.q_bs + (size_t)(qh * Sw + qw_a) * p.q_rs + head * RP_D;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[ks] = qw_a < Sw ? ld_chunk(qrow + (ks * 4 + lg) * 8) : zero_chunk();
+        }
+        const size_t plane = ((size_t)b * p.heads + head) * N + (size_t)qh * Sw;
+        for (int nt = 0; nt < NTH; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) Mma<bf16_t>::run(acc, a[ks], ld_chunk(th + rpm_off(nt * 16 + l15, ks * 4 + lg)));
+            const int kh = nt * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qw = mt * 16 + lg * 4 + r;
+                if (qw < Sw && kh < Sh) p.rel_h[(plane + qw) * Sh + kh] = acc[r];
+            }
+        }
+        for (int nt = 0; nt < NTW; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) Mma<bf16_t>::run(acc, a[ks], ld_chunk(tw + rpm_off(nt * 16 + l15, ks * 4 + lg)));
+            const int j = nt * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qw = mt * 16 + lg * 4 + r;
+                const int kw = j - (Sw - 1 - qw);
+                if (qw < Sw && kw >= 0 && kw < Sw) p.rel_w[(plane + qw) * Sw + kw] = acc[r];
+            }
         }
     }
 }
@@ -403,7 +477,11 @@ int relpos_fwd(int dtype, const void* q, long q_rs, long q_bs, const float* tab_
     if (relpos_fill(p, "relpos_fwd", dtype, q, q_rs, q_bs, tab_h, tab_w, B, heads, Sh, Sw)) return -1;
     p.rel_h = rel_h; p.rel_w = rel_w;
     const size_t smem = (size_t)(Sh + 2 * Sw - 1) * RP_PITCH * sizeof(float);
-    if (dtype == SAICV_DTYPE_BF16) {
+    static const int use_mfma = getenv("SAICV_RELPOS_MFMA") ? atoi(getenv("SAICV_RELPOS_MFMA")) : 1;
+    if (dtype == SAICV_DTYPE_BF16 && use_mfma) {
+        const size_t smem_m = (size_t)(((Sh + 15) & ~15) + ((2 * Sw - 1 + 15) & ~15)) * 128;
+        hipLaunchKernelGGL(relpos_fwd_mfma_kernel, dim3(Sh, B), dim3(RP_THREADS), smem_m, st, p);
+    } else if (dtype == SAICV_DTYPE_BF16) {
         auto k = relpos_fwd_kernel<bf16_t>;
         static bool once = (rp_allow_lds(k), true); (void)once;
         hipLaunchKernelGGL(k, dim3(Sh, B), dim3(RP_THREADS), smem, st, p);

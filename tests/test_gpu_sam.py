@@ -430,7 +430,10 @@ def test_relpos_kernels_match_einsum(grid, dtype):
     rw = tw[(torch.arange(sw)[:, None] - torch.arange(sw)[None, :] + sw - 1).cuda()]
     ref_h = torch.einsum('bhwnc,hkc->bnhwk', rq, rh).reshape(bw * heads, n, sh)
     ref_w = torch.einsum('bhwnc,wkc->bnhwk', rq, rw).reshape(bw * heads, n, sw)
-    assert rel_err(rel_h, ref_h) < 1e-5 and rel_err(rel_w, ref_w) < 1e-5
+    # fp32: exact-f32 arithmetic.  bf16: the logits come off the matrix cores with the TABLES rounded to bf16 as well (what the
+    # reference's autocast einsum does): 2^-9 per product against the fp32-table einsum this test builds
+    ftol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_err(rel_h, ref_h) < ftol and rel_err(rel_w, ref_w) < ftol
     drh = torch.randn(bw * heads, n, sh, generator=g).cuda()
     drw = torch.randn(bw * heads, n, sw, generator=g).cuda()
     (ref_h * drh).sum().backward(retain_graph=True)
