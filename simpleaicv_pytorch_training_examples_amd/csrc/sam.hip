@@ -239,6 +239,83 @@ __global__ __launch_bounds__(RP_THREADS) void relpos_fwd_mfma_kernel(const RelPo
     }
 }
 
+// dq of the 64 x 64 global blocks on the matrix cores (bf16): dQ^T[c][q] = Th^T[c][kh] dRelH^T[kh][q] + Tw'^T[c][j] dP^T[j][q],
+// dP[q][j] = dRelW[q][j - (Sw - 1 - qw)] (zero outside the row).  Tables are staged TRANSPOSED in LDS (rows = channels), the
+// gradients of the logits are rounded to bf16 as they are loaded; a lane ends up with four consecutive channels of one query
+// and adds them to dq with one 8-byte read-modify-write.
+DEVINL int rpm_off256(int row, int chunk) { return row * 256 + (((chunk ^ row) & 15) << 4); }
+
+__global__ __launch_bounds__(RP_THREADS) void relpos_bwd_dq_mfma_kernel(const RelPosParams p) {
+    constexpr int S = 64, J = 127;
+    __shared__ __attribute__((aligned(16))) char thT[RP_D * 128];      // [c][kh] bf16
+    __shared__ __attribute__((aligned(16))) char twT[RP_D * 256];      // [c][j]  bf16, j = 127 is zero
+    const int qh = blockIdx.x, b = blockIdx.y;
+    for (int i = threadIdx.x; i < S * RP_D; i += RP_THREADS) {
+        const int kh = i / RP_D, c = i - kh * RP_D;
+        const bf16_t v = (bf16_t)p.tab_h[(size_t)(qh - kh + S - 1) * RP_D + c];
+        *reinterpret_cast<bf16_t*>(thT + rpm_off(c, kh >> 3) + (kh & 7) * 2) = v;
+    }
+    for (int i = threadIdx.x; i < 128 * RP_D; i += RP_THREADS) {
+        const int j = i / RP_D, c = i - j * RP_D;
+        const bf16_t v = j < J ? (bf16_t)p.tab_w[(size_t)(J - 1 - j) * RP_D + c] : (bf16_t)0.f;
+        *reinterpret_cast<bf16_t*>(twT + rpm_off256(c, j >> 3) + (j & 7) * 2) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int N = S * S;
+    for (int item = wave; item < p.heads * 4; item += RP_THREADS / 64) {
+        const int head = item >> 2, mt = item & 3;
+        const int qw = mt * 16 + l15;                                 // this lane's query (a column of the product)
+        const size_t row = ((size_t)b * p.heads + head) * N + (size_t)qh * S + qw;
+        u32x4 bh[2], bw[4];
+        {
+            const float* gh = p.rel_h + row * S;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(gh + ks * 32 + lg * 8), x1 = *reinterpret_cast<const f32x4*>(gh + ks * 32 + lg * 8 + 4);
+                const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                bh[ks] = Chunk<bf16_t>::pack(f);
+            }
+            const float* gw = p.rel_w + row * S;
+            const int shift = S - 1 - qw;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float f[8];
+                const int w0 = ks * 32 + lg * 8 - shift;              // the lane's eight consecutive kw
+                if (w0 >= 0 && w0 + 8 <= S) {                         // wholly inside the row: two 4-byte-aligned 16-byte loads
+                    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+                    const f32x4_u x0 = *reinterpret_cast<const f32x4_u*>(gw + w0), x1 = *reinterpret_cast<const f32x4_u*>(gw + w0 + 4);
+                    f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3]; f[4] = x1[0]; f[5] = x1[1]; f[6] = x1[2]; f[7] = x1[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int kw = w0 + e;
+                        f[e] = (kw >= 0 && kw < S) ? gw[kw] : 0.f;
+                    }
+                }
+                bw[ks] = Chunk<bf16_t>::pack(f);
+            }
+        }
+        bf16_t* dq = (bf16_t*)p.dq + (size_t)b * p.q_bs + (size_t)(qh * S + qw) * p.q_rs + head * RP_D;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) Mma<bf16_t>::run(acc, ld_chunk(thT + rpm_off(ct * 16 + l15, ks * 4 + lg)), bh[ks]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Mma<bf16_t>::run(acc, ld_chunk(twT + rpm_off256(ct * 16 + l15, ks * 4 + lg)), bw[ks]);
+            // D^T tile: rows = channels ct*16 + lg*4 + r, column = query l15
+            bf16x4* dst = reinterpret_cast<bf16x4*>(dq + ct * 16 + lg * 4);
+            const bf16x4 old = *dst;
+            bf16x4 nw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nw[r] = (bf16_t)((float)old[r] + acc[r]);
+            *dst = nw;
+        }
+    }
+}
+
 // backward, part 1 (same grid): dq[b, q, head, :] += sum_kh drh * Th[kh] + sum_kw drw * Tw[qw - kw + Sw - 1]
 template <typename T>
 __global__ __launch_bounds__(RP_THREADS) void relpos_bwd_dq_kernel(const RelPosParams p) {
@@ -409,6 +486,99 @@ __global__ __launch_bounds__(RP_THREADS) void relpos_bwd_tab_kernel(const RelPos
     }
 }
 
+// Table gradients of the 64 x 64 global blocks on the matrix cores (bf16 q):
+//   dTh[kh][c]  = sum over (head, qw) of dRelH[q][kh] q[q][c]             (table row qh - kh + 63)
+//   dTw'[j][c]  = sum over (head, qw) of dP[q][j]     q[q][c],  dP[q][j] = dRelW[q][j - (63 - qw)]   (table row 126 - j)
+// for the 64 queries of row qh: contraction over q, so both operands are reduction-major -- staged per head into LDS as bf16
+// ([q][kh], [q][j] with the skew applied while staging, [q][c]) and read with transposing LDS loads (the weight-gradient
+// kernel's fragment scheme and pair swizzle).  Wavefront w owns channel tile w and keeps its 4 + 8 accumulator tiles over all
+// heads; the block adds them into its privatised copy with fp32 atomics.  The FMA kernel above takes 1.33 ms per block.
+DEVINL int rpt_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+template <int CPR> DEVINL int rpt_g(int r) { return CPR >= 16 ? rpt_key(r) : (rpt_key(r) >> 1); }
+// byte offset of 16-byte chunk c8 of row r in an LDS image with CPR chunks per row
+template <int CPR> DEVINL int rpt_off(int r, int c8) { return r * CPR * 16 + ((((c8 >> 1) ^ rpt_g<CPR>(r)) << 5) | ((c8 & 1) << 4)); }
+// transposed fragment: k = rows kbase + lg*8 + {0..7}, m (or n) = columns tile*16 + l15
+template <int CPR> DEVINL u32x4 rpt_frag(const char* img, int kbase, int tile, int l15, int lg) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int row0 = kbase + lg * 8 + (l15 >> 2);
+    const char* q = img + row0 * CPR * 16 + ((tile ^ rpt_g<CPR>(row0)) << 5) + (l15 & 3) * 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * CPR * 16));
+    const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+    return u32x4{a[0], a[1], b[0], b[1]};
+}
+
+__global__ __launch_bounds__(RP_THREADS) void relpos_bwd_tab_mfma_kernel(const RelPosParams p) {
+    constexpr int S = 64;
+    __shared__ __attribute__((aligned(16))) char qimg[S * 128];        // [q][c]  bf16
+    __shared__ __attribute__((aligned(16))) char himg[S * 128];        // [q][kh] bf16
+    __shared__ __attribute__((aligned(16))) char wimg[S * 256];        // [q][j]  bf16, j = kw + 63 - qw
+    const int qh = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;        // wave = channel tile
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int N = S * S;
+    f32x4 ah[4], aw[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ah[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) aw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int head = 0; head < p.heads; ++head) {
+        const size_t row0 = ((size_t)b * p.heads + head) * N + (size_t)qh * S;
+        __syncthreads();                                               // the previous head's fragments are consumed
+        for (int i = threadIdx.x; i < S * 8; i += RP_THREADS) {        // q and dRelH: 8 chunks per row
+            const int q = i >> 3, c8 = i & 7;
+            st_chunk(qimg + rpt_off<8>(q, c8), ld_chunk((const bf16_t*)p.q + (size_t)b * p.q_bs + (size_t)(qh * S + q) * p.q_rs + head * RP_D + c8 * 8));
+            const float* g = p.rel_h + (row0 + q) * S + c8 * 8;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(g), x1 = *reinterpret_cast<const f32x4*>(g + 4);
+            const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            st_chunk(himg + rpt_off<8>(q, c8), Chunk<bf16_t>::pack(f));
+        }
+        for (int i = threadIdx.x; i < S * 16; i += RP_THREADS) {       // dP: 16 chunks per row, skewed by 63 - qw
+            const int q = i >> 4, c8 = i & 15;
+            const float* g = p.rel_w + (row0 + q) * S;
+            const int w0 = c8 * 8 - (S - 1 - q);
+            float f[8];
+            if (w0 >= 0 && w0 + 8 <= S) {
+                typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+                const f32x4_u x0 = *reinterpret_cast<const f32x4_u*>(g + w0), x1 = *reinterpret_cast<const f32x4_u*>(g + w0 + 4);
+                f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3]; f[4] = x1[0]; f[5] = x1[1]; f[6] = x1[2]; f[7] = x1[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int kw = w0 + e;
+                    f[e] = (kw >= 0 && kw < S) ? g[kw] : 0.f;
+                }
+            }
+            st_chunk(wimg + rpt_off<16>(q, c8), Chunk<bf16_t>::pack(f));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4 bq = rpt_frag<8>(qimg, ks * 32, wave, l15, lg);            // B: k = q, n = channels of this wavefront's tile
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) Mma<bf16_t>::run(ah[mt], rpt_frag<8>(himg, ks * 32, mt, l15, lg), bq);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) Mma<bf16_t>::run(aw[mt], rpt_frag<16>(wimg, ks * 32, mt, l15, lg), bq);
+        }
+    }
+    // D tile: rows m = mt*16 + lg*4 + r (kh or j), column = channel wave*16 + l15
+    const int copy = (blockIdx.y * gridDim.x + blockIdx.x) % RP_COPIES;
+    float* dh = p.dtab_h + (size_t)copy * p.copy_stride;
+    float* dw = p.dtab_w + (size_t)copy * p.copy_stride;
+    const int c = wave * 16 + l15;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dh + (size_t)(qh - (mt * 16 + lg * 4 + r) + S - 1) * RP_D + c, ah[mt][r]);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = mt * 16 + lg * 4 + r;
+            if (j < 2 * S - 1) unsafeAtomicAdd(dw + (size_t)(2 * S - 2 - j) * RP_D + c, aw[mt][r]);
+        }
+}
+
 // dst[i] += sum over the privatised copies
 __global__ __launch_bounds__(256) void relpos_tab_reduce_kernel(const float* __restrict__ ws, long copy_stride, int n,
                                                                 float* __restrict__ dst_h, int n_h, float* __restrict__ dst_w) {
@@ -522,11 +692,19 @@ int relpos_bwd(int dtype, const void* q, void* dq, long q_rs, long q_bs, const f
         else { auto k2 = relpos_bwd_tab_kernel<TT, 8, 8>; static bool o3 = (rp_allow_lds(k2), true); (void)o3;                                \
             hipLaunchKernelGGL(k2, dim3(Sh, B), dim3(RP_THREADS), (size_t)(RP_TILE * RP_PITCH + RP_TILE * 128 + RP_TILE * (64 + 128)) * sizeof(float) + 3 * RP_TILE * sizeof(int), st, p); } \
     } while (0)
+    static const int use_mfma = getenv("SAICV_RELPOS_MFMA") ? atoi(getenv("SAICV_RELPOS_MFMA")) : 1;
     if (dtype == SAICV_DTYPE_BF16) {
-        auto k1 = relpos_bwd_dq_kernel<bf16_t>;
-        static bool once = (rp_allow_lds(k1), true); (void)once;
-        hipLaunchKernelGGL(k1, dim3(Sh, B), dim3(RP_THREADS), smem1, st, p);
-        if (dtab_h) RP_TAB(bf16_t);
+        if (use_mfma && Sh == 64 && Sw == 64) {
+            hipLaunchKernelGGL(relpos_bwd_dq_mfma_kernel, dim3(Sh, B), dim3(RP_THREADS), 0, st, p);
+        } else {
+            auto k1 = relpos_bwd_dq_kernel<bf16_t>;
+            static bool once = (rp_allow_lds(k1), true); (void)once;
+            hipLaunchKernelGGL(k1, dim3(Sh, B), dim3(RP_THREADS), smem1, st, p);
+        }
+        if (dtab_h) {
+            if (use_mfma && Sh == 64 && Sw == 64) hipLaunchKernelGGL(relpos_bwd_tab_mfma_kernel, dim3(Sh, B), dim3(RP_THREADS), 0, st, p);
+            else RP_TAB(bf16_t);
+        }
     } else {
         auto k1 = relpos_bwd_dq_kernel<float>;
         static bool once = (rp_allow_lds(k1), true); (void)once;
