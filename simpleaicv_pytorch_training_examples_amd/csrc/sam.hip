@@ -243,75 +243,82 @@ __global__ __launch_bounds__(RP_THREADS) void relpos_fwd_mfma_kernel(const RelPo
 // dP[q][j] = dRelW[q][j - (Sw - 1 - qw)] (zero outside the row).  Tables are staged TRANSPOSED in LDS (rows = channels), the
 // gradients of the logits are rounded to bf16 as they are loaded; a lane ends up with four consecutive channels of one query
 // and adds them to dq with one 8-byte read-modify-write.
-DEVINL int rpm_off256(int row, int chunk) { return row * 256 + (((chunk ^ row) & 15) << 4); }
-
-__global__ __launch_bounds__(RP_THREADS) void relpos_bwd_dq_mfma_kernel(const RelPosParams p) {
-    constexpr int S = 64, J = 127;
-    __shared__ __attribute__((aligned(16))) char thT[RP_D * 128];      // [c][kh] bf16
-    __shared__ __attribute__((aligned(16))) char twT[RP_D * 256];      // [c][j]  bf16, j = 127 is zero
-    const int qh = blockIdx.x, b = blockIdx.y;
-    for (int i = threadIdx.x; i < S * RP_D; i += RP_THREADS) {
-        const int kh = i / RP_D, c = i - kh * RP_D;
-        const bf16_t v = (bf16_t)p.tab_h[(size_t)(qh - kh + S - 1) * RP_D + c];
-        *reinterpret_cast<bf16_t*>(thT + rpm_off(c, kh >> 3) + (kh & 7) * 2) = v;
+// LDS image with CH 16-byte chunks per row (CH = 4, 8, 16), XOR-swizzled by the row
+template <int CH> DEVINL int rpm_offc(int row, int chunk) {
+    return row * CH * 16 + (((chunk ^ (row >> (CH == 8 ? 1 : CH == 16 ? 0 : 2))) & (CH - 1)) << 4);
+}
+// eight consecutive floats row[w0 .. w0+7] of a row of S floats (zero outside [0, S)), rounded to bf16
+template <bool ALIGNED = false>
+DEVINL u32x4 rp_load8(const float* __restrict__ row, int w0, int S) {
+    float f[8];
+    if constexpr (ALIGNED) {                          // caller guarantees: 16-byte aligned and wholly inside the row
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + w0), x1 = *reinterpret_cast<const f32x4*>(row + w0 + 4);
+        const float g[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        return Chunk<bf16_t>::pack(g);
     }
-    for (int i = threadIdx.x; i < 128 * RP_D; i += RP_THREADS) {
+    if (w0 >= 0 && w0 + 8 <= S) {                     // wholly inside: two 4-byte-aligned 16-byte loads
+        typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+        const f32x4_u x0 = *reinterpret_cast<const f32x4_u*>(row + w0), x1 = *reinterpret_cast<const f32x4_u*>(row + w0 + 4);
+        f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3]; f[4] = x1[0]; f[5] = x1[1]; f[6] = x1[2]; f[7] = x1[3];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = w0 + e;
+            f[e] = (k >= 0 && k < S) ? row[k] : 0.f;
+        }
+    }
+    return Chunk<bf16_t>::pack(f);
+}
+
+// KH / KW: 32-wide k-steps of the kh / j contractions (2 / 4 for the 64 x 64 global blocks, 1 / 1 for windows up to 16 x 16)
+template <int KH, int KW>
+__global__ __launch_bounds__(RP_THREADS) void relpos_bwd_dq_mfma_kernel(const RelPosParams p) {
+    constexpr int CHH = KH * 4, CHW = KW * 4;                          // chunks per LDS row
+    __shared__ __attribute__((aligned(16))) char thT[RP_D * CHH * 16];  // [c][kh] bf16, zero beyond Sh
+    __shared__ __attribute__((aligned(16))) char twT[RP_D * CHW * 16];  // [c][j]  bf16, zero beyond 2 Sw - 2
+    const int qh = blockIdx.x, b = blockIdx.y;
+    const int Sh = KH == 2 ? 64 : p.Sh, Sw = KH == 2 ? 64 : p.Sw, J = 2 * Sw - 1;       // the global-block instantiation is 64 x 64 (constants fold)
+    for (int i = threadIdx.x; i < KH * 32 * RP_D; i += RP_THREADS) {
+        const int kh = i / RP_D, c = i - kh * RP_D;
+        const bf16_t v = kh < Sh ? (bf16_t)p.tab_h[(size_t)(qh - kh + Sh - 1) * RP_D + c] : (bf16_t)0.f;
+        *reinterpret_cast<bf16_t*>(thT + rpm_offc<CHH>(c, kh >> 3) + (kh & 7) * 2) = v;
+    }
+    for (int i = threadIdx.x; i < KW * 32 * RP_D; i += RP_THREADS) {
         const int j = i / RP_D, c = i - j * RP_D;
         const bf16_t v = j < J ? (bf16_t)p.tab_w[(size_t)(J - 1 - j) * RP_D + c] : (bf16_t)0.f;
-        *reinterpret_cast<bf16_t*>(twT + rpm_off256(c, j >> 3) + (j & 7) * 2) = v;
+        *reinterpret_cast<bf16_t*>(twT + rpm_offc<CHW>(c, j >> 3) + (j & 7) * 2) = v;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int N = S * S;
-    for (int item = wave; item < p.heads * 4; item += RP_THREADS / 64) {
-        const int head = item >> 2, mt = item & 3;
+    const int N = Sh * Sw, MT = (Sw + 15) >> 4;
+    for (int item = wave; item < p.heads * MT; item += RP_THREADS / 64) {
+        const int head = item / MT, mt = item - head * MT;
         const int qw = mt * 16 + l15;                                 // this lane's query (a column of the product)
-        const size_t row = ((size_t)b * p.heads + head) * N + (size_t)qh * S + qw;
-        u32x4 bh[2], bw[4];
-        {
-            const float* gh = p.rel_h + row * S;
+        const bool qok = qw < Sw;
+        const size_t row = ((size_t)b * p.heads + head) * N + (size_t)qh * Sw + (qok ? qw : 0);
+        u32x4 bh[KH], bw[KW];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(gh + ks * 32 + lg * 8), x1 = *reinterpret_cast<const f32x4*>(gh + ks * 32 + lg * 8 + 4);
-                const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                bh[ks] = Chunk<bf16_t>::pack(f);
-            }
-            const float* gw = p.rel_w + row * S;
-            const int shift = S - 1 - qw;
+        for (int ks = 0; ks < KH; ++ks) bh[ks] = qok ? rp_load8<KH == 2>(p.rel_h + row * Sh, ks * 32 + lg * 8, Sh) : zero_chunk();      // KH == 2: Sh == 64
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                float f[8];
-                const int w0 = ks * 32 + lg * 8 - shift;              // the lane's eight consecutive kw
-                if (w0 >= 0 && w0 + 8 <= S) {                         // wholly inside the row: two 4-byte-aligned 16-byte loads
-                    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-                    const f32x4_u x0 = *reinterpret_cast<const f32x4_u*>(gw + w0), x1 = *reinterpret_cast<const f32x4_u*>(gw + w0 + 4);
-                    f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3]; f[4] = x1[0]; f[5] = x1[1]; f[6] = x1[2]; f[7] = x1[3];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int kw = w0 + e;
-                        f[e] = (kw >= 0 && kw < S) ? gw[kw] : 0.f;
-                    }
-                }
-                bw[ks] = Chunk<bf16_t>::pack(f);
-            }
-        }
-        bf16_t* dq = (bf16_t*)p.dq + (size_t)b * p.q_bs + (size_t)(qh * S + qw) * p.q_rs + head * RP_D;
+        for (int ks = 0; ks < KW; ++ks) bw[ks] = qok ? rp_load8(p.rel_w + row * Sw, ks * 32 + lg * 8 - (Sw - 1 - qw), Sw) : zero_chunk();
+        bf16_t* dq = (bf16_t*)p.dq + (size_t)b * p.q_bs + (size_t)(qh * Sw + (qok ? qw : 0)) * p.q_rs + head * RP_D;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) Mma<bf16_t>::run(acc, ld_chunk(thT + rpm_off(ct * 16 + l15, ks * 4 + lg)), bh[ks]);
+            for (int ks = 0; ks < KH; ++ks) Mma<bf16_t>::run(acc, ld_chunk(thT + rpm_offc<CHH>(ct * 16 + l15, ks * 4 + lg)), bh[ks]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) Mma<bf16_t>::run(acc, ld_chunk(twT + rpm_off256(ct * 16 + l15, ks * 4 + lg)), bw[ks]);
+            for (int ks = 0; ks < KW; ++ks) Mma<bf16_t>::run(acc, ld_chunk(twT + rpm_offc<CHW>(ct * 16 + l15, ks * 4 + lg)), bw[ks]);
             // D^T tile: rows = channels ct*16 + lg*4 + r, column = query l15
-            bf16x4* dst = reinterpret_cast<bf16x4*>(dq + ct * 16 + lg * 4);
-            const bf16x4 old = *dst;
-            bf16x4 nw;
+            if (qok) {
+                bf16x4* dst = reinterpret_cast<bf16x4*>(dq + ct * 16 + lg * 4);
+                const bf16x4 old = *dst;
+                bf16x4 nw;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) nw[r] = (bf16_t)((float)old[r] + acc[r]);
-            *dst = nw;
+                for (int r = 0; r < 4; ++r) nw[r] = (bf16_t)((float)old[r] + acc[r]);
+                *dst = nw;
+            }
         }
     }
 }
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(RP_THREADS) void relpos_bwd_tab_kernel(const RelPos
 // kernel's fragment scheme and pair swizzle).  Wavefront w owns channel tile w and keeps its 4 + 8 accumulator tiles over all
 // heads; the block adds them into its privatised copy with fp32 atomics.  The FMA kernel above takes 1.33 ms per block.
 DEVINL int rpt_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
-template <int CPR> DEVINL int rpt_g(int r) { return CPR >= 16 ? rpt_key(r) : (rpt_key(r) >> 1); }
+template <int CPR> DEVINL int rpt_g(int r) { return CPR >= 16 ? rpt_key(r) : CPR == 8 ? (rpt_key(r) >> 1) : CPR == 4 ? (rpt_key(r) >> 2) : 0; }
 // byte offset of 16-byte chunk c8 of row r in an LDS image with CPR chunks per row
 template <int CPR> DEVINL int rpt_off(int r, int c8) { return r * CPR * 16 + ((((c8 >> 1) ^ rpt_g<CPR>(r)) << 5) | ((c8 & 1) << 4)); }
 // transposed fragment: k = rows kbase + lg*8 + {0..7}, m (or n) = columns tile*16 + l15
@@ -508,57 +515,47 @@ template <int CPR> DEVINL u32x4 rpt_frag(const char* img, int kbase, int tile, i
     return u32x4{a[0], a[1], b[0], b[1]};
 }
 
+// KQ: 32-wide k-steps over the queries of a row; MH / MW: 16-row tiles of kh / j (2, 4, 8 for 64 x 64; 1, 1, 2 up to 16 x 16)
+template <int KQ, int MH, int MW>
 __global__ __launch_bounds__(RP_THREADS) void relpos_bwd_tab_mfma_kernel(const RelPosParams p) {
-    constexpr int S = 64;
-    __shared__ __attribute__((aligned(16))) char qimg[S * 128];        // [q][c]  bf16
-    __shared__ __attribute__((aligned(16))) char himg[S * 128];        // [q][kh] bf16
-    __shared__ __attribute__((aligned(16))) char wimg[S * 256];        // [q][j]  bf16, j = kw + 63 - qw
+    constexpr int QR = KQ * 32, CH = MH * 2, CW = MW * 2;
+    __shared__ __attribute__((aligned(16))) char qimg[QR * 128];          // [q][c]  bf16, zero rows beyond Sw
+    __shared__ __attribute__((aligned(16))) char himg[QR * CH * 16];      // [q][kh] bf16
+    __shared__ __attribute__((aligned(16))) char wimg[QR * CW * 16];      // [q][j]  bf16, j = kw + Sw - 1 - qw
     const int qh = blockIdx.x, b = blockIdx.y;
+    const int Sh = KQ == 2 ? 64 : p.Sh, Sw = KQ == 2 ? 64 : p.Sw, J = 2 * Sw - 1;       // the global-block instantiation is 64 x 64 (constants fold)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;        // wave = channel tile
     const int l15 = lane & 15, lg = lane >> 4;
-    const int N = S * S;
-    f32x4 ah[4], aw[8];
+    const int N = Sh * Sw;
+    f32x4 ah[MH], aw[MW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ah[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MH; ++i) ah[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) aw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MW; ++i) aw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int head = 0; head < p.heads; ++head) {
-        const size_t row0 = ((size_t)b * p.heads + head) * N + (size_t)qh * S;
+        const size_t row0 = ((size_t)b * p.heads + head) * N + (size_t)qh * Sw;
         __syncthreads();                                               // the previous head's fragments are consumed
-        for (int i = threadIdx.x; i < S * 8; i += RP_THREADS) {        // q and dRelH: 8 chunks per row
+        for (int i = threadIdx.x; i < QR * 8; i += RP_THREADS) {
             const int q = i >> 3, c8 = i & 7;
-            st_chunk(qimg + rpt_off<8>(q, c8), ld_chunk((const bf16_t*)p.q + (size_t)b * p.q_bs + (size_t)(qh * S + q) * p.q_rs + head * RP_D + c8 * 8));
-            const float* g = p.rel_h + (row0 + q) * S + c8 * 8;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(g), x1 = *reinterpret_cast<const f32x4*>(g + 4);
-            const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            st_chunk(himg + rpt_off<8>(q, c8), Chunk<bf16_t>::pack(f));
+            st_chunk(qimg + rpt_off<8>(q, c8), q < Sw ? ld_chunk((const bf16_t*)p.q + (size_t)b * p.q_bs + (size_t)(qh * Sw + q) * p.q_rs + head * RP_D + c8 * 8)
+                                                      : zero_chunk());
         }
-        for (int i = threadIdx.x; i < S * 16; i += RP_THREADS) {       // dP: 16 chunks per row, skewed by 63 - qw
-            const int q = i >> 4, c8 = i & 15;
-            const float* g = p.rel_w + (row0 + q) * S;
-            const int w0 = c8 * 8 - (S - 1 - q);
-            float f[8];
-            if (w0 >= 0 && w0 + 8 <= S) {
-                typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-                const f32x4_u x0 = *reinterpret_cast<const f32x4_u*>(g + w0), x1 = *reinterpret_cast<const f32x4_u*>(g + w0 + 4);
-                f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3]; f[4] = x1[0]; f[5] = x1[1]; f[6] = x1[2]; f[7] = x1[3];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int kw = w0 + e;
-                    f[e] = (kw >= 0 && kw < S) ? g[kw] : 0.f;
-                }
-            }
-            st_chunk(wimg + rpt_off<16>(q, c8), Chunk<bf16_t>::pack(f));
+        for (int i = threadIdx.x; i < QR * CH; i += RP_THREADS) {
+            const int q = i / CH, c8 = i - q * CH;
+            st_chunk(himg + rpt_off<CH>(q, c8), q < Sw ? rp_load8<KQ == 2>(p.rel_h + (row0 + q) * Sh, c8 * 8, Sh) : zero_chunk());      // KQ == 2: 64 x 64
+        }
+        for (int i = threadIdx.x; i < QR * CW; i += RP_THREADS) {      // dP: skewed by Sw - 1 - qw
+            const int q = i / CW, c8 = i - q * CW;
+            st_chunk(wimg + rpt_off<CW>(q, c8), q < Sw ? rp_load8(p.rel_w + (row0 + q) * Sw, c8 * 8 - (Sw - 1 - q), Sw) : zero_chunk());
         }
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KQ; ++ks) {
             const u32x4 bq = rpt_frag<8>(qimg, ks * 32, wave, l15, lg);            // B: k = q, n = channels of this wavefront's tile
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) Mma<bf16_t>::run(ah[mt], rpt_frag<8>(himg, ks * 32, mt, l15, lg), bq);
+            for (int mt = 0; mt < MH; ++mt) Mma<bf16_t>::run(ah[mt], rpt_frag<CH>(himg, ks * 32, mt, l15, lg), bq);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) Mma<bf16_t>::run(aw[mt], rpt_frag<16>(wimg, ks * 32, mt, l15, lg), bq);
+            for (int mt = 0; mt < MW; ++mt) Mma<bf16_t>::run(aw[mt], rpt_frag<CW>(wimg, ks * 32, mt, l15, lg), bq);
         }
     }
     // D tile: rows m = mt*16 + lg*4 + r (kh or j), column = channel wave*16 + l15
@@ -567,15 +564,18 @@ __global__ __launch_bounds__(RP_THREADS) void relpos_bwd_tab_mfma_kernel(const R
     float* dw = p.dtab_w + (size_t)copy * p.copy_stride;
     const int c = wave * 16 + l15;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MH; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dh + (size_t)(qh - (mt * 16 + lg * 4 + r) + S - 1) * RP_D + c, ah[mt][r]);
+        for (int r = 0; r < 4; ++r) {
+            const int kh = mt * 16 + lg * 4 + r;
+            if (kh < Sh) unsafeAtomicAdd(dh + (size_t)(qh - kh + Sh - 1) * RP_D + c, ah[mt][r]);
+        }
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = mt * 16 + lg * 4 + r;
-            if (j < 2 * S - 1) unsafeAtomicAdd(dw + (size_t)(2 * S - 2 - j) * RP_D + c, aw[mt][r]);
+            if (j < J) unsafeAtomicAdd(dw + (size_t)(J - 1 - j) * RP_D + c, aw[mt][r]);
         }
 }
 
@@ -695,14 +695,17 @@ int relpos_bwd(int dtype, const void* q, void* dq, long q_rs, long q_bs, const f
     static const int use_mfma = getenv("SAICV_RELPOS_MFMA") ? atoi(getenv("SAICV_RELPOS_MFMA")) : 1;
     if (dtype == SAICV_DTYPE_BF16) {
         if (use_mfma && Sh == 64 && Sw == 64) {
-            hipLaunchKernelGGL(relpos_bwd_dq_mfma_kernel, dim3(Sh, B), dim3(RP_THREADS), 0, st, p);
+            hipLaunchKernelGGL((relpos_bwd_dq_mfma_kernel<2, 4>), dim3(Sh, B), dim3(RP_THREADS), 0, st, p);
+        } else if (use_mfma && Sh <= 16 && Sw <= 16) {
+            hipLaunchKernelGGL((relpos_bwd_dq_mfma_kernel<1, 1>), dim3(Sh, B), dim3(RP_THREADS), 0, st, p);
         } else {
             auto k1 = relpos_bwd_dq_kernel<bf16_t>;
             static bool once = (rp_allow_lds(k1), true); (void)once;
             hipLaunchKernelGGL(k1, dim3(Sh, B), dim3(RP_THREADS), smem1, st, p);
         }
         if (dtab_h) {
-            if (use_mfma && Sh == 64 && Sw == 64) hipLaunchKernelGGL(relpos_bwd_tab_mfma_kernel, dim3(Sh, B), dim3(RP_THREADS), 0, st, p);
+            if (use_mfma && Sh == 64 && Sw == 64) hipLaunchKernelGGL((relpos_bwd_tab_mfma_kernel<2, 4, 8>), dim3(Sh, B), dim3(RP_THREADS), 0, st, p);
+            else if (use_mfma && Sh <= 16 && Sw <= 16) hipLaunchKernelGGL((relpos_bwd_tab_mfma_kernel<1, 1, 2>), dim3(Sh, B), dim3(RP_THREADS), 0, st, p);
             else RP_TAB(bf16_t);
         }
     } else {

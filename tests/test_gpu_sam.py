@@ -443,9 +443,9 @@ def test_relpos_kernels_match_einsum(grid, dtype):
     gh, gw = ops_tfm.relpos_bwd(q, dq, heads, sh, sw, th, tw, drh, drw, True)
     tol = 1e-4 if dtype == torch.float32 else 1e-2        # bf16: dq is rounded on store
     assert rel_err(dq, ql.grad) < tol
-    # bf16 at 64 x 64: the table gradients come off the matrix cores with the logit gradients rounded to bf16 (as the reference's
+    # bf16 at 64 x 64 and for windows up to 16 x 16: the table gradients come off the matrix cores with the logit gradients rounded to bf16 (as the reference's
     # autocast einsum backward does); everything else is fp32 FMA
-    ttol = 5e-3 if (dtype == torch.bfloat16 and grid == (64, 64)) else 1e-4
+    ttol = 5e-3 if (dtype == torch.bfloat16 and (grid == (64, 64) or max(grid) <= 16)) else 1e-4
     assert rel_err(gh, th.grad) < ttol and rel_err(gw, tw.grad) < ttol
     assert float(dqkv[:, :, c:].abs().sum()) == 0.0       # only the q slice is touched
 
