@@ -387,6 +387,10 @@ int saicv_sam_prompt_tokens(const float* points, int Np, int pad, const float* b
 int saicv_sam_prompt_tokens_bwd(const float* dtokens, const int* kinds, float* dtable, int BT, int C, void* stream);
 int saicv_sam_grid_pe(const float* gauss, int F, int S, float* out, void* stream);
 
+/* DETR sine position embedding (reference detection/models/backbones/detr_resnet.py:28-64): mask u8 / bool [B][H][W] (non-zero =
+ * padding) -> out fp32 [B][2F][H][W]; H * W <= 8192. */
+int saicv_detr_sine_pe(const unsigned char* mask, float* out, int B, int H, int W, int F, float temperature, float eps, void* stream);
+
 /* ---- depthwise convolution ---------------------------------
  * nn.Conv2d(C, C, K, stride, padding, dilation, groups=C) and its backward: reference
  * SimpleAICV/classification/backbones/van.py:30,68,75 (3x3 / 5x5 / dilated 7x7 of the LKA block) and convformer.py (7x7 of the

@@ -14,6 +14,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from ..... import ops
+from ....._lib import check, lib, ptr, require_gpu, stream
 from ....classification.backbones.resnet import BasicBlock, Bottleneck, ConvBnActBlock, _init_like_reference
 from ....classification.common import load_state_dict
 
@@ -27,8 +28,9 @@ __all__ = [
 
 
 class PositionEmbeddingBlock(nn.Module):
-    """Sine position embedding of the unpadded region; [B, H, W] bool mask (True = padding) -> [B, 2*inplanes, H, W].
-    ~1k tokens per image: host-scale tensor arithmetic, kept in fp32 tensor ops."""
+    """Sine position embedding of the unpadded region; [B, H, W] bool mask (True = padding) -> [B, 2*inplanes, H, W] fp32.
+    One kernel (`saicv_detr_sine_pe`, csrc/input.hip): per sample the running counts of un-padded pixels per column / row are
+    normalised to [0, 2 pi] and expanded to sin / cos features (reference detr_resnet.py:28-64)."""
 
     def __init__(self, inplanes=128, temperature=10000, eps=1e-6):
         super(PositionEmbeddingBlock, self).__init__()
@@ -39,19 +41,14 @@ class PositionEmbeddingBlock(nn.Module):
 
     def forward(self, masks):
         assert masks is not None
-        device = masks.device
-        not_masks = ~masks
-        y_embed = torch.cumsum(not_masks, 1, dtype=torch.float32)
-        x_embed = torch.cumsum(not_masks, 2, dtype=torch.float32)
-        y_embed = y_embed / (y_embed[:, -1:, :] + self.eps) * self.scale
-        x_embed = x_embed / (x_embed[:, :, -1:] + self.eps) * self.scale
-        dim_t = torch.arange(self.inplanes, dtype=torch.float32, device=device)
-        dim_t = self.temperature ** (2 * (dim_t // 2) / self.inplanes)
-        pos_x = x_embed[:, :, :, None] / dim_t
-        pos_y = y_embed[:, :, :, None] / dim_t
-        pos_x = torch.stack((torch.sin(pos_x[:, :, :, 0::2]), torch.cos(pos_x[:, :, :, 1::2])), dim=4).flatten(3)
-        pos_y = torch.stack((torch.sin(pos_y[:, :, :, 0::2]), torch.cos(pos_y[:, :, :, 1::2])), dim=4).flatten(3)
-        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+        require_gpu(masks)
+        m = masks.contiguous()
+        m = m if m.dtype in (torch.bool, torch.uint8) else (m != 0)
+        b, h, w = m.shape
+        out = torch.empty((b, 2 * self.inplanes, h, w), dtype=torch.float32, device=m.device)
+        check(lib().saicv_detr_sine_pe(ptr(m), ptr(out), b, h, w, self.inplanes, float(self.temperature), float(self.eps), stream()),
+              'detr_sine_pe')
+        return out
 
 
 class DetrResNetBackbone(nn.Module):

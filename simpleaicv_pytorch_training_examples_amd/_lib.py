@@ -139,6 +139,7 @@ SIGNATURES = {
     'saicv_mask_loss_grad_up4': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
     'saicv_mixup_cutmix': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'saicv_soft_labels': (c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, c_int, c_int, _P]),
+    'saicv_detr_sine_pe': (c_int, [_P, _P, c_int, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, _P]),
     'saicv_sam_prompt_tokens': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, ctypes.c_float, _P, _P, c_int, _P]),
     'saicv_sam_prompt_tokens_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P]),
     'saicv_sam_grid_pe': (c_int, [_P, c_int, c_int, _P, _P]),

@@ -214,6 +214,42 @@ __global__ __launch_bounds__(256) void grid_pe_kernel(const float* __restrict__ 
     out[(size_t)(F + f) * S * S + r] = cosf(ph);
 }
 
+
+// ---- DETR sine position embedding (f3): reference detection/models/backbones/detr_resnet.py:28-64.  One block per sample: the
+// running counts of un-padded pixels down each column / along each row (the reference's two cumsums) live in LDS, are
+// normalised by the column / row totals to [0, 2 pi] and expanded to F sine / cosine features each: out[b][c][y][x], channels
+// [0, F) from the row coordinate, [F, 2F) from the column coordinate, feature k = sin (k even) / cos (k odd) of
+// coordinate / temperature^(2 (k / 2) / F).  No trainable input, no backward.
+__global__ __launch_bounds__(256) void detr_sine_pe_kernel(const unsigned char* __restrict__ mask, float* __restrict__ out, int H, int W,
+                                                           int F, float temperature, float eps) {
+    extern __shared__ float pe_smem[];
+    float* ye = pe_smem;                 // [H][W]
+    float* xe = pe_smem + H * W;
+    const int b = blockIdx.x;
+    const unsigned char* m = mask + (size_t)b * H * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        float run = 0.f;
+        for (int y = 0; y < H; ++y) { run += m[y * W + x] ? 0.f : 1.f; ye[y * W + x] = run; }
+    }
+    for (int y = threadIdx.x; y < H; y += blockDim.x) {
+        float run = 0.f;
+        for (int x = 0; x < W; ++x) { run += m[y * W + x] ? 0.f : 1.f; xe[y * W + x] = run; }
+    }
+    __syncthreads();
+    const float two_pi = 6.283185307179586f;
+    float* o = out + (size_t)b * 2 * F * H * W;
+    // blockIdx.y splits the 2F x H x W outputs of a sample (the counts above are recomputed per block: H + W short loops)
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < 2 * F * H * W; i += gridDim.y * blockDim.x) {
+        const int c = i / (H * W), r = i - c * (H * W), y = r / W, x = r - y * W;
+        const bool isy = c < F;
+        const int k = isy ? c : c - F;
+        const float tot = isy ? ye[(H - 1) * W + x] : xe[y * W + (W - 1)];
+        const float coord = (isy ? ye[r] : xe[r]) / (tot + eps) * two_pi;
+        const float v = coord / powf(temperature, (float)(2 * (k / 2)) / (float)F);
+        o[i] = (k & 1) ? cosf(v) : sinf(v);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -288,6 +324,14 @@ int saicv_sam_grid_pe(const float* gauss, int F, int S, float* out, void* stream
     SAICV_REQUIRE(gauss && out && F > 0 && S > 0, "saicv_sam_grid_pe: bad arguments");
     hipLaunchKernelGGL(grid_pe_kernel, dim3((F * S * S + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gauss, F, S, out);
     return saicv::check_launch("sam_grid_pe");
+}
+
+int saicv_detr_sine_pe(const unsigned char* mask, float* out, int B, int H, int W, int F, float temperature, float eps, void* stream) {
+    SAICV_REQUIRE(mask && out && B > 0 && H > 0 && W > 0 && F > 0, "saicv_detr_sine_pe: bad arguments");
+    SAICV_REQUIRE((size_t)H * W * 8 <= 64 * 1024, "saicv_detr_sine_pe: %d x %d feature map (two fp32 planes must fit 64 KiB of LDS)", H, W);
+    hipLaunchKernelGGL(detr_sine_pe_kernel, dim3(B, 32), dim3(256), (size_t)H * W * 8, static_cast<hipStream_t>(stream), mask, out, H, W, F,
+                       temperature, eps);
+    return saicv::check_launch("detr_sine_pe");
 }
 
 }  // extern "C"

@@ -192,3 +192,29 @@ def test_sam_prompt_tokens_match_the_formula_and_route_gradients(have_points, ha
     want = _tokens_ref(torch.cat([grid.reshape(1, -1, 2), torch.full((1, 4096, 1), 2.0)], -1), None,
                        enc.pe_layer.positional_encoding_gaussian_matrix.cpu(), table, 1024, pad=False)
     assert float((pe.permute(1, 2, 0).reshape(4096, 256).double() - want[0]).abs().max()) < 2e-5
+
+
+def test_detr_sine_position_embedding_matches_the_formula():
+    """saicv_detr_sine_pe against an fp64 restatement of reference detr_resnet.py:37-64 (two cumulative sums of the un-padded mask,
+    normalised to 2 pi, divided by temperature^(2 (k // 2) / F), sin on even / cos on odd features, row features first)."""
+    import math
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models.backbones.detr_resnet import PositionEmbeddingBlock
+    g = torch.Generator().manual_seed(9)
+    b, h, w, f = 3, 25, 42, 128
+    masks = torch.ones(b, h, w, dtype=torch.bool)
+    for i, (hh, ww) in enumerate([(25, 42), (19, 30), (7, 41)]):
+        masks[i, :hh, :ww] = False
+    masks[1, 3, 5] = True                                     # a hole: the counts skip it
+    pe = PositionEmbeddingBlock(inplanes=f).cuda()(masks.cuda()).cpu()
+    nm = (~masks).double()
+    ye, xe = nm.cumsum(1), nm.cumsum(2)
+    ye = ye / (ye[:, -1:, :] + 1e-6) * 2 * math.pi
+    xe = xe / (xe[:, :, -1:] + 1e-6) * 2 * math.pi
+    k = torch.arange(f, dtype=torch.float64)
+    dim_t = 10000 ** (2 * (k // 2) / f)
+    def feats(e):
+        v = e[..., None] / dim_t
+        return torch.where(k % 2 == 0, v.sin(), v.cos())
+    ref = torch.cat([feats(ye), feats(xe)], -1).permute(0, 3, 1, 2)
+    assert tuple(pe.shape) == (b, 2 * f, h, w) and pe.dtype == torch.float32
+    assert float((pe.double() - ref).abs().max()) < 2e-5
