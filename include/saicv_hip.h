@@ -404,6 +404,26 @@ int saicv_dwconv2d_dgrad(int dtype, const void* dy, const void* wt, void* dx, in
 int saicv_dwconv2d_wgrad(int dtype, const void* dy, const void* x, float* dwt, float* dbias, int N, int H, int W, int C, int OH,
                          int OW, int K, int stride, int pad, int dil, void* stream);
 
+/* ---- streaming glue of the convolutional backbones that reuse the hot-path blocks (csrc/elemwise.hip) ---- */
+/* nn.ReLU / nn.LeakyReLU(slope) / nn.SiLU (kind 0 / 1 / 2) on a dense tensor of n elements (n % (16 / element size) == 0):
+ * reference classification/backbones/darknet.py:16-33 (ActivationBlock), van.py:44,103, convformer.py:53,86.
+ * The backward takes the forward INPUT x: dx = dy * act'(x). */
+int saicv_act_fwd(int dtype, int kind, double slope, const void* x, void* y, size_t n, void* stream);
+int saicv_act_bwd(int dtype, int kind, double slope, const void* dy, const void* x, void* dx, size_t n, void* stream);
+/* out = a * b on tensors of one dense layout (van.py:91 `u * attn`); da = dy * b, db = dy * a (either may be NULL) */
+int saicv_mul_fwd(int dtype, const void* a, const void* b, void* out, size_t n, void* stream);
+int saicv_mul_bwd(int dtype, const void* dy, const void* a, const void* b, void* da, void* db, size_t n, void* stream);
+/* out[m][c] = x[m][c] + s[c] * y[m][c] on [M][C] (NHWC) tensors, s fp32 [C]; x NULL: s * y; s NULL: x + y.
+ * van.py:181-185 (x + layer_scale * branch), the residual joins of darknet.py (Darknet53Block) and convformer.py:157-163.
+ * Backward of the branch: dy = s * dout (dy NULL: skipped; s NULL: ones), ds[c] += sum_m dout * y (ds NULL: skipped; fp32 atomics). */
+int saicv_channel_scale_add_fwd(int dtype, const void* x, const void* y, const float* s, void* out, size_t M, int C, void* stream);
+int saicv_channel_scale_add_bwd(int dtype, const void* dout, const void* y, const float* s, void* dy, float* ds, size_t M, int C,
+                                void* stream);
+/* per-channel sum / sum of squares of x[M][C] ADDED into sum[C] / sq[C] (fp32, zeroed by the caller): statistics of a
+ * BatchNorm2d whose input is not a convolution output (van.py:176,178,260; convformer.py:34-35,143,149); feed them to
+ * saicv_bn_finalize_fwd(rows = 1), then saicv_bn_act_fwd / saicv_bn_act_bwd as for the fused blocks. */
+int saicv_bn_stats(int dtype, const void* x, size_t M, int C, float* sum, float* sq, void* stream);
+
 /* ---- gradient all-reduce over RCCL / xGMI ------------------------------------------------
  * The reducer of nn.parallel.DistributedDataParallel (reference tools/train_classification_model.py:217-227 wraps the
  * model; tools/scripts.py:183-226 relies on gradients being averaged when backward() returns): contiguous ranges of the

@@ -146,6 +146,13 @@ SIGNATURES = {
     'saicv_dwconv2d_fwd': (c_int, [c_int, _P, _P, _P, _P] + [c_int] * 10 + [_P]),
     'saicv_dwconv2d_dgrad': (c_int, [c_int, _P, _P, _P] + [c_int] * 10 + [_P]),
     'saicv_dwconv2d_wgrad': (c_int, [c_int, _P, _P, _P, _P] + [c_int] * 10 + [_P]),
+    'saicv_act_fwd': (c_int, [c_int, c_int, c_double, _P, _P, c_size_t, _P]),
+    'saicv_act_bwd': (c_int, [c_int, c_int, c_double, _P, _P, _P, c_size_t, _P]),
+    'saicv_mul_fwd': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
+    'saicv_mul_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'saicv_channel_scale_add_fwd': (c_int, [c_int, _P, _P, _P, _P, c_size_t, c_int, _P]),
+    'saicv_channel_scale_add_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
+    'saicv_bn_stats': (c_int, [c_int, _P, c_size_t, c_int, _P, _P, _P]),
     'saicv_sam_sample_point': (c_int, [c_int, _P, _P, c_long, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _P, _P,
                                        c_int, c_int, c_int, _P]),
     'saicv_comm_available': (c_int, []),

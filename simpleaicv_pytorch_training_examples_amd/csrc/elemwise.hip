@@ -1,0 +1,317 @@
+// Streaming glue of the convolutional backbones that reuse the hot-path blocks: the activations,
+// gates and per-channel scales between the GEMM / depthwise / BatchNorm kernels of
+//   reference SimpleAICV/classification/backbones/darknet.py:16-33  (nn.LeakyReLU(0.1) / nn.SiLU / nn.ReLU after BatchNorm),
+//   van.py:86-93 (u * attn), :181-185 (x + layer_scale * branch), :176 (BatchNorm2d on a block input),
+//   convformer.py:40-78 (ReLU between the pointwise linears), :157-163 (x + branch).
+// All HBM-bound: 16-byte chunks (8 bf16 / 4 f32), one pass per tensor, fp32 arithmetic, grid-stride loops sized for
+// ~8 workgroups per CU.  Reductions over pixels (per-channel statistics, the gradient of a per-channel scale) keep a
+// chunk column per lane group, reduce across the workgroup in LDS and leave one fp32 atomic per channel and workgroup.
+#include "common.h"
+#include "saicv_internal.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+inline int ew_grid(size_t items) {
+    size_t g = (items + EW_THREADS - 1) / EW_THREADS;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+enum { ACT_RELU = 0, ACT_LEAKY = 1, ACT_SILU = 2 };
+
+template <int KIND> DEVINL float act_val(float x, float slope) {
+    if (KIND == ACT_RELU) return x > 0.f ? x : 0.f;
+    if (KIND == ACT_LEAKY) return x > 0.f ? x : x * slope;
+    const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    return x * s;
+}
+template <int KIND> DEVINL float act_der(float x, float slope) {
+    if (KIND == ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    if (KIND == ACT_LEAKY) return x > 0.f ? 1.f : slope;
+    const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    return s * fmaf(x, 1.f - s, 1.f);
+}
+
+// y = act(x)  |  dx = dy * act'(x)
+template <typename T, int KIND, bool BWD>
+__global__ __launch_bounds__(EW_THREADS) void act_kernel(const T* __restrict__ a, const T* __restrict__ x, T* __restrict__ out,
+                                                         size_t chunks, float slope) {
+    constexpr int N = Chunk<T>::N;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < chunks; i += (size_t)gridDim.x * EW_THREADS) {
+        float xv[N], o[N];
+        Chunk<T>::unpack(ld_chunk(x + i * N), xv);
+        if (BWD) {
+            float g[N];
+            Chunk<T>::unpack(ld_chunk(a + i * N), g);
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = g[j] * act_der<KIND>(xv[j], slope);
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = act_val<KIND>(xv[j], slope);
+        }
+        st_chunk(out + i * N, Chunk<T>::pack(o));
+    }
+}
+
+// out = a * b  |  da = dy * b, db = dy * a
+template <typename T, bool BWD>
+__global__ __launch_bounds__(EW_THREADS) void mul_kernel(const T* __restrict__ dy, const T* __restrict__ a, const T* __restrict__ b,
+                                                         T* __restrict__ o0, T* __restrict__ o1, size_t chunks) {
+    constexpr int N = Chunk<T>::N;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < chunks; i += (size_t)gridDim.x * EW_THREADS) {
+        float av[N], bv[N], r0[N];
+        Chunk<T>::unpack(ld_chunk(a + i * N), av);
+        Chunk<T>::unpack(ld_chunk(b + i * N), bv);
+        if (BWD) {
+            float g[N], r1[N];
+            Chunk<T>::unpack(ld_chunk(dy + i * N), g);
+#pragma unroll
+            for (int j = 0; j < N; ++j) { r0[j] = g[j] * bv[j]; r1[j] = g[j] * av[j]; }
+            if (o0) st_chunk(o0 + i * N, Chunk<T>::pack(r0));
+            if (o1) st_chunk(o1 + i * N, Chunk<T>::pack(r1));
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) r0[j] = av[j] * bv[j];
+            st_chunk(o0 + i * N, Chunk<T>::pack(r0));
+        }
+    }
+}
+
+// out[m][c] = x[m][c] + s[c] * y[m][c]      (x NULL: s * y;  s NULL: x + y)
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void scale_add_kernel(const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ s,
+                                                               T* __restrict__ out, size_t chunks, int cpr) {
+    constexpr int N = Chunk<T>::N;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < chunks; i += (size_t)gridDim.x * EW_THREADS) {
+        float yv[N], o[N];
+        Chunk<T>::unpack(ld_chunk(y + i * N), yv);
+        if (s) {
+            const int c0 = (int)(i % (size_t)cpr) * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j) yv[j] *= s[c0 + j];
+        }
+        if (x) {
+            float xv[N];
+            Chunk<T>::unpack(ld_chunk(x + i * N), xv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = xv[j] + yv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = yv[j];
+        }
+        st_chunk(out + i * N, Chunk<T>::pack(o));
+    }
+}
+
+// Column reductions over the rows of a [M][C] tensor.  A workgroup owns `cw` chunk columns (a power of two <= 64) and a range of
+// rows; lane = column (fastest) x row lane.  MODE 0: sum[c] += x, sq[c] += x^2 (BatchNorm statistics of a block input);
+// MODE 1: dy = s * dout (optional), ds[c] += dout * y (gradient of the per-channel scale, van.py:181).
+template <typename T, int MODE>
+__global__ __launch_bounds__(EW_THREADS) void colred_kernel(const T* __restrict__ p0, const T* __restrict__ p1, const float* __restrict__ s,
+                                                            T* __restrict__ dy, float* __restrict__ r0, float* __restrict__ r1,
+                                                            size_t M, int C, int cw, size_t rows_per_block) {
+    constexpr int N = Chunk<T>::N;
+    __shared__ float red[EW_THREADS * N * (MODE == 0 ? 2 : 1)];
+    const int cpr = C / N;
+    const int col = blockIdx.x * cw + (threadIdx.x % cw);
+    const int rl = threadIdx.x / cw, nrl = EW_THREADS / cw;
+    const size_t m0 = (size_t)blockIdx.y * rows_per_block;
+    size_t m1 = m0 + rows_per_block;
+    if (m1 > M) m1 = M;
+    float a0[N], a1[N], sv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { a0[j] = 0.f; a1[j] = 0.f; sv[j] = 1.f; }
+    if (col < cpr) {
+        if (MODE == 1 && s) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) sv[j] = s[col * N + j];
+        }
+        for (size_t m = m0 + rl; m < m1; m += nrl) {
+            const size_t off = m * C + (size_t)col * N;
+            float v[N];
+            Chunk<T>::unpack(ld_chunk(p0 + off), v);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) { a0[j] += v[j]; a1[j] = fmaf(v[j], v[j], a1[j]); }
+            } else {
+                if (r0) {
+                    float yv[N];
+                    Chunk<T>::unpack(ld_chunk(p1 + off), yv);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) a0[j] = fmaf(v[j], yv[j], a0[j]);
+                }
+                if (dy) {
+                    float o[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) o[j] = v[j] * sv[j];
+                    st_chunk(dy + off, Chunk<T>::pack(o));
+                }
+            }
+        }
+    }
+    if (MODE == 1 && !r0) return;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        red[threadIdx.x * N + j] = a0[j];
+        if (MODE == 0) red[EW_THREADS * N + threadIdx.x * N + j] = a1[j];
+    }
+    __syncthreads();
+    if (rl == 0 && col < cpr) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float t0 = 0.f, t1 = 0.f;
+            for (int r = 0; r < nrl; ++r) {
+                t0 += red[(r * cw + threadIdx.x) * N + j];
+                if (MODE == 0) t1 += red[EW_THREADS * N + (r * cw + threadIdx.x) * N + j];
+            }
+            atomicAdd(r0 + col * N + j, t0);
+            if (MODE == 0) atomicAdd(r1 + col * N + j, t1);
+        }
+    }
+}
+
+struct ColGeom { int cw; dim3 grid; size_t rpb; };
+inline ColGeom col_geom(size_t M, int cpr) {
+    ColGeom g;
+    g.cw = 1;
+    while (g.cw * 2 <= cpr && g.cw * 2 <= 64) g.cw *= 2;
+    const int groups = (cpr + g.cw - 1) / g.cw;
+    // ~2048 workgroups over the chip, at most 1024 row ranges (= atomics per channel), at least 64 rows per range
+    size_t ranges = (2048 + groups - 1) / groups;
+    if (ranges > 1024) ranges = 1024;
+    size_t rpb = (M + ranges - 1) / ranges;
+    if (rpb < 64) rpb = 64;
+    ranges = (M + rpb - 1) / rpb;
+    g.rpb = rpb;
+    g.grid = dim3(groups, (unsigned)ranges);
+    return g;
+}
+
+inline int ew_check(const char* what, int dtype, size_t n) {
+    SAICV_REQUIRE(dtype == SAICV_DTYPE_BF16 || dtype == SAICV_DTYPE_F32, "%s: dtype %d", what, dtype);
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(n % e == 0, "%s: %zu elements are not whole 16-byte chunks", what, n);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// nn.ReLU / nn.LeakyReLU(slope) / nn.SiLU on a dense tensor of n elements (kind 0 / 1 / 2): darknet.py:16-33, van.py:44, :103
+int saicv_act_fwd(int dtype, int kind, double slope, const void* x, void* y, size_t n, void* stream) {
+    if (ew_check("act_fwd", dtype, n)) return -1;
+    SAICV_REQUIRE(kind >= 0 && kind <= 2, "act_fwd: kind %d", kind);
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t chunks = n / (dtype == SAICV_DTYPE_BF16 ? 8 : 4);
+#define ACT(TT, KK) hipLaunchKernelGGL((act_kernel<TT, KK, false>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const TT*)nullptr, (const TT*)x, (TT*)y, chunks, (float)slope)
+    if (dtype == SAICV_DTYPE_BF16) { if (kind == 0) ACT(bf16_t, 0); else if (kind == 1) ACT(bf16_t, 1); else ACT(bf16_t, 2); }
+    else { if (kind == 0) ACT(float, 0); else if (kind == 1) ACT(float, 1); else ACT(float, 2); }
+#undef ACT
+    return saicv::check_launch("act_fwd");
+}
+
+// dx = dy * act'(x)   (x = the forward INPUT)
+int saicv_act_bwd(int dtype, int kind, double slope, const void* dy, const void* x, void* dx, size_t n, void* stream) {
+    if (ew_check("act_bwd", dtype, n)) return -1;
+    SAICV_REQUIRE(kind >= 0 && kind <= 2, "act_bwd: kind %d", kind);
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t chunks = n / (dtype == SAICV_DTYPE_BF16 ? 8 : 4);
+#define ACT(TT, KK) hipLaunchKernelGGL((act_kernel<TT, KK, true>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const TT*)dy, (const TT*)x, (TT*)dx, chunks, (float)slope)
+    if (dtype == SAICV_DTYPE_BF16) { if (kind == 0) ACT(bf16_t, 0); else if (kind == 1) ACT(bf16_t, 1); else ACT(bf16_t, 2); }
+    else { if (kind == 0) ACT(float, 0); else if (kind == 1) ACT(float, 1); else ACT(float, 2); }
+#undef ACT
+    return saicv::check_launch("act_bwd");
+}
+
+// out = a * b, same dense layout (van.py:91  `u * attn`)
+int saicv_mul_fwd(int dtype, const void* a, const void* b, void* out, size_t n, void* stream) {
+    if (ew_check("mul_fwd", dtype, n)) return -1;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t chunks = n / (dtype == SAICV_DTYPE_BF16 ? 8 : 4);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL((mul_kernel<bf16_t, false>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const bf16_t*)nullptr, (const bf16_t*)a,
+                           (const bf16_t*)b, (bf16_t*)out, (bf16_t*)nullptr, chunks);
+    else
+        hipLaunchKernelGGL((mul_kernel<float, false>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const float*)nullptr, (const float*)a,
+                           (const float*)b, (float*)out, (float*)nullptr, chunks);
+    return saicv::check_launch("mul_fwd");
+}
+
+// da = dy * b, db = dy * a (either may be NULL)
+int saicv_mul_bwd(int dtype, const void* dy, const void* a, const void* b, void* da, void* db, size_t n, void* stream) {
+    if (ew_check("mul_bwd", dtype, n)) return -1;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t chunks = n / (dtype == SAICV_DTYPE_BF16 ? 8 : 4);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL((mul_kernel<bf16_t, true>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const bf16_t*)dy, (const bf16_t*)a,
+                           (const bf16_t*)b, (bf16_t*)da, (bf16_t*)db, chunks);
+    else
+        hipLaunchKernelGGL((mul_kernel<float, true>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const float*)dy, (const float*)a,
+                           (const float*)b, (float*)da, (float*)db, chunks);
+    return saicv::check_launch("mul_bwd");
+}
+
+// out[m][c] = x[m][c] + s[c] * y[m][c] over a [M][C] (NHWC) tensor; x NULL: s * y; s NULL: x + y (residual joins of
+// darknet.py Darknet53Block, convformer.py:157-163; layer scale of van.py:181-185)
+int saicv_channel_scale_add_fwd(int dtype, const void* x, const void* y, const float* s, void* out, size_t M, int C, void* stream) {
+    if (ew_check("channel_scale_add_fwd", dtype, (size_t)C)) return -1;
+    SAICV_REQUIRE(x != nullptr || s != nullptr, "channel_scale_add_fwd: neither an addend nor a scale");
+    if (M == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    const size_t chunks = M * (size_t)(C / e);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL((scale_add_kernel<bf16_t>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const bf16_t*)x, (const bf16_t*)y, s,
+                           (bf16_t*)out, chunks, C / e);
+    else
+        hipLaunchKernelGGL((scale_add_kernel<float>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const float*)x, (const float*)y, s,
+                           (float*)out, chunks, C / e);
+    return saicv::check_launch("channel_scale_add_fwd");
+}
+
+// backward of the scaled branch: dy = s * dout (dy NULL: not wanted; s NULL: ones), ds[c] += sum_m dout * y (ds NULL: not wanted;
+// fp32 atomics into a buffer the caller zeroed or accumulates in)
+int saicv_channel_scale_add_bwd(int dtype, const void* dout, const void* y, const float* s, void* dy, float* ds, size_t M, int C,
+                                void* stream) {
+    if (ew_check("channel_scale_add_bwd", dtype, (size_t)C)) return -1;
+    SAICV_REQUIRE(ds == nullptr || y != nullptr, "channel_scale_add_bwd: the scale gradient needs the branch output");
+    if (M == 0 || (dy == nullptr && ds == nullptr)) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    const ColGeom g = col_geom(M, C / e);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL((colred_kernel<bf16_t, 1>), g.grid, dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (const bf16_t*)y, s, (bf16_t*)dy, ds,
+                           (float*)nullptr, M, C, g.cw, g.rpb);
+    else
+        hipLaunchKernelGGL((colred_kernel<float, 1>), g.grid, dim3(EW_THREADS), 0, st, (const float*)dout, (const float*)y, s, (float*)dy, ds,
+                           (float*)nullptr, M, C, g.cw, g.rpb);
+    return saicv::check_launch("channel_scale_add_bwd");
+}
+
+// per-channel sum and sum of squares of x[M][C], ADDED into sum[C] / sq[C] (fp32, zeroed by the caller): the statistics of a
+// BatchNorm2d whose input is not a convolution output (van.py:176,178 norm1 / norm2, :260 stage norm; convformer.py:143,149);
+// saicv_bn_finalize_fwd(rows = 1) turns them into mean / invstd / scale / shift as for the convolution epilogues' rows
+int saicv_bn_stats(int dtype, const void* x, size_t M, int C, float* sum, float* sq, void* stream) {
+    if (ew_check("bn_stats", dtype, (size_t)C)) return -1;
+    if (M == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    const ColGeom g = col_geom(M, C / e);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL((colred_kernel<bf16_t, 0>), g.grid, dim3(EW_THREADS), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr,
+                           (bf16_t*)nullptr, sum, sq, M, C, g.cw, g.rpb);
+    else
+        hipLaunchKernelGGL((colred_kernel<float, 0>), g.grid, dim3(EW_THREADS), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr,
+                           (float*)nullptr, sum, sq, M, C, g.cw, g.rpb);
+    return saicv::check_launch("bn_stats");
+}
+
+}  // extern "C"

@@ -584,7 +584,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(const T* __r
 //  * outputs are computed TRANSPOSED (A = operand^T fragment, B = probabilities), so a lane ends up with four consecutive
 //    d of one row and stores 8 bytes instead of four scattered 2-byte elements.
 // 4 wavefronts per workgroup, two workgroups per CU (LDS), pairs of tiles dealt round-robin to the wavefronts.
-constexpr int ATT2_THREADS = 256;
+// TPW = 16-row tiles per wavefront: 2 (four wavefronts per workgroup, fragment reads shared by the pair) or 1 (eight wavefronts,
+// half the registers: four wavefronts per SIMD stay resident)
+template <int TPW> struct Att2 { static constexpr int THREADS = TPW == 2 ? 256 : 512; };
 
 DEVINL u32x4 tr_pair(const char* q) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -606,7 +608,8 @@ DEVINL void st_bf16x4(bf16_t* dst, const f32x4& v, float mul) {
     *reinterpret_cast<bf16x4*>(dst) = pk;
 }
 
-__global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+template <int TPW>
+__global__ __launch_bounds__(Att2<TPW>::THREADS, TPW == 2 ? 2 : 4) void attention_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                          bf16_t* __restrict__ dqkv, int B, int N, int H, float scale) {
     typedef bf16_t T;
@@ -626,7 +629,9 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
     const T* ob = out + (size_t)b * N * C + h * 64;
     const T* dob = dout + (size_t)b * N * C + h * 64;
     T* dqb = dqkv + (size_t)b * N * RS + h * 64;
+    constexpr int ATT2_THREADS = Att2<TPW>::THREADS;
     constexpr int NW = ATT2_THREADS / 64;
+    constexpr int RPW = 16 * TPW;                  // rows owned by a wavefront per item
 
     // ---- phase 0: D[q] = dO[q] . O[q], two threads per query row; log-sum-exp in log2 units
     for (int i = threadIdx.x; i < Np * 2; i += ATT2_THREADS) {
@@ -664,15 +669,15 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
         for (int dt = 0; dt < 4; ++dt) tro[dt] = trow * 128 + ((((dt * 2 + ((l15 & 3) >> 1)) ^ tsw) & 7) << 4) + ((l15 & 1) << 3);
     }
     const float c2 = scale * 1.4426950408889634f;
-    const int npair = nblk;                        // pairs of 16-row tiles = 32-row blocks
+    const int npair = (N + RPW - 1) / RPW;         // items: groups of TPW 16-row tiles
 
     // ---- phase A: dQ for the 32 queries of a pair; S^T tiles (rows keys, column = this lane's query)
     for (int pr = wave; pr < npair; pr += NW) {
-        u32x4 qf[2][2], dof[2][2];
-        float lq[2], dqv[2];
+        u32x4 qf[TPW][2], dof[TPW][2];
+        float lq[TPW], dqv[TPW];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            const int row = pr * 32 + qi * 16 + l15;
+        for (int qi = 0; qi < TPW; ++qi) {
+            const int row = pr * RPW + qi * 16 + l15;
             const bool ok = row < N;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -682,9 +687,9 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
             lq[qi] = Ls[row];
             dqv[qi] = Dq[row];
         }
-        f32x4 o[2][4];
+        f32x4 o[TPW][4];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
+        for (int qi = 0; qi < TPW; ++qi)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[qi][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int blk = 0; blk < nblk; ++blk) {
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) kT[dt] = tr_pair(kb + tro[dt]);
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
+            for (int qi = 0; qi < TPW; ++qi) {
                 f32x4 ds[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -717,8 +722,8 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
             }
         }
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            const int row = pr * 32 + qi * 16 + l15;
+        for (int qi = 0; qi < TPW; ++qi) {
+            const int row = pr * RPW + qi * 16 + l15;
             if (row < N) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) st_bf16x4(dqb + (size_t)row * RS + dt * 16 + lg * 4, o[qi][dt], scale);
@@ -732,10 +737,10 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
 
     // ---- phase B: dK, dV for the 32 keys of a pair; tiles with rows = queries, column = this lane's key
     for (int pr = wave; pr < npair; pr += NW) {
-        u32x4 kf[2][2], vf[2][2];
+        u32x4 kf[TPW][2], vf[TPW][2];
 #pragma unroll
-        for (int ki = 0; ki < 2; ++ki) {
-            const int row = pr * 32 + ki * 16 + l15;
+        for (int ki = 0; ki < TPW; ++ki) {
+            const int row = pr * RPW + ki * 16 + l15;
             const bool ok = row < N;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -743,9 +748,9 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
                 vf[ki][s] = ok ? ld_chunk(qb + 2 * C + (size_t)row * RS + (s * 4 + lg) * 8) : zero_chunk();
             }
         }
-        f32x4 dv[2][4], dk[2][4];
+        f32x4 dv[TPW][4], dk[TPW][4];
 #pragma unroll
-        for (int ki = 0; ki < 2; ++ki)
+        for (int ki = 0; ki < TPW; ++ki)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) { dv[ki][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[ki][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         for (int blk = 0; blk < nblk; ++blk) {
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
                 qT[dt] = tr_pair(qp + tro[dt]);
             }
 #pragma unroll
-            for (int ki = 0; ki < 2; ++ki) {
+            for (int ki = 0; ki < TPW; ++ki) {
                 f32x4 pt[2], dst_[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -793,8 +798,8 @@ __global__ __launch_bounds__(ATT2_THREADS, 2) void attention_bwd2_kernel(const b
             }
         }
 #pragma unroll
-        for (int ki = 0; ki < 2; ++ki) {
-            const int row = pr * 32 + ki * 16 + l15;
+        for (int ki = 0; ki < TPW; ++ki) {
+            const int row = pr * RPW + ki * 16 + l15;
             if (row < N) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -946,13 +951,22 @@ int attention_bwd(int dtype, const void* qkv, const void* out, const void* dout,
     // bf16: SAICV_ATTN_BWD2=1 selects the two-tiles-per-wavefront kernel.  Measured equal on the ViT-B step (42.58 vs 42.64 ms,
     // profiles/r03_tn_dma_and_attention.md): half the VALU / LDS instructions per MFMA, but 221 registers leave two
     // wavefronts per SIMD to hide the three staging round trips of a workgroup, where the one-tile kernel has four.
-    static const int two = getenv("SAICV_ATTN_BWD2") ? atoi(getenv("SAICV_ATTN_BWD2")) : 0;
+    // =2: the same instruction mix with one tile per wavefront (128 registers, four wavefronts per SIMD).  Read per call.
+    const char* env2 = getenv("SAICV_ATTN_BWD2");
+    const int two = env2 ? atoi(env2) : 0;
     if (dtype == SAICV_DTYPE_BF16 && two) {
         const size_t smem = (size_t)2 * Np * 128 + 2 * Np * sizeof(float);
-        auto k = attention_bwd2_kernel;
-        static bool once = (allow_lds(k, 2 * 256 * 128 + 2048), true);
-        (void)once;
-        hipLaunchKernelGGL(k, dim3(B * H), dim3(ATT2_THREADS), smem, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, (float)scale);
+        if (two == 2) {                 // the lean instruction mix with ONE tile per wavefront (eight wavefronts, 4 per SIMD)
+            auto k = attention_bwd2_kernel<1>;
+            static bool once = (allow_lds(k, 2 * 256 * 128 + 2048), true);
+            (void)once;
+            hipLaunchKernelGGL(k, dim3(B * H), dim3(512), smem, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, (float)scale);
+        } else {
+            auto k = attention_bwd2_kernel<2>;
+            static bool once = (allow_lds(k, 2 * 256 * 128 + 2048), true);
+            (void)once;
+            hipLaunchKernelGGL(k, dim3(B * H), dim3(256), smem, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, (float)scale);
+        }
         return check_launch("attention_bwd");
     }
     if (dtype == SAICV_DTYPE_BF16) {

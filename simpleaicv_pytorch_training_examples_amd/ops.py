@@ -762,7 +762,8 @@ class ConvFn(torch.autograd.Function):
         dt = x.dtype
         n, c, h, w = x.shape
         k, ci, r, s = weight.shape
-        if c != ci:
+        if c != ci and not (c > ci and c - ci < 8 and not ctx.needs_input_grad[0]):
+            # c > ci: an image batch zero-padded to whole chunks by pack_input() (stems; no input gradient)
             raise ValueError(f'input has {c} channels, weight expects {ci}')
         need_dx = ctx.needs_input_grad[0]
         wf, wd = packed_weight(weight, dt, c, need_dx)
@@ -819,7 +820,7 @@ class ConvFn(torch.autograd.Function):
             KernelTimer.end(t0, 'igemm_nt', flops, 0)
         if ctx.needs_input_grad[1]:
             gw = _arena_grad(weight)
-            direct = gw is not None and weight.is_contiguous(memory_format=torch.channels_last)
+            direct = gw is not None and c == weight.shape[1] and weight.is_contiguous(memory_format=torch.channels_last)
             dw = gw if direct else torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=x.device)
             if direct and WGRAD_SIDE_STREAM:
                 with _SideStream(dy, x):
@@ -897,6 +898,218 @@ class DepthwiseConvFn(torch.autograd.Function):
 
 def depthwise_conv2d(x, weight, bias=None, stride=1, pad=0, dilation=1):
     return DepthwiseConvFn.apply(x, weight, bias, stride, pad, dilation)
+
+
+# ------------------------------------------------------------------------------ streaming glue (csrc/elemwise.hip)
+ACT_KINDS = {'relu': 0, 'leakyrelu': 1, 'silu': 2}
+
+
+def _dense(x):
+    """x as a dense tensor whose memory order the elementwise kernels may walk: NHWC for 4-d tensors, row-major otherwise."""
+    return _nhwc(x) if x.dim() == 4 else x.contiguous()
+
+
+def _like(x, other):
+    """`other` in x's dtype and dense layout"""
+    other = _dense(other)
+    return other if other.dtype == x.dtype else other.to(x.dtype)
+
+
+class ActFn(torch.autograd.Function):
+    """nn.ReLU / nn.LeakyReLU(slope) / nn.SiLU as one streaming pass (reference darknet.py:16-33, van.py:44,103,
+    convformer.py:53,86).  The forward input is kept for the backward (dx = dy * act'(x))."""
+
+    @staticmethod
+    def forward(ctx, x, kind, slope):
+        require_gpu(x)
+        x = _dense(x)
+        y = torch.empty_like(x)
+        check(lib().saicv_act_fwd(dtype_code(x.dtype), kind, float(slope), ptr(x), ptr(y), x.numel(), stream()), 'act_fwd')
+        ctx.save_for_backward(x)
+        ctx.cfg = (kind, float(slope))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        kind, slope = ctx.cfg
+        dy = _like(x, dy)
+        dx = torch.empty_like(x)
+        check(lib().saicv_act_bwd(dtype_code(x.dtype), kind, slope, ptr(dy), ptr(x), ptr(dx), x.numel(), stream()), 'act_bwd')
+        return dx, None, None
+
+
+def act(x, kind, slope=0.):
+    return ActFn.apply(x, ACT_KINDS[kind], slope)
+
+
+class MulFn(torch.autograd.Function):
+    """a * b of two activations of one shape (reference van.py:91)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        require_gpu(a, b)
+        a = _dense(a)
+        b = _like(a, b)
+        out = torch.empty_like(a)
+        check(lib().saicv_mul_fwd(dtype_code(a.dtype), ptr(a), ptr(b), ptr(out), a.numel(), stream()), 'mul_fwd')
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = _like(a, dy)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(a) if ctx.needs_input_grad[1] else None
+        check(lib().saicv_mul_bwd(dtype_code(a.dtype), ptr(dy), ptr(a), ptr(b), ptr(da), ptr(db), a.numel(), stream()), 'mul_bwd')
+        return da, db
+
+
+def mul(a, b):
+    return MulFn.apply(a, b)
+
+
+class ScaleAddFn(torch.autograd.Function):
+    """x + s[c] * y on NHWC activations, s a per-channel parameter ([C] after flattening; None: plain x + y): the layer-scaled
+    residual of reference van.py:181-185 and the residual joins of darknet.py / convformer.py:157-163."""
+
+    @staticmethod
+    def forward(ctx, x, y, s):
+        require_gpu(x, y)
+        y = _nhwc(y)
+        x = _like(y, x)
+        n, c, h, w = y.shape
+        sf = s.detach().reshape(-1).float().contiguous() if s is not None else None
+        if sf is not None and sf.numel() != c:
+            raise ValueError(f'scale of {sf.numel()} values for {c} channels')
+        out = torch.empty_like(y)
+        check(lib().saicv_channel_scale_add_fwd(dtype_code(y.dtype), ptr(x), ptr(y), ptr(sf), ptr(out), n * h * w, c, stream()),
+              'channel_scale_add_fwd')
+        ctx.save_for_backward(y if (s is not None and ctx.needs_input_grad[2]) else None, sf, s)
+        ctx.cfg = (n, c, h, w, y.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, sf, s = ctx.saved_tensors
+        n, c, h, w, dt = ctx.cfg
+        dout = _nhwc(dout)
+        if dout.dtype != dt:
+            dout = dout.to(dt)
+        dx = dout if ctx.needs_input_grad[0] else None
+        if s is None:
+            return dx, (dout if ctx.needs_input_grad[1] else None), None
+        dy = torch.empty_like(dout) if ctx.needs_input_grad[1] else None
+        ds = torch.zeros(c, dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[2] else None
+        check(lib().saicv_channel_scale_add_bwd(dtype_code(dt), ptr(dout), ptr(y), ptr(sf), ptr(dy), ptr(ds), n * h * w, c, stream()),
+              'channel_scale_add_bwd')
+        return dx, dy, (ds.reshape(s.shape).to(s.dtype) if ds is not None else None)
+
+
+def scale_add(x, y, s=None):
+    return ScaleAddFn.apply(x, y, s)
+
+
+class SampleScaleFn(torch.autograd.Function):
+    """x[n] * w[n] on an NHWC activation, w fp32 [N]: stochastic depth of a convolutional residual branch (reference van.py:
+    118-150, convformer.py:99-131 DropPathBlock).  The same kernel both ways (saicv_row_scale over [N*H*W][C] rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        require_gpu(x, w)
+        x = _nhwc(x)
+        n, c, h, wd = x.shape
+        w = w.detach().reshape(-1).float().contiguous()
+        out = torch.empty_like(x)
+        check(lib().saicv_row_scale(dtype_code(x.dtype), ptr(x), ptr(w), ptr(out), n * h * wd, c, h * wd, stream()), 'row_scale')
+        ctx.save_for_backward(w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (w,) = ctx.saved_tensors
+        dout = _nhwc(dout)
+        n, c, h, wd = dout.shape
+        dx = torch.empty_like(dout)
+        check(lib().saicv_row_scale(dtype_code(dout.dtype), ptr(dout), ptr(w), ptr(dx), n * h * wd, c, h * wd, stream()), 'row_scale')
+        return dx, None
+
+
+def sample_scale(x, w):
+    return SampleScaleFn.apply(x, w)
+
+
+class BatchNorm2dFn(torch.autograd.Function):
+    """nn.BatchNorm2d on an activation that is not a convolution output (reference van.py:176,178,260; convformer.py:34-35,
+    143,149): statistics pass -> the finalize kernel of the fused blocks (running statistics, num_batches_tracked) -> apply;
+    backward = the fused blocks' BatchNorm backward without a ReLU gate."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn):
+        require_gpu(x, gamma)
+        x = _nhwc(x)
+        dt = x.dtype
+        n, c, h, w = x.shape
+        M = n * h * w
+        L, st, dev = lib(), stream(), x.device
+        scale = torch.empty(c, dtype=torch.float32, device=dev)
+        shift = torch.empty(c, dtype=torch.float32, device=dev)
+        training = bn.training or not bn.track_running_stats
+        if training:
+            if bn.momentum is None:
+                raise NotImplementedError('BatchNorm2d(momentum=None) is not supported')
+            stats = torch.zeros((2, c), dtype=torch.float32, device=dev)
+            check(L.saicv_bn_stats(dtype_code(dt), ptr(x), M, c, ptr(stats[0]), ptr(stats[1]), st), 'bn_stats')
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            invstd = torch.empty(c, dtype=torch.float32, device=dev)
+            track = bn.training and bn.track_running_stats and bn.running_mean is not None
+            nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
+            ws = torch.empty(L.saicv_bn_ws_floats(c), dtype=torch.float32, device=dev)
+            check(L.saicv_bn_finalize_fwd(ptr(stats[0]), ptr(stats[1]), 1, c, float(M), ptr(gamma), ptr(beta),
+                                          ptr(bn.running_mean) if track else 0, ptr(bn.running_var) if track else 0,
+                                          float(bn.momentum), float(bn.eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(ws),
+                                          ptr(nbt), st), 'bn_finalize_fwd')
+        else:
+            check(L.saicv_bn_eval_coeffs(c, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps),
+                                         ptr(scale), ptr(shift), st), 'bn_eval_coeffs')
+        z = torch.empty_like(x)
+        check(L.saicv_bn_act_fwd(dtype_code(dt), ptr(x), 0, ptr(z), ptr(scale), ptr(shift), M, c, 0, 0, st), 'bn_act_fwd')
+        if training:
+            ctx.save_for_backward(x, gamma, mean, invstd)
+        else:
+            ctx.save_for_backward(None, None, None, scale)
+        ctx.training = training
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        L, st = lib(), stream()
+        dz = _nhwc(dz)
+        n, c, h, w = dz.shape
+        M = n * h * w
+        if not ctx.training:
+            # frozen statistics: dx = scale * dz
+            dt = dz.dtype
+            dx = torch.empty_like(dz)
+            check(L.saicv_channel_scale_add_bwd(dtype_code(dt), ptr(dz), 0, ptr(invstd), ptr(dx), 0, M, c, st), 'bn_eval_bwd')
+            return dx, None, None, None
+        dt = x.dtype
+        if dz.dtype != dt:
+            dz = dz.to(dt)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.saicv_bn_bwd_ws_floats(M, c, dtype_code(dt)), dtype=torch.float32, device=x.device)
+        check(L.saicv_bn_act_bwd(dtype_code(dt), ptr(dz), 0, 0, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), 0, ptr(dgamma),
+                                 ptr(dbeta), M, c, 0, 0, ptr(ws), st), 'bn_act_bwd')
+        return dx, dgamma, dbeta, None
+
+
+def batch_norm2d(x, bn):
+    """bn: the nn.BatchNorm2d holding the parameters and running statistics"""
+    return BatchNorm2dFn.apply(x, bn.weight, bn.bias, bn)
 
 
 class LinearFn(torch.autograd.Function):

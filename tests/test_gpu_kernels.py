@@ -302,6 +302,27 @@ def test_attention(b, n, heads, dt):
     assert rel_err(qd.grad.float(), qr.grad) < tol * 2
 
 
+@pytest.mark.parametrize('mode', ['1', '2'])
+@pytest.mark.parametrize('b,n,heads', [(2, 197, 12), (3, 17, 3), (1, 256, 2), (2, 196, 4), (1, 1, 1), (2, 33, 2)])
+def test_attention_backward_variants(b, n, heads, mode, monkeypatch):
+    """SAICV_ATTN_BWD2 = 1 / 2 (two tiles / one tile per wavefront with the lean instruction mix) against the same reference
+    gradient as the default backward, same tolerance; the switch is read per call."""
+    T = _tfm()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(b * 1000 + n)
+    c = heads * 64
+    qkv = _q(torch.randn(b, n, 3 * c, generator=g), dt)
+    dy = _q(torch.randn(b, n, c, generator=g), dt)
+    scale = 64 ** -0.5
+    qr = qkv.clone().requires_grad_(True)
+    _ref_attention(qr, heads, scale).backward(dy)
+    monkeypatch.setenv('SAICV_ATTN_BWD2', mode)
+    qd = qkv.to(dt).cuda().requires_grad_(True)
+    T.attention(qd, heads, scale).backward(dy.to(dt).cuda())
+    torch.cuda.synchronize()
+    assert rel_err(qd.grad.float(), qr.grad) < TOL[dt] * 2
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_attention_softmax_extremes(dt):
     """one key dominates one query by a huge margin: the max-subtracted softmax must stay finite"""
