@@ -424,6 +424,23 @@ int saicv_channel_scale_add_bwd(int dtype, const void* dout, const void* y, cons
  * saicv_bn_finalize_fwd(rows = 1), then saicv_bn_act_fwd / saicv_bn_act_bwd as for the fused blocks. */
 int saicv_bn_stats(int dtype, const void* x, size_t M, int C, float* sum, float* sq, void* stream);
 
+/* ---- dense-detector training loss (csrc/detloss.hip; reference SimpleAICV/detection/losses.py RetinaLoss :123-433) ---- */
+/* get_batch_anchors_annotations (:330-416): anchors [A][4] fp32 (one image's table, shared by the batch), annots [B][G][5] fp32
+ * (x_min, y_min, x_max, y_max, class; class < 0 = padding row; G <= 1024) -> targets [B][A][5]: the box target of the best-IoU
+ * ground-truth box ([tx, ty, tw, th] when smoothl1 != 0, the box itself otherwise) and the class target -1 (ignored: 0.4 <= IoU
+ * < 0.5, or no ground truth in the image) / 0 (background: IoU < 0.4) / class + 1 (IoU >= 0.5); pos_count[0] += positives. */
+int saicv_retina_assign(const float* anchors, const float* annots, float* targets, float* pos_count, int B, int A, int G,
+                        int smoothl1, void* stream);
+/* compute_batch_focal_loss (:222-262) of ONE pyramid level where the head wrote it: probs [B][Al][C] fp32 against
+ * targets [B][At][5] (this level's anchors start at row `off` of every image).  loss_sum[0] += the sum before the division by
+ * the positive count; dprobs (optional, same shape as probs) = its gradient (zero outside the clamp range [1e-4, 1 - 1e-4]). */
+int saicv_focal_loss_level(const float* probs, const float* targets, float* dprobs, float* loss_sum, int B, int Al, int At, int off,
+                           int C, double alpha, double gamma, void* stream);
+/* compute_batch_smoothl1_loss (:305-328) of one level's positive anchors: reg [B][Al][4] fp32 (16-byte aligned) against
+ * targets[..][0:4]; loss_sum[0] += the sum before the division; dreg (optional) = its gradient. */
+int saicv_smoothl1_level(const float* reg, const float* targets, float* dreg, float* loss_sum, int B, int Al, int At, int off,
+                         double beta, void* stream);
+
 /* ---- gradient all-reduce over RCCL / xGMI ------------------------------------------------
  * The reducer of nn.parallel.DistributedDataParallel (reference tools/train_classification_model.py:217-227 wraps the
  * model; tools/scripts.py:183-226 relies on gradients being averaged when backward() returns): contiguous ranges of the

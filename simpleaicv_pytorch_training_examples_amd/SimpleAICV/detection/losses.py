@@ -1,4 +1,5 @@
-"""DETR set-prediction loss -- drop-in for the reference DETRLoss (SimpleAICV/detection/losses.py:843-1095).
+"""Detection losses -- drop-ins for reference SimpleAICV/detection/losses.py: RetinaLoss (:123-433, at the end of this file) and
+DETRLoss (:843-1095):
 
 Same constructor arguments and output keys (`layer_{i}_cls_loss`, `layer_{i}_box_l1_loss`, `layer_{i}_box_iou_loss`
 for the 6 decoder layers).  Semantics kept: boxes clamped to [1e-4, 1 - 1e-4]; ONE Hungarian matching per image on
@@ -7,6 +8,8 @@ by every layer; weighted cross-entropy with the no-object class at 0.1; L1 and (
 and divided by the number of ground-truth boxes in the batch.  The assignment itself runs on the host with scipy,
 as in the reference (one [100, n_i] matrix per image); everything else is [B, 100, *] tensor arithmetic in fp32.
 """
+import math
+
 import numpy as np
 import scipy.optimize
 import torch
@@ -14,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 __all__ = [
+    'RetinaLoss',
     'DETRLoss',
 ]
 
@@ -186,3 +190,156 @@ class DETRLoss(nn.Module):
                 place_holder = (lo + (m - 1) * (lo - hi)) - positive
             cost_matrix[np.isinf(cost_matrix)] = place_holder
         return scipy.optimize.linear_sum_assignment(cost_matrix)
+
+
+# ---------------------------------------------------------------------------------------------- RetinaNet
+def _box_iou(b1, b2, kind):
+    """IoU family of row-aligned [N, 4] xyxy boxes with the reference IoUMethod's clamps (losses.py:25-120): areas from clamped
+    sides, union / enclosing area / diagonal >= 1e-4."""
+    wh1 = (b1[:, 2:4] - b1[:, 0:2]).clamp(min=0)
+    wh2 = (b2[:, 2:4] - b2[:, 0:2]).clamp(min=0)
+    inter_wh = (torch.min(b1[:, 2:4], b2[:, 2:4]) - torch.max(b1[:, 0:2], b2[:, 0:2])).clamp(min=0)
+    inter = inter_wh[:, 0] * inter_wh[:, 1]
+    union = (wh1[:, 0] * wh1[:, 1] + wh2[:, 0] * wh2[:, 1] - inter).clamp(min=1e-4)
+    iou = inter / union
+    if kind == 'IoU':
+        return iou
+    hull = (torch.max(b1[:, 2:4], b2[:, 2:4]) - torch.min(b1[:, 0:2], b2[:, 0:2])).clamp(min=0)
+    if kind == 'GIoU':
+        area = (hull[:, 0] * hull[:, 1]).clamp(min=1e-4)
+        return iou - (area - union) / area
+    diag2 = (hull[:, 0] ** 2 + hull[:, 1] ** 2).clamp(min=1e-4)
+    dc = (b1[:, 2:4] + b1[:, 0:2]) / 2 - (b2[:, 2:4] + b2[:, 0:2]) / 2
+    centre2 = dc[:, 0] ** 2 + dc[:, 1] ** 2
+    if kind == 'DIoU':
+        return iou - centre2 / diag2
+    if kind == 'CIoU':
+        v = (4 / math.pi ** 2) * (torch.atan(wh2[:, 0] / wh2[:, 1]) - torch.atan(wh1[:, 0] / wh1[:, 1])) ** 2
+        with torch.no_grad():
+            a = v / (1 - iou + v).clamp(min=1e-4)
+        return iou - (centre2 / diag2 + v * a)
+    dw2, dh2 = (wh2[:, 0] - wh1[:, 0]) ** 2, (wh2[:, 1] - wh1[:, 1]) ** 2          # EIoU
+    return iou - (centre2 / diag2 + dw2 / (hull[:, 0] ** 2).clamp(min=1e-4) + dh2 / (hull[:, 1] ** 2).clamp(min=1e-4))
+
+
+class _RetinaLossFn(torch.autograd.Function):
+    """Target assignment, focal loss and SmoothL1 box loss on the HIP kernels of csrc/detloss.hip.  inputs: the anchor table
+    [A, 4], annotations [B, G, 5], then the per-level class probabilities [B, A_l, C] and box offsets [B, A_l, 4] (fp32, dense).
+    Returns (focal sum / positives, SmoothL1 sum / positives, targets [B, A, 5], positives); both losses are 0 when no anchor
+    is positive (losses.py:235-236, :284-285) -- decided on the device, no host synchronisation."""
+
+    @staticmethod
+    def forward(ctx, anchors, annots, alpha, gamma, beta, smoothl1, *heads):
+        from ... import _lib
+        from ...ops import require_gpu
+        L, st = _lib.lib(), _lib.stream()
+        levels = len(heads) // 2
+        cls, reg = heads[:levels], heads[levels:]
+        require_gpu(anchors, annots, *heads)
+        B, G = annots.shape[0], annots.shape[1]
+        sizes = [t.shape[1] for t in cls]
+        At = int(anchors.shape[0])
+        assert sum(sizes) == At, 'anchor table does not match the pyramid levels'
+        dev = annots.device
+        targets = torch.empty((B, At, 5), dtype=torch.float32, device=dev)
+        sums = torch.zeros(3, dtype=torch.float32, device=dev)                  # positives, focal sum, box sum
+        _lib.check(L.saicv_retina_assign(anchors.data_ptr(), annots.data_ptr() if G else None, targets.data_ptr(), sums[0:1].data_ptr(),
+                                         B, At, G, int(smoothl1), st), 'retina_assign')
+        need_c = [ctx.needs_input_grad[6 + i] for i in range(levels)]
+        need_r = [ctx.needs_input_grad[6 + levels + i] for i in range(levels)]
+        grads, off = [], 0
+        for i in range(levels):
+            dc = torch.empty_like(cls[i]) if need_c[i] else None
+            _lib.check(L.saicv_focal_loss_level(cls[i].data_ptr(), targets.data_ptr(), dc.data_ptr() if dc is not None else None,
+                                                sums[1:2].data_ptr(), B, sizes[i], At, off, cls[i].shape[2], float(alpha), float(gamma), st),
+                       'focal_loss_level')
+            grads.append(dc)
+            off += sizes[i]
+        off = 0
+        for i in range(levels):
+            dr = None
+            if smoothl1:
+                dr = torch.empty_like(reg[i]) if need_r[i] else None
+                _lib.check(L.saicv_smoothl1_level(reg[i].data_ptr(), targets.data_ptr(), dr.data_ptr() if dr is not None else None,
+                                                  sums[2:3].data_ptr(), B, sizes[i], At, off, float(beta), st), 'smoothl1_level')
+            grads.append(dr)
+            off += sizes[i]
+        inv = torch.where(sums[0] > 0, 1.0 / sums[0].clamp(min=1.0), torch.zeros_like(sums[0]))
+        ctx.save_for_backward(inv, *[g for g in grads if g is not None])
+        ctx.present = [g is not None for g in grads]
+        ctx.levels = levels
+        ctx.mark_non_differentiable(targets)
+        return sums[1] * inv, sums[2] * inv, targets, sums[0].clone()
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, _gt, _gp):
+        from ... import _lib
+        L, st = _lib.lib(), _lib.stream()
+        inv, *saved = ctx.saved_tensors
+        out, it = [], iter(saved)
+        for j, present in enumerate(ctx.present):
+            if not present:
+                out.append(None)
+                continue
+            d = next(it)
+            scale = ((g_cls if j < ctx.levels else g_box).float() * inv).contiguous()
+            res = torch.empty_like(d)
+            _lib.check(L.saicv_scale_by_scalar(_lib.F32, d.data_ptr(), scale.data_ptr(), res.data_ptr(), d.numel(), st), 'scale_by_scalar')
+            out.append(res)
+        return (None, None, None, None, None, None, *out)
+
+
+class RetinaLoss(nn.Module):
+    """Drop-in for the reference RetinaLoss: same constructor, `forward(preds, annotations) -> {'cls_loss', 'reg_loss'}`.
+    preds = [cls_heads, reg_heads] of RetinaNet (per level [B, H, W, anchors, classes] probabilities / [B, H, W, anchors, 4]
+    offsets), annotations [B, max_annots, 5] padded with -1 rows.  Anchor assignment, the focal loss and the SmoothL1 box loss run
+    on csrc/detloss.hip in place on the per-level tensors; the IoU-family box losses decode the few positive anchors and use
+    tensor arithmetic on them (`_box_iou`)."""
+
+    def __init__(self, areas=[[32, 32], [64, 64], [128, 128], [256, 256], [512, 512]], ratios=[0.5, 1, 2],
+                 scales=[2**0, 2**(1.0 / 3.0), 2**(2.0 / 3.0)], strides=[8, 16, 32, 64, 128], alpha=0.25, gamma=2, beta=1.0 / 9.0,
+                 cls_loss_weight=1., box_loss_weight=1., box_loss_type='SmoothL1'):
+        super(RetinaLoss, self).__init__()
+        assert box_loss_type in ['SmoothL1', 'IoU', 'GIoU', 'DIoU', 'CIoU', 'EIoU'], 'wrong IoU type!'
+        from .models.anchor import RetinaAnchors
+        self.anchors = RetinaAnchors(areas=areas, ratios=ratios, scales=scales, strides=strides)
+        self.alpha, self.gamma, self.beta = alpha, gamma, beta
+        self.cls_loss_weight, self.box_loss_weight = cls_loss_weight, box_loss_weight
+        self.box_loss_type = box_loss_type
+        self._tables = {}
+
+    def _anchor_table(self, sizes, device):
+        key = (tuple(map(tuple, sizes)), str(device))
+        if key not in self._tables:
+            per_level = self.anchors([list(s) for s in sizes])
+            self._tables[key] = torch.cat([torch.from_numpy(a).view(-1, 4) for a in per_level], dim=0).to(device)
+        return self._tables[key]
+
+    def forward(self, preds, annotations):
+        cls_preds, reg_preds = preds
+        sizes = [[t.shape[2], t.shape[1]] for t in cls_preds]                    # [w, h] per level
+        anchors = self._anchor_table(sizes, annotations.device)
+        b = annotations.shape[0]
+        cls = [t.reshape(b, -1, t.shape[-1]).float().contiguous() for t in cls_preds]
+        reg = [t.reshape(b, -1, 4).float().contiguous() for t in reg_preds]
+        smooth = self.box_loss_type == 'SmoothL1'
+        cls_loss, box_loss, targets, positives = _RetinaLossFn.apply(anchors, annotations.float().contiguous(), self.alpha, self.gamma,
+                                                                     self.beta, smooth, *cls, *reg)
+        if not smooth:
+            box_loss = self._iou_box_loss(torch.cat(reg, dim=1), targets, anchors, positives)
+        return {'cls_loss': self.cls_loss_weight * cls_loss, 'reg_loss': self.box_loss_weight * box_loss}
+
+    def _iou_box_loss(self, reg, targets, anchors, positives):
+        pos = targets[..., 4] > 0
+        if not bool(pos.any()):
+            return torch.zeros((), dtype=torch.float32, device=reg.device)
+        boxes = self.snap_txtytwth_to_xyxy(reg[pos], anchors.unsqueeze(0).expand(reg.shape[0], -1, -1)[pos])
+        return (1 - _box_iou(boxes, targets[pos][:, 0:4], self.box_loss_type)).sum() / positives
+
+    @staticmethod
+    def snap_txtytwth_to_xyxy(snap_boxes, anchors):
+        wh = anchors[:, 2:4] - anchors[:, 0:2]
+        centre = anchors[:, 0:2] + 0.5 * wh
+        box_wh = torch.exp(snap_boxes[:, 2:4]) * wh
+        box_centre = snap_boxes[:, :2] * wh + centre
+        return torch.cat([box_centre - 0.5 * box_wh, box_centre + 0.5 * box_wh], dim=1)

@@ -1,2 +1,3 @@
 from .detr import *
 from .retinanet import *
+from .fcos import *

@@ -153,6 +153,9 @@ SIGNATURES = {
     'saicv_channel_scale_add_fwd': (c_int, [c_int, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'saicv_channel_scale_add_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'saicv_bn_stats': (c_int, [c_int, _P, c_size_t, c_int, _P, _P, _P]),
+    'saicv_retina_assign': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'saicv_focal_loss_level': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
+    'saicv_smoothl1_level': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
     'saicv_sam_sample_point': (c_int, [c_int, _P, _P, c_long, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _P, _P,
                                        c_int, c_int, c_int, _P]),
     'saicv_comm_available': (c_int, []),

@@ -1,0 +1,214 @@
+// Dense-detector training loss: what reference SimpleAICV/detection/losses.py RetinaLoss (:123-433)
+// spends its time on, as three kernels over fp32 head outputs that stay where the heads wrote them (per pyramid level):
+//   retina_assign   get_batch_anchors_annotations (:330-396): every anchor against every ground-truth box of its image, IoU >= 0.5
+//                   -> class + 1, IoU < 0.4 -> background 0, between -> ignored -1; box target of the best box ([tx,ty,tw,th] for
+//                   SmoothL1, :398-416).  Ground truth of the image sits in LDS; the IoU arithmetic is written operation by
+//                   operation (no FMA contraction) so that the 0.4 / 0.5 decisions are the reference's.
+//   focal_level     compute_batch_focal_loss (:222-262) on one level's [B][A_l][C] probabilities: loss sum AND its gradient in
+//                   one pass (the torch formulation makes ~15 passes over B x A x C, 49 M elements for 8 images at 640 x 640).
+//   smoothl1_level  compute_batch_smoothl1_loss (:305-328) on the positive anchors of one level, loss sum and gradient.
+// Sums are accumulated with one fp32 atomic per workgroup into a zeroed buffer; the host divides by the positive count.
+#include "common.h"
+#include "saicv_internal.h"
+
+namespace {
+
+constexpr int DL_THREADS = 256;
+constexpr int DL_MAX_GT = 1024;
+
+DEVINL float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < DL_THREADS / 64; ++i) t += red[i];
+    }
+    __syncthreads();
+    return t;     // valid in thread 0
+}
+
+__global__ __launch_bounds__(DL_THREADS) void retina_assign_kernel(const float* __restrict__ anchors, const float* __restrict__ annots,
+                                                                   float* __restrict__ targets, float* __restrict__ pos_count,
+                                                                   int A, int G, int smoothl1) {
+    __shared__ float gt[DL_MAX_GT * 5];
+    __shared__ float red[DL_THREADS / 64];
+    __shared__ int ngt;
+    const int b = blockIdx.y;
+    // valid boxes of this image, in order (the reference drops class < 0 rows first, :345-346)
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int g = 0; g < G; ++g) {
+            const float* r = annots + ((size_t)b * G + g) * 5;
+            if (r[4] >= 0.f) {
+                for (int j = 0; j < 5; ++j) gt[n * 5 + j] = r[j];
+                ++n;
+            }
+        }
+        ngt = n;
+    }
+    __syncthreads();
+    const int n = ngt;
+    const int a = blockIdx.x * DL_THREADS + threadIdx.x;
+    float is_pos = 0.f;
+    if (a < A) {
+        const float ax1 = anchors[a * 4 + 0], ay1 = anchors[a * 4 + 1], ax2 = anchors[a * 4 + 2], ay2 = anchors[a * 4 + 3];
+        float out[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+        if (n > 0) {
+            const float aw = fmaxf(__fsub_rn(ax2, ax1), 0.f), ah = fmaxf(__fsub_rn(ay2, ay1), 0.f);
+            const float a_area = __fmul_rn(aw, ah);
+            float best = -1.f;
+            int bi = 0;
+            for (int g = 0; g < n; ++g) {
+                const float gx1 = gt[g * 5 + 0], gy1 = gt[g * 5 + 1], gx2 = gt[g * 5 + 2], gy2 = gt[g * 5 + 3];
+                const float ow = fmaxf(__fsub_rn(fminf(ax2, gx2), fmaxf(ax1, gx1)), 0.f);
+                const float oh = fmaxf(__fsub_rn(fminf(ay2, gy2), fmaxf(ay1, gy1)), 0.f);
+                const float overlap = __fmul_rn(ow, oh);
+                const float gw = fmaxf(__fsub_rn(gx2, gx1), 0.f), gh = fmaxf(__fsub_rn(gy2, gy1), 0.f);
+                const float uni = fmaxf(__fsub_rn(__fadd_rn(a_area, __fmul_rn(gw, gh)), overlap), 1e-4f);
+                const float iou = __fdiv_rn(overlap, uni);
+                if (iou > best) { best = iou; bi = g; }
+            }
+            float cls = -1.f;
+            if (best < 0.4f) cls = 0.f;
+            if (best >= 0.5f) cls = gt[bi * 5 + 4] + 1.f;
+            const float gx1 = gt[bi * 5 + 0], gy1 = gt[bi * 5 + 1], gx2 = gt[bi * 5 + 2], gy2 = gt[bi * 5 + 3];
+            if (smoothl1) {
+                const float w = ax2 - ax1, h = ay2 - ay1;
+                const float cx = ax1 + 0.5f * w, cy = ay1 + 0.5f * h;
+                const float gw = fmaxf(gx2 - gx1, 1e-4f), gh = fmaxf(gy2 - gy1, 1e-4f);
+                const float gcx = gx1 + 0.5f * gw, gcy = gy1 + 0.5f * gh;
+                out[0] = (gcx - cx) / w;
+                out[1] = (gcy - cy) / h;
+                out[2] = logf(gw / w);
+                out[3] = logf(gh / h);
+            } else {
+                out[0] = gx1; out[1] = gy1; out[2] = gx2; out[3] = gy2;
+            }
+            out[4] = cls;
+            is_pos = cls > 0.f ? 1.f : 0.f;
+        }
+        float* t = targets + ((size_t)b * A + a) * 5;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) t[j] = out[j];
+    }
+    const float cnt = block_sum(is_pos, red);
+    if (threadIdx.x == 0 && cnt != 0.f) atomicAdd(pos_count, cnt);
+}
+
+// one level: probs [B][Al][C], targets [B][At][5] (this level's anchors start at `off`)
+template <bool GAMMA2>
+__global__ __launch_bounds__(DL_THREADS) void focal_level_kernel(const float* __restrict__ probs, const float* __restrict__ targets,
+                                                                 float* __restrict__ dprobs, float* __restrict__ loss_sum, size_t total,
+                                                                 int Al, int At, int off, int C, float alpha, float gamma) {
+    __shared__ float red[DL_THREADS / 64];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * DL_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * DL_THREADS) {
+        const size_t row = i / C;
+        const int c = (int)(i - row * C);
+        const size_t b = row / Al;
+        const int a = (int)(row - b * Al);
+        const float cls = targets[(b * At + off + a) * 5 + 4];
+        float grad = 0.f;
+        if (cls >= 0.f) {
+            const float p0 = probs[i];
+            const float p = fminf(fmaxf(p0, 1e-4f), 1.f - 1e-4f);
+            const bool live = p0 >= 1e-4f && p0 <= 1.f - 1e-4f;         // torch.clamp passes the gradient inside the range only
+            const bool hot = cls > 0.f && (int)cls - 1 == c;
+            const float q = hot ? p : 1.f - p;                           // probability of the true label
+            const float w = hot ? alpha : 1.f - alpha;
+            const float lq = logf(q);
+            const float omq = 1.f - q;
+            float mod, dmod;                                             // (1 - q)^gamma and its derivative by q
+            if (GAMMA2) { mod = omq * omq; dmod = -2.f * omq; }
+            else { mod = powf(omq, gamma); dmod = omq > 0.f ? -gamma * powf(omq, gamma - 1.f) : 0.f; }
+            acc += -w * mod * lq;
+            const float dq = -w * (dmod * lq + mod / q);                 // d loss / d q
+            grad = live ? (hot ? dq : -dq) : 0.f;
+        }
+        if (dprobs) dprobs[i] = grad;
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0 && t != 0.f) atomicAdd(loss_sum, t);
+}
+
+// one level: reg [B][Al][4] against targets[..][0:4] on the rows with class > 0
+__global__ __launch_bounds__(DL_THREADS) void smoothl1_level_kernel(const float* __restrict__ reg, const float* __restrict__ targets,
+                                                                    float* __restrict__ dreg, float* __restrict__ loss_sum, size_t rows,
+                                                                    int Al, int At, int off, float beta) {
+    __shared__ float red[DL_THREADS / 64];
+    float acc = 0.f;
+    for (size_t row = (size_t)blockIdx.x * DL_THREADS + threadIdx.x; row < rows; row += (size_t)gridDim.x * DL_THREADS) {
+        const size_t b = row / Al;
+        const int a = (int)(row - b * Al);
+        const float* t = targets + (b * At + off + a) * 5;
+        const f32x4 r = *reinterpret_cast<const f32x4*>(reg + row * 4);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (t[4] > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = r[j] - t[j];
+                const float x = fabsf(d);
+                if (x >= beta) { acc += x - 0.5f * beta; g[j] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+                else { acc += 0.5f * x * x / beta; g[j] = d / beta; }
+            }
+        }
+        if (dreg) *reinterpret_cast<f32x4*>(dreg + row * 4) = g;
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s);
+}
+
+inline int dl_grid(size_t items) {
+    size_t g = (items + DL_THREADS - 1) / DL_THREADS;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+// anchors [A][4] fp32 (x_min, y_min, x_max, y_max; one image's table, shared by the batch), annots [B][G][5] fp32 (box, class;
+// class < 0 = padding row) -> targets [B][A][5] (box target, class target -1 / 0 / class + 1), pos_count[0] += positives.
+// Reference losses.py:330-416.  G <= 1024.
+int saicv_retina_assign(const float* anchors, const float* annots, float* targets, float* pos_count, int B, int A, int G,
+                        int smoothl1, void* stream) {
+    SAICV_REQUIRE(B > 0 && A > 0 && G >= 0 && G <= DL_MAX_GT, "retina_assign: B=%d A=%d G=%d (G <= %d)", B, A, G, DL_MAX_GT);
+    SAICV_REQUIRE(B <= 65535, "retina_assign: batch %d", B);
+    hipLaunchKernelGGL(retina_assign_kernel, dim3((A + DL_THREADS - 1) / DL_THREADS, B), dim3(DL_THREADS), 0, (hipStream_t)stream, anchors,
+                       annots, targets, pos_count, A, G, smoothl1);
+    return saicv::check_launch("retina_assign");
+}
+
+// focal loss of one pyramid level: probs [B][Al][C] fp32 against targets [B][At][5] (level offset `off`): loss_sum[0] += the
+// un-normalised sum (losses.py:244-258 before the division), dprobs (optional) = its gradient by probs
+int saicv_focal_loss_level(const float* probs, const float* targets, float* dprobs, float* loss_sum, int B, int Al, int At, int off,
+                           int C, double alpha, double gamma, void* stream) {
+    SAICV_REQUIRE(B > 0 && Al > 0 && C > 0 && off >= 0 && off + Al <= At, "focal_loss_level: B=%d Al=%d At=%d off=%d C=%d", B, Al, At, off, C);
+    const size_t total = (size_t)B * Al * C;
+    if (gamma == 2.0)
+        hipLaunchKernelGGL((focal_level_kernel<true>), dim3(dl_grid(total)), dim3(DL_THREADS), 0, (hipStream_t)stream, probs, targets, dprobs,
+                           loss_sum, total, Al, At, off, C, (float)alpha, (float)gamma);
+    else
+        hipLaunchKernelGGL((focal_level_kernel<false>), dim3(dl_grid(total)), dim3(DL_THREADS), 0, (hipStream_t)stream, probs, targets, dprobs,
+                           loss_sum, total, Al, At, off, C, (float)alpha, (float)gamma);
+    return saicv::check_launch("focal_loss_level");
+}
+
+// SmoothL1 box loss of one level's positive anchors: reg [B][Al][4] (16-byte aligned) against targets[..][0:4]; loss_sum[0] +=
+// the un-normalised sum (losses.py:318-326 before the division), dreg (optional) = its gradient by reg
+int saicv_smoothl1_level(const float* reg, const float* targets, float* dreg, float* loss_sum, int B, int Al, int At, int off,
+                         double beta, void* stream) {
+    SAICV_REQUIRE(B > 0 && Al > 0 && off >= 0 && off + Al <= At && beta > 0., "smoothl1_level: B=%d Al=%d At=%d off=%d", B, Al, At, off);
+    SAICV_REQUIRE(((uintptr_t)reg & 15) == 0 && ((uintptr_t)dreg & 15) == 0, "smoothl1_level: box tensors must be 16-byte aligned");
+    const size_t rows = (size_t)B * Al;
+    hipLaunchKernelGGL(smoothl1_level_kernel, dim3(dl_grid(rows)), dim3(DL_THREADS), 0, (hipStream_t)stream, reg, targets, dreg, loss_sum,
+                       rows, Al, At, off, (float)beta);
+    return saicv::check_launch("smoothl1_level");
+}
+
+}  // extern "C"
