@@ -440,6 +440,13 @@ int saicv_focal_loss_level(const float* probs, const float* targets, float* dpro
  * targets[..][0:4]; loss_sum[0] += the sum before the division; dreg (optional) = its gradient. */
 int saicv_smoothl1_level(const float* reg, const float* targets, float* dreg, float* loss_sum, int B, int Al, int At, int off,
                          double beta, void* stream);
+/* FCOSLoss.get_batch_position_annotations (:623-842): points [P][5] fp32 = (x, y, stride, regression range low, high) of one
+ * image's pyramid, annots [B][G][5] -> targets [B][P][5] = (l, t, r, b, class + 1 | 0 for a negative point) -- the layout
+ * saicv_focal_loss_level reads -- and centerness [B][P]; pos_count[0] += positives.  A ground-truth box is a candidate when the
+ * point is strictly inside it, within radius * stride of its centre (center_sample != 0) and max(l, t, r, b) lies inside the
+ * range; the smallest candidate wins. */
+int saicv_fcos_assign(const float* points, const float* annots, float* targets, float* centerness, float* pos_count, int B, int P,
+                      int G, double radius, int center_sample, void* stream);
 
 /* ---- gradient all-reduce over RCCL / xGMI ------------------------------------------------
  * The reducer of nn.parallel.DistributedDataParallel (reference tools/train_classification_model.py:217-227 wraps the

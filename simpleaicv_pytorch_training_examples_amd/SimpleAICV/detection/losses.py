@@ -1,5 +1,5 @@
-"""Detection losses -- drop-ins for reference SimpleAICV/detection/losses.py: RetinaLoss (:123-433, at the end of this file) and
-DETRLoss (:843-1095):
+"""Detection losses -- drop-ins for reference SimpleAICV/detection/losses.py: RetinaLoss (:123-433) and FCOSLoss (:434-842), both at
+the end of this file on the kernels of csrc/detloss.hip, and DETRLoss (:843-1095):
 
 Same constructor arguments and output keys (`layer_{i}_cls_loss`, `layer_{i}_box_l1_loss`, `layer_{i}_box_iou_loss`
 for the 6 decoder layers).  Semantics kept: boxes clamped to [1e-4, 1 - 1e-4]; ONE Hungarian matching per image on
@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 __all__ = [
     'RetinaLoss',
+    'FCOSLoss',
     'DETRLoss',
 ]
 
@@ -343,3 +344,112 @@ class RetinaLoss(nn.Module):
         box_wh = torch.exp(snap_boxes[:, 2:4]) * wh
         box_centre = snap_boxes[:, :2] * wh + centre
         return torch.cat([box_centre - 0.5 * box_wh, box_centre + 0.5 * box_wh], dim=1)
+
+
+# ---------------------------------------------------------------------------------------------- FCOS
+class _FocalLevelsFn(torch.autograd.Function):
+    """focal loss of per-level probabilities [B, P_l, C] against targets [B, P, 5] (csrc/detloss.hip), times `inv` (1 / positives,
+    or 0 when there are none): sum and gradient in one pass per level, no concatenation of the levels."""
+
+    @staticmethod
+    def forward(ctx, targets, inv, alpha, gamma, *cls):
+        from ... import _lib
+        L, st = _lib.lib(), _lib.stream()
+        B, P = targets.shape[0], targets.shape[1]
+        total = torch.zeros(1, dtype=torch.float32, device=targets.device)
+        grads, off = [], 0
+        for i, t in enumerate(cls):
+            d = torch.empty_like(t) if ctx.needs_input_grad[4 + i] else None
+            _lib.check(L.saicv_focal_loss_level(t.data_ptr(), targets.data_ptr(), d.data_ptr() if d is not None else None, total.data_ptr(),
+                                                B, t.shape[1], P, off, t.shape[2], float(alpha), float(gamma), st), 'focal_loss_level')
+            grads.append(d)
+            off += t.shape[1]
+        assert off == P, 'targets do not match the pyramid levels'
+        ctx.save_for_backward(inv, *[g for g in grads if g is not None])
+        ctx.present = [g is not None for g in grads]
+        return total[0] * inv
+
+    @staticmethod
+    def backward(ctx, gout):
+        from ... import _lib
+        L, st = _lib.lib(), _lib.stream()
+        inv, *saved = ctx.saved_tensors
+        scale = (gout.float() * inv).contiguous()
+        out, it = [], iter(saved)
+        for present in ctx.present:
+            if not present:
+                out.append(None)
+                continue
+            d = next(it)
+            res = torch.empty_like(d)
+            _lib.check(L.saicv_scale_by_scalar(_lib.F32, d.data_ptr(), scale.data_ptr(), res.data_ptr(), d.numel(), st), 'scale_by_scalar')
+            out.append(res)
+        return (None, None, None, None, *out)
+
+
+class FCOSLoss(nn.Module):
+    """Drop-in for the reference FCOSLoss: same constructor, `forward(preds, annotations) -> {'cls_loss', 'reg_loss',
+    'center_ness_loss'}`; preds = [cls_heads, reg_heads, center_heads] of FCOS (per level [B, H, W, classes] probabilities,
+    [B, H, W, 4] log-distances, [B, H, W, 1] centre-ness probabilities).  Point assignment and the focal loss run on
+    csrc/detloss.hip over all points; the IoU and centre-ness losses are tensor arithmetic on the positive points only."""
+
+    def __init__(self, strides=[8, 16, 32, 64, 128], mi=[[-1, 64], [64, 128], [128, 256], [256, 512], [512, 100000000]], alpha=0.25,
+                 gamma=2., cls_loss_weight=1., box_loss_weight=1., center_ness_loss_weight=1., box_loss_iou_type='GIoU',
+                 center_sample_radius=1.5, use_center_sample=True):
+        super(FCOSLoss, self).__init__()
+        assert box_loss_iou_type in ['IoU', 'GIoU', 'DIoU', 'CIoU', 'EIoU'], 'wrong IoU type!'
+        from .models.anchor import FCOSPositions
+        self.positions = FCOSPositions(strides=strides)
+        self.alpha, self.gamma = alpha, gamma
+        self.strides, self.mi = strides, mi
+        self.cls_loss_weight, self.box_loss_weight = cls_loss_weight, box_loss_weight
+        self.center_ness_loss_weight = center_ness_loss_weight
+        self.box_loss_iou_type = box_loss_iou_type
+        self.center_sample_radius = center_sample_radius
+        self.use_center_sample = use_center_sample
+        self._tables = {}
+
+    def _point_table(self, sizes, device):
+        """[P, 5] = (x, y, stride, range low, range high) of every point of the pyramid, level after level"""
+        key = (tuple(map(tuple, sizes)), str(device))
+        if key not in self._tables:
+            rows = []
+            for xy, stride, (lo, hi) in zip(self.positions([list(s) for s in sizes]), self.strides, self.mi):
+                xy = torch.from_numpy(xy).view(-1, 2)
+                extra = torch.tensor([float(stride), float(lo), float(hi)], dtype=torch.float32).expand(xy.shape[0], 3)
+                rows.append(torch.cat([xy, extra], dim=1))
+            self._tables[key] = torch.cat(rows, dim=0).contiguous().to(device)
+        return self._tables[key]
+
+    def forward(self, preds, annotations):
+        from ... import _lib
+        cls_preds, reg_preds, center_preds = preds
+        dev = annotations.device
+        b = annotations.shape[0]
+        points = self._point_table([[t.shape[2], t.shape[1]] for t in cls_preds], dev)
+        P = points.shape[0]
+        annots = annotations.float().contiguous()
+        targets = torch.empty((b, P, 5), dtype=torch.float32, device=dev)
+        centerness = torch.empty((b, P), dtype=torch.float32, device=dev)
+        positives = torch.zeros(1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().saicv_fcos_assign(points.data_ptr(), annots.data_ptr() if annots.shape[1] else None, targets.data_ptr(),
+                                                centerness.data_ptr(), positives.data_ptr(), b, P, annots.shape[1],
+                                                float(self.center_sample_radius), int(self.use_center_sample), _lib.stream()), 'fcos_assign')
+        inv = torch.where(positives[0] > 0, 1.0 / positives[0].clamp(min=1.0), torch.zeros_like(positives[0]))
+        cls = [t.reshape(b, -1, t.shape[-1]).float().contiguous() for t in cls_preds]
+        cls_loss = _FocalLevelsFn.apply(targets, inv, self.alpha, self.gamma, *cls)
+        pos = targets[..., 4] > 0
+        if bool(pos.any()):
+            reg = torch.exp(torch.cat([t.reshape(b, -1, 4) for t in reg_preds], dim=1).float()[pos])
+            ctr_pred = torch.cat([t.reshape(b, -1) for t in center_preds], dim=1).float().clamp(min=1e-4, max=1. - 1e-4)[pos]
+            xy = points[:, 0:2].unsqueeze(0).expand(b, -1, -1)[pos]
+            ltrb, ctr = targets[pos][:, 0:4], centerness[pos]
+            pred_boxes = torch.cat([xy - reg[:, 0:2], xy + reg[:, 2:4]], dim=1)
+            gt_boxes = torch.cat([xy - ltrb[:, 0:2], xy + ltrb[:, 2:4]], dim=1)
+            reg_loss = ((1 - _box_iou(pred_boxes, gt_boxes, self.box_loss_iou_type)) * ctr).sum() * inv
+            ctr_loss = -(ctr * torch.log(ctr_pred) + (1. - ctr) * torch.log(1. - ctr_pred)).sum() * inv
+        else:
+            reg_loss = torch.zeros((), dtype=torch.float32, device=dev)
+            ctr_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        return {'cls_loss': self.cls_loss_weight * cls_loss, 'reg_loss': self.box_loss_weight * reg_loss,
+                'center_ness_loss': self.center_ness_loss_weight * ctr_loss}

@@ -161,6 +161,76 @@ __global__ __launch_bounds__(DL_THREADS) void smoothl1_level_kernel(const float*
     if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s);
 }
 
+
+// FCOSLoss.get_batch_position_annotations (losses.py:623-842): every feature-map point against every ground-truth box of its
+// image.  A box is a candidate for a point when the point lies strictly inside it, within `radius` strides of its centre (centre
+// sampling) and the largest of the four side distances falls inside the level's regression range (m0, m1); the candidate with the
+// smallest box area wins.  points [P][5] = (x, y, stride, m0, m1).  targets [B][P][5] = (l, t, r, b, class + 1 | 0),
+// centerness [B][P] = sqrt(min(l, r) / max(l, r) * min(t, b) / max(t, b)) | 0.  Same operation order as the reference (no FMA
+// contraction in the tests that decide membership).
+__global__ __launch_bounds__(DL_THREADS) void fcos_assign_kernel(const float* __restrict__ points, const float* __restrict__ annots,
+                                                                 float* __restrict__ targets, float* __restrict__ centerness,
+                                                                 float* __restrict__ pos_count, int P, int G, float radius, int center_sample) {
+    __shared__ float gt[DL_MAX_GT * 5];
+    __shared__ float red[DL_THREADS / 64];
+    __shared__ int ngt;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int g = 0; g < G; ++g) {
+            const float* r = annots + ((size_t)b * G + g) * 5;
+            if (r[4] >= 0.f) {
+                for (int j = 0; j < 5; ++j) gt[n * 5 + j] = r[j];
+                ++n;
+            }
+        }
+        ngt = n;
+    }
+    __syncthreads();
+    const int n = ngt;
+    const int p = blockIdx.x * DL_THREADS + threadIdx.x;
+    float is_pos = 0.f;
+    if (p < P) {
+        const float x = points[p * 5 + 0], y = points[p * 5 + 1], stride = points[p * 5 + 2], m0 = points[p * 5 + 3], m1 = points[p * 5 + 4];
+        const float judge = __fmul_rn(stride, radius);
+        float out[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float ctr = 0.f, best_area = 0.f;
+        bool found = false;
+        for (int g = 0; g < n; ++g) {
+            const float x1 = gt[g * 5 + 0], y1 = gt[g * 5 + 1], x2 = gt[g * 5 + 2], y2 = gt[g * 5 + 3];
+            const float l = __fsub_rn(x, x1), t = __fsub_rn(y, y1), r = __fsub_rn(x2, x), bt = __fsub_rn(y2, y);
+            const float mn = fminf(fminf(l, t), fminf(r, bt));
+            if (!(mn > 0.f)) continue;
+            if (center_sample) {
+                const float cx = __fdiv_rn(__fadd_rn(x2, x1), 2.f), cy = __fdiv_rn(__fadd_rn(y2, y1), 2.f);
+                const float dx = __fsub_rn(x, cx), dy = __fsub_rn(y, cy);
+                const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+                if (!(dist < judge)) continue;
+            }
+            const float mx = fmaxf(fmaxf(l, t), fmaxf(r, bt));
+            if (!(mx > m0) || !(mx < m1)) continue;
+            const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+            if (!found || area < best_area) {
+                found = true;
+                best_area = area;
+                out[0] = l; out[1] = t; out[2] = r; out[3] = bt;
+                out[4] = gt[g * 5 + 4] + 1.f;
+            }
+        }
+        if (found) {
+            const float l = out[0], t = out[1], r = out[2], bt = out[3];
+            ctr = __fsqrt_rn(__fmul_rn(__fdiv_rn(fminf(l, r), fmaxf(l, r)), __fdiv_rn(fminf(t, bt), fmaxf(t, bt))));
+            is_pos = 1.f;
+        }
+        float* o = targets + ((size_t)b * P + p) * 5;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) o[j] = out[j];
+        centerness[(size_t)b * P + p] = ctr;
+    }
+    const float cnt = block_sum(is_pos, red);
+    if (threadIdx.x == 0 && cnt != 0.f) atomicAdd(pos_count, cnt);
+}
+
 inline int dl_grid(size_t items) {
     size_t g = (items + DL_THREADS - 1) / DL_THREADS;
     if (g > 4096) g = 4096;
@@ -209,6 +279,17 @@ int saicv_smoothl1_level(const float* reg, const float* targets, float* dreg, fl
     hipLaunchKernelGGL(smoothl1_level_kernel, dim3(dl_grid(rows)), dim3(DL_THREADS), 0, (hipStream_t)stream, reg, targets, dreg, loss_sum,
                        rows, Al, At, off, (float)beta);
     return saicv::check_launch("smoothl1_level");
+}
+
+// FCOS point assignment (reference losses.py:623-842): points [P][5] fp32 = (x, y, stride, range low, range high) of one image's
+// pyramid, annots [B][G][5] -> targets [B][P][5] = (l, t, r, b, class + 1 or 0), centerness [B][P], pos_count[0] += positives.
+int saicv_fcos_assign(const float* points, const float* annots, float* targets, float* centerness, float* pos_count, int B, int P,
+                      int G, double radius, int center_sample, void* stream) {
+    SAICV_REQUIRE(B > 0 && P > 0 && G >= 0 && G <= DL_MAX_GT, "fcos_assign: B=%d P=%d G=%d (G <= %d)", B, P, G, DL_MAX_GT);
+    SAICV_REQUIRE(B <= 65535, "fcos_assign: batch %d", B);
+    hipLaunchKernelGGL(fcos_assign_kernel, dim3((P + DL_THREADS - 1) / DL_THREADS, B), dim3(DL_THREADS), 0, (hipStream_t)stream, points, annots,
+                       targets, centerness, pos_count, P, G, (float)radius, center_sample);
+    return saicv::check_launch("fcos_assign");
 }
 
 }  // extern "C"
