@@ -447,6 +447,11 @@ int saicv_smoothl1_level(const float* reg, const float* targets, float* dreg, fl
  * range; the smallest candidate wins. */
 int saicv_fcos_assign(const float* points, const float* annots, float* targets, float* centerness, float* pos_count, int B, int P,
                       int G, double radius, int center_sample, void* stream);
+/* Evaluation: first-maximum class and its probability per anchor / point of ONE level (reference SimpleAICV/detection/decode.py
+ * RetinaDecoder :219-230; FCOSDecoder :331-343 with centerness [B][Al]: score = sqrt(probability * centre-ness)), written at the
+ * level's offset of [B][At] score / class arrays: the [B][At][C] tensor never leaves the device. */
+int saicv_det_best_class(const float* probs, const float* centerness, float* scores, int* classes, int B, int Al, int At, int off, int C,
+                         void* stream);
 
 /* ---- gradient all-reduce over RCCL / xGMI ------------------------------------------------
  * The reducer of nn.parallel.DistributedDataParallel (reference tools/train_classification_model.py:217-227 wraps the

@@ -157,6 +157,7 @@ SIGNATURES = {
     'saicv_focal_loss_level': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
     'saicv_smoothl1_level': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
     'saicv_fcos_assign': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_double, c_int, _P]),
+    'saicv_det_best_class': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_sam_sample_point': (c_int, [c_int, _P, _P, c_long, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _P, _P,
                                        c_int, c_int, c_int, _P]),
     'saicv_comm_available': (c_int, []),

@@ -16,6 +16,9 @@ namespace {
 constexpr int DL_THREADS = 256;
 constexpr int DL_MAX_GT = 1024;
 
+// correctly rounded fp32 square root (the double result rounds to the fp32 one): scores and membership tests must equal numpy's / torch's
+DEVINL float sqrt_exact(float v) { return (float)sqrt((double)v); }
+
 DEVINL float block_sum(float v, float* red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(DL_THREADS) void fcos_assign_kernel(const float* __
             if (center_sample) {
                 const float cx = __fdiv_rn(__fadd_rn(x2, x1), 2.f), cy = __fdiv_rn(__fadd_rn(y2, y1), 2.f);
                 const float dx = __fsub_rn(x, cx), dy = __fsub_rn(y, cy);
-                const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+                const float dist = sqrt_exact(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
                 if (!(dist < judge)) continue;
             }
             const float mx = fmaxf(fmaxf(l, t), fmaxf(r, bt));
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(DL_THREADS) void fcos_assign_kernel(const float* __
         }
         if (found) {
             const float l = out[0], t = out[1], r = out[2], bt = out[3];
-            ctr = __fsqrt_rn(__fmul_rn(__fdiv_rn(fminf(l, r), fmaxf(l, r)), __fdiv_rn(fminf(t, bt), fmaxf(t, bt))));
+            ctr = sqrt_exact(__fmul_rn(__fdiv_rn(fminf(l, r), fmaxf(l, r)), __fdiv_rn(fminf(t, bt), fmaxf(t, bt))));
             is_pos = 1.f;
         }
         float* o = targets + ((size_t)b * P + p) * 5;
@@ -229,6 +232,29 @@ __global__ __launch_bounds__(DL_THREADS) void fcos_assign_kernel(const float* __
     }
     const float cnt = block_sum(is_pos, red);
     if (threadIdx.x == 0 && cnt != 0.f) atomicAdd(pos_count, cnt);
+}
+
+// Evaluation-time candidate scores of one pyramid level (reference SimpleAICV/detection/decode.py RetinaDecoder :219-230,
+// FCOSDecoder :331-343): per anchor / point the first-maximum class of its C probabilities and that probability -- for FCOS
+// sqrt(probability * centre-ness) -- so that only [B][At] scores and classes (and later the few hundred surviving candidates)
+// leave the device instead of the [B][At][C] tensor the reference copies to the host.
+__global__ __launch_bounds__(DL_THREADS) void best_class_kernel(const float* __restrict__ probs, const float* __restrict__ centerness,
+                                                                float* __restrict__ scores, int* __restrict__ classes, size_t rows, int Al,
+                                                                int At, int off, int C) {
+    for (size_t row = (size_t)blockIdx.x * DL_THREADS + threadIdx.x; row < rows; row += (size_t)gridDim.x * DL_THREADS) {
+        const float* p = probs + row * C;
+        float best = p[0];
+        int bc = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = p[c];
+            if (v > best) { best = v; bc = c; }
+        }
+        if (centerness) best = sqrt_exact(__fmul_rn(best, centerness[row]));
+        const size_t b = row / Al;
+        const size_t o = b * At + off + (row - b * Al);
+        scores[o] = best;
+        classes[o] = bc;
+    }
 }
 
 inline int dl_grid(size_t items) {
@@ -290,6 +316,17 @@ int saicv_fcos_assign(const float* points, const float* annots, float* targets, 
     hipLaunchKernelGGL(fcos_assign_kernel, dim3((P + DL_THREADS - 1) / DL_THREADS, B), dim3(DL_THREADS), 0, (hipStream_t)stream, points, annots,
                        targets, centerness, pos_count, P, G, (float)radius, center_sample);
     return saicv::check_launch("fcos_assign");
+}
+
+// per-anchor best class and score of one level: probs [B][Al][C] fp32, centerness NULL or [B][Al] fp32 (FCOS: score =
+// sqrt(probability * centre-ness)) -> scores / classes [B][At] at this level's offset.  decode.py:219-230, :331-343.
+int saicv_det_best_class(const float* probs, const float* centerness, float* scores, int* classes, int B, int Al, int At, int off, int C,
+                         void* stream) {
+    SAICV_REQUIRE(B > 0 && Al > 0 && C > 0 && off >= 0 && off + Al <= At, "det_best_class: B=%d Al=%d At=%d off=%d C=%d", B, Al, At, off, C);
+    const size_t rows = (size_t)B * Al;
+    hipLaunchKernelGGL(best_class_kernel, dim3(dl_grid(rows)), dim3(DL_THREADS), 0, (hipStream_t)stream, probs, centerness, scores, classes,
+                       rows, Al, At, off, C);
+    return saicv::check_launch("det_best_class");
 }
 
 }  // extern "C"

@@ -334,3 +334,45 @@ def test_anchor_and_position_tables_are_bit_identical_to_the_reference():
             same(a, d)
         for a, d in zip(FCOSPositions()(t['sizes']), t['positions']):
             same(a, d)
+
+
+def test_dense_decoder_host_stages_match_the_reference():
+    """DecodeMethod / DetNMSMethod / box decoding of SimpleAICV/detection/decode.py on the host, fed with ALL anchors the way the
+    reference feeds them (arg-max in numpy here; on the GPU the decoders take it from csrc/detloss.hip -- tests/test_gpu_decoders.py),
+    against the detections the reference decoders produced (oracle/make_golden_decoders.py): identical scores, classes and boxes."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.decode import RetinaDecoder, FCOSDecoder
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'oracle'))
+    try:
+        import make_golden_decoders as m
+    finally:
+        sys.path.pop(0)
+    fx = torch.load(os.path.join(root, 'tests', 'golden', 'dense_decoders.pt'), weights_only=True)
+    cls, reg = m.retina_inputs()
+    b = cls[0].shape[0]
+    probs = np.concatenate([t.numpy().reshape(b, -1, t.shape[-1]) for t in cls], axis=1)
+    regs = np.concatenate([t.numpy().reshape(b, -1, 4) for t in reg], axis=1)
+    classes = probs.argmax(axis=2)
+    scores = np.take_along_axis(probs, classes[..., None], axis=2)[..., 0]
+    for name, ref in fx['retina'].items():
+        dec = RetinaDecoder(**ref['config'])
+        table = np.concatenate([a.reshape(-1, 4) for a in dec.anchors([[t.shape[2], t.shape[1]] for t in cls])], axis=0)
+        boxes = dec.snap_txtytwth_to_x1y1x2y2(regs, np.repeat(table[None], b, axis=0))
+        s, c, bx = dec.decode_function(scores, classes, boxes)
+        assert np.array_equal(s, ref['scores'].numpy()) and np.array_equal(c, ref['classes'].numpy()) and np.array_equal(bx, ref['boxes'].numpy()), name
+    cls, reg, ctr = m.fcos_inputs()
+    probs = np.concatenate([t.numpy().reshape(b, -1, t.shape[-1]) for t in cls], axis=1)
+    regs = np.concatenate([t.numpy().reshape(b, -1, 4) for t in reg], axis=1)
+    ctrs = np.concatenate([t.numpy().reshape(b, -1) for t in ctr], axis=1)
+    classes = probs.argmax(axis=2)
+    scores = np.sqrt(np.take_along_axis(probs, classes[..., None], axis=2)[..., 0] * ctrs)
+    for name, ref in fx['fcos'].items():
+        dec = FCOSDecoder(**ref['config'])
+        table = np.concatenate([p.reshape(-1, 2) for p in dec.positions([[t.shape[2], t.shape[1]] for t in cls])], axis=0)
+        boxes = dec.snap_ltrb_to_x1y1x2y2(regs, np.repeat(table[None], b, axis=0))
+        s, c, bx = dec.decode_function(scores, classes, boxes)
+        assert np.array_equal(s, ref['scores'].numpy()) and np.array_equal(c, ref['classes'].numpy()) and np.array_equal(bx, ref['boxes'].numpy()), name
