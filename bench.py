@@ -1,6 +1,6 @@
 """Training-throughput bench of the SimpleAICV DDP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model resnet50|vit_base_patch16|sam_b_encoder|resnet50_detr|resnet50_detr_config|sam_b]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model resnet50|vit_base_patch16|sam_b_encoder|resnet50_detr|resnet50_detr_config|resnet50_retinanet|resnet50_fcos|sam_b]
                     [--batch B] [--no-cpu-baseline] [--no-secondary] [--eager]
 
 A step = forward + loss + backward + gradient all-reduce + optimizer step of one per-GPU batch of synthetic data that
@@ -47,8 +47,13 @@ CONFIG_DIR = {'resnet50': '00.classification_training/imagenet/resnet50',
               'vit_base_patch16': '00.classification_training/imagenet/vit_base_patch16_for_self_train_mae_pretrain',
               # the reference's own DETR / SAM training configurations (1024^2 canvases), through their loops
               'resnet50_detr_config': '03.detection_training/coco/res50_detr_yoloresize1024',
+              'resnet50_retinanet': '03.detection_training/coco/res50_retinanet_yoloresize1024',
+              'resnet50_fcos': '03.detection_training/coco/res50_fcos_yoloresize1024',
               'sam_b': '13.interactive_segmentation_training/13.1.sam_segmentation_training/sam_b_training'}
 LOOP_MODELS = {'resnet50_detr_config': ('tools.scripts.train_detection', 8, 1024, 3 * 189.1 * (768 * 1024) / (800 * 1344)),
+               # dense detectors through the same loop (reference per-GPU batch 32 / 8 = 4); no FLOP figure is published for them
+               'resnet50_retinanet': ('tools.scripts.train_detection', 4, 1024, 0.0),
+               'resnet50_fcos': ('tools.scripts.train_detection', 4, 1024, 0.0),
                # full SAM step: one encoder pass (972.1 GFLOP fwd) + 1 + decoder_iters light decoder passes
                'sam_b': ('tools.interactive_segmentation_scripts.train_sam_segmentation', 8, 1024, 3 * 972.1)}
 PMC_FILE = 'profiles/r03_pmc_hbm_traffic.json'
@@ -202,7 +207,7 @@ def loop_workload(name, args, world, rank, device):
     logger = logging.getLogger('saicv_bench')
     logger.addHandler(logging.NullHandler())
     logger.propagate = False
-    fn = scripts.train_detection if name == 'resnet50_detr_config' else interactive_segmentation_scripts.train_sam_segmentation
+    fn = scripts.train_detection if LOOP_MODELS[name][0].endswith('train_detection') else interactive_segmentation_scripts.train_sam_segmentation
     state = {'loss': float('nan')}
 
     def run(k):

@@ -1,5 +1,5 @@
-"""Batch collater of the DETR pipeline -- drop-in for the reference DETRDetectionCollater
-(SimpleAICV/detection/common.py:291-363).
+"""Batch collaters of the detection pipelines -- drop-ins for the reference DetectionCollater (SimpleAICV/detection/common.py:
+243-288; RetinaNet / FCOS: image canvas + padded annotations) and DETRDetectionCollater (:291-363).
 
 Device-side input contract it defines: image [B, 3, S, S] fp32 as a `.permute(0, 3, 1, 2)` VIEW of an NHWC
 batch (channels-last memory, NCHW shape -- exactly what the conv kernels stream), mask [B, S, S] bool with
@@ -48,4 +48,32 @@ class DETRDetectionCollater:
             'size': np.array([x['size'] for x in data], dtype=np.float32),
             'scaled_annots': torch.from_numpy(scaled).float(),
             'scaled_size': np.array(scaled_sizes, dtype=np.float32),
+        }
+
+
+class DetectionCollater:
+    """images at the top-left of a zero [B, S, S, 3] canvas handed over as its NCHW view, annotations [B, max_annots_num, 5]
+    (xyxy + class) padded with -1 rows, per-image scale / size arrays (reference :243-288)."""
+
+    def __init__(self, resize=800, resize_type='retina_style', max_annots_num=100):
+        assert resize_type in ['retina_style', 'yolo_style']
+        self.resize = resize
+        if resize_type == 'retina_style':
+            self.resize = int(round(self.resize * 1333. / 800))
+        self.max_annots_num = max_annots_num
+
+    def __call__(self, data):
+        n, s, m = len(data), self.resize, self.max_annots_num
+        canvas = np.zeros((n, s, s, 3), dtype=np.float32)
+        annots = np.full((n, m, 5), -1, dtype=np.float32)
+        for i, sample in enumerate(data):
+            image, a = sample['image'], sample['annots']
+            canvas[i, 0:image.shape[0], 0:image.shape[1], :] = image
+            if a.shape[0] > 0:
+                annots[i, :a.shape[0], :] = a
+        return {
+            'image': torch.from_numpy(canvas).permute(0, 3, 1, 2).float(),
+            'annots': torch.from_numpy(annots).float(),
+            'scale': np.array([x['scale'] for x in data], dtype=np.float32),
+            'size': np.array([x['size'] for x in data], dtype=np.float32),
         }
