@@ -98,6 +98,9 @@ int saicv_conv2d_dgrad(const saicv_conv_desc* d, const void* dy, const void* wd,
  * Accumulates with fp32 atomics: zero dw first for a plain gradient. */
 int saicv_conv2d_wgrad(const saicv_conv_desc* d, const void* dy, const void* x, float* dw,
                        void* stream);
+/* the same with the bias gradient: dbias[K] (fp32) += column sums of dy, taken from the dY tiles the kernel already holds
+ * (the workgroups of the first weight-tile column add them): no separate pass over dy for a biased nn.Conv2d */
+int saicv_conv2d_wgrad_bias(const saicv_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias, void* stream);
 /* nn.Linear on the same kernels: y[M][N] = addend + row_scale[m / rows_per_scale] * (x[M][K] wf[N][K]^T + bias)
  * (addend / row_scale optional: the residual add and drop-path of vit.py:159-163 fused into the
  * epilogue); dx[M][K] = dy[M][N] wd[K][N]^T (+ addend); dw[N][K] (fp32) += dy^T x and, when dbias

@@ -79,6 +79,7 @@ SIGNATURES = {
     'saicv_conv2d_fwd': (c_int, [_PD, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'saicv_conv2d_dgrad': (c_int, [_PD, _P, _P, _P, _P]),
     'saicv_conv2d_wgrad': (c_int, [_PD, _P, _P, _P, _P]),
+    'saicv_conv2d_wgrad_bias': (c_int, [_PD, _P, _P, _P, _P, _P]),
     'saicv_colsum': (c_int, [c_int, _P, c_int, c_int, _P, _P]),
     'saicv_linear_fwd': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     'saicv_linear_dgrad': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P, _P]),

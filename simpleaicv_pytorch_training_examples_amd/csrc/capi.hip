@@ -161,6 +161,14 @@ int saicv_conv2d_wgrad(const saicv_conv_desc* d, const void* dy, const void* x, 
                     M, d->K, d->R * d->S * d->C, S(stream));
 }
 
+int saicv_conv2d_wgrad_bias(const saicv_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
+                            void* stream) {
+    if (check_desc(d, "saicv_conv2d_wgrad_bias")) return -1;
+    const int M = d->N * d->OH * d->OW;
+    return igemm_tn(d->dtype, dy, x, dw, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad,
+                    M, d->K, d->R * d->S * d->C, S(stream), dbias);
+}
+
 int saicv_linear_fwd(int dtype, const void* x, const void* wf, const float* bias, void* y, int M, int K, int N,
                      int out_f32, const void* addend, const float* row_scale, int rows_per_scale, void* stream) {
     EpiExtra ex;

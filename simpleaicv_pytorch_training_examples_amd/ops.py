@@ -818,6 +818,12 @@ class ConvFn(torch.autograd.Function):
             t0 = KernelTimer.begin('igemm_nt')
             check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
             KernelTimer.end(t0, 'igemm_nt', flops, 0)
+        want_b = bias is not None and ctx.needs_input_grad[2]
+        tb = gb = None
+        bias_done = False
+        if want_b:
+            gb = _arena_grad(bias)
+            tb = gb if gb is not None else torch.zeros(k, dtype=torch.float32, device=x.device)
         if ctx.needs_input_grad[1]:
             gw = _arena_grad(weight)
             direct = gw is not None and c == weight.shape[1] and weight.is_contiguous(memory_format=torch.channels_last)
@@ -829,20 +835,25 @@ class ConvFn(torch.autograd.Function):
                     KernelTimer.end(t0, 'igemm_tn', flops, 0)
             else:
                 t0 = KernelTimer.begin('igemm_tn')
-                check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
+                # the bias gradient rides along: column sums of the dY tiles the weight-gradient kernel already holds
+                check(L.saicv_conv2d_wgrad_bias(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), ptr(tb), st), 'conv2d_wgrad')
                 KernelTimer.end(t0, 'igemm_tn', flops, 0)
+                bias_done = want_b
             if not direct:
                 dwt = _weight_grad(dw, weight, c)
-        if bias is not None and ctx.needs_input_grad[2]:
-            gb = _arena_grad(bias)
-            tb = gb if gb is not None else torch.zeros(k, dtype=torch.float32, device=x.device)
-            check(L.saicv_colsum(dtype_code(dt), ptr(dy), M, k, ptr(tb), st), 'colsum')
+        if want_b:
+            if not bias_done:                   # no weight gradient wanted (or it ran on the side stream): its own pass
+                check(L.saicv_colsum(dtype_code(dt), ptr(dy), M, k, ptr(tb), st), 'colsum')
             if gb is None:
                 db = tb
         return dx, dwt, db, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0):
+    # under autocast a convolution computes in the autocast dtype whatever its input's dtype (torch.autocast casts conv2d's
+    # operands): an fp32 activation -- e.g. the output of a bilinear resize, which autocast runs in fp32 -- is cast here
+    if torch.is_autocast_enabled('cuda') and x.is_floating_point() and x.dtype != compute_dtype():
+        x = x.to(compute_dtype())
     return ConvFn.apply(x, weight, bias, stride, pad)
 
 
@@ -897,6 +908,8 @@ class DepthwiseConvFn(torch.autograd.Function):
 
 
 def depthwise_conv2d(x, weight, bias=None, stride=1, pad=0, dilation=1):
+    if torch.is_autocast_enabled('cuda') and x.is_floating_point() and x.dtype != compute_dtype():
+        x = x.to(compute_dtype())
     return DepthwiseConvFn.apply(x, weight, bias, stride, pad, dilation)
 
 
