@@ -427,6 +427,16 @@ int saicv_channel_scale_add_bwd(int dtype, const void* dout, const void* y, cons
  * saicv_bn_finalize_fwd(rows = 1), then saicv_bn_act_fwd / saicv_bn_act_bwd as for the fused blocks. */
 int saicv_bn_stats(int dtype, const void* x, size_t M, int C, float* sum, float* sq, void* stream);
 
+/* ---- nn.GroupNorm (+ ReLU) on NHWC activations (csrc/groupnorm.hip; reference SimpleAICV/detection/models/head.py:101-124) ---- */
+size_t saicv_groupnorm_ws_floats(int N, int C);
+/* y = [relu](GroupNorm_G(x)) on x [N][HW][C] (C % (16 / element size) == 0), fp32 arithmetic; gamma / beta fp32 [C] or NULL.
+ * Saves mean_rstd [2][N][G] and the per-(sample, channel) affine coefficients ab [2][N][C] (y = x * a + b) for the backward. */
+int saicv_groupnorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, float* ab, float* ws,
+                        int N, int HW, int C, int G, double eps, int relu, void* stream);
+/* dx; dgamma[C] / dbeta[C] fp32 are ADDED to (NULL: not wanted); with relu the gate is recomputed from x * a + b */
+int saicv_groupnorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const float* ab, void* dx,
+                        float* dgamma, float* dbeta, float* ws, int N, int HW, int C, int G, int relu, void* stream);
+
 /* ---- dense-detector training loss (csrc/detloss.hip; reference SimpleAICV/detection/losses.py RetinaLoss :123-433) ---- */
 /* get_batch_anchors_annotations (:330-416): anchors [A][4] fp32 (one image's table, shared by the batch), annots [B][G][5] fp32
  * (x_min, y_min, x_max, y_max, class; class < 0 = padding row; G <= 1024) -> targets [B][A][5]: the box target of the best-IoU

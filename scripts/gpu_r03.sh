@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 GPU runner: one parametrised script instead of one file per experiment.
 #   gpurun --timeout N -- 'bash scripts/gpu_r03.sh <tag> <steps...>'
-# steps: tests[:<pytest args>]  testsall  smoke  sweep[:linear|conv]  kbench  lbench  bench[:<bench.py args>]  prof:<model>
+# steps: tests[:<pytest args>]  testsall  testsx[:<workers>]  smoke  sweep[:linear|conv]  kbench  lbench  bench[:<bench.py args>]  prof:<model>
 #        entries (the three entry scripts end to end through torch.distributed.run, DETR resumed from latest.pth)
 # Companions: gpu_ab_env.sh (same-box A/B of environment switches on a model bench), gpu_lb_env.sh (the same with the
 # isolated linear GEMMs), gpu_pmc_r03.sh (PMC HBM traffic of the default command), gpu_tiles.sh (tile-geometry sweep).
@@ -15,6 +15,7 @@ for step in "$@"; do
   case $name in
     tests)  timeout 1500 python -m pytest tests -m gpu -q -x ${arg:-} > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log ;;
     testsall) timeout 1800 python -m pytest tests -m gpu -q ${arg:-} > $O/pytest_gpu.log 2>&1; tail -15 $O/pytest_gpu.log ;;
+    testsx) timeout 900 python -m pytest tests -m gpu -q -n ${arg:-4} --dist loadfile > $O/pytest_gpu.log 2>&1; tail -15 $O/pytest_gpu.log ;;   # the suite over xdist workers sharing the GPU (files stay on one worker)
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     sweep)  timeout 900 python scripts/nt_sweep.py ${arg:-all} > $O/nt_sweep_${arg:-all}.jsonl 2> $O/nt_sweep.err; tail -3 $O/nt_sweep_${arg:-all}.jsonl | cut -c1-600; tail -3 $O/nt_sweep.err ;;
     kbench) KB_ITERS=10 timeout 600 python scripts/kernel_bench.py > $O/kernel_microbench.jsonl 2> $O/kbench.err; tail -4 $O/kernel_microbench.jsonl | cut -c1-400 ;;

@@ -4,7 +4,8 @@ names (`cls_head.*`, `reg_head.{0,2,4}.*`) and xavier init order.
 RetinaNet (:15-86) and FCOS (:88-181), SURVEY.md 8(f) rank 2: towers of 3x3 convolutions (+ GroupNorm for FCOS) + ReLU shared
 by all pyramid levels and 3x3 output convolutions; same module trees (`cls_head.{0,2,4,6}`, `cls_out`, ...), N(0, 0.01)
 weights, zero biases and the focal-loss prior on `cls_out.bias`, drawn in the reference's order.  The convolutions run on the
-implicit-GEMM kernel (`ops.conv2d`); ReLU, GroupNorm and the fp32 sigmoids are elementwise ops on the NHWC tensors."""
+implicit-GEMM kernel (`ops.conv2d`), GroupNorm + ReLU on `csrc/groupnorm.hip` (`ops.group_norm`); the lone ReLUs and the fp32
+sigmoids are elementwise ops on the NHWC tensors."""
 import math
 
 import torch
@@ -15,14 +16,24 @@ from .... import ops, ops_tfm
 
 
 def _tower(x, seq):
-    """Conv2d (-> GroupNorm) -> ReLU stacks of a head on NHWC data."""
-    for layer in seq:
+    """Conv2d (-> GroupNorm) -> ReLU stacks of a head on NHWC data.  GroupNorm and the ReLU behind it are one node
+    (ops.group_norm, csrc/groupnorm.hip); channel counts its 16-byte chunks do not divide fall back to the tensor op."""
+    layers = list(seq)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
         if isinstance(layer, nn.Conv2d):
             x = ops.conv2d(x, layer.weight, layer.bias, layer.stride[0], layer.padding[0])
         elif isinstance(layer, nn.GroupNorm):
-            x = F.group_norm(x, layer.num_groups, layer.weight, layer.bias, layer.eps)
+            fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
+            if layer.num_channels % 8 == 0:
+                x = ops.group_norm(x, layer, relu=fuse)
+                i += int(fuse)
+            else:
+                x = F.group_norm(x, layer.num_groups, layer.weight, layer.bias, layer.eps)
         else:
             x = torch.relu(x)
+        i += 1
     return x
 
 

@@ -159,6 +159,9 @@ SIGNATURES = {
     'saicv_smoothl1_level': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),
     'saicv_fcos_assign': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_double, c_int, _P]),
     'saicv_det_best_class': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_groupnorm_ws_floats': (c_size_t, [c_int, c_int]),
+    'saicv_groupnorm_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_int, _P]),
+    'saicv_groupnorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_sam_sample_point': (c_int, [c_int, _P, _P, c_long, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _P, _P,
                                        c_int, c_int, c_int, _P]),
     'saicv_comm_available': (c_int, []),

@@ -1125,6 +1125,56 @@ def batch_norm2d(x, bn):
     return BatchNorm2dFn.apply(x, bn.weight, bn.bias, bn)
 
 
+class GroupNormFn(torch.autograd.Function):
+    """nn.GroupNorm (+ the ReLU behind it) on an NHWC activation in the compute dtype, fp32 arithmetic (csrc/groupnorm.hip): the
+    normalisation of the FCOS head towers (reference detection/models/head.py:101-124).  Two streaming passes each way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu):
+        require_gpu(x)
+        x = _nhwc(x)
+        n, c, h, w = x.shape
+        dev = x.device
+        mean_rstd = torch.empty((2, n, groups), dtype=torch.float32, device=dev)
+        ab = torch.empty((2, n, c), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib().saicv_groupnorm_ws_floats(n, c), dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        check(lib().saicv_groupnorm_fwd(dtype_code(x.dtype), ptr(x), ptr(weight), ptr(bias), ptr(y), ptr(mean_rstd), ptr(ab), ptr(ws),
+                                        n, h * w, c, groups, float(eps), int(relu), stream()), 'groupnorm_fwd')
+        ctx.save_for_backward(x, weight, bias, mean_rstd, ab)
+        ctx.cfg = (groups, bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean_rstd, ab = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        n, c, h, w = x.shape
+        dy = _nhwc(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dev = x.device
+        dx = torch.empty_like(x)
+        want_w = weight is not None and ctx.needs_input_grad[1]
+        want_b = bias is not None and ctx.needs_input_grad[2]
+        gw = _arena_grad(weight) if want_w else None
+        gb = _arena_grad(bias) if want_b else None
+        dgamma = gw if gw is not None else (torch.zeros(c, dtype=torch.float32, device=dev) if want_w else None)
+        dbeta = gb if gb is not None else (torch.zeros(c, dtype=torch.float32, device=dev) if want_b else None)
+        ws = torch.empty(lib().saicv_groupnorm_ws_floats(n, c), dtype=torch.float32, device=dev)
+        check(lib().saicv_groupnorm_bwd(dtype_code(x.dtype), ptr(dy), ptr(x), ptr(weight), ptr(mean_rstd), ptr(ab), ptr(dx), ptr(dgamma),
+                                        ptr(dbeta), ptr(ws), n, h * w, c, groups, int(relu), stream()), 'groupnorm_bwd')
+        return (dx, dgamma if (want_w and gw is None) else None, dbeta if (want_b and gb is None) else None, None, None, None)
+
+
+def group_norm(x, gn, relu=False):
+    """gn: the nn.GroupNorm holding the parameters; under autocast the activation is normalised in the autocast dtype's storage
+    with fp32 arithmetic (the reference's autocast runs group_norm in fp32 and the next convolution casts its input back)"""
+    if torch.is_autocast_enabled('cuda') and x.is_floating_point() and x.dtype != compute_dtype():
+        x = x.to(compute_dtype())
+    return GroupNormFn.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b on the implicit-GEMM kernel (1x1 geometry).  nn.Linear of resnet.py:204."""
 

@@ -173,3 +173,38 @@ def test_statistics_pass_at_a_stage_sized_activation_is_additive():
     assert rel_err(full, lo + hi) < 1e-5
     xd = x.double().view(-1, 32)
     assert rel_err(full[0], xd.sum(0)) < 1e-4 and rel_err(full[1], (xd * xd).sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=IDS)
+@pytest.mark.parametrize('relu', [False, True], ids=['plain', 'relu'])
+@pytest.mark.parametrize('shape,groups', [((2, 256, 12, 10), 32), ((3, 64, 5, 7), 32), ((1, 32, 3, 3), 4), ((2, 96, 9, 9), 3)])
+def test_group_norm_on_nhwc(shape, groups, relu, dt):
+    """csrc/groupnorm.hip against F.group_norm (+ F.relu) in fp32 on the same (rounded) operands: output, input gradient,
+    dgamma, dbeta; groups of one chunk (FCOS: 256 channels / 32 groups), of two bf16 chunks... and of 32 channels"""
+    from simpleaicv_pytorch_training_examples_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + groups)
+    r = _rnd(dt)
+    c = shape[1]
+    gn = nn.GroupNorm(groups, c)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    x = r(torch.randn(shape, generator=g) * 1.7 + 0.4)
+    dy = r(torch.randn(shape, generator=g))
+    xr = x.clone().requires_grad_(True)
+    ref = F.group_norm(xr, groups, gn.weight, gn.bias, gn.eps)
+    if relu:
+        ref = F.relu(ref)
+    ref.backward(dy)
+    wr, br = gn.weight.grad.clone(), gn.bias.grad.clone()
+    gn.zero_grad()
+    gn.cuda()
+    xd = _dev(x, dt).requires_grad_(True)
+    y = ops.group_norm(xd, gn, relu=relu)
+    y.backward(_dev(dy, dt))
+    torch.cuda.synchronize()
+    f32 = dt == torch.float32
+    assert y.dtype == dt and rel_err(y.float().cpu(), ref.detach()) < (1e-4 if f32 else 1e-2)
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < (2e-4 if f32 else 2e-2)
+    assert rel_err(gn.weight.grad.cpu(), wr) < (1e-4 if f32 else 2e-2)
+    assert rel_err(gn.bias.grad.cpu(), br) < (1e-4 if f32 else 2e-2)
