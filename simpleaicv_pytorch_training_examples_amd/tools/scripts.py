@@ -3,6 +3,9 @@
   all_reduce_operation_in_group_for_variables  (reference :26-33)
   test_classification                          (reference :36-113)
   train_classification                         (reference :116-275)
+  compute_voc_ap / compute_ious / evaluate_voc_detection / test_detection   (reference :503-739, :884-897; the COCO
+                                               variant needs pycocotools, which the bench image does not have)
+  train_detection                              (reference :900-1092)
 
 Loop semantics are kept -- skip a batch when ANY rank saw inf/nan input or a zero/inf/nan loss,
 gradient accumulation with `no_sync()`, optional clipping, GradScaler step/update, EMA, mean-
@@ -20,6 +23,8 @@ iterations late:
 """
 import collections
 import time
+
+import numpy as np
 
 import os
 
@@ -351,3 +356,127 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
         return bad, loss_value, images.size(0)
 
     return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5)
+
+
+# ---------------------------------------------------------------------------------------------- detection evaluation
+def compute_voc_ap(recall, precision, use_07_metric=False):
+    """area under the precision envelope (VOC >= 2010) or the 11-point average (VOC 2007); reference :503-532"""
+    recall, precision = np.asarray(recall, dtype=np.float64), np.asarray(precision, dtype=np.float64)
+    if use_07_metric:
+        ap = 0.
+        for t in np.arange(0., 1.1, 0.1):
+            hit = recall >= t
+            ap = ap + (np.max(precision[hit]) if hit.any() else 0) / 11.
+        return ap
+    r = np.concatenate(([0.], recall, [1.]))
+    env = np.maximum.accumulate(np.concatenate(([0.], precision, [0.]))[::-1])[::-1]      # precision envelope from the right
+    step = np.where(r[1:] != r[:-1])[0]
+    return np.sum((r[step + 1] - r[step]) * env[step + 1])
+
+
+def compute_ious(a, b):
+    """[N, 4] x [M, 4] xyxy boxes -> IoU [N, M] (no clamp on degenerate unions, as the reference :535-556)"""
+    a, b = np.expand_dims(a, axis=1), np.expand_dims(b, axis=0)
+    overlap = np.prod(np.maximum(0.0, np.minimum(a[..., 2:], b[..., 2:]) - np.maximum(a[..., :2], b[..., :2])), axis=-1)
+    area_a = np.prod(a[..., 2:] - a[..., :2], axis=-1)
+    area_b = np.prod(b[..., 2:] - b[..., :2], axis=-1)
+    return overlap / (area_a + area_b - overlap)
+
+
+def _voc_class_ap(gt_boxes, pred_boxes, pred_scores, threshold):
+    """AP of one class at one IoU threshold.  Per image, predictions are visited in the order the decoder emitted them; each
+    takes its best-IoU ground-truth box if that box is still free and the IoU reaches the threshold (reference :676-706)."""
+    flags, scores, total = [], [], 0
+    for boxes, preds, sc in zip(gt_boxes, pred_boxes, pred_scores):
+        total += len(boxes)
+        if len(preds) == 0:
+            continue
+        scores.append(sc)
+        hit = np.zeros(len(preds))
+        if boxes.shape[0] > 0:
+            iou = compute_ious(boxes, preds)                              # [gt, pred]
+            best = np.argmax(iou, axis=0)
+            best_iou = iou[best, np.arange(len(preds))]
+            taken = np.zeros(boxes.shape[0], dtype=bool)
+            for j in range(len(preds)):
+                if best_iou[j] >= threshold and not taken[best[j]]:
+                    hit[j] = 1
+                    taken[best[j]] = True
+        flags.append(hit)
+    if not scores:
+        tp = fp = np.zeros((0,))
+    else:
+        order = np.argsort(-np.concatenate(scores))
+        hit = np.concatenate(flags)[order]
+        tp, fp = np.cumsum(hit), np.cumsum(1 - hit)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        recall = tp / total
+    precision = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    return compute_voc_ap(recall, precision, use_07_metric=False)
+
+
+def evaluate_voc_detection(test_loader, model, criterion, decoder, config):
+    """VOC-style mAP at every threshold of config.eval_voc_iou_threshold_list (reference :559-739): forward + loss + decode per
+    batch, boxes back to the original image scale and clipped to it, then per class and threshold the matching above."""
+    model.eval()
+    batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
+    batch_size = int(config.batch_size // config.gpus_num)
+    device = _device_of(model)
+    on_gpu = device.type == 'cuda'
+    is_detr = 'detr' in config.network
+    preds, gts = [], []
+    with torch.no_grad():
+        end = time.time()
+        for data in test_loader:
+            images, annots, scales, sizes = data['image'].to(device), data['annots'].to(device), data['scale'], data['size']
+            if on_gpu:
+                torch.cuda.synchronize()
+            data_time.update(time.time() - end, images.size(0))
+            end = time.time()
+            outs = model(images, data['mask'].to(device)) if is_detr else model(images)
+            loss = sum(criterion(outs, annots).values())
+            losses.update(float(loss), images.size(0))
+            pred_scores, pred_classes, pred_boxes = decoder(outs, data['scaled_size']) if is_detr else decoder(outs)
+            unscale = np.expand_dims(np.expand_dims(scales, axis=-1), axis=-1)
+            pred_boxes = pred_boxes / unscale
+            if on_gpu:
+                torch.cuda.synchronize()
+            batch_time.update(time.time() - end, images.size(0))
+            annots = annots.cpu().numpy()
+            gt_bboxes, gt_classes = annots[:, :, 0:4] / unscale, annots[:, :, 4]
+            for sc, cl, bx, gb, gc, size in zip(pred_scores, pred_classes, pred_boxes, gt_bboxes, gt_classes, sizes):
+                live = cl > -1
+                sc, cl, bx = sc[live], cl[live], bx[live].copy()
+                bx[:, 0:2] = np.maximum(bx[:, 0:2], 0)
+                bx[:, 2] = np.minimum(bx[:, 2], size[1])
+                bx[:, 3] = np.minimum(bx[:, 3], size[0])
+                preds.append([bx, cl, sc])
+                gts.append([gb[gc > -1], gc[gc > -1]])
+            end = time.time()
+    result_dict = collections.OrderedDict()
+    result_dict['test_loss'] = losses.avg
+    result_dict['per_image_load_time'] = f'{data_time.avg / batch_size * 1000:.3f}ms'
+    result_dict['per_image_inference_time'] = f'{batch_time.avg / batch_size * 1000:.3f}ms'
+    per_class = collections.OrderedDict()
+    for thr in config.eval_voc_iou_threshold_list:
+        aps = collections.OrderedDict()
+        for c in range(config.num_classes):
+            aps[c] = 100 * _voc_class_ap([g[0][g[1] == c] for g in gts], [p[0][p[1] == c] for p in preds],
+                                         [p[2][p[1] == c] for p in preds], thr)
+        result_dict[f'IoU={thr:.2f},area=all,maxDets=100,mAP'] = sum(float(v) for v in aps.values()) / config.num_classes
+        per_class[f'IoU={thr:.2f},area=all,maxDets=100,per_class_ap'] = aps
+    result_dict.update(per_class)
+    return result_dict
+
+
+def evaluate_coco_detection(test_loader, model, criterion, decoder, config):
+    raise RuntimeError("eval_type 'COCO' needs pycocotools (reference tools/scripts.py:742-881), which this image does not provide; "
+                       "use eval_type = 'VOC' (evaluate_voc_detection)")
+
+
+def test_detection(test_loader, model, criterion, decoder, config):
+    """reference :884-897"""
+    assert config.eval_type in ['COCO', 'VOC']
+    if getattr(config, 'use_ema_model', False):
+        model = config.ema_model.ema_model
+    return {'COCO': evaluate_coco_detection, 'VOC': evaluate_voc_detection}[config.eval_type](test_loader, model, criterion, decoder, config)

@@ -5,9 +5,10 @@ launched the same way:
     torchrun --nproc_per_node=N --master_addr 127.0.0.1 --master_port P \\
         -m simpleaicv_pytorch_training_examples_amd.tools.train_detection_model --work-dir ./
 
-One process per GPU; backend "nccl" (= RCCL over xGMI on ROCm).  The COCO / VOC evaluation pass of the
-reference (`test_detection`, decoder + pycocotools) is outside the training hot path and not part of this
-engine: the best model is tracked on the training loss.  Checkpoints: checkpoints/latest.pth = {epoch, time,
+One process per GPU; backend "nccl" (= RCCL over xGMI on ROCm).  The evaluation pass the reference runs at
+`config.eval_epoch` is not wired into this entry script -- its COCO form needs pycocotools, which the image does not
+have; `tools.scripts.test_detection` provides the VOC form (decoders + mAP, pinned to the reference's result dict in
+tests/test_host_logic.py) for callers that want it -- so the best model is tracked on the training loss.  Checkpoints: checkpoints/latest.pth = {epoch, time,
 best_loss, train_loss, lr, model_state_dict (`module.`-prefixed), optimizer_state_dict, scheduler_state_dict}.
 """
 import argparse

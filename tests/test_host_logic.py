@@ -376,3 +376,46 @@ def test_dense_decoder_host_stages_match_the_reference():
         boxes = dec.snap_ltrb_to_x1y1x2y2(regs, np.repeat(table[None], b, axis=0))
         s, c, bx = dec.decode_function(scores, classes, boxes)
         assert np.array_equal(s, ref['scores'].numpy()) and np.array_equal(c, ref['classes'].numpy()) and np.array_equal(bx, ref['boxes'].numpy()), name
+
+
+@pytest.mark.parametrize('variant', ['all_classes', 'class_without_ground_truth'])
+def test_voc_detection_evaluation_matches_the_reference(variant):
+    """tools.scripts.evaluate_voc_detection / test_detection against the result dict the REFERENCE produced from the same stub
+    model / criterion / decoder (oracle/make_golden_voc_eval.py): loss, mAP at ten IoU thresholds, per-class AP -- and the NaN the
+    reference reports when a class has detections but no ground truth."""
+    import math
+    import os
+    import sys
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'oracle'))
+    try:
+        import make_golden_voc_eval as m
+    finally:
+        sys.path.pop(0)
+    fx = torch.load(os.path.join(root, 'tests', 'golden', 'voc_eval.pt'), weights_only=False)[variant]
+    loader, model, criterion, decoder, config = m.stubs(variant == 'class_without_ground_truth')
+    res = scripts.test_detection(loader, model, criterion, decoder, config)
+    assert list(res.keys()) == list(fx.keys())
+    assert abs(res['test_loss'] - fx['test_loss']) < 1e-6
+
+    def same(a, b):
+        return (math.isnan(a) and math.isnan(b)) or abs(a - b) <= 1e-9 * max(1.0, abs(b))
+
+    for k, v in fx.items():
+        if k.endswith('mAP'):
+            assert same(float(res[k]), v), (k, res[k], v)
+        elif k.endswith('per_class_ap'):
+            assert set(res[k].keys()) == set(v.keys())
+            for c, ap in v.items():
+                assert same(float(res[k][c]), ap), (k, c, res[k][c], ap)
+
+
+def test_coco_evaluation_says_what_is_missing():
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts
+
+    class C:
+        eval_type = 'COCO'
+
+    with pytest.raises(RuntimeError, match='pycocotools'):
+        scripts.test_detection([], None, None, None, C())

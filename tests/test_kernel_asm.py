@@ -21,3 +21,25 @@ def test_ticket_register_of_persistent_kernels_is_untouched_between_draw_and_use
     assert len(report) == 32                                  # 4 geometries x fwd / dgrad x pointwise / gather x plain / fused epilogue
     for name, reg, draws, boxes in report:
         assert draws >= 2 and boxes == 1, (name, reg, draws, boxes)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('source', ['elemwise.hip', 'detloss.hip', 'groupnorm.hip'])
+def test_streaming_kernels_of_the_late_additions_keep_their_registers(source, tmp_path):
+    """The HBM-bound kernels added for the convolutional backbones and the dense detectors (csrc/elemwise.hip, detloss.hip,
+    groupnorm.hip) must not spill (no scratch memory) and must leave room for at least four wavefronts per SIMD (<= 128 vector
+    registers): their only way to hide HBM latency is occupancy."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, 'simpleaicv_pytorch_training_examples_amd', 'csrc')
+    out = str(tmp_path / 'k.s')
+    subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-S', '--cuda-device-only',
+                    '-o', out, os.path.join(csrc, source)], check=True, capture_output=True)
+    text = open(out).read()
+    kernels = re.findall(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', text, re.S)
+    assert len(kernels) >= 6, source
+    for name, body in kernels:
+        scratch = int(re.search(r'\.amdhsa_private_segment_fixed_size\s+(\d+)', body).group(1))
+        vgprs = int(re.search(r'\.amdhsa_next_free_vgpr\s+(\d+)', body).group(1))
+        assert scratch == 0, (name, scratch)
+        assert vgprs <= 128, (name, vgprs)
