@@ -419,3 +419,24 @@ def test_coco_evaluation_says_what_is_missing():
 
     with pytest.raises(RuntimeError, match='pycocotools'):
         scripts.test_detection([], None, None, None, C())
+
+
+@pytest.mark.parametrize('case', ['yolo', 'retina'])
+def test_detection_collater_matches_the_reference(case):
+    """DetectionCollater (RetinaNet / FCOS batches) against the batch the REFERENCE collater built from the same samples
+    (oracle/make_golden_collater.py): canvas values and its NHWC-strided NCHW view, padded annotations, scale / size arrays"""
+    import os
+    import sys
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.common import DetectionCollater
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'oracle'))
+    try:
+        import make_golden_collater as m
+    finally:
+        sys.path.pop(0)
+    fx = torch.load(os.path.join(root, 'tests', 'golden', 'detection_collater.pt'), weights_only=True)[case]
+    out = DetectionCollater(**fx['config'])(m.samples())
+    assert set(out) == {'image', 'annots', 'scale', 'size'}
+    assert out['image'].dtype == torch.float32 and tuple(out['image'].stride()) == tuple(fx['image_stride'])
+    assert torch.equal(out['image'], fx['image']) and torch.equal(out['annots'], fx['annots'])
+    assert torch.equal(torch.from_numpy(out['scale']), fx['scale']) and torch.equal(torch.from_numpy(out['size']), fx['size'])
