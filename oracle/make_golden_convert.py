@@ -48,7 +48,17 @@ def reference_rule(key, common, other):
     return None
 
 
+def reference_van_filter_list():
+    """the module-level set literal `filter_list` of the reference's VAN converter (:14-37)"""
+    path = os.path.join(os.path.dirname(REF), 'convert_van_weight_from_pytorch_offical_weight.py')
+    for node in ast.parse(open(path).read()).body:
+        if isinstance(node, ast.Assign) and node.targets[0].id == 'filter_list':
+            return sorted(ast.literal_eval(node.value))
+    raise RuntimeError('filter_list not found')
+
+
 def main():
+    json.dump({'filter_list': reference_van_filter_list()}, open(os.path.join(os.path.dirname(OUT), 'convert_van_filter.json'), 'w'), indent=0)
     common, other = reference_tables()
     out = {}
     for name, blocks, bott in (('resnet18', [2, 2, 2, 2], False), ('resnet50', [3, 4, 6, 3], True)):

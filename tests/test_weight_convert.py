@@ -66,3 +66,58 @@ def test_official_mae_checkpoint_keeps_the_encoder_only():
     official['pos_embed'] = torch.zeros(1, 257, 768)
     kept2, dropped2, uninit2 = convert_official_mae_state_dict(official, model)
     assert 'pos_embed' in dropped2 and 'pos_embed' in uninit2
+
+
+def test_van_converter_skips_what_the_reference_skips():
+    """the skip table must equal the reference converter's `filter_list` (tests/golden/convert_van_filter.json, read from the
+    reference source by oracle/make_golden_convert.py); layer scales and foreign keys stay out; the rest loads"""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.weight_convert import convert_official_van_state_dict
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.weight_convert.convert_van_weight_from_pytorch_offical_weight import SKIPPED_KEYS
+    ref = json.load(open(os.path.join(os.path.dirname(GOLDEN), 'convert_van_filter.json')))['filter_list']
+    assert sorted(SKIPPED_KEYS) == ref
+    model = backbones.__dict__['van_b0'](**{'num_classes': 1000})
+    target = model.state_dict()
+    g = torch.Generator().manual_seed(3)
+    official = {k: (torch.randn(v.shape, generator=g) if v.dtype.is_floating_point else v.clone()) for k, v in target.items()}
+    official['block1.0.layer_scale_1'] = torch.ones(32)                  # [C] in the release, [1, C, 1, 1] here
+    official['norm1.weight'] = torch.ones(32)                            # LayerNorm of the release
+    official['some.new.key'] = torch.zeros(2)
+    kept, foreign, skipped = convert_official_van_state_dict({'state_dict': official}, model)
+    assert foreign == ['some.new.key']
+    assert set(skipped) == {k for k in target if k in SKIPPED_KEYS or 'layer_scale' in k}
+    assert set(kept) == set(target) - set(skipped)
+    before = {k: v.clone() for k, v in target.items()}
+    missing, unexpected = model.load_state_dict(kept, strict=False)
+    # (load_state_dict does not report an absent num_batches_tracked as missing)
+    assert unexpected == [] and set(missing) == {k for k in skipped if not k.endswith('num_batches_tracked')}
+    after = model.state_dict()
+    assert all(torch.equal(after[k], official[k]) for k in kept) and all(torch.equal(after[k], before[k]) for k in skipped)
+
+
+def test_convformer_and_sam_encoder_converters_keep_matching_tensors_only():
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.weight_convert import convert_official_convformer_state_dict
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.weight_convert import convert_official_sam_encoder_state_dict
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.backbones.convformer import MetaFormer
+    model = MetaFormer(embedding_planes=[32, 64, 96, 128], block_nums=[1, 1, 2, 1], num_classes=10)
+    target = model.state_dict()
+    official = {k: torch.full_like(v, 2) for k, v in target.items()}
+    official['head.weight'] = torch.zeros(21841, 128)                     # the 21k classifier of the release
+    official['stages.0.0.res_scale1.scale'] = torch.ones(32)              # a parameter this ConvFormer does not have
+    kept, foreign, reshaped = convert_official_convformer_state_dict(official, model)
+    assert foreign == ['stages.0.0.res_scale1.scale'] and reshaped == ['head.weight']
+    assert set(kept) == set(target) - {'head.weight'}
+    model.load_state_dict(kept, strict=False)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.image_encoder = torch.nn.Linear(4, 3)
+            self.mask_decoder = torch.nn.Linear(3, 2)
+
+    sam = Tiny()
+    official = {'image_encoder.weight': torch.ones(3, 4), 'image_encoder.bias': torch.ones(5), 'image_encoder.neck.0.weight': torch.ones(1),
+                'mask_decoder.weight': torch.ones(2, 3)}
+    kept, foreign, reshaped = convert_official_sam_encoder_state_dict(official, sam)
+    assert list(kept) == ['weight'] and foreign == ['image_encoder.neck.0.weight'] and reshaped == ['image_encoder.bias']
+    sam.image_encoder.load_state_dict(kept, strict=False)
+    assert torch.equal(sam.image_encoder.weight, torch.ones(3, 4))
