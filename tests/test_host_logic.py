@@ -146,7 +146,7 @@ def test_mixup_cutmix_collater_matches_reference_fixture():
 
 
 def test_benchmark_configs_import_like_reference_configs_and_collate():
-    """The five benchmark copies of the reference train_config.py files import through the `SimpleAICV` /
+    """The seven benchmark copies of the reference train_config.py files import through the `SimpleAICV` /
     `tools` aliases exactly as the reference spells them, build their model on the CPU, and their dataset + collater
     produce the loader contract of each loop."""
     import importlib.util
@@ -159,6 +159,10 @@ def test_benchmark_configs_import_like_reference_configs_and_collate():
             ('vit_base_patch16', {'image': (2, 3, 224, 224), 'label': (2, 1000)}),
         '03.detection_training/coco/res50_detr_yoloresize1024':
             ('resnet50_detr', {'image': (2, 3, 1024, 1024), 'mask': (2, 1024, 1024), 'scaled_annots': (2, 100, 5)}),
+        '03.detection_training/coco/res50_retinanet_yoloresize1024':
+            ('resnet50_retinanet', {'image': (2, 3, 1024, 1024), 'annots': (2, 100, 5)}),
+        '03.detection_training/coco/res50_fcos_yoloresize1024':
+            ('resnet50_fcos', {'image': (2, 3, 1024, 1024), 'annots': (2, 100, 5)}),
         '13.interactive_segmentation_training/13.1.sam_segmentation_training/sam_b_training':
             ('sam_b', {'image': (2, 3, 1024, 1024), 'mask': (2, 1, 1024, 1024), 'prompt_point': (2, 1, 3), 'prompt_box': (2, 4),
                        'prompt_mask': (2, 1, 256, 256)}),
