@@ -1091,7 +1091,14 @@ class BatchNorm2dFn(torch.autograd.Function):
         if training:
             ctx.save_for_backward(x, gamma, mean, invstd)
         else:
-            ctx.save_for_backward(None, None, None, scale)
+            # frozen statistics: dx needs only scale; the affine parameters still get gradients (torch does the same in eval mode):
+            # dgamma = sum dz * (x - running_mean) * rsqrt(running_var + eps), dbeta = sum dz -- keep x only when one is asked for
+            need_affine = bool(gamma.requires_grad or (beta is not None and beta.requires_grad))
+            if need_affine:
+                rinv = torch.rsqrt(bn.running_var.detach().float() + float(bn.eps))
+                ctx.save_for_backward(x, bn.running_mean.detach().float().clone(), rinv, scale)
+            else:
+                ctx.save_for_backward(None, None, None, scale)
         ctx.training = training
         return z
 
@@ -1103,11 +1110,23 @@ class BatchNorm2dFn(torch.autograd.Function):
         n, c, h, w = dz.shape
         M = n * h * w
         if not ctx.training:
-            # frozen statistics: dx = scale * dz
+            # frozen statistics: dx = scale * dz (invstd holds scale here); with x saved also the affine gradients
             dt = dz.dtype
             dx = torch.empty_like(dz)
-            check(L.saicv_channel_scale_add_bwd(dtype_code(dt), ptr(dz), 0, ptr(invstd), ptr(dx), 0, M, c, st), 'bn_eval_bwd')
-            return dx, None, None, None
+            if x is None:
+                check(L.saicv_channel_scale_add_bwd(dtype_code(dt), ptr(dz), 0, ptr(invstd), ptr(dx), 0, M, c, st), 'bn_eval_bwd')
+                return dx, None, None, None
+            rmean, rinv, scale = gamma, mean, invstd            # the eval-mode save order: (x, running_mean, rsqrt(var + eps), scale)
+            if dz.dtype != x.dtype:
+                dz = dz.to(x.dtype)
+                dx = torch.empty_like(dz)
+            sums = torch.zeros((3, c), dtype=torch.float32, device=dz.device)      # sum dz | sum dz^2 (unused) | sum dz * x
+            check(L.saicv_bn_stats(dtype_code(dz.dtype), ptr(dz), M, c, ptr(sums[0]), ptr(sums[1]), st), 'bn_eval_bwd_sum')
+            check(L.saicv_channel_scale_add_bwd(dtype_code(dz.dtype), ptr(dz), ptr(x), ptr(scale), ptr(dx), ptr(sums[2]), M, c, st),
+                  'bn_eval_bwd')
+            dbeta = sums[0]
+            dgamma = rinv * (sums[2] - rmean * dbeta)
+            return dx, dgamma, dbeta.clone(), None
         dt = x.dtype
         if dz.dtype != dt:
             dz = dz.to(dt)

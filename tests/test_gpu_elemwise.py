@@ -130,13 +130,25 @@ def test_batchnorm_on_a_block_input(shape, dt):
     xr = x.clone().requires_grad_(True)
     ref = ref_bn(xr)
     dz = r(torch.randn(shape, generator=g))
+    ref_bn.zero_grad()
     ref.backward(dz)
     xd = _dev(x, dt).requires_grad_(True)
+    bn.zero_grad()
     z = ops.batch_norm2d(xd, bn)
     z.backward(_dev(dz, dt))
     assert int(bn.num_batches_tracked) == 2
     assert rel_err(z.float().cpu(), ref.detach()) < (1e-4 if f32 else 1e-2)
     assert rel_err(xd.grad.float().cpu(), xr.grad) < (1e-4 if f32 else 1e-2)
+    # frozen statistics still train the affine parameters (torch: dgamma = sum dz * xhat, dbeta = sum dz in eval mode too)
+    assert bn.weight.grad is not None and bn.bias.grad is not None
+    assert rel_err(bn.weight.grad.cpu(), ref_bn.weight.grad) < (2e-4 if f32 else 2e-2)
+    assert rel_err(bn.bias.grad.cpu(), ref_bn.bias.grad) < (1e-4 if f32 else 2e-2)
+    # ... and a frozen layer (requires_grad off) keeps the cheap path: input gradient only
+    for q in bn.parameters():
+        q.requires_grad_(False)
+    xd2 = _dev(x, dt).requires_grad_(True)
+    ops.batch_norm2d(xd2, bn).backward(_dev(dz, dt))
+    assert rel_err(xd2.grad.float().cpu(), xr.grad) < (1e-4 if f32 else 1e-2)
 
 
 @pytest.mark.parametrize('dt', DTYPES, ids=IDS)
