@@ -56,7 +56,16 @@ LOOP_MODELS = {'resnet50_detr_config': ('tools.scripts.train_detection', 8, 1024
                'resnet50_fcos': ('tools.scripts.train_detection', 4, 1024, 0.0),
                # full SAM step: one encoder pass (972.1 GFLOP fwd) + 1 + decoder_iters light decoder passes
                'sam_b': ('tools.interactive_segmentation_scripts.train_sam_segmentation', 8, 1024, 3 * 972.1)}
-PMC_FILE = 'profiles/r03_pmc_hbm_traffic.json'
+# HBM bytes per launch per kernel family, from separate rocprofv3 --pmc passes of the same command (scripts/gpu_pmc_r04.sh)
+PMC_FILES = {'resnet50': ['profiles/r04_pmc_hbm_traffic.json', 'profiles/r03_pmc_hbm_traffic.json', 'profiles/r02_pmc_hbm_traffic.json'],
+             'vit_base_patch16': ['profiles/r04_pmc_hbm_traffic_vit_base_patch16.json']}
+# what each bracketed family is in the rocprofv3 kernel lists
+FAMILY_KERNELS = {'igemm_nt': 'igemm_nt1_kernel (implicit-GEMM conv / linear: forward + data gradient)',
+                  'igemm_tn': 'igemm_tn_dma_kernel (weight gradient)',
+                  'bn_act_fwd': 'bn_act_fwd_kernel (BatchNorm apply + residual + ReLU)',
+                  'bn_act_bwd': 'bn_bwd_apply_kernel (+ bn_bwd_reduce_kernel where the reduction is not fused into the data gradient)',
+                  'layernorm_fwd': 'layernorm_fwd_kernel', 'layernorm_bwd': 'layernorm_bwd_kernel (+ colreduce)',
+                  'attention_fwd': 'sa_fwd_kernel / attention_fwd_kernel', 'attention_bwd': 'attention_bwd_kernel / sa_bwd_dq + sa_bwd_dkv'}
 
 
 def parse():
@@ -75,8 +84,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
-    ap.add_argument('--kernel-breakdown', action='store_true',
-                    help='bracket every kernel family with HIP events in the eager pricing pass (default: only the dominant kernel)')
+    ap.add_argument('--kernel-breakdown', action='store_true', help='(default since r04; kept for old command lines)')
+    ap.add_argument('--dominant-only', action='store_true',
+                    help='bracket only the dominant kernel with HIP events in the eager pricing pass (default: every instrumented family)')
+    ap.add_argument('--no-sam', action='store_true', help='skip the sam_b_encoder object of the default line')
     return ap.parse_args()
 
 
@@ -366,7 +377,7 @@ def measure(name, args, world, rank, device, use_graph, primary):
     # ---- price the dominant kernel: an eager pass of the same steps with HIP events on the launch stream
     if not args.no_kernel_timer:
         cfg_graph = name in CONFIG_DIR and name not in LOOP_MODELS and use_graph
-        ops.KernelTimer.only = None if args.kernel_breakdown else {'igemm_nt'}
+        ops.KernelTimer.only = {'igemm_nt'} if args.dominant_only else None
         ops.KernelTimer.records = []
         k = min(args.steps, 5)
         if cfg_graph:
@@ -383,11 +394,11 @@ def measure(name, args, world, rank, device, use_graph, primary):
         if 'igemm_nt' in summ:
             kk = summ['igemm_nt']
             achieved = kk['flops'] / (kk['ms'] * 1e-3) / 1e12
-            traffic = pmc_traffic('igemm_nt') if name == 'resnet50' else None
+            traffic, traffic_file = pmc_traffic(name, 'igemm_nt')
             res['roofline'] = {'kernel': 'igemm_nt_kernel (implicit-GEMM conv / linear, fwd + dgrad)', 'bound': 'mfma',
                                'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                               'traffic_source': (f'{PMC_FILE} (separate rocprofv3 --pmc passes of this command, not this run)'
+                               'traffic_source': (f'{traffic_file} (separate rocprofv3 --pmc passes of this command, not this run)'
                                                   if traffic is not None else None),
                                'launches': kk['calls'], 'avg_launch_us': round(kk['ms'] * 1e3 / kk['calls'], 2),
                                # what the SHAPES allow: sum over the launches of max(flops / MFMA peak, algorithmic bytes /
@@ -398,11 +409,28 @@ def measure(name, args, world, rank, device, use_graph, primary):
                                                'algorithmic_GB': round(kk['bytes'] / k / 1e9, 2)},
                                'measured_in': f'{k} eager steps after the timed windows (HIP events on the launch stream; '
                                               'events cannot bracket kernels inside a replayed hipGraph)'}
-            res['kernel_breakdown_ms_per_step'] = {t: round(v['ms'] / k, 3) for t, v in summ.items()}
-            for t, v in summ.items():
+            top = sorted(summ.items(), key=lambda tv: -tv[1]['ms'])
+            res['kernel_breakdown_ms_per_step'] = {t: round(v['ms'] / k, 3) for t, v in top}
+            res['kernel_breakdown_note'] = ('HIP events around every launch of the instrumented families in the eager pricing pass '
+                                            '(they cover the GEMM, normalisation and attention kernels; pooling, loss, optimizer and '
+                                            'tensor glue are the rest of ms_per_step)')
+            for t, v in top:
+                if t == 'igemm_nt':
+                    continue            # priced against the MFMA peak in `roofline` (its bytes are in roofline.shape_bound)
+                fam = {'kernel': FAMILY_KERNELS.get(t, t), 'ms_per_step': round(v['ms'] / k, 3), 'launches_per_step': round(v['calls'] / k, 1)}
                 if v['bytes'] > 0:
-                    res.setdefault('hbm_kernels', {})[t] = {'GB/s': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
-                                                            'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 8e12, 4)}
+                    # memory-bound families: algorithmic bytes (tensors read + written once) / measured time against HBM3E
+                    fam.update({'bound': 'hbm', 'algorithmic_GB_per_step': round(v['bytes'] / k / 1e9, 2),
+                                'GB/s': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
+                                'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 8e12, 4)})
+                    pm, _ = pmc_traffic(name, {'bn_act_bwd': 'bn_bwd_apply'}.get(t, t.replace('_fwd', '').replace('_bwd', '') if t.startswith('layernorm') else t))
+                    if pm is not None:
+                        fam['pmc_bytes_per_launch'] = pm
+                    res.setdefault('hbm_kernels', {})[t] = fam
+                elif v['flops'] > 0:
+                    fam.update({'bound': 'mfma', 'TFLOP/s': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
+                                'frac_of_mfma_peak': round(v['flops'] / (v['ms'] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)})
+                    res.setdefault('mfma_kernels', {})[t] = fam
     return res
 
 
@@ -447,16 +475,16 @@ def _set_graph(name, on):
         cfg.use_step_graph = on
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
-    same command, corrected as MI355X_MICROARCH.md prescribes); None when the summary is absent.  Counters cannot be
-    collected inside the timed run itself."""
-    for f in (PMC_FILE, 'profiles/r02_pmc_hbm_traffic.json', 'profiles/r01e_pmc_hbm_traffic.json'):
+def pmc_traffic(model, kernel):
+    """(HBM bytes per launch of `kernel` in `model`'s step, file) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes); (None, None) when no summary holds it.
+    Counters cannot be collected inside the timed run itself."""
+    for f in PMC_FILES.get(model, []):
         try:
-            return json.load(open(os.path.join(ROOT, f)))['kernels'][kernel]['bytes_per_launch']
+            return json.load(open(os.path.join(ROOT, f)))['kernels'][kernel]['bytes_per_launch'], f
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -609,6 +637,26 @@ def worker(args):
         secondary = guarded('vit_base_patch16', False)
         if watchdog is not None:
             watchdog.set()
+    sam = None
+    if args.model == 'resnet50' and not args.no_secondary and not args.no_sam and world == 1:
+        # BASELINE.json configs[4] on the driver line: SAM ViT-B image encoder, 3 x 1024 x 1024, the reference's per-GPU batch of
+        # 20 (sam_b_training/train_config.py:221), ONE timed window of 5 steps (~0.6 s) + the kernel pricing pass
+        import argparse as _ap
+        import gc
+        for cfg in _CONFIGS.values():           # drop the captured step graphs (and their memory pools) of the two classification runs
+            for attr in ('_saicv_step_graphs', 'model', 'ema_model'):
+                if hasattr(cfg, attr):
+                    setattr(cfg, attr, None)
+        _CONFIGS.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+        a2 = _ap.Namespace(**vars(args))
+        a2.batch, a2.steps, a2.warmup, a2.max_windows, a2.min_gpu_seconds = 20, 5, 2, 1, 0.0
+        try:
+            sam = measure('sam_b_encoder', a2, world, rank, device, False, False)
+            sam['steps'], sam['warmup'] = a2.steps, a2.warmup
+        except Exception as e:      # noqa: BLE001 -- the headline must not die with the third object
+            sam = {'error': f'{type(e).__name__}: {e}'}
 
     if rank == 0:
         out = {'metric': 'training images/sec/node', 'value': primary['value'], 'unit': 'images/s', 'n_gpus': world,
@@ -619,6 +667,8 @@ def worker(args):
                          'barrier + synchronize (max over ranks)')
         if secondary is not None:
             out['secondary'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **secondary}
+        if sam is not None:
+            out['sam_b_encoder'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **sam}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model)
         line = json.dumps(out)

@@ -1,0 +1,87 @@
+"""Round-4 fixtures, produced by RUNNING THE REFERENCE (imported from /root/reference).  TEST INFRASTRUCTURE.
+
+Build container only:   python oracle/make_golden_r04.py [names...]
+
+convbnact_variants        reference classification ConvBnActBlock (resnet.py:19-48) in the forms round 3 refused:
+                          has_bn=False (biased convolution, with and without ReLU) and a depthwise block (groups == channels,
+                          BatchNorm + ReLU): state_dict, output, input / parameter gradients, BatchNorm buffers after the step.
+sam_block_relpos_resized  reference segment_anything Block (image_encoder.py:201-239) whose relative-position tables were built
+                          for an 8 x 8 grid, run on a 16 x 16 grid: get_rel_pos interpolates the 15-row tables to 31 rows
+                          (image_encoder.py:96-103) -- the path ops_tfm.resize_rel_pos restates; output, input gradient and
+                          every parameter gradient (incl. the two tables, whose gradient flows back through the interpolation).
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+
+
+def convbnact_variants(name='convbnact_variants'):
+    from SimpleAICV.classification.backbones.resnet import ConvBnActBlock
+    cases = {}
+    specs = [('bias_relu_3x3', dict(inplanes=16, planes=32, kernel_size=3, stride=1, padding=1, groups=1, has_bn=False, has_act=True), 16),
+             ('bias_only_1x1_s2', dict(inplanes=32, planes=24, kernel_size=1, stride=2, padding=0, groups=1, has_bn=False, has_act=False), 32),
+             ('depthwise_bn_relu', dict(inplanes=32, planes=32, kernel_size=3, stride=1, padding=1, groups=32, has_bn=True, has_act=True), 32)]
+    for i, (key, kw, cin) in enumerate(specs):
+        torch.manual_seed(10 + i)
+        blk = ConvBnActBlock(**kw).train()
+        with torch.no_grad():                    # non-trivial biases / affine parameters (the defaults are 0 / 1)
+            for n, p in blk.named_parameters():
+                if p.dim() == 1:
+                    p.copy_(torch.randn_like(p) * 0.3 + (1.0 if n == 'layer.1.weight' else 0.0))
+        g = torch.Generator().manual_seed(100 + i)
+        x = torch.randn(4, cin, 12, 12, generator=g, requires_grad=True)
+        sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+        out = blk(x)
+        probe = torch.randn(out.shape, generator=g)
+        (out * probe).sum().backward()
+        cases[key] = {'kwargs': kw, 'state_dict': sd, 'x': x.detach().clone(), 'probe': probe, 'out': out.detach().clone(),
+                      'dx': x.grad.clone(), 'grads': {n: p.grad.clone() for n, p in blk.named_parameters()},
+                      'buffers_after': {n: b.detach().clone() for n, b in blk.named_buffers()}}
+        print(key, [(n, tuple(p.shape)) for n, p in blk.named_parameters()], float(out.norm()))
+    path = os.path.join(OUT, name + '.pt')
+    torch.save({'name': name, 'cases': cases, 'torch_version': torch.__version__}, path)
+    print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
+def sam_block_relpos_resized(name='sam_block_relpos_resized'):
+    from oracle.torch_oracle import sam_randomize_zero_init
+    from SimpleAICV.interactive_segmentation.models.segment_anything.image_encoder import Block
+    torch.manual_seed(3)
+    blk = Block(inplanes=128, head_nums=2, mlp_ratio=4.0, input_size=(8, 8), window_size=0).train()
+    sam_randomize_zero_init(blk.named_parameters(), 103)         # the tables are zero-initialised in the reference
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 16, 16, 128, generator=g, requires_grad=True)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    assert sd['attn.rel_pos_h'].shape[0] == 15
+    out = blk(x)
+    probe = torch.randn(out.shape, generator=g)
+    (out * probe).sum().backward()
+    fx = {'name': name, 'state_dict': sd, 'x': x.detach().clone(), 'probe': probe, 'out': out.detach().clone(), 'dx': x.grad.clone(),
+          'grads': {n: p.grad.clone() for n, p in blk.named_parameters()}, 'torch_version': torch.__version__}
+    path = os.path.join(OUT, name + '.pt')
+    torch.save(fx, path)
+    print(f'{name}: out norm {float(out.norm()):.4f}, d rel_pos_h norm {float(fx["grads"]["attn.rel_pos_h"].norm()):.4e} -> {path} '
+          f'({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit(f'{REF} not present: golden fixtures can only be (re)generated in the build container')
+    sys.path.insert(0, REF)
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    if not only or 'convbnact_variants' in only:
+        convbnact_variants()
+    if not only or 'sam_block_relpos_resized' in only:
+        sam_block_relpos_resized()
+
+
+if __name__ == '__main__':
+    main()

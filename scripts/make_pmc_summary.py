@@ -9,8 +9,8 @@ import csv
 import json
 import sys
 
-FAMILIES = ['igemm_nt', 'igemm_tn', 'bn_bwd_apply', 'bn_bwd_reduce', 'bn_act_fwd', 'maxpool', 'sgd_flat', 'layernorm',
-            'attention', 'sa_fwd', 'sa_bwd']
+FAMILIES = ['igemm_nt', 'igemm_tn', 'bn_bwd_apply', 'bn_bwd_reduce', 'bn_act_fwd', 'maxpool', 'sgd_flat', 'adamw_flat', 'layernorm_fwd',
+            'layernorm_bwd', 'attention_bwd', 'attention_fwd', 'sa_fwd', 'sa_bwd', 'row_scale', 'pack_weight']
 
 
 def family(name):
@@ -22,6 +22,7 @@ def family(name):
 
 def main():
     d, steps, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    model = sys.argv[4] if len(sys.argv) > 4 else 'resnet50'
     agg = collections.defaultdict(lambda: {'launches': 0, 'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         seen = collections.Counter()
@@ -36,7 +37,7 @@ def main():
         for k, n in seen.items():
             agg[k]['launches'] = max(agg[k]['launches'], n)
     out = {'_doc': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over '
-                   '`python bench.py --steps 2 --warmup 1` (ResNet-50 b256 bf16); counters are KiB; FETCH_SIZE doubled per '
+                   f'`python bench.py --model {model} --steps 2 --warmup 1 --eager` (b256 bf16); counters are KiB; FETCH_SIZE doubled per '
                    'MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); WRITE_SIZE uncorrected',
            'steps_profiled': steps, 'kernels': {}}
     for k, v in sorted(agg.items()):

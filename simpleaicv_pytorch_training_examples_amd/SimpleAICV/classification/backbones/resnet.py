@@ -30,31 +30,48 @@ __all__ = [
 
 
 class ConvBnActBlock(nn.Module):
+    """Conv2d -> BatchNorm2d -> ReLU with the reference's switches (resnet.py:19-48): `has_bn=False` makes the convolution
+    biased and drops the normalisation (conv + bias epilogue, then one ReLU pass); `groups == inplanes == planes` is a
+    depthwise convolution (csrc/dwconv.hip).  Other group counts are not built."""
 
     def __init__(self, inplanes, planes, kernel_size, stride, padding, groups=1, has_bn=True, has_act=True):
         super(ConvBnActBlock, self).__init__()
-        if groups != 1:
-            raise NotImplementedError('grouped convolution is outside the ResNet/ViT/DETR/SAM hot path')
-        if not has_bn:
-            raise NotImplementedError('ConvBnActBlock(has_bn=False) is not on the hot path')
+        self.depthwise = groups != 1 and groups == inplanes and groups == planes
+        if groups != 1 and not self.depthwise:
+            raise NotImplementedError(f'ConvBnActBlock(groups={groups}) with {inplanes} -> {planes} channels: only dense '
+                                      '(groups=1) and depthwise (groups == inplanes == planes) convolutions have kernels')
         # nn.Conv2d / nn.BatchNorm2d are used as parameter containers only (state_dict keys
-        # layer.0.weight, layer.1.{weight,bias,running_mean,running_var,num_batches_tracked}).
+        # layer.0.weight[, layer.0.bias], layer.1.{weight,bias,running_mean,running_var,num_batches_tracked}).
         self.layer = nn.Sequential(
-            nn.Conv2d(inplanes, planes, kernel_size, stride=stride, padding=padding, groups=groups, bias=False),
-            nn.BatchNorm2d(planes),
+            nn.Conv2d(inplanes, planes, kernel_size, stride=stride, padding=padding, groups=groups, bias=not has_bn),
+            nn.BatchNorm2d(planes) if has_bn else nn.Sequential(),
             nn.ReLU(inplace=True) if has_act else nn.Sequential(),
         )
         self.stride = stride
         self.padding = padding
+        self.has_bn = has_bn
         self.has_act = has_act
 
     def forward(self, x, residual=None, act=None, want_skip=False):
         """`residual` / `act` let the enclosing residual block fuse its add + ReLU in here; `want_skip` also
         returns the input as an alias the block uses for its shortcut, so that the shortcut's gradient is
         added inside this conv's dgrad epilogue (no separate gradient-sum kernel)."""
-        conv, bn = self.layer[0], self.layer[1]
+        conv = self.layer[0]
         relu = self.has_act if act is None else act
-        return ops.conv_bn_act(x, conv.weight, bn, self.stride, self.padding, relu, residual, want_skip)
+        if self.has_bn and not self.depthwise:
+            return ops.conv_bn_act(x, conv.weight, self.layer[1], self.stride, self.padding, relu, residual, want_skip)
+        # the unfused forms: [depthwise] convolution (+ bias) -> [BatchNorm] -> [+ residual] -> [ReLU], one kernel each
+        if self.depthwise:
+            y = ops.depthwise_conv2d(x, conv.weight, conv.bias, self.stride, self.padding)
+        else:
+            y = ops.conv2d(x, conv.weight, conv.bias, self.stride, self.padding)
+        if self.has_bn:
+            y = ops.batch_norm2d(y, self.layer[1])
+        if residual is not None:
+            y = ops.scale_add(residual, y)
+        if relu:
+            y = ops.act(y, 'relu')
+        return (y, x) if want_skip else y
 
 
 class BasicBlock(nn.Module):

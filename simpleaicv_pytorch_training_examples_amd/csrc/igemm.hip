@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
                     if (mrow0 + (g + j) * RPP < Mc) st_chunk(o + (g + j) * ostep, v[j]);
             }
         }
-    } else if (aligned && !remap && p.act_mode == 0 && (p.Nn % OEPC) == 0) {   // uniform
+    } else if (aligned && !remap && (p.act_mode == 0 || p.act_mode == 4) && (p.Nn % OEPC) == 0) {   // uniform
         // residual add / drop-path scale (forward and data gradient) and the data gradient's gated shortcut and
         // BatchNorm-backward sums, on dense rows of whole chunks: four rows at a time, every global load of the group
         // (addend, y, the two mask bytes) in flight before the first use
@@ -1390,6 +1390,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
             const int mrow0 = tile_m * BM_T + orow0;
             const char* ls = smem + orow0 * OPITCH + oc * 16;
             const bool addp = p.addend != nullptr, scalep = p.row_scale != nullptr;
+            const bool mulp = p.act_mode == 4;          // out = (acc + bias) * addend: the stored gelu'() of an MLP (grouped loads instead of the rolled loop)
             const bool gatep = DGRAD_EXTRAS && p.addend_gate != nullptr, maskp = DGRAD_EXTRAS && p.bs_mask != nullptr;
             const TO* const addend = reinterpret_cast<const TO*>(p.addend);
             const TO* const ybn = reinterpret_cast<const TO*>(p.bs_y);
@@ -1426,8 +1427,13 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
                         if (addp || scalep) {
                             float a[OEPC];
                             Chunk<TO>::unpack(av[j], a);
+                            if (mulp) {
 #pragma unroll
-                            for (int e = 0; e < OEPC; ++e) f[e] = fmaf(sc[j], f[e], ((gb[j] >> e) & 1u) ? a[e] : 0.f);
+                                for (int e = 0; e < OEPC; ++e) f[e] *= a[e];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < OEPC; ++e) f[e] = fmaf(sc[j], f[e], ((gb[j] >> e) & 1u) ? a[e] : 0.f);
+                            }
                             v[j] = Chunk<TO>::pack(f);
                             if (bstats) Chunk<TO>::unpack(v[j], f);      // the sums are over what is stored
                         }

@@ -235,7 +235,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 #pragma unroll
         for (int k = 0; k < E; ++k) acc[k] = 0.f;
         if (active) {
-            for (int r = r0 + ty; r < r1; r += rpp) {
+            // four independent 16-byte loads in flight per thread (one at a time left the 77 MB bias-gradient pass of the ViT patch
+            // embedding latency-bound: 207 us against 15 us of HBM time)
+            int r = r0 + ty;
+            for (; r + 3 * rpp < r1; r += 4 * rpp) {
+                u32x4 c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c[u] = ld_chunk(x + (size_t)(r + u * rpp) * N + cb * E);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v[E];
+                    Chunk<T>::unpack(c[u], v);
+#pragma unroll
+                    for (int k = 0; k < E; ++k) acc[k] += v[k];
+                }
+            }
+            for (; r < r1; r += rpp) {
                 float v[E];
                 Chunk<T>::unpack(ld_chunk(x + (size_t)r * N + cb * E), v);
 #pragma unroll
@@ -376,7 +391,7 @@ int colsum(int dtype, const void* x, int M, int N, float* out, hipStream_t st) {
     const int cpr = N / e;
     const int rpp = cpr >= 256 ? 1 : 256 / cpr;
     int slabs = M / (rpp * 8);                 // >= 8 passes per slab
-    if (slabs > 1024) slabs = 1024;
+    if (slabs > 2048) slabs = 2048;
     if (slabs < 1) slabs = 1;
     const int rows_per = (M + slabs - 1) / slabs;
     slabs = (M + rows_per - 1) / rows_per;

@@ -153,8 +153,10 @@ def ln_fwd(x2, weight, bias, eps):
     y = torch.empty_like(x2)
     mean = torch.empty(m, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(m, dtype=torch.float32, device=x2.device)
+    t0 = KernelTimer.begin('layernorm_fwd')
     check(lib().saicv_layernorm_fwd(dtype_code(x2.dtype), ptr(x2), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd),
                                     m, c, float(eps), stream()), 'layernorm_fwd')
+    KernelTimer.end(t0, 'layernorm_fwd', 0, 2.0 * m * c * x2.element_size() + 8.0 * m)      # x read, y written, mean / rstd
     return y, mean, rstd
 
 
@@ -171,8 +173,11 @@ def ln_bwd(dy, x2, weight, bias, mean, rstd, addend=None):
     dy = dy.contiguous()
     if dy.dtype != x2.dtype:
         dy = dy.to(x2.dtype)
+    t0 = KernelTimer.begin('layernorm_bwd')
     check(L.saicv_layernorm_bwd(dtype_code(x2.dtype), ptr(dy), ptr(x2), ptr(weight), ptr(mean), ptr(rstd), ptr(addend),
                                 ptr(dx), ptr(dg), ptr(db), ptr(ws), m, c, int(direct), stream()), 'layernorm_bwd')
+    # dy, x (and the residual-stream addend) read, dx written; the partial dgamma / dbeta rows are noise next to them
+    KernelTimer.end(t0, 'layernorm_bwd', 0, (3.0 + (1.0 if addend is not None else 0.0)) * m * c * x2.element_size() + 8.0 * m)
     if direct:
         return dx, None, None
     return dx, dg, db
@@ -201,8 +206,10 @@ def attn_fwd(qkv, b, n, heads, scale):
         return out.view(b * n, c), lse.view(b, heads, n)
     out = torch.empty((b * n, c), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((b, heads, n), dtype=torch.float32, device=qkv.device)
+    t0 = KernelTimer.begin('attention_fwd')
     check(lib().saicv_attention_fwd(dtype_code(qkv.dtype), ptr(qkv), ptr(out), ptr(lse), b, n, heads, c // heads,
                                     float(scale), stream()), 'attention_fwd')
+    KernelTimer.end(t0, 'attention_fwd', 4.0 * b * heads * n * n * (c // heads), 0)
     return out, lse
 
 
@@ -215,8 +222,10 @@ def attn_bwd(qkv, out, dout, lse, b, n, heads, scale):
         sattn_bwd(q3[:, :, :c], q3[:, :, c:2 * c], q3[:, :, 2 * c:], out.view(b, n, c), dout.contiguous().view(b, n, c),
                   lse.view(b * heads, n), heads, scale, g3[:, :, :c], g3[:, :, c:2 * c], g3[:, :, 2 * c:])
         return dqkv
+    t0 = KernelTimer.begin('attention_bwd')
     check(lib().saicv_attention_bwd(dtype_code(qkv.dtype), ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), b, n,
                                     heads, c // heads, float(scale), stream()), 'attention_bwd')
+    KernelTimer.end(t0, 'attention_bwd', 10.0 * b * heads * n * n * (c // heads), 0)        # five N x N x D products
     return dqkv
 
 
@@ -254,7 +263,9 @@ def sattn_fwd(q, k, v, heads, scale, key_bias=None, rel_h=None, rel_w=None, drop
     out = torch.empty((d.B, d.Nq, q.shape[2]), dtype=q.dtype, device=q.device)
     lse = torch.empty((d.B * heads, d.Nq), dtype=torch.float32, device=q.device)
     d.out, d.o_bs, d.o_rs, d.lse = ptr(out), out.stride(0), out.stride(1), ptr(lse)
+    t0 = KernelTimer.begin('attention_fwd')
     check(lib().saicv_attention_stream_fwd(dtype_code(q.dtype), hd, d, stream()), 'attention_stream_fwd')
+    KernelTimer.end(t0, 'attention_fwd', 4.0 * d.B * heads * d.Nq * d.Nk * hd, 0)
     return out, lse
 
 
@@ -275,7 +286,9 @@ def sattn_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv, key_bias=None, 
     if rel_h is not None:
         drh, drw = torch.empty_like(rel_h), torch.empty_like(rel_w)
         d.d_rel_h, d.d_rel_w = ptr(drh), ptr(drw)
+    t0 = KernelTimer.begin('attention_bwd')
     check(lib().saicv_attention_stream_bwd(dtype_code(q.dtype), hd, d, stream()), 'attention_stream_bwd')
+    KernelTimer.end(t0, 'attention_bwd', 10.0 * d.B * heads * d.Nq * d.Nk * hd, 0)
     return drh, drw
 
 
@@ -563,8 +576,8 @@ def window_unpartition(win, ws, pad_hw, hw, addend=None):
 
 def _rel_tables_ok(sh, sw, rel_pos_h, rel_pos_w):
     if rel_pos_h.shape[0] != 2 * sh - 1 or rel_pos_w.shape[0] != 2 * sw - 1:
-        raise NotImplementedError(f'relative-position tables of length {rel_pos_h.shape[0]} / {rel_pos_w.shape[0]} for a '
-                                  f'{sh} x {sw} grid: interpolated tables (get_rel_pos, image_encoder.py:96-103) are not supported')
+        raise ValueError(f'relative-position tables of length {rel_pos_h.shape[0]} / {rel_pos_w.shape[0]} for a {sh} x {sw} grid: '
+                         'resample them first (ops_tfm.resize_rel_pos; sam_attn_sublayer does)')
     if rel_pos_h.shape[1] != 64 or not (rel_pos_h.is_contiguous() and rel_pos_w.is_contiguous()):
         raise NotImplementedError('relative-position tables must be contiguous [2S-1, 64] fp32')
 
@@ -662,9 +675,43 @@ class SamAttnSubLayerFn(torch.autograd.Function):
         return dx.view(b, hh, ww, c), dlw, dlb, dqw, dqb, dpw, dpb, g_rh, g_rw, None, None, None
 
 
+_REL_RESIZE = {}
+
+
+def resize_rel_pos(table, length):
+    """A relative-position table [L, C] resampled to [length, C]: the 1-D linear interpolation (half-pixel centres, edge clamp)
+    that get_rel_pos applies when a checkpoint's table was trained on another grid (reference segment_anything/
+    image_encoder.py:96-103, F.interpolate(mode='linear')).  Written as table' = A . table with the constant [length, L]
+    two-diagonal interpolation matrix A: a 127 x 27 x 64 product is tensor glue, and autograd's matmul backward (A^T . d table')
+    carries the gradient back to the parameter -- the kernels downstream see an ordinary [2S-1, 64] fp32 table."""
+    src_len = table.shape[0]
+    if src_len == length:
+        return table
+    key = (src_len, length, table.device)
+    a = _REL_RESIZE.get(key)
+    if a is None:
+        # fp32 like ATen's upsample_linear1d (scale = L / length as a float, index = scale * (i + 0.5) - 0.5)
+        scale = torch.tensor(src_len, dtype=torch.float32) / torch.tensor(length, dtype=torch.float32)
+        pos = (scale * (torch.arange(length, dtype=torch.float32) + 0.5) - 0.5).clamp_(min=0.0)
+        lo = pos.floor().long().clamp_(max=src_len - 1)
+        hi = (lo + 1).clamp_(max=src_len - 1)
+        frac = pos - lo.float()
+        a = torch.zeros((length, src_len), dtype=torch.float32)
+        rows = torch.arange(length)
+        a.index_put_((rows, lo), 1.0 - frac, accumulate=True)
+        a.index_put_((rows, hi), frac, accumulate=True)
+        a = a.to(table.device)
+        _REL_RESIZE[key] = a
+    with torch.autocast(table.device.type, enabled=False):       # the tables stay fp32 whatever the surrounding autocast says
+        return (a @ table.float()).contiguous()
+
+
 def sam_attn_sublayer(x, norm, attn, window):
+    sh, sw = (window, window) if window > 0 else (x.shape[1], x.shape[2])
+    rel_h = resize_rel_pos(attn.rel_pos_h, 2 * sh - 1)
+    rel_w = resize_rel_pos(attn.rel_pos_w, 2 * sw - 1)
     return SamAttnSubLayerFn.apply(x, norm.weight, norm.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight,
-                                   attn.proj.bias, attn.rel_pos_h, attn.rel_pos_w, attn.head_nums, norm.eps, window)
+                                   attn.proj.bias, rel_h, rel_w, attn.head_nums, norm.eps, window)
 
 
 # ------------------------------------------------------------------------------ patch embedding
