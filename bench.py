@@ -191,7 +191,7 @@ def classification_workload(name, args, world, rank, device, use_graph):
     return run, model, config.scaler, state, info, batch, 224
 
 
-def loop_workload(name, args, world, rank, device):
+def loop_workload(name, args, world, rank, device, use_graph=False):
     """DETR / full SAM through the reference's own config and loop (eager launches: both loops have host-side work per
     iteration -- the Hungarian assignment, the prompt-type draw)."""
     import numpy as np
@@ -208,6 +208,11 @@ def loop_workload(name, args, world, rank, device):
     config.host_sync_lag = 2
     config.print_interval = 10 ** 9
     config.use_ema_model = getattr(config, 'use_ema_model', False)
+    # whole-step capture where the loop allows it (r04): a criterion without host reads and with static shapes (RetinaLoss with
+    # SmoothL1); DETR (Hungarian assignment on the host), FCOS (positive-only IoU terms) and the SAM loop (prompt draws) stay eager
+    graphed = bool(use_graph and LOOP_MODELS[name][0].endswith('train_detection') and 'detr' not in getattr(config, 'network', '')
+                   and getattr(config.train_criterion, 'capturable', False))
+    config.use_step_graph = graphed
     model = config.model.to(device)
     optimizer, _ = utils.build_optimizer(config, model)
     scheduler = utils.Scheduler(config, optimizer)
@@ -224,8 +229,11 @@ def loop_workload(name, args, world, rank, device):
     def run(k):
         state['loss'] = fn(DeviceLoader([data] * k, config.batch_size, iters_per_epoch), model, config.train_criterion,
                            optimizer, scheduler, 1, logger, config)
+        graphs = getattr(config, '_saicv_step_graphs', None)
+        state['step_graph'] = next(iter(graphs.values())) if graphs else None
 
     info = {'config_file': cfg_path, 'loop': loop_name, 'optimizer': config.optimizer[0], 'param_groups': len(optimizer.param_groups)}
+    state['graphed'] = graphed
     return run, model, config.scaler, state, info, batch, size
 
 
@@ -314,8 +322,8 @@ def measure(name, args, world, rank, device, use_graph, primary):
     import torch.distributed as dist
     from simpleaicv_pytorch_training_examples_amd import ops
     if name in LOOP_MODELS:
-        use_graph = False
-        run, model, scaler, state, info, batch, size = loop_workload(name, args, world, rank, device)
+        run, model, scaler, state, info, batch, size = loop_workload(name, args, world, rank, device, use_graph)
+        use_graph = state['graphed']
     elif name in CONFIG_DIR:
         run, model, scaler, state, info, batch, size = classification_workload(name, args, world, rank, device, use_graph)
     else:
@@ -376,7 +384,7 @@ def measure(name, args, world, rank, device, use_graph, primary):
     }
     # ---- price the dominant kernel: an eager pass of the same steps with HIP events on the launch stream
     if not args.no_kernel_timer:
-        cfg_graph = name in CONFIG_DIR and name not in LOOP_MODELS and use_graph
+        cfg_graph = name in CONFIG_DIR and use_graph
         ops.KernelTimer.only = {'igemm_nt'} if args.dominant_only else None
         ops.KernelTimer.records = []
         k = min(args.steps, 5)
@@ -446,24 +454,94 @@ def want_step_graph(eager, force_graph, world, env):
     return True if world == 1 else (force_graph or env in (None, '', '1'))
 
 
-def _arm_watchdog(seconds):
-    """N > 1 only: if warm-up + capture + the first timed windows of the captured step have not finished after `seconds`
-    (an RCCL collective that never completes inside a replay cannot raise), EVERY rank re-executes itself with --eager: same
-    PID (the launcher keeps its children), a fresh HIP / RCCL state, the same rendezvous variables.  Returns the event that
-    disarms it."""
+class WatchdogVote:
+    """N > 1 only.  A captured N-rank step whose RCCL collective never completes inside a replay cannot raise, so a timer guards
+    warm-up + capture + the first timed windows.  The DECISION is collective: a rank that times out locally while
+    another one just finished must not re-execute alone -- the ranks would then disagree on graph vs eager and on the RCCL
+    communicator state, which is the hang the watchdog exists to prevent.  Protocol over the job's key-value store (the
+    torch.distributed default store; host-side TCP, usable while the main thread sits in a GPU wait):
+        every rank:   set  wd/<epoch>/done/<rank>   when its guarded section finished;
+        rank 0:       at the deadline -- or as soon as every done key exists -- publishes  wd/<epoch>/decision = "ok" | "reexec";
+        every rank:   blocks (in its watchdog thread) on that ONE key and acts on it: "reexec" -> the whole job re-executes
+                      itself with --eager (same PIDs: the launcher keeps its children; fresh HIP / RCCL state).
+    `act` is injectable so that tests can drive the protocol with threads and a HashStore."""
+
+    def __init__(self, store, rank, world, seconds, epoch, act=None, poll=0.2):
+        import threading
+        self.store, self.rank, self.world, self.seconds, self.epoch = store, rank, world, seconds, epoch
+        self.act = act or self._reexec
+        self.poll = poll
+        self.decision = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _key(self, what):
+        return f'wd/{self.epoch}/{what}'
+
+    def finished(self):
+        """The guarded section of THIS rank is over (called from the main thread)."""
+        self.store.set(self._key(f'done/{self.rank}'), b'1')
+
+    def _all_done(self):
+        keys = [self._key(f'done/{r}') for r in range(self.world)]
+        try:
+            return bool(self.store.check(keys))
+        except Exception:       # noqa: BLE001 -- a store that cannot answer counts as "not done"
+            return False
+
+    def _run(self):
+        deadline = time.time() + self.seconds
+        if self.rank == 0:
+            verdict = b'reexec'
+            while time.time() < deadline:
+                if self._all_done():
+                    verdict = b'ok'
+                    break
+                time.sleep(self.poll)
+            else:
+                verdict = b'ok' if self._all_done() else b'reexec'
+            self.store.set(self._key('decision'), verdict)
+        # every rank (rank 0 included) reads the one published decision; other ranks wait as long as rank 0 may take
+        while True:
+            try:
+                if self.store.check([self._key('decision')]):
+                    break
+            except Exception:   # noqa: BLE001
+                pass
+            if time.time() > deadline + 60:
+                # rank 0 itself is gone or its store unreachable: nothing collective is possible any more
+                self.decision = 'reexec'
+                return self.act(self.seconds, 'no decision from rank 0')
+            time.sleep(self.poll)
+        self.decision = self.store.get(self._key('decision')).decode()
+        if self.decision == 'reexec':
+            self.act(self.seconds, 'collective decision')
+
+    @staticmethod
+    def _reexec(seconds, why):
+        sys.stderr.write(f'[bench] captured N-rank step did not finish within {seconds:.0f} s on every rank ({why}): '
+                         're-executing with --eager\n')
+        sys.stderr.flush()
+        os.environ['SAICV_BENCH_REEXEC'] = '1'
+        argv = [a for a in sys.argv if a != '--graph'] + ['--eager']
+        os.execv(sys.executable, [sys.executable] + argv)
+
+
+def _arm_last_resort(seconds, world):
+    """After a watchdog re-execution (or with SAICV_BENCH_HARD_LIMIT_S set): if even the eager run does not finish, rank 0
+    prints a diagnosable JSON line -- value null, the reason -- and every rank exits non-zero instead of hanging the driver."""
     import threading
-    done = threading.Event()
 
     def run():
-        if not done.wait(seconds):
-            sys.stderr.write(f'[bench] captured N-rank step did not finish within {seconds:.0f} s: re-executing with --eager\n')
-            sys.stderr.flush()
-            os.environ['SAICV_BENCH_REEXEC'] = '1'
-            argv = [a for a in sys.argv if a != '--graph'] + ['--eager']
-            os.execv(sys.executable, [sys.executable] + argv)
+        time.sleep(seconds)
+        if int(os.environ.get('RANK', '0')) == 0:
+            print(json.dumps({'metric': 'training images/sec/node', 'value': None, 'unit': 'images/s', 'n_gpus': world,
+                              'higher_is_better': True, 'error': f'bench.py did not finish within {seconds:.0f} s after falling back '
+                              'to eager launches (a rank is stuck in a collective or died): no number is reported',
+                              'graph_fallback': os.environ.get('SAICV_BENCH_REEXEC') == '1'}), flush=True)
+        os._exit(3)
 
     threading.Thread(target=run, daemon=True).start()
-    return done
 
 
 _CONFIGS = {}
@@ -610,15 +688,27 @@ def worker(args):
         dist.all_reduce(probe)                         # RCCL really connects `world` ranks before anything is timed
         assert int(probe) == world, f'RCCL all-reduce over {world} ranks returned {float(probe)}'
     want_graph = want_step_graph(args.eager, args.graph, world, os.environ.get('SAICV_STEP_GRAPH'))
-    watchdog = None
-    if world > 1 and want_graph and os.environ.get('SAICV_BENCH_REEXEC') != '1':
-        watchdog = _arm_watchdog(float(os.environ.get('SAICV_BENCH_WATCHDOG_S', '300')))
+    reexeced = os.environ.get('SAICV_BENCH_REEXEC') == '1'
+    wd_seconds = float(os.environ.get('SAICV_BENCH_WATCHDOG_S', '300'))
+    guard = world > 1 and want_graph and not reexeced
+
+    def new_watchdog(epoch):
+        from torch.distributed import distributed_c10d as c10d
+        return WatchdogVote(c10d._get_default_store(), rank, world, wd_seconds, epoch)
+
+    if world > 1 and (reexeced or os.environ.get('SAICV_BENCH_HARD_LIMIT_S')):
+        _arm_last_resort(float(os.environ.get('SAICV_BENCH_HARD_LIMIT_S', str(3 * wd_seconds))), world)
+    watchdog = new_watchdog(0) if guard else None
+    if os.environ.get('SAICV_BENCH_INJECT_STALL') == str(rank) and not reexeced:
+        time.sleep(wd_seconds + 30)         # test hook: this rank never reaches its first collective in time
 
     def guarded(name, primary):
         try:
             return measure(name, args, world, rank, device, want_graph, primary)
         except Exception as e:      # noqa: BLE001
-            if not want_graph or name not in CONFIG_DIR or name in LOOP_MODELS:
+            if not want_graph or name not in CONFIG_DIR or name in LOOP_MODELS or world > 1:
+                # several ranks: a rank-local fallback would split the job (graph here, eager there); the failure is fatal
+                # and the launcher reports it
                 raise
             print(f'[bench] step graph failed for {name} ({type(e).__name__}: {e}); falling back to eager launches', file=sys.stderr)
             torch.cuda.synchronize()
@@ -626,17 +716,17 @@ def worker(args):
 
     primary = guarded(args.model, True)
     if watchdog is not None:
-        watchdog.set()                  # the captured N-rank step replayed and was timed: the watchdog stands down
+        watchdog.finished()             # this rank's captured step replayed and was timed; rank 0 decides for everybody
     secondary = None
     if args.model == 'resnet50' and not args.no_secondary:
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        if watchdog is not None:        # the secondary workload captures its own step: same guard, same fallback
-            watchdog = _arm_watchdog(float(os.environ.get('SAICV_BENCH_WATCHDOG_S', '300')))
+        if guard:                       # the secondary workload captures its own step: same vote, next epoch
+            watchdog = new_watchdog(1)
         secondary = guarded('vit_base_patch16', False)
-        if watchdog is not None:
-            watchdog.set()
+        if guard:
+            watchdog.finished()
     sam = None
     if args.model == 'resnet50' and not args.no_secondary and not args.no_sam and world == 1:
         # BASELINE.json configs[4] on the driver line: SAM ViT-B image encoder, 3 x 1024 x 1024, the reference's per-GPU batch of
@@ -663,6 +753,9 @@ def worker(args):
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': primary['ms_per_step'], 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic'}
         out.update({k: v for k, v in primary.items() if k not in ('value', 'ms_per_step')})
+        if reexeced:
+            out['graph_fallback'] = ('the captured N-rank step did not finish within the watchdog limit on every rank; the job '
+                                     're-executed itself with --eager (collective decision over the process-group store)')
         out['timing'] = (f'median of {len(primary["windows_ms_per_step"])} windows of exactly {args.steps} steps, each bracketed by '
                          'barrier + synchronize (max over ranks)')
         if secondary is not None:

@@ -308,6 +308,10 @@ class RetinaLoss(nn.Module):
         self.cls_loss_weight, self.box_loss_weight = cls_loss_weight, box_loss_weight
         self.box_loss_type = box_loss_type
         self._tables = {}
+        # SmoothL1: every decision (assignment, positive count) stays on the device and every shape is static -> the training step
+        # can be captured as one hipGraph (tools/scripts.py _epoch_loop).  The IoU-family box losses index the positive anchors with
+        # a boolean mask (a host synchronisation and a data-dependent shape): eager only.
+        self.capturable = box_loss_type == 'SmoothL1'
 
     def _anchor_table(self, sizes, device):
         key = (tuple(map(tuple, sizes)), str(device))

@@ -24,6 +24,7 @@
 //   2 Sw == 64 (SAM global blocks): a 64-key chunk is exactly one kh row, so rel_w lives in 16
 //     registers per tile and rel_h is one value per chunk; gradients accumulate in registers;
 //   3 anything else: LDS tables + LDS atomics (slow, kept for generality).
+#include <stdlib.h>
 #include "common.h"
 #include "saicv_internal.h"
 #include "../../include/saicv_hip.h"
@@ -445,6 +446,206 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
         float l = l_run[qt];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
+        const int qrow = q0 + qt * 16 + l15;
+        if (lg == 0 && qrow < p.Nq) p.lse[(size_t)bh * p.Nq + qrow] = (m_run[qt] + log2f(l)) * LN2;
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float iq = __shfl(inv, lg * 4 + r, 64);
+            const int q = q0 + qt * 16 + lg * 4 + r;
+            if (q < p.Nq) {
+#pragma unroll
+                for (int dt = 0; dt < S::DT; ++dt) og[(size_t)q * p.o_rs + dt * 16 + l15] = from_f32<T>(o[qt][dt][r] * iq);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward, r04 structure (REL 0 / 2, no dropout)
+// Same tiling as sa_fwd_kernel (four wavefronts x 32 queries, 64-key chunks, S^T accumulators) with what the r04 profile said
+// the r03 kernel waits for taken off the chunk's critical path:
+//  * the K / V stream is a THREE-slot LDS-DMA ring with a counted vmcnt: two chunks are in flight while one is consumed (one
+//    chunk of lead did not cover an L2 round trip under load: 0.14-0.16 of the MFMA peak with the matrix cores idle most of a
+//    chunk) -- and no ordinary global load is left inside the loop (the compiler waits vmcnt(0) for those, which drains the
+//    ring): the rel_h rows of the block's 128 queries are staged in LDS once (REL 2), the key-bias row as before (REL 0);
+//  * the reductions over the four lane groups (row maximum, final normaliser) are v_permlane16_swap / v_permlane32_swap
+//    (two VALU instructions each) instead of ds_bpermute round trips through the LDS crossbar;
+//  * the running maximum moves only when a row's maximum grew by more than 2^RESCALE_LOG2 (guide T13): P stays <= 256, and
+//    the per-chunk broadcast of alpha to the O layout (eight more ds_bpermute) plus 32 multiplies happen on the first chunks
+//    only -- a wave-uniform branch the other chunks skip.
+// Numerics: P = exp2(s - m) with the same m in the normaliser and in P.V, so the result is the softmax for any m <= max + 8;
+// bf16 P carries 8 bits either way.
+constexpr float SA_RESCALE_LOG2 = 8.f;
+constexpr int SA_RING = 3;
+
+// op over lanes l, l^16, l^32, l^48 in registers (gfx950 permlane swaps; both halves of a swap hold the pair's two values)
+DEVINL float sa_lg_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+DEVINL float sa_lg_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <typename T, int D, int REL>
+__global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p) {
+    using S = SA<T, D>;
+    static_assert(REL == 0 || REL == 2, "r04 forward: no bias / key bias (REL 0) or the 64-wide decomposed bias (REL 2)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int sa_lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, lg = lane >> 4;
+    constexpr int STAGE = 2 * S::CHUNK_BYTES;                 // K chunk | V chunk
+    char* KV = smem;                                          // [SA_RING][K | V]
+    float* aux = reinterpret_cast<float*>(smem + SA_RING * STAGE);      // REL 2: rel_h rows [128 queries][Sh] * log2(e); REL 0: key bias
+    const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
+    const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
+    const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
+    const int q0 = blk * SA_BROWS + wave * SA_WROWS;
+    const __amdgpu_buffer_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
+    const int nchunk = (p.Nk + SA_CHUNK - 1) / SA_CHUNK;
+    // ring prologue first: the two chunks stream in under the rest of the set-up
+    S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.v_rs, 0, p.Nk, wave, lane);
+    if (nchunk > 1) {
+        S::dma(k_rsrc, KV + STAGE, p.k_rs, SA_CHUNK, p.Nk, wave, lane);
+        S::dma(v_rsrc, KV + STAGE + S::CHUNK_BYTES, p.v_rs, SA_CHUNK, p.Nk, wave, lane);
+    }
+    const float* kb = nullptr;
+    if constexpr (REL == 0) {
+        if (p.key_bias != nullptr) {                          // host: Nk <= SA_KB_LDS on this path
+            const float* kbg = p.key_bias + (size_t)b * p.Nk;
+            for (int i = threadIdx.x; i < p.Nk; i += SA_THREADS) aux[i] = kbg[i] * LOG2E;
+            kb = aux;
+        }
+    } else {
+        // rel_h[q][kh] of the block's queries, TRANSPOSED [kh][128 queries]: a chunk reads one row, 16 consecutive floats per
+        // lane group (conflict free), and two workgroups still share a CU (3 x 16 KiB ring + 32 KiB = 80 KiB each)
+        const int rows = min(SA_BROWS, p.Nq - blk * SA_BROWS);
+        const float* rg = p.rel_h + ((size_t)bh * p.Nq + (size_t)blk * SA_BROWS) * p.Sh;
+        for (int i = threadIdx.x; i < SA_BROWS * p.Sh; i += SA_THREADS) {
+            const int r = i / p.Sh, c = i - r * p.Sh;
+            aux[c * SA_BROWS + r] = r < rows ? rg[(size_t)r * p.Sh + c] * LOG2E : 0.f;
+        }
+    }
+    float rwreg[2][16];
+    if constexpr (REL == 2) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = q0 + qt * 16 + l15;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (q < p.Nq) v = *reinterpret_cast<const f32x4*>(p.rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rwreg[qt][kt * 4 + r] = v[r] * LOG2E;
+            }
+        }
+    }
+    u32x4 qf[2][S::STEPS];
+    S::gmem_frags(qf[0], qg, p.q_rs, q0, p.Nq, l15, lg);
+    S::gmem_frags(qf[1], qg, p.q_rs, q0 + 16, p.Nq, l15, lg);
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    f32x4 o[2][S::DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < S::DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float c2 = p.scale * LOG2E;
+    const float* rhcol = aux + wave * SA_WROWS + l15;          // REL 2: + ci * SA_BROWS (+ 16 for the second query tile)
+    // every ordinary load of the prologue has been consumed into registers / LDS before the first counted wait below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    int slot = 0;                                             // ring slot of the chunk being consumed
+    for (int ci = 0; ci < nchunk; ++ci) {
+        const int k0 = ci * SA_CHUNK;
+        const char* Ks = KV + slot * STAGE;
+        const char* Vs = Ks + S::CHUNK_BYTES;
+        // chunk ci has landed: behind it at most chunk ci + 1 (2 * NLD loads per thread) is still in flight
+        if (ci + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S::NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ... for every wavefront; chunk ci - 1's slot is free again
+        if (ci + 2 < nchunk) {
+            const int ns = slot == 0 ? 2 : slot - 1;          // (slot + 2) % 3
+            S::dma(k_rsrc, KV + ns * STAGE, p.k_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, KV + ns * STAGE + S::CHUNK_BYTES, p.v_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
+        }
+        f32x4 st[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            u32x4 kf[S::STEPS];
+            S::lds_frags(kf, Ks, kt * 16, l15, lg);
+            st[0][kt] = S::tile(kf, qf[0]);
+            st[1][kt] = S::tile(kf, qf[1]);
+        }
+        const bool tail = k0 + SA_CHUNK > p.Nk;
+        float rowb[2] = {0.f, 0.f};                           // REL 2: the chunk is one kh row -> one bias value per query
+        if constexpr (REL == 2) {
+            rowb[0] = rhcol[ci * SA_BROWS];
+            rowb[1] = rhcol[ci * SA_BROWS + 16];
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            // logits in the log2 domain WITHOUT the per-row constant rowb (it joins the exponent's offset below)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = st[qt][kt][r] * c2;
+                    if constexpr (REL == 2) sv += rwreg[qt][kt * 4 + r];
+                    if constexpr (REL == 0) {
+                        if (kb) sv += kb[min(k0 + kt * 16 + lg * 4 + r, p.Nk - 1)];
+                    }
+                    if (tail && k0 + kt * 16 + lg * 4 + r >= p.Nk) sv = -INFINITY;
+                    st[qt][kt][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = sa_lg_max(mx) + rowb[qt];
+            // deferred rescale: the reference point moves only when this row's maximum outgrew it by 2^8
+            const bool grow = mx > m_run[qt] + SA_RESCALE_LOG2;
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {    // wave-uniform: rare after the first chunks
+                const float m_new = grow ? mx : m_run[qt];
+                const float alpha = fast_exp2(m_run[qt] - m_new);           // first chunk: exp2(-inf) = 0
+                m_run[qt] = m_new;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float aq = __shfl(alpha, lg * 4 + r, 64);         // O rows are queries lg*4 + r
+#pragma unroll
+                    for (int dt = 0; dt < S::DT; ++dt) o[qt][dt][r] *= aq;
+                }
+            }
+            const float off = rowb[qt] - m_run[qt];
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fast_exp2(st[qt][kt][r] + off);
+                    st[qt][kt][r] = e;
+                    psum += e;
+                }
+            l_run[qt] += psum;                                // per-lane partial; combined over the lane groups at the end
+        }
+        {
+            const f32x4 a0[2] = {st[0][0], st[1][0]}, a1[2] = {st[0][1], st[1][1]};
+            pvN<T, S::ROWB, S::DT, 2>(o, a0, a1, Vs, 0, l15, lg);
+            const f32x4 b0[2] = {st[0][2], st[1][2]}, b1[2] = {st[0][3], st[1][3]};
+            pvN<T, S::ROWB, S::DT, 2>(o, b0, b1, Vs, 32, l15, lg);
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    T* og = (T*)p.out + (size_t)b * p.o_bs + h * D;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float l = sa_lg_sum(l_run[qt]);
         const int qrow = q0 + qt * 16 + l15;
         if (lg == 0 && qrow < p.Nq) p.lse[(size_t)bh * p.Nq + qrow] = (m_run[qt] + log2f(l)) * LN2;
         const float inv = 1.f / l;
@@ -946,6 +1147,23 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
     const size_t tab = (REL == 1 || REL == 3) ? (size_t)SA_WAVES * SA_WROWS * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
     const size_t kbl = (REL == 0 && p.key_bias && p.Nk <= SA_KB_LDS) ? (size_t)p.Nk * sizeof(float) : 0;
     if (which == 0) {
+        if constexpr (!DROP && (REL == 0 || REL == 2) && sizeof(T) == 2) {
+            // r04 forward (three-slot ring, in-register reductions, deferred rescale); SAICV_SA_FWD2=0 selects the r03 kernel
+            // measured (r04e, one box, us r03 -> r04): SAM global N = 4096 with rel-pos 985 -> 838; plain d64 N = 4096 709 -> 689;
+            // ViT N = 197 level; DETR d32 N = 1764 100 -> 107 -- so by default the decomposed-bias launches take it, SAICV_SA_FWD2=2
+            // sends every eligible launch there, =0 none
+            static const int fwd2_env = getenv("SAICV_SA_FWD2") ? atoi(getenv("SAICV_SA_FWD2")) : 1;
+            const bool fwd2 = fwd2_env == 2 || (fwd2_env == 1 && REL == 2);
+            const size_t aux = REL == 2 ? (size_t)SA_BROWS * p.Sh * sizeof(float) : (p.key_bias ? (size_t)p.Nk * sizeof(float) : 0);
+            if (fwd2 && (REL == 2 ? p.key_bias == nullptr : (p.key_bias == nullptr || p.Nk <= SA_KB_LDS))) {
+                auto k2 = sa_fwd2_kernel<T, D, REL>;
+                static bool once2 = (sa_allow_lds(k2), true);
+                (void)once2;
+                hipLaunchKernelGGL(k2, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
+                                   SA_RING * 2 * chunk + aux, st, p);
+                return saicv::check_launch("attention_stream");
+            }
+        }
         auto k = sa_fwd_kernel<T, D, REL, DROP>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;

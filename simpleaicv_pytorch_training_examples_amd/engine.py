@@ -528,10 +528,15 @@ class StepGraph:
             cb()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        dump = os.environ.get('SAICV_GRAPH_DUMP')       # path: write the captured graph as DOT (hipGraphDebugDotPrint) -- which
+        if dump:                                        # kernels sit on which branch, e.g. the bucket all-reduces (tests/test_gpu_ddp.py)
+            graph.enable_debug_mode()
         with torch.cuda.graph(graph):
             ops._ZeroPool.zero_all()    # the statistics scratch starts a replay all-zero, whatever ran eagerly in between
             out = self.fn(*args)
             ops.join_side_stream()      # every forked stream rejoins before the capture ends
+        if dump:
+            graph.debug_dump(dump)
         self.graph, self.static_out = graph, out
         torch.cuda.synchronize()
 

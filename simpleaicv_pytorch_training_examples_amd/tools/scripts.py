@@ -240,12 +240,19 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
     return losses.avg * acc_steps
 
 
-def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, total_name, iter_width):
+def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, total_name, iter_width,
+                graph_inputs=None):
     """Shared iteration engine of the dict-loss loops (detection here; the SAM loop in
     interactive_segmentation_scripts.py follows the same scheme): `step_fn(data)` runs forward + loss and
     returns (bad flag tensor, {name: loss tensor}, batch size).  Everything else -- accumulation, the single
     packed all-reduce of [skip, total, terms...], device-side skip, clipping, scaler, EMA, scheduler, lagged
-    host reads and the reference log line -- is common."""
+    host reads and the reference log line -- is common.
+
+    config.use_step_graph + `graph_inputs(data) -> tuple of device tensors` (r04): the WHOLE iteration -- forward, criterion,
+    backward with its bucket all-reduces, unscale / clip / fused optimizer step, zero_grad, EMA -- is captured once
+    (engine.StepGraph) and replayed, exactly as train_classification does; `step_fn` is then called with that tuple.  Only for
+    criteria without host reads and with static shapes (RetinaLoss with SmoothL1; DETR's Hungarian assignment and the
+    positive-only IoU branches of FCOSLoss are not), accumulation_steps == 1 and fixed-size batches."""
     losses = AverageMeter()
     local_rank = config.local_rank
     main = local_rank == 0 and getattr(config, 'total_rank', 0) == 0
@@ -277,9 +284,9 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
                 terms = ''.join(f'{k}: {v / float(config.gpus_num) * acc_steps:.4f}, ' for k, v in zip(keys, vals[2:]))
                 logger.info(log_fmt.format(loss=loss * acc_steps) + terms)
 
-    micro = 0      # accumulation phase by issued micro-batch (see train_classification)
-    for data in train_loader:
-        micro += 1
+    def forward_backward(data, boundary):
+        """forward, criterion, (scaled) backward; -> (packed [skip, total, terms...] reduced over the ranks, batch size)"""
+        nonlocal keys
         bad, loss_value, n = step_fn(data)
         if keys is None:
             keys = list(loss_value.keys())
@@ -287,7 +294,6 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
         terms = torch.stack([loss_value[k].detach().float() for k in keys]) / acc_steps
         bad = bad | (loss == 0.) | ~torch.isfinite(loss) | ~torch.isfinite(terms).all()
         loss = loss / acc_steps
-        boundary = micro % acc_steps == 0
         scaled = scaler.scale(loss) if scaler is not None else loss
         if boundary:
             scaled.backward()
@@ -296,30 +302,68 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
                 scaled.backward()
         packed = torch.cat([torch.stack([bad.float(), loss.detach().float()]), terms])
         all_reduce_sum_packed(packed, model, config.group)
+        return packed, n
+
+    def update(packed):
+        if hasattr(model, 'finish_gradient_sync'):
+            model.finish_gradient_sync()
+        skip_flag = packed[0:1]
+        if getattr(config, 'skip_inf_nan_grad', False) or scaler is not None:
+            optimizer.check_finite()
+            skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
+        inv_scale = scaler.state[2:3] if scaler is not None else None
+        if clip_value > 0:
+            optimizer.clip_grad_value_(clip_value, inv_scale)
+            inv_scale = None
+        if clip_norm > 0:
+            optimizer.clip_grad_norm_(clip_norm, inv_scale)
+            inv_scale = None
+        optimizer.step(inv_scale, skip_flag)
+        if scaler is not None:
+            scaler._found_inf = optimizer.found_inf
+            scaler.update()
+        optimizer.zero_grad()
+        if getattr(config, 'use_ema_model', False):
+            config.ema_model.update(model, skip_flag)
+
+    step_graph = None
+    if (graph_inputs is not None and getattr(config, 'use_step_graph', False) and acc_steps == 1
+            and _device_of(model).type == 'cuda'):
+        from .. import engine
+        batch_n = [0]
+
+        def whole_step(*tensors):
+            packed, n = forward_backward(tensors, True)
+            batch_n[0] = n
+            update(packed)
+            return packed
+        cache = getattr(config, '_saicv_step_graphs', None)
+        if cache is None:
+            cache = {}
+            config._saicv_step_graphs = cache
+        key = (id(model), id(optimizer))
+        step_graph = cache.get(key)
+        if step_graph is None:
+            step_graph = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3),
+                                          before_replay=(optimizer.refresh_hyper,))
+            cache[key] = step_graph
+
+    micro = 0      # accumulation phase by issued micro-batch (see train_classification)
+    for data in train_loader:
+        micro += 1
+        boundary = micro % acc_steps == 0
+        if step_graph is not None:
+            tensors = graph_inputs(data)
+            packed = step_graph(*tensors).clone()
+            n = tensors[0].size(0)
+        else:
+            packed, n = forward_backward(data, boundary)
         if carried_bad is not None:
             packed = torch.cat([torch.maximum(packed[0:1], carried_bad), packed[1:]])
         carried_bad = None if boundary else packed[0:1]
         if boundary:
-            if hasattr(model, 'finish_gradient_sync'):
-                model.finish_gradient_sync()
-            skip_flag = packed[0:1]
-            if getattr(config, 'skip_inf_nan_grad', False) or scaler is not None:
-                optimizer.check_finite()
-                skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
-            inv_scale = scaler.state[2:3] if scaler is not None else None
-            if clip_value > 0:
-                optimizer.clip_grad_value_(clip_value, inv_scale)
-                inv_scale = None
-            if clip_norm > 0:
-                optimizer.clip_grad_norm_(clip_norm, inv_scale)
-                inv_scale = None
-            optimizer.step(inv_scale, skip_flag)
-            if scaler is not None:
-                scaler._found_inf = optimizer.found_inf
-                scaler.update()
-            optimizer.zero_grad()
-            if getattr(config, 'use_ema_model', False):
-                config.ema_model.update(model, skip_flag)
+            if step_graph is None:
+                update(packed)
             scheduler.step(optimizer, iter_index / iters + (epoch - 1))
             log_fmt = None
             if iter_index % int(config.print_interval * acc_steps) == 0:
@@ -344,18 +388,28 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
     is_detr = 'detr' in config.network
 
     def step_fn(data):
-        images = data['image'].to(device, non_blocking=True)
-        host_targets = data['scaled_annots'] if is_detr else data['annots']
-        targets = host_targets.to(device, non_blocking=True)
-        if is_detr and not host_targets.is_cuda:
-            targets._saicv_host = host_targets           # DETRLoss selects the valid rows on the host (no per-image device sync)
+        if isinstance(data, tuple):                      # captured step: (images, targets) already on the device, static buffers
+            images, targets = data
+        else:
+            images = data['image'].to(device, non_blocking=True)
+            host_targets = data['scaled_annots'] if is_detr else data['annots']
+            targets = host_targets.to(device, non_blocking=True)
+            if is_detr and not host_targets.is_cuda:
+                targets._saicv_host = host_targets       # DETRLoss selects the valid rows on the host (no per-image device sync)
         bad = any_nonfinite(images, targets)
         with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
             outs = model(images, data['mask'].to(device, non_blocking=True)) if is_detr else model(images)
             loss_value = criterion(outs, targets)
         return bad, loss_value, images.size(0)
 
-    return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5)
+    # the dense detectors' step has no host read (anchor assignment, focal loss and SmoothL1 are decided on the device): it can be
+    # captured whole.  DETR's Hungarian assignment runs on the host between forward and loss, and criteria that index by a
+    # data-dependent positive mask (`capturable = False`, e.g. the IoU branches) have dynamic shapes: those stay eager.
+    graph_inputs = None
+    if not is_detr and getattr(criterion, 'capturable', False):
+        def graph_inputs(data):
+            return (data['image'].to(device, non_blocking=True), data['annots'].to(device, non_blocking=True))
+    return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5, graph_inputs)
 
 
 # ---------------------------------------------------------------------------------------------- detection evaluation

@@ -95,6 +95,49 @@ def test_stream_attention_matches_fp32_reference(case, dtype):
         assert rel_err(drw, rl[1].grad) < tol
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('pattern', ['ramp', 'spike', 'flat'])
+def test_stream_attention_forward_deferred_rescale_branch(pattern, dtype):
+    """The r04 forward moves its running maximum only when a row's maximum outgrows it by 2^8 (csrc/attn_stream.hip,
+    sa_fwd2_kernel).  Random logits almost never take that branch after the first chunk, so it gets inputs that force it:
+    `ramp` -- key norms grow chunk by chunk, the maximum creeps up by a few log2 units per chunk (cumulative growth must
+    trigger the move, a single step must not have to); `spike` -- one key in the sixth chunk dominates one query by hundreds
+    of units; `flat` -- identical logits (nothing ever grows).  Checked against the fp32 softmax with rel-pos bias and without."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    b, heads, d, n = 1, 2, 64, 512
+    c = heads * d
+    g = torch.Generator().manual_seed(17)
+    q = torch.randn(b, n, c, generator=g)
+    k = torch.randn(b, n, c, generator=g)
+    v = torch.randn(b, n, c, generator=g)
+    if pattern == 'ramp':
+        k = k * (1.0 + 0.9 * (torch.arange(n) // 64).float())[None, :, None]
+        q = q * 2.0
+    elif pattern == 'spike':
+        k[0, 5 * 64 + 7, :64] = q[0, 33, :64] * 6.0           # head 0: key 327 ~ 6 |q|^2 * scale for query 33
+    else:
+        q = torch.zeros_like(q)
+    for rel in (None, (8, 64)):
+        rel_h = rel_w = None
+        if rel:
+            rel_h = torch.randn(b * heads, n, rel[0], generator=g).cuda()
+            rel_w = torch.randn(b * heads, n, rel[1], generator=g).cuda()
+        qd, kd, vd = (t.cuda().to(dtype).contiguous() for t in (q, k, v))
+        out, lse = ops_tfm.sattn_fwd(qd, kd, vd, heads, d ** -0.5, None, rel_h, rel_w)
+        torch.cuda.synchronize()
+        ref = _ref_attention(qd.float(), kd.float(), vd.float(), heads, d ** -0.5, None, rel_h, rel_w)
+        qh = qd.float().view(b, n, heads, d).transpose(1, 2)
+        kh = kd.float().view(b, n, heads, d).transpose(1, 2)
+        sc = qh @ kh.transpose(-1, -2) * d ** -0.5
+        if rel:
+            sc = (sc.view(b, heads, n, rel[0], rel[1]) + rel_h.view(b, heads, n, rel[0], 1) + rel_w.view(b, heads, n, 1, rel[1])).view(b, heads, n, n)
+        ref_lse = torch.logsumexp(sc, -1).view(b * heads, n)
+        tol = 2e-4 if dtype == torch.float32 else 3e-2
+        assert torch.isfinite(out.float()).all()
+        assert rel_err(out, ref) < tol, (pattern, rel)
+        assert float((lse - ref_lse).abs().max()) < (1e-3 if dtype == torch.float32 else 5e-2) * max(1.0, float(ref_lse.abs().max()) * 0.05), (pattern, rel)
+
+
 def test_stream_attention_rejects_bad_arguments():
     from simpleaicv_pytorch_training_examples_amd import ops_tfm
     q = torch.randn(1, 16, 48, device='cuda')

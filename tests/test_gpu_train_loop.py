@@ -516,3 +516,67 @@ def test_sam_loop_follows_the_reference_loop(regime, monkeypatch):
     worst = _gate_trajectory(got, fx, 1e-3, 2e-3)
     print(f'[sam trajectory {regime}] worst relative loss error {worst:.2e}')
     assert abs(avg - fx['avg_loss']) / fx['avg_loss'] < 2e-3
+
+
+def test_detection_step_graph_replays_the_same_training_as_eager_launches():
+    """r04: the dense detectors' iteration has no host read -- anchor assignment, focal loss and SmoothL1 are
+    decided on the device -- so train_detection captures it whole (config.use_step_graph, criterion.capturable) like
+    train_classification does.  resnet18_retinanet, bf16 autocast, 10 iterations: the replayed graph must train like the eager
+    loop, within a small multiple of how far two eager runs end up from each other."""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import FCOSLoss, RetinaLoss
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import retinanet
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts, utils
+    steps, batch, size = 10, 4, 256
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for s in range(steps):
+        images = torch.randn(batch, 3, size, size, generator=g)
+        annots = -torch.ones(batch, 8, 5)
+        for b in range(batch):
+            n = 2 + (s + b) % 4
+            xy = torch.rand(n, 2, generator=g) * (size - 96)
+            wh = torch.rand(n, 2, generator=g) * 80 + 16
+            annots[b, :n, 0:2], annots[b, :n, 2:4] = xy, xy + wh
+            annots[b, :n, 4] = torch.randint(0, 20, (n,), generator=g).float()
+        batches.append({'image': images, 'annots': annots})
+
+    class Loader(list):
+        dataset = [None] * (steps * batch)
+
+    def run(use_graph):
+        class config:
+            pass
+        config.network = 'resnet18_retinanet'
+        config.optimizer = ('AdamW', {'lr': 1e-4, 'global_weight_decay': False, 'weight_decay': 1e-3, 'no_weight_decay_layer_name_list': []})
+        config.scheduler = ('CosineLR', {'warm_up_epochs': 1, 'min_lr': 1e-6})       # the lr moves every iteration
+        config.epochs, config.batch_size, config.accumulation_steps, config.print_interval = 2, batch, 1, 1
+        config.use_amp, config.use_ema_model, config.local_rank, config.gpus_num, config.group = True, False, 0, 1, None
+        config.clip_max_norm, config.sync_bn, config.host_sync_lag = 0.0, False, 2
+        config.use_step_graph = use_graph
+        torch.manual_seed(0)
+        model = retinanet.resnet18_retinanet(num_classes=20).cuda()
+        optimizer, _ = utils.build_optimizer(config, model)
+        scheduler = utils.Scheduler(config, optimizer)
+        model, config.ema_model, config.scaler = utils.build_training_mode(config, model)
+        crit = RetinaLoss()
+        assert crit.capturable and not RetinaLoss(box_loss_type='GIoU').capturable and not getattr(FCOSLoss(), 'capturable', False)
+        got, restore = _spy_average_meter()
+        try:
+            scripts.train_detection(Loader(batches), model, crit, optimizer, scheduler, 1, logging.getLogger('saicv_det_graph'), config)
+        finally:
+            restore()
+        torch.cuda.synchronize()
+        return got, model.arena.flat_param.clone(), getattr(config, '_saicv_step_graphs', {})
+
+    eager, p_eager, _ = run(False)
+    eager2, p_eager2, _ = run(False)
+    graph, p_graph, graphs = run(True)
+    assert len(graphs) == 1 and next(iter(graphs.values())).graph is not None and next(iter(graphs.values())).replays >= steps - 3
+    assert len(eager) == len(graph) == steps
+    noise = float((p_eager - p_eager2).norm() / p_eager.norm())
+    rel = float((p_eager - p_graph).norm() / p_eager.norm())
+    print(f'[detection step graph] parameters after {steps} iterations: graph vs eager {rel:.2e}, eager vs eager {noise:.2e}')
+    assert rel < max(3 * noise, 5e-3), (rel, noise)
+    spread = max(abs(a - c) for a, c in zip(eager, eager2))
+    for i, (a, b, c) in enumerate(zip(eager, graph, eager2)):
+        assert abs(a - b) < max(3 * abs(a - c), 3 * spread, 0.05 * max(abs(a), 0.1)), (i, a, b, c)

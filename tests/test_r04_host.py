@@ -33,3 +33,55 @@ def test_convbnact_block_switches_keep_the_reference_parameter_contract():
         for k in sd:
             assert sd[k].shape == c['state_dict'][k].shape, (key, k)
         blk.load_state_dict(c['state_dict'])
+
+
+def _vote(world, finish_after, seconds=1.0):
+    """Drive bench.WatchdogVote with `world` in-process ranks over one HashStore: rank r calls finished() after
+    finish_after[r] seconds (None: never).  -> (decisions, acted)."""
+    import threading
+    import time
+    import torch.distributed as dist
+    import bench
+    store = dist.HashStore()
+    acted = []
+    lock = threading.Lock()
+
+    def act(secs, why, r):
+        with lock:
+            acted.append((r, why))
+
+    votes = [bench.WatchdogVote(store, r, world, seconds, epoch=7, act=lambda s, w, r=r: act(s, w, r), poll=0.02) for r in range(world)]
+
+    def finisher(r):
+        if finish_after[r] is not None:
+            time.sleep(finish_after[r])
+            votes[r].finished()
+
+    ts = [threading.Thread(target=finisher, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for v in votes:
+        v.thread.join(seconds + 10)
+        assert not v.thread.is_alive()
+    return [v.decision for v in votes], sorted(acted)
+
+
+def test_watchdog_vote_everyone_finished_nobody_reexecutes():
+    decisions, acted = _vote(3, [0.05, 0.1, 0.2])
+    assert decisions == ['ok', 'ok', 'ok'] and acted == []
+
+
+def test_watchdog_vote_one_stalled_rank_sends_every_rank_to_eager():
+    decisions, acted = _vote(3, [0.05, None, 0.1])
+    assert decisions == ['reexec'] * 3
+    assert [r for r, _ in acted] == [0, 1, 2] and all(w == 'collective decision' for _, w in acted)
+
+
+def test_watchdog_vote_is_one_decision_even_when_a_rank_finishes_just_after_the_deadline():
+    """The race ADVICE r03 describes: rank 0 done in time, rank 1 a moment too late.  Per-rank timers would send only rank 1 to
+    eager; the vote gives every rank the same answer (here: reexec, because rank 0 published before rank 1's key existed)."""
+    decisions, acted = _vote(2, [0.1, 1.3], seconds=1.0)
+    assert len(set(decisions)) == 1
+    assert (decisions[0] == 'reexec') == (len(acted) == 2)
