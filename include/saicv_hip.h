@@ -220,6 +220,21 @@ int saicv_maxpool_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, 
                       int OH, int OW, int K, int stride, int pad, void* stream);
 int saicv_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W,
                       int C, int OH, int OW, int K, int stride, int pad, void* stream);
+/* BatchNorm-apply + ReLU + MaxPool2d as ONE pass over the convolution output y (the ResNet stem: ConvBnActBlock followed by
+ * nn.MaxPool2d(3, 2, 1), reference classification/backbones/resnet.py:172-184, 226-229; same in detection/models/backbones/
+ * detr_resnet.py): out = maxpool(relu(scale[c] * y + shift[c])), idx = window position of the first maximum (as saicv_maxpool_fwd).
+ * The full-resolution activation and its ReLU mask are never written.  C / (16 / element size) must divide 256. */
+int saicv_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N, int H,
+                              int W, int C, int OH, int OW, int K, int stride, int pad, void* stream);
+/* Its backward, fused with the BatchNorm backward: from dout (gradient of the pooled tensor) and idx the gradient reaching the
+ * BatchNorm output is rebuilt per input pixel (gather form, ReLU gate from scale * y + shift > 0), reduced per channel (ws: 2 * C
+ * floats, zeroed here) and turned into dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)); dgamma / dbeta written
+ * (accumulate = 0) or added to (1).  Training statistics only (mean / invstd of THIS batch); K <= 2 * stride + 1. */
+size_t saicv_bn_relu_maxpool_bwd_ws_floats(int C);
+int saicv_bn_relu_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, const void* y, const float* gamma, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, void* dy, float* dgamma, float* dbeta,
+                              int accumulate, float* ws, int N, int H, int W, int C, int OH, int OW, int K, int stride, int pad,
+                              void* stream);
 /* nn.AdaptiveAvgPool2d((1,1)), resnet.py:203 */
 int saicv_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream);
 int saicv_avgpool_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, void* stream);

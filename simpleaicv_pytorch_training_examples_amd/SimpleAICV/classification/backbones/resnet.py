@@ -52,13 +52,16 @@ class ConvBnActBlock(nn.Module):
         self.has_bn = has_bn
         self.has_act = has_act
 
-    def forward(self, x, residual=None, act=None, want_skip=False):
+    def forward(self, x, residual=None, act=None, want_skip=False, pool=None):
         """`residual` / `act` let the enclosing residual block fuse its add + ReLU in here; `want_skip` also
         returns the input as an alias the block uses for its shortcut, so that the shortcut's gradient is
-        added inside this conv's dgrad epilogue (no separate gradient-sum kernel)."""
+        added inside this conv's dgrad epilogue (no separate gradient-sum kernel).  `pool` = (kernel, stride, padding) of the
+        nn.MaxPool2d that follows the block (the stem): BatchNorm-apply, ReLU and the pooling run as one pass."""
         conv = self.layer[0]
         relu = self.has_act if act is None else act
         if self.has_bn and not self.depthwise:
+            if pool is not None:
+                return ops.conv_bn_act(x, conv.weight, self.layer[1], self.stride, self.padding, relu, pool=pool)
             return ops.conv_bn_act(x, conv.weight, self.layer[1], self.stride, self.padding, relu, residual, want_skip)
         # the unfused forms: [depthwise] convolution (+ bias) -> [BatchNorm] -> [+ residual] -> [ReLU], one kernel each
         if self.depthwise:
@@ -182,8 +185,13 @@ class ResNet(_ResNetBase):
 
     def forward(self, x):
         x = ops.pack_stem_input(x, self.conv1.layer[0])  # compute dtype; the 7x7 stride-2 stem takes a space-to-depth image
-        x = self.conv1(x)
-        x = ops.max_pool2d(x, self.maxpool1.kernel_size, self.maxpool1.stride, self.maxpool1.padding)
+        mp = self.maxpool1
+        if (ops.STEM_POOL_FUSE and self.conv1.has_act and isinstance(mp.kernel_size, int) and isinstance(mp.stride, int)
+                and isinstance(mp.padding, int) and mp.kernel_size <= 2 * mp.stride + 1 and mp.dilation == 1 and not mp.ceil_mode):
+            x = self.conv1(x, pool=(mp.kernel_size, mp.stride, mp.padding))       # conv -> [BN + ReLU + MaxPool as one pass]
+        else:
+            x = self.conv1(x)
+            x = ops.max_pool2d(x, mp.kernel_size, mp.stride, mp.padding)
         x = self._stages(x, self.use_gradient_checkpoint)
         return self._head(x)
 

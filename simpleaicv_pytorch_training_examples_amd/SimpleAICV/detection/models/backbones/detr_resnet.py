@@ -81,8 +81,12 @@ class DetrResNetBackbone(nn.Module):
 
     def forward(self, x):
         x = ops.pack_stem_input(x, self.conv1.layer[0])  # compute dtype; the 7x7 stride-2 stem takes a space-to-depth image
-        x = self.conv1(x)
-        x = ops.max_pool2d(x, self.maxpool1.kernel_size, self.maxpool1.stride, self.maxpool1.padding)
+        mp = self.maxpool1
+        if ops.STEM_POOL_FUSE and isinstance(mp.kernel_size, int) and mp.kernel_size <= 2 * mp.stride + 1 and mp.dilation == 1 and not mp.ceil_mode:
+            x = self.conv1(x, pool=(mp.kernel_size, mp.stride, mp.padding))       # conv -> [BN + ReLU + MaxPool as one pass]
+        else:
+            x = self.conv1(x)
+            x = ops.max_pool2d(x, mp.kernel_size, mp.stride, mp.padding)
         outs = []
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             x = checkpoint(stage, x, use_reentrant=False) if self.use_gradient_checkpoint else stage(x)

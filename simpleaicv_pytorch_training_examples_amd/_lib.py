@@ -103,6 +103,9 @@ SIGNATURES = {
     'saicv_bn_act_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, _P, _P]),
     'saicv_maxpool_fwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_maxpool_bwd': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_bn_relu_maxpool_fwd': (c_int, [c_int, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    'saicv_bn_relu_maxpool_bwd_ws_floats': (c_size_t, [c_int]),
+    'saicv_bn_relu_maxpool_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P] + [c_int] * 9 + [_P]),
     'saicv_avgpool_fwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_avgpool_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -50,6 +50,9 @@ int bn_bwd_from_partials(int, const void*, const void*, const void*, const float
                          const float*, int, void*, void*, float*, float*, size_t, int, int, int, float*, hipStream_t);
 int maxpool_fwd(int, const void*, void*, uint8_t*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int maxpool_bwd(int, const void*, const uint8_t*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int bn_relu_maxpool_fwd(int, const void*, const float*, const float*, void*, uint8_t*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int bn_relu_maxpool_bwd(int, const void*, const uint8_t*, const void*, const float*, const float*, const float*, const float*, const float*,
+                        void*, float*, float*, int, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int avgpool_fwd(int, const void*, void*, int, int, int, hipStream_t);
 int avgpool_bwd(int, const void*, void*, int, int, int, hipStream_t);
 int softmax_ce_fwd(const float*, const void*, int, int, int, float*, float*, float*, hipStream_t);
@@ -327,6 +330,19 @@ int saicv_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx,
                       int C, int OH, int OW, int K, int stride, int pad, void* stream) {
     return maxpool_bwd(dtype, dout, idx, dx, N, H, W, C, OH, OW, K, stride, pad, S(stream));
 }
+int saicv_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N, int H,
+                              int W, int C, int OH, int OW, int K, int stride, int pad, void* stream) {
+    return bn_relu_maxpool_fwd(dtype, y, scale, shift, out, idx, N, H, W, C, OH, OW, K, stride, pad, S(stream));
+}
+size_t saicv_bn_relu_maxpool_bwd_ws_floats(int C) { return 2 * (size_t)C; }
+int saicv_bn_relu_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, const void* y, const float* gamma, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, void* dy, float* dgamma, float* dbeta,
+                              int accumulate, float* ws, int N, int H, int W, int C, int OH, int OW, int K, int stride, int pad,
+                              void* stream) {
+    return bn_relu_maxpool_bwd(dtype, dout, idx, y, gamma, mean, invstd, scale, shift, dy, dgamma, dbeta, accumulate, ws, N, H, W, C,
+                               OH, OW, K, stride, pad, S(stream));
+}
+
 int saicv_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream) {
     return avgpool_fwd(dtype, x, out, N, HW, C, S(stream));
 }

@@ -171,6 +171,227 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// BatchNorm-apply + ReLU + MaxPool in one pass (r04): the ResNet stem, `x = self.conv1(x); x = self.maxpool1(x)` of reference
+// SimpleAICV/classification/backbones/resnet.py:226-229 (ConvBnActBlock :19-48, then nn.MaxPool2d(3, 2, 1)).  The full-resolution
+// activation z = relu(scale * y + shift) -- 411 MB at batch 256 -- is never written: the pooling windows read the convolution
+// output y and apply the per-channel affine + ReLU on the fly (values rounded to T as bn_act_fwd would have stored them, so the
+// maxima and the first-maximum tie rule are those of the unfused pair).  Backward: the gradient of the pooled tensor is gathered
+// back to every input pixel through the recorded window positions (as maxpool_bwd does), gated by the ReLU (scale * y + shift
+// > 0) and fed straight into the BatchNorm backward: one pass for the two per-channel sums, one that writes d y.  Neither the
+// pooled gradient scattered to full resolution nor z's mask exist.  HBM per step at b256: forward 1.41 -> 0.57 GB, backward
+// 2.67 -> ~1.5 GB.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, T* __restrict__ out,
+                                                                  uint8_t* __restrict__ idx, int Nimg, int H, int W, int C, int OH,
+                                                                  int OW, int K, int stride, int pad) {
+    constexpr int N = Chunk<T>::N;
+    const int cpr = C / N;
+    const size_t total = (size_t)Nimg * OH * OW * cpr;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;      // a multiple of cpr (host): a thread keeps its channel chunk
+    const int cb = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % cpr);
+    float sc[N], sh[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { sc[j] = scale[cb * N + j]; sh[j] = shift[cb * N + j]; }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        size_t pix = i / cpr;
+        const int ow = (int)(pix % OW); pix /= OW;
+        const int oh = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        float best[N];
+        int bi[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+        bool first = true;
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = oh * stride - pad + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < K; ++kw) {
+                const int iw = ow * stride - pad + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float v[N];
+                Chunk<T>::unpack(ld_chunk(y + ((size_t)(n * H + ih) * W + iw) * C + cb * N), v);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float z = round_through<T>(fmaxf(fmaf(sc[j], v[j], sh[j]), 0.f));
+                    if (first || z > best[j] || z != z) { best[j] = z; bi[j] = kh * K + kw; }
+                }
+                first = false;
+            }
+        }
+        const size_t o = (((size_t)(n * OH + oh)) * OW + ow) * C + cb * N;
+        st_chunk(out + o, Chunk<T>::pack(best));
+#pragma unroll
+        for (int j = 0; j < N; ++j) idx[o + j] = (uint8_t)bi[j];
+    }
+}
+
+// g[n,h,w,c] = [scale * y + shift > 0] * sum of dout over the windows whose recorded maximum sits at (h, w): the gradient that
+// reaches the BatchNorm output.  (At most 2 x 2 windows cover a pixel for K <= 2 * stride + 1; the host checks that.)
+template <typename T>
+DEVINL void pooled_grad(float (&g)[Chunk<T>::N], const T* __restrict__ dout, const uint8_t* __restrict__ idx, const float* yv,
+                        const float* sc, const float* sh, int n, int h, int w, int cb, int C, int OH, int OW, int K, int stride,
+                        int pad) {
+    constexpr int N = Chunk<T>::N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = 0.f;
+    const int oh_lo = max(0, (h + pad - (K - 1) + stride - 1) / stride), oh_hi = min(OH - 1, (h + pad) / stride);
+    const int ow_lo = max(0, (w + pad - (K - 1) + stride - 1) / stride), ow_hi = min(OW - 1, (w + pad) / stride);
+    if (oh_hi < oh_lo || ow_hi < ow_lo) return;
+    u32x4 cg[4];
+    uint8_t ib[4][N];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                // all eight loads in flight before the first use
+        const int oh = oh_lo + (q >> 1), ow = ow_lo + (q & 1);
+        ok[q] = oh <= oh_hi && ow <= ow_hi;
+        const size_t o = (((size_t)(n * OH + min(oh, oh_hi))) * OW + min(ow, ow_hi)) * C + cb * N;
+        cg[q] = ld_chunk(dout + o);
+        if (N == 8) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(idx + o);
+            __builtin_memcpy(ib[q], &raw, 8);
+        } else {
+            const uint32_t raw = *reinterpret_cast<const uint32_t*>(idx + o);
+            __builtin_memcpy(ib[q], &raw, 4);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!ok[q]) continue;
+        const int oh = oh_lo + (q >> 1), ow = ow_lo + (q & 1);
+        const int want = (h - (oh * stride - pad)) * K + (w - (ow * stride - pad));
+        float d[N];
+        Chunk<T>::unpack(cg[q], d);
+#pragma unroll
+        for (int j = 0; j < N; ++j) g[j] += (ib[q][j] == want) ? d[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = fmaf(sc[j], yv[j], sh[j]) > 0.f ? g[j] : 0.f;
+}
+
+// pass 1: sums[0][c] += sum g, sums[1][c] += sum g * (y - mean) * invstd   (fp32 atomics, one pair per channel and workgroup).
+// Walks the POOLED tensor (a quarter of the pixels): every pooled element sends its gradient to exactly one input position, the
+// recorded maximum of its window, so the sums over input pixels are sums over pooled elements of d * [gate] * (1 | xhat) with y
+// taken at that position -- the window's chunks are re-read as in the forward pass (L2 hits), the per-channel position selects.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                                         const T* __restrict__ y, const float* __restrict__ mean,
+                                                                         const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                                         const float* __restrict__ shift, float* __restrict__ sums,
+                                                                         int Nimg, int H, int W, int C, int OH, int OW, int K, int stride,
+                                                                         int pad) {
+    constexpr int N = Chunk<T>::N;
+    const int cpr = C / N;
+    const size_t total = (size_t)Nimg * OH * OW * cpr;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    const int cb = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % cpr);
+    float sc[N], sh[N], mu[N], is[N], sg[N], sx[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        sc[j] = scale[cb * N + j]; sh[j] = shift[cb * N + j]; mu[j] = mean[cb * N + j]; is[j] = invstd[cb * N + j];
+        sg[j] = 0.f; sx[j] = 0.f;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        size_t pix = i / cpr;
+        const int ow = (int)(pix % OW); pix /= OW;
+        const int oh = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        const size_t o = (((size_t)(n * OH + oh)) * OW + ow) * C + cb * N;
+        float d[N];
+        Chunk<T>::unpack(ld_chunk(dout + o), d);
+        uint8_t ib[N];
+        if (N == 8) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(idx + o);
+            __builtin_memcpy(ib, &raw, 8);
+        } else {
+            const uint32_t raw = *reinterpret_cast<const uint32_t*>(idx + o);
+            __builtin_memcpy(ib, &raw, 4);
+        }
+        float ya[N];                                   // y at each channel's recorded maximum
+#pragma unroll
+        for (int j = 0; j < N; ++j) ya[j] = 0.f;
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = oh * stride - pad + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < K; ++kw) {
+                const int iw = ow * stride - pad + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float v[N];
+                Chunk<T>::unpack(ld_chunk(y + ((size_t)(n * H + ih) * W + iw) * C + cb * N), v);
+                const int pos = kh * K + kw;
+#pragma unroll
+                for (int j = 0; j < N; ++j) ya[j] = (ib[j] == pos) ? v[j] : ya[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float g = fmaf(sc[j], ya[j], sh[j]) > 0.f ? d[j] : 0.f;
+            sg[j] += g;
+            sx[j] = fmaf(g, (ya[j] - mu[j]) * is[j], sx[j]);
+        }
+    }
+    __shared__ float red[256 * 16];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { red[threadIdx.x * 2 * N + j] = sg[j]; red[threadIdx.x * 2 * N + N + j] = sx[j]; }
+    __syncthreads();
+    // threads tid, tid + cpr, tid + 2 cpr, ... share a channel chunk (256 % cpr == 0)
+    for (int o = threadIdx.x; o < cpr * 2 * N; o += 256) {
+        const int c0 = o / (2 * N), e = o - c0 * 2 * N;
+        float a = 0.f;
+        for (int t = c0; t < 256; t += cpr) a += red[t * 2 * N + e];
+        const int which = e / N, j = e - which * N;
+        unsafeAtomicAdd(sums + (size_t)which * C + c0 * N + j, a);
+    }
+}
+
+// pass 2: dy = gamma * invstd * (g - mean(g) - xhat * mean(g xhat)); workgroup 0 also leaves dgamma / dbeta
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_apply_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                                        const T* __restrict__ y, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                        const float* __restrict__ sums, T* __restrict__ dy,
+                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                                        int Nimg, int H, int W, int C, int OH, int OW, int K, int stride,
+                                                                        int pad) {
+    constexpr int N = Chunk<T>::N;
+    const int cpr = C / N;
+    const size_t total = (size_t)Nimg * H * W * cpr;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    const int cb = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % cpr);
+    const float inv_m = 1.f / ((float)Nimg * (float)H * (float)W);
+    float sc[N], sh[N], mu[N], is[N], k0[N], mg[N], mx[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int c = cb * N + j;
+        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+        k0[j] = gamma[c] * is[j];
+        mg[j] = sums[c] * inv_m;
+        mx[j] = sums[C + c] * inv_m;
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            if (accumulate) { dbeta[c] += sums[c]; dgamma[c] += sums[C + c]; }
+            else { dbeta[c] = sums[c]; dgamma[c] = sums[C + c]; }
+        }
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        size_t pix = i / cpr;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const int n = (int)(pix / H);
+        const size_t off = ((size_t)(n * H + h) * W + w) * C + cb * N;
+        float yv[N], g[N], o[N];
+        Chunk<T>::unpack(ld_chunk(y + off), yv);
+        pooled_grad<T>(g, dout, idx, yv, sc, sh, n, h, w, cb, C, OH, OW, K, stride, pad);
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = k0[j] * (g[j] - mg[j] - (yv[j] - mu[j]) * is[j] * mx[j]);
+        st_chunk(dy + off, Chunk<T>::pack(o));
+    }
+}
+
 inline int sgrid(size_t total) {
     size_t b = (total + 255) / 256;
     if (b > 4096) b = 4096;
@@ -205,6 +426,38 @@ int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N
     else
         hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, (const float*)dout, idx, (float*)dx, Nimg, H, W, C, OH, OW, K, stride, pad);
     return check_launch("maxpool_bwd");
+}
+
+int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int Nimg, int H,
+                        int W, int C, int OH, int OW, int K, int stride, int pad, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && 256 % (C / n) == 0, "bn_relu_maxpool_fwd: C=%d must be %d x a power of two <= 256", C, n);
+    SAICV_REQUIRE(K * K <= 255, "bn_relu_maxpool_fwd: window too large");
+    const size_t total = (size_t)Nimg * OH * OW * (C / n);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (bf16_t*)out, idx, Nimg, H, W, C, OH, OW, K, stride, pad);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, (const float*)y, scale, shift, (float*)out, idx, Nimg, H, W, C, OH, OW, K, stride, pad);
+    return check_launch("bn_relu_maxpool_fwd");
+}
+
+int bn_relu_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, const void* y, const float* gamma, const float* mean,
+                        const float* invstd, const float* scale, const float* shift, void* dy, float* dgamma, float* dbeta,
+                        int accumulate, float* ws, int Nimg, int H, int W, int C, int OH, int OW, int K, int stride, int pad,
+                        hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && 256 % (C / n) == 0, "bn_relu_maxpool_bwd: C=%d must be %d x a power of two <= 256", C, n);
+    SAICV_REQUIRE(K <= 2 * stride + 1, "bn_relu_maxpool_bwd: K=%d, stride=%d: more than 2 x 2 windows cover a pixel", K, stride);
+    if (hipMemsetAsync(ws, 0, 2 * (size_t)C * sizeof(float), st) != hipSuccess) { set_error("bn_relu_maxpool_bwd: memset failed"); return -1; }
+    const size_t total = (size_t)Nimg * H * W * (C / n), ptotal = (size_t)Nimg * OH * OW * (C / n);
+    if (dtype == SAICV_DTYPE_BF16) {
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<bf16_t>, dim3(sgrid(ptotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad);
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, gamma, mean, invstd, scale, shift, ws, (bf16_t*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
+    } else {
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<float>, dim3(sgrid(ptotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad);
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, gamma, mean, invstd, scale, shift, ws, (float*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
+    }
+    return check_launch("bn_relu_maxpool_bwd");
 }
 
 int avgpool_fwd(int dtype, const void* x, void* out, int Nimg, int HW, int C, hipStream_t st) {

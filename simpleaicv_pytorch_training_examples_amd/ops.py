@@ -291,6 +291,8 @@ def pack_input(x, dtype=None, cp=8):
 
 
 STEM_S2D = _os.environ.get('SAICV_STEM_S2D', '1') == '1'
+# BatchNorm-apply + ReLU + MaxPool of the ResNet stem as one pass (csrc/pool.hip bn_relu_maxpool_*); 0: the unfused pair
+STEM_POOL_FUSE = _os.environ.get('SAICV_STEM_POOL_FUSE', '1') == '1'
 
 
 def pack_stem_input(x, conv, dtype=None):
@@ -484,8 +486,10 @@ class ConvBnActFn(torch.autograd.Function):
     residual tail of BasicBlock / Bottleneck (:94-95, :152-153)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, pad, relu, want_skip=False):
-        """want_skip: also return the (NHWC) input as a second output.  A residual block routes its shortcut
+    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, pad, relu, want_skip=False, pool=None):
+        """pool = (kernel, stride, padding): the MaxPool2d behind the block runs in the same pass as BatchNorm-apply + ReLU
+        (the ResNet stem; csrc/pool.hip bn_relu_maxpool_*), the full-resolution activation is never written.
+        want_skip: also return the (NHWC) input as a second output.  A residual block routes its shortcut
         through that alias, so the shortcut's gradient reaches THIS node's backward and is added in the
         dgrad kernel's epilogue instead of by a separate elementwise add."""
         require_gpu(x, weight)
@@ -523,7 +527,10 @@ class ConvBnActFn(torch.autograd.Function):
         scale = torch.empty(k, dtype=torch.float32, device=dev)
         shift = torch.empty(k, dtype=torch.float32, device=dev)
         mean = invstd = None
-        inline = training and BN_INLINE and k <= 2048
+        if pool is not None and (residual is not None or not relu or want_skip):
+            raise ValueError('the fused max-pool follows a plain conv -> BatchNorm -> ReLU block')
+        # (the pooled form takes scale / shift from the finalize kernel: one 6 us launch, stem only)
+        inline = training and BN_INLINE and k <= 2048 and pool is None
         if training:
             rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
             t0 = KernelTimer.begin('igemm_nt')
@@ -558,6 +565,28 @@ class ConvBnActFn(torch.autograd.Function):
             check(L.saicv_bn_eval_coeffs(k, ptr(gamma), ptr(beta), ptr(bn.running_mean),
                                          ptr(bn.running_var), float(bn.eps), ptr(scale), ptr(shift), st),
                   'bn_eval_coeffs')
+        if pool is not None:
+            pk, ps, pp = pool
+            poh, pow_ = (d.OH + 2 * pp - pk) // ps + 1, (d.OW + 2 * pp - pk) // ps + 1
+            zp = _empty_nhwc(n, k, poh, pow_, dt, dev)
+            idx = torch.empty((n, poh, pow_, k), dtype=torch.uint8, device=dev)
+            t0 = KernelTimer.begin('bn_act_fwd')
+            check(L.saicv_bn_relu_maxpool_fwd(dtype_code(dt), ptr(y), ptr(scale), ptr(shift), ptr(zp), ptr(idx), n, d.OH, d.OW, k,
+                                              poh, pow_, pk, ps, pp, st), 'bn_relu_maxpool_fwd')
+            es = y.element_size()
+            KernelTimer.end(t0, 'bn_act_fwd', 0, float(M) * k * es + float(n) * poh * pow_ * k * (es + 1))
+            if training:
+                ctx.save_for_backward(x, weight, gamma, y, idx, mean, invstd)
+            else:
+                ctx.save_for_backward(x, weight, gamma, y, None, None, scale)
+            ctx.cfg = (stride, pad, True, False, training, d, wd)
+            ctx.pool = (pk, ps, pp, poh, pow_, scale, shift)
+            ctx.beta_ref = beta
+            ctx.gated_res = False
+            ctx.link = None
+            ctx.applies_gate = False
+            return zp
+        ctx.pool = None
         if residual is not None:
             residual = _nhwc(residual)
             if residual.dtype != dt:
@@ -613,6 +642,8 @@ class ConvBnActFn(torch.autograd.Function):
             dz = dz.to(dt)
         n, k, oh, ow = y.shape
         M = n * oh * ow
+        if ctx.pool is not None:
+            return ConvBnActFn._backward_pooled(ctx, dz, x, weight, gamma, y, mask, mean, invstd)
         if gate_in is not None:
             if relu:
                 raise RuntimeError('a gated shortcut gradient reached a BatchNorm node with its own ReLU')
@@ -732,10 +763,63 @@ class ConvBnActFn(torch.autograd.Function):
             if not direct:
                 dwt = _weight_grad_s2d(dw, weight, c, gw) if ctx.s2d is not None else _weight_grad(dw, weight, c)
         return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
-                dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None, None)
+                dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None, None, None)
 
 
-def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None, want_skip=False):
+def _conv_bn_act_backward_pooled(ctx, dz, x, weight, gamma, y, idx, mean, invstd):
+    """backward of the pooled stem block: pooled gradient -> (max-pool backward + ReLU gate + BatchNorm backward in two passes over
+    y) -> dy at full resolution -> [data gradient] + weight gradient, as ConvBnActFn.backward does behind its BatchNorm kernels."""
+    stride, pad, _, _, _, d, wd = ctx.cfg
+    pk, ps, pp, poh, pow_, scale, shift = ctx.pool
+    L, st = lib(), stream()
+    dt, dev = y.dtype, y.device
+    n, k, oh, ow = y.shape
+    M = n * oh * ow
+    dy = _empty_nhwc(n, k, oh, ow, dt, dev)
+    beta = ctx.beta_ref
+    gg, gb = _arena_grad(gamma), _arena_grad(beta)
+    direct_bn = gg is not None and gb is not None
+    dgamma = gg if direct_bn else torch.empty(k, dtype=torch.float32, device=dev)
+    dbeta = gb if direct_bn else torch.empty(k, dtype=torch.float32, device=dev)
+    ws = torch.empty(L.saicv_bn_relu_maxpool_bwd_ws_floats(k), dtype=torch.float32, device=dev)
+    t0 = KernelTimer.begin('bn_act_bwd')
+    check(L.saicv_bn_relu_maxpool_bwd(dtype_code(dt), ptr(dz), ptr(idx), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(scale),
+                                      ptr(shift), ptr(dy), ptr(dgamma), ptr(dbeta), int(direct_bn), ptr(ws), n, oh, ow, k, poh, pow_,
+                                      pk, ps, pp, st), 'bn_relu_maxpool_bwd')
+    es = y.element_size()
+    KernelTimer.end(t0, 'bn_act_bwd', 0, 3.0 * M * k * es + 2.0 * n * poh * pow_ * k * (es + 1))       # y twice + dy; dout + idx twice
+    if direct_bn:
+        dgamma = dbeta = None
+    c = x.shape[1]
+    flops = 2.0 * M * k * weight.shape[2] * weight.shape[3] * min(c, weight.shape[1])
+    dx = None
+    if ctx.needs_input_grad[0]:
+        if wd is None:
+            _, wd = packed_weight(weight, dt, c, True)
+        dx = _empty_nhwc(n, c, x.shape[2], x.shape[3], dt, dev)
+        t0 = KernelTimer.begin('igemm_nt')
+        check(L.saicv_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(wd), ptr(dx), st), 'conv2d_dgrad')
+        KernelTimer.end(t0, 'igemm_nt', flops, 0)
+    dwt = None
+    if ctx.needs_input_grad[1]:
+        gw = _arena_grad(weight)
+        direct = gw is not None and c == weight.shape[1] and weight.is_contiguous(memory_format=torch.channels_last)
+        dw = gw if direct else torch.zeros((k, d.R, d.S, c), dtype=torch.float32, device=dev)
+        t0 = KernelTimer.begin('igemm_tn')
+        check(L.saicv_conv2d_wgrad(ctypes.byref(d), ptr(dy), ptr(x), ptr(dw), st), 'conv2d_wgrad')
+        KernelTimer.end(t0, 'igemm_tn', flops, 0)
+        if not direct:
+            dwt = _weight_grad_s2d(dw, weight, c, gw) if ctx.s2d is not None else _weight_grad(dw, weight, c)
+    return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
+            None, None, None, None, None, None, None)
+
+
+ConvBnActFn._backward_pooled = staticmethod(_conv_bn_act_backward_pooled)
+
+
+def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None, want_skip=False, pool=None):
+    if pool is not None:
+        return ConvBnActFn.apply(x, weight, bn.weight, bn.bias, None, bn, stride, pad, relu, False, pool)
     out = ConvBnActFn.apply(x, weight, bn.weight, bn.bias, residual, bn, stride, pad, relu, want_skip)
     z = out[0] if want_skip else out
     node = z.grad_fn

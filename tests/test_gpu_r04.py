@@ -197,3 +197,61 @@ def test_sam_block_with_interpolated_relative_position_tables(dtype):
         assert p.grad is not None, n
         assert p.grad.shape == fx['grads'][n].shape, n           # the tables keep their 15 rows; the gradient comes back through A^T
         assert rel_err(p.grad, fx['grads'][n]) < (2e-3 if f32 else 8e-2), n
+
+
+# ------------------------------------------------------------------------------------------------ fused stem: BN + ReLU + MaxPool
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(4, 3, 64, 64), (2, 3, 50, 70), (3, 3, 33, 47)])
+def test_stem_bn_relu_maxpool_fused_equals_the_unfused_pair_and_torch(shape, dtype, monkeypatch):
+    """ResNet stem: conv 7x7/2 -> BatchNorm -> ReLU -> MaxPool(3, 2, 1) (reference resnet.py:172-184, 226-229) with the last three
+    as ONE pass over the convolution output (csrc/pool.hip bn_relu_maxpool_*): output, running statistics and every gradient
+    against (a) the same block with the unfused kernels (SAICV_STEM_POOL_FUSE=0) and (b) torch's own modules on the CPU in fp32.
+    Odd extents exercise the border windows and the pixels no window covers."""
+    import torch.nn as nn
+    from simpleaicv_pytorch_training_examples_amd import ops
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.backbones.resnet import ConvBnActBlock
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    ref = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1))
+    with torch.no_grad():
+        ref[1].weight.copy_(torch.rand(64, generator=g) + 0.5)
+        ref[1].bias.copy_(torch.randn(64, generator=g) * 0.3)
+    out_ref = ref(x)
+    probe = torch.randn(out_ref.shape, generator=g)
+    (out_ref * probe).sum().backward()
+
+    def run(fuse):
+        monkeypatch.setattr(ops, 'STEM_POOL_FUSE', fuse)
+        blk = ConvBnActBlock(3, 64, 7, 2, 3)
+        blk.layer[0].weight.data.copy_(ref[0].weight.data)
+        blk.layer[1].load_state_dict({k: v for k, v in ref[1].state_dict().items()})
+        blk.layer[1].running_mean.zero_()
+        blk.layer[1].running_var.fill_(1.0)
+        blk.layer[1].num_batches_tracked.zero_()
+        blk = blk.cuda().train()
+        ctx = torch.autocast('cuda', dtype=torch.bfloat16) if dtype == torch.bfloat16 else torch.autocast('cuda', enabled=False)
+        with ctx:
+            xin = ops.pack_stem_input(x.cuda(), blk.layer[0])
+            if fuse:
+                out = blk(xin, pool=(3, 2, 1))
+            else:
+                out = ops.max_pool2d(blk(xin), 3, 2, 1)
+        (out.float() * probe.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        return out.float(), {n: p.grad.clone() for n, p in blk.named_parameters()}, blk.layer[1].running_var.clone()
+
+    out_f, g_f, rv_f = run(True)
+    out_u, g_u, rv_u = run(False)
+    f32 = dtype == torch.float32
+    # fused vs unfused: the same arithmetic on the same rounded values -> the pooled maxima agree to the last bit in fp32 (the
+    # affine is one FMA in both) and up to rare one-ulp bf16 ties otherwise; gradients differ only by summation order
+    assert rel_err(out_f, out_u) < (1e-6 if f32 else 8e-3)
+    assert rel_err(rv_f, rv_u) < 1e-6
+    for n in g_f:
+        assert _l2_err(g_f[n], g_u[n]) < (2e-5 if f32 else 2e-2), n
+    # against torch (fp32 CPU)
+    assert rel_err(out_f, out_ref) < (1e-3 if f32 else 3e-2)
+    names = {'layer.0.weight': ref[0].weight.grad, 'layer.1.weight': ref[1].weight.grad, 'layer.1.bias': ref[1].bias.grad}
+    for n, r in names.items():
+        assert _l2_err(g_f[n], r) < (1e-3 if f32 else 1.5e-1), n        # bf16 against an fp32 reference: the conv output is rounded before the statistics
+    assert rel_err(rv_f, ref[1].running_var) < (1e-3 if f32 else 1e-2)
