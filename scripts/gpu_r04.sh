@@ -22,6 +22,11 @@ for step in "$@"; do
     lbench) timeout 600 python scripts/linear_bench.py > $O/linear_bench.jsonl 2> $O/lbench.err; cat $O/linear_bench.jsonl | cut -c1-300 ;;
     bench)  timeout 900 python bench.py ${arg:-} > $O/bench_$(echo "${arg:-default}" | tr -c 'a-zA-Z0-9\n' '_').log 2>&1; tail -1 $O/bench_$(echo "${arg:-default}" | tr -c 'a-zA-Z0-9\n' '_').log | cut -c1-700 ;;
     prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$arg -o $arg -- python $GRAFT_REPO_ROOT/bench.py --model $arg --no-secondary --no-cpu-baseline --max-windows 2 --steps 5 --warmup 5 > $O/prof_$arg.log 2>&1); f=$(find $O/prof_$arg -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${arg}_rocprofv3_kernel_stats.csv && head -12 $f | cut -c1-200; t=$(find $O/prof_$arg -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python scripts/trace_compact.py $t > $O/${arg}_kernel_trace_compact.csv ;;
+    ddpsync)
+      # world of one, the gradient synchronisation forced on (SAICV_DDP_FORCE_SYNC=1), the step captured: the RCCL kernels of the bucket
+      # all-reduces must show up once per bucket per replayed step, between the backward kernels
+      (cd /tmp && SAICV_DDP_FORCE_SYNC=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ddpsync -o ddpsync -- python $GRAFT_REPO_ROOT/bench.py --model ${arg:-resnet50} --no-secondary --no-cpu-baseline --no-kernel-timer --max-windows 1 --steps 5 --warmup 5 > $O/prof_ddpsync.log 2>&1)
+      t=$(find $O/prof_ddpsync -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python scripts/trace_compact.py $t > $O/ddpsync_kernel_trace_compact.csv && python scripts/ddp_trace_summary.py $O/ddpsync_kernel_trace_compact.csv | tee $O/ddpsync_summary.txt ;;
     entries)
       export PYTHONPATH=$GRAFT_REPO_ROOT
       run() { timeout 420 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $1 -m simpleaicv_pytorch_training_examples_amd.tools.$2 --work-dir ./ ; }
