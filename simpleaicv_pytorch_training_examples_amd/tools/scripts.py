@@ -524,8 +524,80 @@ def evaluate_voc_detection(test_loader, model, criterion, decoder, config):
 
 
 def evaluate_coco_detection(test_loader, model, criterion, decoder, config):
-    raise RuntimeError("eval_type 'COCO' needs pycocotools (reference tools/scripts.py:742-881), which this image does not provide; "
-                       "use eval_type = 'VOC' (evaluate_voc_detection)")
+    """COCO-style evaluation (reference :742-881): forward + loss + decode per batch, boxes back to the original image scale,
+    clipped, converted to [x, y, w, h], then the twelve COCO summary numbers (x 100) under the reference's keys.  The reference
+    hands the detections to pycocotools' COCOeval; here the same protocol runs in numpy (tools/cocoeval_numpy.py).  Ground truth:
+    `config.test_dataset.coco.dataset` (a COCO annotation dict, as pycocotools holds it) when the dataset has one, else the
+    annotations the loader delivers (un-scaled; every box a regular, non-crowd object with area w * h) -- which is what the
+    synthetic benchmark datasets provide."""
+    from . import cocoeval_numpy as CE
+    model.eval()
+    batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
+    test_dataset = config.test_dataset
+    batch_size = int(config.batch_size // config.gpus_num)
+    device = _device_of(model)
+    on_gpu = device.type == 'cuda'
+    is_detr = 'detr' in config.network
+    image_id_of = getattr(test_dataset, 'image_ids', None)
+    cat_of = getattr(test_dataset, 'coco_label_to_cat_id', None)
+    coco = getattr(test_dataset, 'coco', None)
+    results, gts, image_ids = [], [], []
+    with torch.no_grad():
+        end = time.time()
+        for i, data in enumerate(test_loader):
+            images, annots, scales, sizes = data['image'].to(device), data['annots'].to(device), data['scale'], data['size']
+            if on_gpu:
+                torch.cuda.synchronize()
+            data_time.update(time.time() - end, images.size(0))
+            end = time.time()
+            outs = model(images, data['mask'].to(device)) if is_detr else model(images)
+            loss = sum(criterion(outs, annots).values())
+            losses.update(float(loss), images.size(0))
+            scores, classes, boxes = decoder(outs, data['scaled_size']) if is_detr else decoder(outs)
+            unscale = np.expand_dims(np.expand_dims(scales, axis=-1), axis=-1)
+            boxes = boxes / unscale
+            if on_gpu:
+                torch.cuda.synchronize()
+            batch_time.update(time.time() - end, images.size(0))
+            annots_np = annots.cpu().numpy()
+            for b in range(images.size(0)):
+                index = i * batch_size + b
+                img_id = image_id_of[index] if image_id_of is not None else index
+                image_ids.append(img_id)
+                pb = boxes[b].copy()
+                pb[:, 0], pb[:, 1] = np.maximum(pb[:, 0], 0), np.maximum(pb[:, 1], 0)
+                pb[:, 2], pb[:, 3] = np.minimum(pb[:, 2], sizes[b][1]), np.minimum(pb[:, 3], sizes[b][0])
+                pb[:, 2:] -= pb[:, :2]                                  # COCO boxes are [x_min, y_min, w, h]
+                for sc, cl, bx in zip(scores[b], classes[b], pb):
+                    if int(cl) == -1:
+                        break
+                    results.append({'image_id': img_id, 'category_id': cat_of[int(cl)] if cat_of is not None else int(cl),
+                                    'score': float(sc), 'bbox': bx.tolist()})
+                if coco is None:
+                    for row in annots_np[b]:
+                        if row[4] < 0:
+                            continue
+                        x0, y0, x1, y1 = (row[0:4] / float(np.asarray(scales[b]).reshape(-1)[0])).tolist()
+                        gts.append({'image_id': img_id, 'category_id': cat_of[int(row[4])] if cat_of is not None else int(row[4]),
+                                    'bbox': [x0, y0, x1 - x0, y1 - y0], 'area': (x1 - x0) * (y1 - y0), 'iscrowd': 0})
+            end = time.time()
+    result_dict = collections.OrderedDict()
+    result_dict['test_loss'] = losses.avg
+    result_dict['per_image_load_time'] = f'{data_time.avg / batch_size * 1000:.3f}ms'
+    result_dict['per_image_inference_time'] = f'{batch_time.avg / batch_size * 1000:.3f}ms'
+    if len(results) == 0:
+        for name in CE.STAT_NAMES:
+            result_dict[name] = 0
+        return result_dict
+    cats = None
+    if coco is not None:
+        ds = coco.dataset
+        gts = [dict(a) for a in ds['annotations'] if a['image_id'] in set(image_ids)]
+        cats = [c['id'] for c in ds['categories']]
+    stats, _, _ = CE.evaluate_bbox(gts, results, image_ids=image_ids, category_ids=cats)
+    for name, v in zip(CE.STAT_NAMES, stats):
+        result_dict[name] = v * 100
+    return result_dict
 
 
 def test_detection(test_loader, model, criterion, decoder, config):

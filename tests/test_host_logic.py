@@ -415,14 +415,30 @@ def test_voc_detection_evaluation_matches_the_reference(variant):
                 assert same(float(res[k][c]), ap), (k, c, res[k][c], ap)
 
 
-def test_coco_evaluation_says_what_is_missing():
+def test_coco_evaluation_runs_through_the_reference_result_keys():
+    """tools.scripts.test_detection with eval_type = 'COCO' (reference tools/scripts.py:742-881): the stub model / criterion /
+    decoder of the VOC fixture replayed through the numpy COCO protocol -- the reference's twelve result keys in its order, values
+    in [0, 100], mAP@0.5 >= mAP@0.5:0.95, and the same detections scored against themselves give 100."""
+    import os
+    import sys
+    from simpleaicv_pytorch_training_examples_amd.tools import cocoeval_numpy as CE
     from simpleaicv_pytorch_training_examples_amd.tools import scripts
-
-    class C:
-        eval_type = 'COCO'
-
-    with pytest.raises(RuntimeError, match='pycocotools'):
-        scripts.test_detection([], None, None, None, C())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'oracle'))
+    try:
+        import make_golden_voc_eval as m
+    finally:
+        sys.path.pop(0)
+    loader, model, criterion, decoder, config = m.stubs(False)
+    config.eval_type = 'COCO'
+    config.test_dataset = object()          # no .coco / .image_ids: ground truth comes from the loader's own annotations
+    res = scripts.test_detection(loader, model, criterion, decoder, config)
+    keys = list(res.keys())
+    assert keys[:3] == ['test_loss', 'per_image_load_time', 'per_image_inference_time'] and keys[3:] == list(CE.STAT_NAMES)
+    vals = [res[k] for k in CE.STAT_NAMES]
+    assert all(v == -100 or 0.0 <= v <= 100.0 for v in vals), vals
+    assert res[CE.STAT_NAMES[1]] >= res[CE.STAT_NAMES[0]] > 0.0
+    assert res[CE.STAT_NAMES[8]] >= res[CE.STAT_NAMES[7]] >= res[CE.STAT_NAMES[6]]      # recall grows with the detection budget
 
 
 @pytest.mark.parametrize('case', ['yolo', 'retina'])

@@ -85,3 +85,75 @@ def test_watchdog_vote_is_one_decision_even_when_a_rank_finishes_just_after_the_
     decisions, acted = _vote(2, [0.1, 1.3], seconds=1.0)
     assert len(set(decisions)) == 1
     assert (decisions[0] == 'reexec') == (len(acted) == 2)
+
+
+# ------------------------------------------------------------------------------------------------ numpy COCO evaluation
+def _gt(img, cat, box, crowd=0):
+    return {'image_id': img, 'category_id': cat, 'bbox': list(box), 'area': box[2] * box[3], 'iscrowd': crowd}
+
+
+def _dt(img, cat, box, score):
+    return {'image_id': img, 'category_id': cat, 'bbox': list(box), 'score': score}
+
+
+def test_cocoeval_perfect_detections_score_one_in_every_populated_cell():
+    from simpleaicv_pytorch_training_examples_amd.tools import cocoeval_numpy as CE
+    boxes = {0: [(10, 10, 20, 20), (100, 50, 60, 60)], 1: [(5, 5, 200, 150)], 2: [(30, 30, 10, 12)]}
+    gts = [_gt(i, c, b) for i, bs in boxes.items() for c, b in enumerate(bs)]
+    dts = [_dt(i, c, b, 0.9 - 0.1 * c) for i, bs in boxes.items() for c, b in enumerate(bs)]
+    stats, precision, recall = CE.evaluate_bbox(gts, dts)
+    assert all(abs(s - 1.0) < 1e-12 for s in stats), stats          # small, medium and large boxes are all present
+    assert precision.shape == (10, 101, 2, 4, 3) and recall.shape == (10, 2, 4, 3)
+
+
+def test_cocoeval_hand_worked_precision_recall_curve():
+    """One image, one category, two ground-truth boxes; detections: 0.9 exact on the first, 0.8 nowhere, 0.7 with IoU 0.62 on the
+    second.  t <= 0.60: TP FP TP -> recall (.5 .5 1), precision envelope (1 2/3 2/3): AP = (51 + 50 * 2/3) / 101.  t >= 0.65: TP FP FP
+    -> AP = 51 / 101.  mAR@100 = (3 * 1 + 7 * 0.5) / 10; with one detection per image only the first box is ever found."""
+    from simpleaicv_pytorch_training_examples_amd.tools import cocoeval_numpy as CE
+    gts = [_gt(7, 3, (0, 0, 100, 100)), _gt(7, 3, (200, 200, 100, 100))]
+    dts = [_dt(7, 3, (0, 0, 100, 100), 0.9), _dt(7, 3, (500, 500, 100, 100), 0.8), _dt(7, 3, (200, 200, 100, 62), 0.7)]
+    stats, precision, _ = CE.evaluate_bbox(gts, dts)
+    hi, lo = (51 + 50 * 2 / 3) / 101, 51 / 101
+    assert abs(stats[1] - hi) < 1e-9                                # IoU = 0.50
+    assert abs(stats[2] - lo) < 1e-9                                # IoU = 0.75
+    assert abs(stats[0] - (3 * hi + 7 * lo) / 10) < 1e-9
+    assert abs(stats[8] - (3 * 1.0 + 7 * 0.5) / 10) < 1e-9          # mAR, 100 detections
+    assert abs(stats[6] - 0.5) < 1e-12                              # mAR, 1 detection per image
+    assert stats[3] == -1 and stats[4] == -1 and abs(stats[5] - stats[0]) < 1e-12      # both boxes are "large" (area 10 000)
+    assert abs(precision[0, 0, 0, 0, 2] - 1.0) < 1e-12 and abs(precision[0, 100, 0, 0, 2] - 2 / 3) < 1e-12      # tp / (tp + fp + spacing(1))
+
+
+def test_cocoeval_crowd_and_area_rules():
+    """A detection on a crowd box is ignored (no TP, no FP) and the crowd box may absorb several; a ground-truth box outside the
+    area range is ignored there, and so is an unmatched detection whose own area is outside it."""
+    from simpleaicv_pytorch_training_examples_amd.tools import cocoeval_numpy as CE
+    gts = [_gt(0, 1, (0, 0, 20, 20)), _gt(0, 1, (300, 300, 200, 200), crowd=1)]
+    dts = [_dt(0, 1, (0, 0, 20, 20), 0.9), _dt(0, 1, (310, 310, 50, 50), 0.8), _dt(0, 1, (400, 400, 60, 60), 0.7)]
+    stats, _, _ = CE.evaluate_bbox(gts, dts)
+    assert abs(stats[0] - 1.0) < 1e-12 and abs(stats[8] - 1.0) < 1e-12      # the two detections inside the crowd box cost nothing
+    assert abs(stats[3] - 1.0) < 1e-12 and stats[5] == -1                   # one small regular box; no regular large one
+    # without the crowd flag the same two detections are false positives against a second regular box they overlap too little
+    gts[1]['iscrowd'] = 0
+    stats2, _, _ = CE.evaluate_bbox(gts, dts)
+    assert stats2[0] < 0.6 and abs(stats2[8] - 0.5) < 1e-12
+
+
+def test_cocoeval_is_invariant_under_monotone_score_maps_and_sensitive_to_order():
+    import numpy as np
+    from simpleaicv_pytorch_training_examples_amd.tools import cocoeval_numpy as CE
+    rng = np.random.RandomState(0)
+    gts, dts = [], []
+    for img in range(6):
+        for k in range(4):
+            x, y, w, h = rng.rand(4) * np.array([300, 300, 120, 120]) + np.array([0, 0, 8, 8])
+            gts.append(_gt(img, k % 2, (x, y, w, h)))
+            jit = rng.randn(4) * np.array([4, 4, 6, 6])
+            dts.append(_dt(img, k % 2, (x + jit[0], y + jit[1], max(w + jit[2], 2), max(h + jit[3], 2)), float(rng.rand())))
+        for _ in range(3):
+            dts.append(_dt(img, int(rng.randint(2)), tuple(rng.rand(4) * 300 + 5), float(rng.rand() * 0.5)))
+    a, _, _ = CE.evaluate_bbox(gts, dts)
+    b, _, _ = CE.evaluate_bbox(gts, [dict(d, score=d['score'] ** 3 + 1.0) for d in dts])
+    assert np.allclose(a, b) and 0.05 < a[0] < 1.0
+    worse, _, _ = CE.evaluate_bbox(gts, [dict(d, score=1.0 - d['score']) for d in dts])
+    assert worse[0] < a[0]
