@@ -201,6 +201,16 @@ int saicv_bn_act_fwd_stats(int dtype, const void* y, const void* res, void* z, c
                            int stat_rows, double count, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, double momentum, double eps, long long* num_batches_tracked, float* mean,
                            float* invstd, size_t M, int C, int relu, void* relu_mask, void* stream);
+/* The residual join of a block whose shortcut is convolution + BatchNorm (reference resnet.py:90-95, :148-153: `identity =
+ * self.downsample_conv(inputs); x = x + identity; x = self.relu(x)`): res is the shortcut convolution's RAW output and its
+ * BatchNorm-apply (res_scale[c] * res + res_shift[c], from saicv_bn_finalize_fwd / saicv_bn_eval_coeffs) happens in this pass, the
+ * normalised shortcut is never written.  stat_sum != NULL: the main branch's statistics as in saicv_bn_act_fwd_stats (scale /
+ * shift unused); stat_sum == NULL: scale / shift given as in saicv_bn_act_fwd (the statistics arguments unused). */
+int saicv_bn_act_fwd_join(int dtype, const void* y, const void* res, const float* res_scale, const float* res_shift, void* z,
+                          const float* scale, const float* shift, const float* stat_sum, const float* stat_sq, int stat_rows,
+                          double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          double momentum, double eps, long long* num_batches_tracked, float* mean, float* invstd, size_t M, int C,
+                          int relu, void* relu_mask, void* stream);
 /* backward counterpart: part_g / part_gx are `rows` atomically accumulated rows (saicv_conv2d_dgrad_fused with part_rows > 0);
  * coefficients, dgamma and dbeta come out of the one streaming kernel */
 int saicv_bn_act_bwd_inline(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,

@@ -52,14 +52,18 @@ class ConvBnActBlock(nn.Module):
         self.has_bn = has_bn
         self.has_act = has_act
 
-    def forward(self, x, residual=None, act=None, want_skip=False, pool=None):
+    def forward(self, x, residual=None, act=None, want_skip=False, pool=None, defer=False):
         """`residual` / `act` let the enclosing residual block fuse its add + ReLU in here; `want_skip` also
         returns the input as an alias the block uses for its shortcut, so that the shortcut's gradient is
         added inside this conv's dgrad epilogue (no separate gradient-sum kernel).  `pool` = (kernel, stride, padding) of the
-        nn.MaxPool2d that follows the block (the stem): BatchNorm-apply, ReLU and the pooling run as one pass."""
+        nn.MaxPool2d that follows the block (the stem): BatchNorm-apply, ReLU and the pooling run as one pass.  `defer`: the block
+        is a residual block's shortcut and its output goes ONLY into the `residual` argument of the block's last convolution,
+        which then applies this BatchNorm itself (ops.conv_bn_act)."""
         conv = self.layer[0]
         relu = self.has_act if act is None else act
         if self.has_bn and not self.depthwise:
+            if defer and not relu and residual is None and not want_skip and pool is None:
+                return ops.conv_bn_act(x, conv.weight, self.layer[1], self.stride, self.padding, False, defer=True)
             if pool is not None:
                 return ops.conv_bn_act(x, conv.weight, self.layer[1], self.stride, self.padding, relu, pool=pool)
             return ops.conv_bn_act(x, conv.weight, self.layer[1], self.stride, self.padding, relu, residual, want_skip)
@@ -93,7 +97,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out, skip = self.conv1(x, want_skip=True)
-        identity = self.downsample_conv(skip) if self.downsample else skip
+        identity = self.downsample_conv(skip, defer=ops.DS_JOIN_FUSE) if self.downsample else skip
         # relu(bn2(conv2(out)) + identity), fused into conv2's BN-apply kernel
         return self.conv2(out, residual=identity, act=True)
 
@@ -116,7 +120,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out, skip = self.conv1(x, want_skip=True)
-        identity = self.downsample_conv(skip) if self.downsample else skip
+        identity = self.downsample_conv(skip, defer=ops.DS_JOIN_FUSE) if self.downsample else skip
         out = self.conv2(out)
         return self.conv3(out, residual=identity, act=True)
 

@@ -40,7 +40,7 @@ class DETRDecoder:
             scores, classes, xyxy = scores[keep], classes[keep].astype(np.float32), xyxy[keep].astype(np.float32)
             if scores.shape[0] == 0:
                 continue
-            order = np.argsort(-scores)[:self.topn]
+            order = np.argsort(-scores, kind='stable')[:self.topn]       # equal scores keep their candidate (anchor) order
             n = min(self.max_object_num, order.shape[0])
             batch_scores[i, :n] = scores[order][:n]
             batch_classes[i, :n] = classes[order][:n]
@@ -150,7 +150,12 @@ class _DenseDecoder:
         dm = self.decode_function
         k = min(dm.topn, total)
         masked = torch.where(scores > dm.min_score_threshold, scores, torch.full_like(scores, float('-inf')))
-        top_scores, top_idx = torch.topk(masked, k, dim=1)
+        # ties: (score descending, anchor index ascending) -- a STABLE device sort, then the first k.  torch.topk picks arbitrary
+        # members of a tie at the cut (bf16 heads and saturated sigmoids produce many equal scores), which changed which boxes
+        # reached NMS from run to run.  The reference argsorts all anchors with numpy's default (unstable) sort, so its own order
+        # inside a tie is an accident of that array; lowest anchor index first is the deterministic reading of it.
+        order = torch.sort(masked, dim=1, descending=True, stable=True)
+        top_scores, top_idx = order.values[:, :k], order.indices[:, :k]
         top_classes = torch.gather(classes, 1, top_idx)
         top_reg = torch.gather(reg, 1, top_idx.unsqueeze(-1).expand(-1, -1, reg_dim))
         top_scores, top_idx, top_classes, top_reg = (t.cpu().numpy() for t in (top_scores, top_idx, top_classes, top_reg))

@@ -90,6 +90,8 @@ SIGNATURES = {
     'saicv_conv2d_fwd_stats': (c_int, [_PD, _P, _P, _P, _P, _P, c_int, _P]),
     'saicv_bn_act_fwd_stats': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_double, _P, _P, _P, _P, c_double, c_double, _P, _P, _P,
                                        c_size_t, c_int, c_int, _P, _P]),
+    'saicv_bn_act_fwd_join': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_double, _P, _P, _P, _P, c_double, c_double,
+                                      _P, _P, _P, c_size_t, c_int, c_int, _P, _P]),
     'saicv_bn_act_bwd_inline': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_size_t, c_int, c_int,
                                         c_int, _P]),
     'saicv_bn_act_bwd_from_partials': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_size_t, c_int,

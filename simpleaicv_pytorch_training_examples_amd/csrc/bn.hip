@@ -154,6 +154,9 @@ struct BnFwdInline {
     const float* gamma; const float* beta; float eps, momentum;
     float* running_mean; float* running_var; long long* num_batches_tracked;
     float* mean_out; float* invstd_out;
+    // r04: the residual is a RAW convolution output whose BatchNorm-apply happens here (the downsample branch of a residual
+    // block: res = res_scale[c] * res + res_shift[c]); NULL = the residual is a finished activation
+    const float* res_scale; const float* res_shift;
 };
 
 template <typename T, bool RELU, bool RES, bool HOIST, bool SELF>
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         scale = lsc;
         shift = lsh;
     }
-    float sc[N], sh[N];
+    float sc[N], sh[N], rsc[N], rsh[N];
+    const bool res_affine = RES && st.res_scale != nullptr;                  // uniform
     auto load_coeffs = [&](int c0) {
 #pragma unroll
         for (int j = 0; j < N; j += 4) {
@@ -200,6 +204,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
             const f32x4 b = *reinterpret_cast<const f32x4*>(shift + c0 + j);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { sc[j + k] = a[k]; sh[j + k] = b[k]; }
+            if (res_affine) {
+                const f32x4 ra = *reinterpret_cast<const f32x4*>(st.res_scale + c0 + j);
+                const f32x4 rb = *reinterpret_cast<const f32x4*>(st.res_shift + c0 + j);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rsc[j + k] = ra[k]; rsh[j + k] = rb[k]; }
+            }
         }
     };
     if (HOIST) load_coeffs((int)((first * N) % (size_t)C));
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float o = fmaf(v[j], sc[j], sh[j]);
-            if (RES) o += rr[j];
+            if (RES) o += res_affine ? fmaf(rr[j], rsc[j], rsh[j]) : rr[j];
             if (RELU) {
                 bits |= (o > 0.f ? 1u : 0u) << j;
                 o = fmaxf(o, 0.f);
@@ -477,13 +487,15 @@ int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* ru
 template <typename T>
 static int bn_act_fwd_t(const void* y, const void* res, void* z, const float* scale,
                         const float* shift, size_t M, int C, int relu, uint8_t* mask, hipStream_t st,
-                        const BnFwdInline* inl = nullptr) {
+                        const BnFwdInline* inl = nullptr, const float* res_scale = nullptr, const float* res_shift = nullptr) {
     constexpr int N = Chunk<T>::N;
     const size_t nchunks = M * (size_t)C / N;
     const int grid = stream_grid(nchunks);
     const T* yy = (const T*)y; const T* rr = (const T*)res; T* zz = (T*)z;
     const bool hoist = ((size_t)grid * 256) % (size_t)(C / N) == 0;
-    const BnFwdInline none = {};
+    BnFwdInline none = {};
+    none.res_scale = res_scale;
+    none.res_shift = res_shift;
 #define LAUNCH2(R, S, H) do { if (inl) hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, H, true>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C, mask, *inl); \
                               else hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, S, H, false>), dim3(grid), dim3(256), 0, st, yy, rr, zz, scale, shift, nchunks, C, mask, none); } while (0)
 #define LAUNCH(R, S) do { if (hoist) LAUNCH2(R, S, true); else LAUNCH2(R, S, false); } while (0)
@@ -514,6 +526,29 @@ int bn_act_fwd_stats(int dtype, const void* y, const void* res, void* z, const f
                        num_batches_tracked, mean_out, invstd_out};
     if (dtype == SAICV_DTYPE_BF16) return bn_act_fwd_t<bf16_t>(y, res, z, nullptr, nullptr, M, C, relu, (uint8_t*)relu_mask, st, &inl);
     return bn_act_fwd_t<float>(y, res, z, nullptr, nullptr, M, C, relu, (uint8_t*)relu_mask, st, &inl);
+}
+
+// the residual join of a block whose shortcut is a convolution + BatchNorm (downsample): that BatchNorm's apply happens in this
+// pass (res_scale / res_shift), its output is never written.  sum != NULL: the main branch's statistics arrive as atomically
+// accumulated rows (as bn_act_fwd_stats), else scale / shift are given (as bn_act_fwd).
+int bn_act_fwd_join(int dtype, const void* y, const void* res, const float* res_scale, const float* res_shift, void* z,
+                    const float* scale, const float* shift, const float* sum, const float* sq, int rows, double count,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var, double momentum, double eps,
+                    long long* num_batches_tracked, float* mean_out, float* invstd_out, size_t M, int C, int relu, void* relu_mask,
+                    hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && C % 4 == 0, "bn_act_fwd_join: C=%d must be a multiple of %d", C, n);
+    SAICV_REQUIRE(res && res_scale && res_shift, "bn_act_fwd_join: residual and its coefficients are required");
+    if (sum != nullptr) {
+        SAICV_REQUIRE(C <= kInlineMaxC && sq && rows >= 1 && rows <= 64 && mean_out && invstd_out, "bn_act_fwd_join: statistics rows / outputs missing (C=%d)", C);
+        BnFwdInline inl = {sum, sq, rows, (float)count, gamma, beta, (float)eps, (float)momentum, running_mean, running_var,
+                           num_batches_tracked, mean_out, invstd_out, res_scale, res_shift};
+        if (dtype == SAICV_DTYPE_BF16) return bn_act_fwd_t<bf16_t>(y, res, z, nullptr, nullptr, M, C, relu, (uint8_t*)relu_mask, st, &inl);
+        return bn_act_fwd_t<float>(y, res, z, nullptr, nullptr, M, C, relu, (uint8_t*)relu_mask, st, &inl);
+    }
+    SAICV_REQUIRE(scale && shift, "bn_act_fwd_join: scale / shift missing");
+    if (dtype == SAICV_DTYPE_BF16) return bn_act_fwd_t<bf16_t>(y, res, z, scale, shift, M, C, relu, (uint8_t*)relu_mask, st, nullptr, res_scale, res_shift);
+    return bn_act_fwd_t<float>(y, res, z, scale, shift, M, C, relu, (uint8_t*)relu_mask, st, nullptr, res_scale, res_shift);
 }
 
 // rows of partials produced by bn_bwd (so the caller can size the workspace)

@@ -44,6 +44,9 @@ int bn_bwd(int, const void*, const void*, const void*, const void*, const float*
            void*, float*, float*, size_t, int, int, int, float*, hipStream_t);
 int bn_act_fwd_stats(int, const void*, const void*, void*, const float*, const float*, int, double, const float*, const float*,
                      float*, float*, double, double, long long*, float*, float*, size_t, int, int, void*, hipStream_t);
+int bn_act_fwd_join(int, const void*, const void*, const float*, const float*, void*, const float*, const float*, const float*,
+                    const float*, int, double, const float*, const float*, float*, float*, double, double, long long*, float*,
+                    float*, size_t, int, int, void*, hipStream_t);
 int bn_bwd_inline(int, const void*, const void*, const void*, const float*, const float*, const float*, const float*,
                   const float*, int, void*, void*, float*, float*, size_t, int, int, int, hipStream_t);
 int bn_bwd_from_partials(int, const void*, const void*, const void*, const float*, const float*, const float*, const float*,
@@ -305,6 +308,15 @@ int saicv_bn_act_fwd_stats(int dtype, const void* y, const void* res, void* z, c
                            float* invstd, size_t M, int C, int relu, void* relu_mask, void* stream) {
     return bn_act_fwd_stats(dtype, y, res, z, stat_sum, stat_sq, stat_rows, count, gamma, beta, running_mean, running_var,
                             momentum, eps, num_batches_tracked, mean, invstd, M, C, relu, relu_mask, S(stream));
+}
+int saicv_bn_act_fwd_join(int dtype, const void* y, const void* res, const float* res_scale, const float* res_shift, void* z,
+                          const float* scale, const float* shift, const float* stat_sum, const float* stat_sq, int stat_rows,
+                          double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          double momentum, double eps, long long* num_batches_tracked, float* mean, float* invstd, size_t M, int C,
+                          int relu, void* relu_mask, void* stream) {
+    return bn_act_fwd_join(dtype, y, res, res_scale, res_shift, z, scale, shift, stat_sum, stat_sq, stat_rows, count, gamma, beta,
+                           running_mean, running_var, momentum, eps, num_batches_tracked, mean, invstd, M, C, relu, relu_mask,
+                           S(stream));
 }
 int saicv_bn_act_bwd_inline(int dtype, const void* dz, const void* relu_mask, const void* y, const float* gamma,
                             const float* mean, const float* invstd, const float* part_g, const float* part_gx, int rows,

@@ -291,6 +291,10 @@ def pack_input(x, dtype=None, cp=8):
 
 
 STEM_S2D = _os.environ.get('SAICV_STEM_S2D', '1') == '1'
+# the convolution + BatchNorm shortcut of a residual block hands its raw output to the block's join, which applies the
+# shortcut's BatchNorm in the same pass as the main branch's (one write + one read of the widest tensor of the block less);
+# SAICV_DS_JOIN_FUSE=0 materialises the normalised shortcut as before
+DS_JOIN_FUSE = _os.environ.get('SAICV_DS_JOIN_FUSE', '1') == '1'
 # BatchNorm-apply + ReLU + MaxPool of the ResNet stem as one pass (csrc/pool.hip bn_relu_maxpool_*); 0: the unfused pair
 STEM_POOL_FUSE = _os.environ.get('SAICV_STEM_POOL_FUSE', '1') == '1'
 
@@ -486,8 +490,12 @@ class ConvBnActFn(torch.autograd.Function):
     residual tail of BasicBlock / Bottleneck (:94-95, :152-153)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, pad, relu, want_skip=False, pool=None):
-        """pool = (kernel, stride, padding): the MaxPool2d behind the block runs in the same pass as BatchNorm-apply + ReLU
+    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, pad, relu, want_skip=False, pool=None, defer=False):
+        """defer: the node is the convolution + BatchNorm shortcut of a residual block; it returns the RAW convolution output
+        tagged with its BatchNorm coefficients (conv_bn_act hangs `_saicv_deferred` on it) and the one consumer -- the join node
+        that takes it as `residual` -- applies them in its own pass (csrc/bn.hip bn_act_fwd_join).  The gradient that comes back
+        is the one of the normalised shortcut, so the backward below is the ordinary one.
+        pool = (kernel, stride, padding): the MaxPool2d behind the block runs in the same pass as BatchNorm-apply + ReLU
         (the ResNet stem; csrc/pool.hip bn_relu_maxpool_*), the full-resolution activation is never written.
         want_skip: also return the (NHWC) input as a second output.  A residual block routes its shortcut
         through that alias, so the shortcut's gradient reaches THIS node's backward and is added in the
@@ -496,6 +504,9 @@ class ConvBnActFn(torch.autograd.Function):
         in_link = getattr(x, '_saicv_bn', None) if BN_FUSE else None
         xin = x
         res_gate_ok = bool(residual is not None and getattr(residual, '_saicv_gate_ok', False))
+        res_affine = getattr(residual, '_saicv_deferred', None) if residual is not None else None
+        if defer and (residual is not None or relu or want_skip or pool is not None):
+            raise ValueError('a deferred BatchNorm-apply belongs to a plain convolution + BatchNorm shortcut')
         x = _nhwc(x)
         dt = x.dtype
         n, c, h, w = x.shape
@@ -531,10 +542,13 @@ class ConvBnActFn(torch.autograd.Function):
             raise ValueError('the fused max-pool follows a plain conv -> BatchNorm -> ReLU block')
         # (the pooled form takes scale / shift from the finalize kernel: one 6 us launch, stem only)
         inline = training and BN_INLINE and k <= 2048 and pool is None
+        atomic_rows = inline
+        if defer:
+            inline = False                   # scale / shift must exist as tensors: the finalize launch stays (over the few rows)
         if training:
             rows = L.saicv_conv2d_stat_rows(ctypes.byref(d))
             t0 = KernelTimer.begin('igemm_nt')
-            if inline:
+            if atomic_rows:
                 rows = _stat_rows(rows)
                 stats = _ZeroPool.take(2 * rows * k, dev).view(2, rows, k)
                 check(L.saicv_conv2d_fwd_stats(ctypes.byref(d), ptr(x), ptr(wf), ptr(y), ptr(stats[0]), ptr(stats[1]), rows, st),
@@ -587,16 +601,44 @@ class ConvBnActFn(torch.autograd.Function):
             ctx.applies_gate = False
             return zp
         ctx.pool = None
+        if defer:
+            ConvBnActFn._deferred = (scale, shift)
+            if training:
+                ctx.save_for_backward(x, weight, gamma, y, None, mean, invstd)
+            else:
+                ctx.save_for_backward(x, weight, gamma, y, None, None, scale)
+            ctx.cfg = (stride, pad, False, False, training, d, wd)
+            ctx.beta_ref = beta
+            ctx.gated_res = False
+            ctx.link = None
+            ctx.applies_gate = bool(BN_FUSE and training)
+            return y
         if residual is not None:
+            res_in = residual
             residual = _nhwc(residual)
             if residual.dtype != dt:
                 residual = residual.to(dt)
+            if res_affine is not None and (residual is not res_in or residual.shape != y.shape):
+                # not the tensor the coefficients were made for (a layout / dtype change in between): apply them here
+                residual = (residual.float() * res_affine[0].view(1, -1, 1, 1) + res_affine[1].view(1, -1, 1, 1)).to(dt)
+                residual = _nhwc(residual)
+                res_affine = None
         z = _empty_nhwc(n, k, d.OH, d.OW, dt, dev)
         # backward needs only the sign of z: one byte per 16-byte chunk instead of re-reading z twice
         mask = (torch.empty(M * k // _lib.epc(dt), dtype=torch.uint8, device=dev)
                 if (relu and training and any(ctx.needs_input_grad)) else None)
         t0 = KernelTimer.begin('bn_act_fwd')
-        if inline:
+        if res_affine is not None:
+            # the shortcut arrives as a raw convolution output + its BatchNorm coefficients: applied on the fly
+            check(L.saicv_bn_act_fwd_join(dtype_code(dt), ptr(y), ptr(residual), ptr(res_affine[0]), ptr(res_affine[1]), ptr(z),
+                                          0 if inline else ptr(scale), 0 if inline else ptr(shift),
+                                          ptr(stats[0]) if inline else 0, ptr(stats[1]) if inline else 0, rows if inline else 0,
+                                          float(M), ptr(gamma), ptr(beta), ptr(bn.running_mean) if (inline and track) else 0,
+                                          ptr(bn.running_var) if (inline and track) else 0,
+                                          float(bn.momentum) if inline else 0.0, float(bn.eps), ptr(nbt) if inline else 0,
+                                          ptr(mean) if inline else 0, ptr(invstd) if inline else 0, M, k, int(relu), ptr(mask), st),
+                  'bn_act_fwd_join')
+        elif inline:
             # the kernel derives mean / invstd / scale / shift from the few statistics rows itself (and updates the running
             # statistics and num_batches_tracked): no finalize launch between the convolution and this one
             check(L.saicv_bn_act_fwd_stats(dtype_code(dt), ptr(y), ptr(residual), ptr(z), ptr(stats[0]), ptr(stats[1]), rows,
@@ -763,7 +805,7 @@ class ConvBnActFn(torch.autograd.Function):
             if not direct:
                 dwt = _weight_grad_s2d(dw, weight, c, gw) if ctx.s2d is not None else _weight_grad(dw, weight, c)
         return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None,
-                dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None, None, None)
+                dbeta if ctx.needs_input_grad[3] else None, dres, None, None, None, None, None, None, None)
 
 
 def _conv_bn_act_backward_pooled(ctx, dz, x, weight, gamma, y, idx, mean, invstd):
@@ -811,15 +853,24 @@ def _conv_bn_act_backward_pooled(ctx, dz, x, weight, gamma, y, idx, mean, invstd
         if not direct:
             dwt = _weight_grad_s2d(dw, weight, c, gw) if ctx.s2d is not None else _weight_grad(dw, weight, c)
     return (dx, dwt, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-            None, None, None, None, None, None, None)
+            None, None, None, None, None, None, None, None)
 
 
 ConvBnActFn._backward_pooled = staticmethod(_conv_bn_act_backward_pooled)
 
 
-def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None, want_skip=False, pool=None):
+def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None, want_skip=False, pool=None, defer=False):
+    """defer=True: ONLY for a tensor whose single consumer is the `residual` argument of another conv_bn_act call (what comes
+    back is the raw convolution output; its values are not the block's output until that consumer applies the coefficients)."""
     if pool is not None:
         return ConvBnActFn.apply(x, weight, bn.weight, bn.bias, None, bn, stride, pad, relu, False, pool)
+    if defer:
+        ConvBnActFn._deferred = None
+        out = ConvBnActFn.apply(x, weight, bn.weight, bn.bias, None, bn, stride, pad, False, False, None, True)
+        out._saicv_deferred, ConvBnActFn._deferred = ConvBnActFn._deferred, None
+        if BN_FUSE and out.grad_fn is not None and getattr(out.grad_fn, 'applies_gate', False):
+            out._saicv_gate_ok = True
+        return out
     out = ConvBnActFn.apply(x, weight, bn.weight, bn.bias, residual, bn, stride, pad, relu, want_skip)
     z = out[0] if want_skip else out
     node = z.grad_fn

@@ -255,3 +255,106 @@ def test_stem_bn_relu_maxpool_fused_equals_the_unfused_pair_and_torch(shape, dty
     for n, r in names.items():
         assert _l2_err(g_f[n], r) < (1e-3 if f32 else 1.5e-1), n        # bf16 against an fp32 reference: the conv output is rounded before the statistics
     assert rel_err(rv_f, ref[1].running_var) < (1e-3 if f32 else 1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ shortcut BatchNorm applied in the join
+def _torch_block(kind, inplanes, planes, stride):
+    """plain-torch restatement of the reference BasicBlock / Bottleneck (resnet.py:51-97, :100-155) for the CPU side"""
+    import torch.nn as nn
+
+    def cba(i, o, k, s, p, act):
+        return nn.Sequential(nn.Conv2d(i, o, k, s, p, bias=False), nn.BatchNorm2d(o), nn.ReLU() if act else nn.Sequential())
+
+    class Blk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            if kind == 'basic':
+                self.conv1, self.conv2 = cba(inplanes, planes, 3, stride, 1, True), cba(planes, planes, 3, 1, 1, False)
+                out = planes
+            else:
+                self.conv1, self.conv2 = cba(inplanes, planes, 1, 1, 0, True), cba(planes, planes, 3, stride, 1, True)
+                self.conv3 = cba(planes, planes * 4, 1, 1, 0, False)
+                out = planes * 4
+            self.downsample_conv = cba(inplanes, out, 1, stride, 0, False)
+
+        def forward(self, x):
+            y = self.conv2(self.conv1(x))
+            if kind != 'basic':
+                y = self.conv3(y)
+            return torch.relu(y + self.downsample_conv(x))
+    return Blk()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('kind,inplanes,planes,stride,hw', [('bottleneck', 64, 64, 1, 14), ('bottleneck', 256, 128, 2, 14),
+                                                             ('basic', 64, 128, 2, 12), ('bottleneck', 1024, 768, 2, 8)])
+@pytest.mark.parametrize('inline', [True, False], ids=['atomic_rows', 'finalize'])
+def test_shortcut_batchnorm_applied_inside_the_join(kind, inplanes, planes, stride, hw, dtype, inline, monkeypatch):
+    """`identity = downsample_conv(x); x = relu(x + identity)` (reference resnet.py:90-95, :148-153) with the shortcut's
+    BatchNorm-apply moved into the join pass (ops.DS_JOIN_FUSE, csrc/bn.hip bn_act_fwd_join): output, running statistics of BOTH
+    BatchNorms and every gradient against (a) the materialised form (SAICV_DS_JOIN_FUSE=0) and (b) torch modules on the CPU.
+    The last case (3072 output channels) takes the finalize-kernel form of the main branch even with atomic rows on."""
+    from simpleaicv_pytorch_training_examples_amd import ops
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.backbones.resnet import BasicBlock, Bottleneck
+    monkeypatch.setattr(ops, 'BN_INLINE', inline)
+    g = torch.Generator().manual_seed(inplanes + planes + hw)
+    ref = _torch_block(kind, inplanes, planes, stride)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3 + (1.0 if n.endswith('1.weight') else 0.0))
+    x = torch.randn(4, inplanes, hw, hw, generator=g).to(dtype).float()          # both sides see the same (rounded) input
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    out_ref = ref(xr)
+    probe = torch.randn(out_ref.shape, generator=g)
+    (out_ref * probe).sum().backward()
+    ref_grads = {n.replace('.0.', '.layer.0.').replace('.1.', '.layer.1.'): p.grad for n, p in ref.named_parameters()}
+    ref_bufs = {n.replace('.1.', '.layer.1.'): b for n, b in ref.named_buffers()}
+
+    def run(fuse):
+        monkeypatch.setattr(ops, 'DS_JOIN_FUSE', fuse)
+        blk = (BasicBlock if kind == 'basic' else Bottleneck)(inplanes, planes, stride)
+        blk.load_state_dict({k.replace('.0.', '.layer.0.').replace('.1.', '.layer.1.'): v for k, v in sd0.items()})
+        for m in blk.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        blk = blk.cuda().train()
+        xin = x.cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ctx = torch.autocast('cuda', dtype=torch.bfloat16) if dtype == torch.bfloat16 else torch.autocast('cuda', enabled=False)
+        with ctx:
+            out = blk(xin)
+        (out.float() * probe.cuda()).sum().backward()
+        with torch.no_grad(), ctx:
+            out_eval = blk.eval()(xin.detach()).float()
+        torch.cuda.synchronize()
+        return (out.float(), xin.grad.float(), {n: p.grad.clone() for n, p in blk.named_parameters()},
+                {n: b.clone().float() for n, b in blk.named_buffers()}, out_eval)
+
+    out_f, dx_f, g_f, b_f, ev_f = run(True)
+    out_u, dx_u, g_u, b_u, ev_u = run(False)
+    f32 = dtype == torch.float32
+    # (a) fused vs materialised: in fp32 the only difference is one rounding of the normalised shortcut that no longer happens
+    # (it stays in registers); in bf16 that rounding was a bf16 one, so the fused form is the MORE accurate of the two
+    assert _l2_err(out_f, out_u) < (1e-6 if f32 else 4e-3)
+    assert _l2_err(ev_f, ev_u) < (1e-6 if f32 else 4e-3)
+    # (bf16 gradients: the dropped rounding moves a few ReLU gates of the join, 2-4 % in L2 -- both forms are equally far from fp32)
+    # fp32: 2e-5 is what summation order gives; ONE join gate whose pre-activation sits within an ulp of zero flipping between
+    # the two forms moves a gradient by ~1e-3 (measured on the smoke model, __graft_entry__.py) -- hence 5e-3, the outputs above
+    # (which a flip at zero does not move) carry the tight bound
+    assert _l2_err(dx_f, dx_u) < (5e-3 if f32 else 6e-2)
+    for n in g_f:
+        assert _l2_err(g_f[n], g_u[n]) < (5e-3 if f32 else 6e-2), n
+    for n in b_f:
+        assert _l2_err(b_f[n], b_u[n]) < (1e-5 if f32 else 1e-4), n       # (means near zero summed by atomics in a free order)
+    # (b) against torch in fp32 on the CPU
+    assert _l2_err(out_f, out_ref) < (1e-4 if f32 else 1e-2)
+    # bf16: every activation is rounded to 8 bits before the next statistics / ReLU gate; gradients at 14 x 14 x 4 samples sit
+    # 5-10 % from an fp32 run (the materialised form is as far: checked above against it at 2e-2)
+    # fp32 against torch: different summation trees in the convolutions put a handful of the 1e5 ReLU gates on the other side of
+    # zero; with 4 x 4 x 4 .. 14 x 14 x 4 samples per BatchNorm channel each flip is visible at the 1e-3 .. 1e-2 level
+    assert _l2_err(dx_f, xr.grad) < (2e-2 if f32 else 1.5e-1)
+    for n, r in ref_grads.items():
+        assert _l2_err(g_f[n], r) < (2e-2 if f32 else 1.5e-1), n
+    for n, r in ref_bufs.items():
+        assert _l2_err(b_f[n], r.float()) < (1e-4 if f32 else 1e-2), n
