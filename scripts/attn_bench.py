@@ -34,9 +34,10 @@ def run(name, b, heads, d, n, rel, kb):
                       'bwd_us': round(tb * 1e6, 1), 'bwd_tf': round(2.5 * fl / tb / 1e12, 1)}), flush=True)
 
 
-run('sam_global_b8', 8, 12, 64, 4096, (64, 64), False)
-run('sam_window_b8', 200, 12, 64, 196, (14, 14), False)
-run('detr_enc_b8', 8, 8, 32, 1764, None, True)
-run('plain_d64_n4096_b8', 8, 12, 64, 4096, None, False)
-run('vit_b256_n197', 256, 12, 64, 197, None, False)
-run('sam_window_norel_b8', 200, 12, 64, 196, None, False)
+CASES = [('sam_global_b8', 8, 12, 64, 4096, (64, 64), False), ('sam_window_b8', 200, 12, 64, 196, (14, 14), False),
+         ('detr_enc_b8', 8, 8, 32, 1764, None, True), ('plain_d64_n4096_b8', 8, 12, 64, 4096, None, False),
+         ('vit_b256_n197', 256, 12, 64, 197, None, False), ('sam_window_norel_b8', 200, 12, 64, 196, None, False)]
+ONLY = [c for c in os.environ.get('ATTN_CASES', '').split(',') if c]
+for case in CASES:
+    if not ONLY or case[0] in ONLY:
+        run(*case)

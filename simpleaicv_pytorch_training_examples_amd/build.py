@@ -9,6 +9,10 @@ LIB = os.path.join(HERE, 'libsaicv_hip.so')
 SOURCES = ['igemm.hip', 'bn.hip', 'pool.hip', 'loss.hip', 'pack.hip', 'optim.hip', 'tfm.hip', 'attn_stream.hip', 'maskloss.hip', 'sam.hip', 'samtail.hip', 'input.hip', 'dwconv.hip', 'elemwise.hip', 'detloss.hip', 'groupnorm.hip', 'comm.hip', 'capi.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
          '-Wno-unused-result', '-Wno-unused-value']
+# attn_stream.hip: the running-maximum chains of the softmax are v_max3_f32 only when the compiler need not quiet signalling
+# NaNs first (one v_max x, x per logit otherwise); no value in these kernels is ever NaN by construction (masked logits are -inf,
+# the first chunk of a row always holds a finite one)
+EXTRA_FLAGS = {'attn_stream.hip': ['-fno-honor-nans', '-Wno-inline-asm']}      # (the LDS-DMA statement names m0 as clobbered)
 
 
 def _hipcc():
@@ -40,7 +44,7 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print('[saicv build]', ' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -117,6 +117,36 @@ template <> DEVINL int sa_swz<64>(int row) { const int q = (row >> 2) & 3; retur
 template <> DEVINL int sa_swz<128>(int row) { return (row >> 1) & 7; }
 template <> DEVINL int sa_swz<256>(int row) { return row & 15; }
 
+// LDS-DMA as an assembly statement.  Through the builtin the compiler tracks the transfer as a pending LDS write and puts a
+// vmcnt wait for it in front of every later LDS access it cannot tell apart from the destination -- the ds_read_tr intrinsics
+// of the P.V / dS.K steps in particular: the r04 instruction streams showed s_waitcnt vmcnt(0..2) between the two MFMA groups
+// of EVERY chunk, i.e. the next chunk's L2 round trip exposed in the middle of the current one (SQ_WAIT_ANY 27-61 % of the
+// wavefront cycles).  The statement hides the LDS side; completion is what the kernels' own counted vmcnt + barrier at the top
+// of a chunk establish (both carry a memory clobber).  The compiler's own vmcnt arithmetic stays safe: counters retire in
+// order, an unknown older transfer only makes its waits longer than it thinks.  m0 = destination of the wavefront's 1 KiB
+// piece; one wait state between writing m0 and the DMA reading it (LDS-DMA m0 hazard, gfx9).
+typedef u32x4 sa_rsrc_t;
+DEVINL sa_rsrc_t sa_make_rsrc(const void* g, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(g);
+    return sa_rsrc_t{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+DEVINL unsigned sa_lds_addr(const void* lds) {
+    typedef __attribute__((address_space(3))) const char lds_char;
+    return (unsigned)reinterpret_cast<unsigned long long>((lds_char*)lds);
+}
+DEVINL void sa_dma16(const sa_rsrc_t& rs, unsigned lds_dst, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rs) : "memory", "m0");
+}
+
+// "These registers are final": an empty statement that takes them as operands.  The compiler finishes its own pending loads
+// into them HERE -- before the chunk loop -- instead of at their first use inside it, where its s_waitcnt vmcnt(n) (n = the
+// loads IT knows to be younger) would also wait for the DMA pieces it knows nothing about, in every chunk.
+template <typename V> DEVINL void sa_settle(V& v) { asm volatile("" : "+v"(v)); }
+template <typename V, int N> DEVINL void sa_settle(V (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) sa_settle(v[i]);
+}
+
 template <typename T, int D>
 struct SA {
     static constexpr int EPC = ElemTraits<T>::EPC;
@@ -148,20 +178,25 @@ struct SA {
         }
     };
     // the same chunk global -> LDS by DMA (no staging registers): the DMA fills wave-linear 16-byte slots, so the
-    // image's XOR swizzle is applied to the SOURCE address; rows >= nvalid come back as zeros (buffer bounds)
-    static DEVINL __amdgpu_buffer_rsrc_t rsrc(const T* g, long rs, int nvalid) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g), 0, (int)(((size_t)(nvalid - 1) * rs + D) * sizeof(T)), 0x00020000);
+    // image's XOR swizzle is applied to the SOURCE address.  Rows >= nvalid come back as zeros through the buffer bounds
+    // alone: the descriptor ends behind row nvalid - 1 (rs >= D), every later row starts past it -- no select per piece
+    // (the host checks that the whole operand stays below 2 GiB, so the 32-bit offsets cannot wrap)
+    static DEVINL sa_rsrc_t rsrc(const T* g, long rs, int nvalid) {
+        return sa_make_rsrc(g, (unsigned)(((size_t)(nvalid - 1) * rs + D) * sizeof(T)));
     }
-    static DEVINL void dma(const __amdgpu_buffer_rsrc_t& r, char* lds, long rs, int r0, int nvalid, int wave, int lane) {
-        typedef __attribute__((address_space(3))) void lds_void;
+    // per-lane byte offset of piece j inside a chunk that starts at row 0 (constant over the kernel: hoisted by the caller's loop)
+    static DEVINL unsigned dma_lane_off(long rs, int j, int wave, int lane) {
+        const int slot = (j * SA_WAVES + wave) * 64 + lane;
+        const int row = slot / DCH, pos = slot - row * DCH;
+        const int c = pos ^ sa_swz<ROWB>(row);
+        return (unsigned)(((size_t)row * rs + c * EPC) * sizeof(T));
+    }
+    static DEVINL void dma(const sa_rsrc_t& r, char* lds, long rs, int r0, int nvalid, int wave, int lane) {
+        const unsigned base = (unsigned)((size_t)r0 * rs * sizeof(T));          // wave-uniform
+        const unsigned dst = sa_lds_addr(lds) + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int slot = (j * SA_WAVES + wave) * 64 + lane;
-            const int row = slot / DCH, pos = slot - row * DCH;
-            const int c = pos ^ sa_swz<ROWB>(row);
-            const unsigned off = (r0 + row) < nvalid ? (unsigned)(((size_t)(r0 + row) * rs + c * EPC) * sizeof(T)) : 0xfffffff0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(lds + (j * SA_WAVES + wave) * 1024), 16, (int)off, 0, 0, 0);
-        }
+        for (int j = 0; j < NLD; ++j)
+            sa_dma16(r, dst + j * SA_WAVES * 1024, dma_lane_off(rs, j, wave, lane) + base);      // (the vector offset is what the bounds check sees)
     }
     static DEVINL void lds_frags(u32x4 (&f)[STEPS], const char* lds, int row0, int l15, int lg) {
 #pragma unroll
@@ -175,6 +210,12 @@ struct SA {
     }
     static DEVINL f32x4 tile(const u32x4 (&a)[STEPS], const u32x4 (&b)[STEPS]) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) Mma<T>::run(acc, a[s], b[s]);
+        return acc;
+    }
+    // the same chain on top of a C operand the caller keeps in registers (a row constant such as -D costs nothing this way)
+    static DEVINL f32x4 tile_c(const u32x4 (&a)[STEPS], const u32x4 (&b)[STEPS], f32x4 acc) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) Mma<T>::run(acc, a[s], b[s]);
         return acc;
@@ -257,7 +298,7 @@ template <typename T> struct SARel {
 };
 
 // ------------------------------------------------------------------------------------ forward
-template <typename T, int D, int REL, bool DROP>
+template <typename T, int D, int REL, bool DROP, bool KB>
 // (256, 2): two workgroups per CU; the backward kernels spill under that bound and are faster at one
 __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p) {
     using S = SA<T, D>;
@@ -270,20 +311,22 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     const int sa_lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, lg = lane >> 4;
     char* KV = smem;                                      // [2 buffers][K chunk | V chunk], filled by DMA
     float* rh = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES) + wave * SA_WROWS * (p.Sh + p.Sw + 2);
     float* rw = rh + SA_WROWS * (p.Sh + 1);
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
-    const float* kb = p.key_bias ? p.key_bias + (size_t)b * p.Nk : nullptr;
-    if constexpr (REL == 0) {        // DETR: the key-bias row goes to LDS once; a global load inside the chunk loop
-        if (kb != nullptr && p.Nk <= SA_KB_LDS) {       // would wait behind the next chunk's DMA (vmcnt is in order)
-            float* kbs = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
-            for (int i = threadIdx.x; i < p.Nk; i += SA_THREADS) kbs[i] = kb[i];
-            kb = kbs;                                   // published by the first barrier of the loop
-        }
+    // DETR: the key-bias row (* log2 e, zero-padded to whole chunks) goes to LDS once -- a global load inside the chunk loop
+    // would be waited for behind the next chunk's DMA (vmcnt is in order); published by the first barrier of the loop
+    const float* kbs = reinterpret_cast<const float*>(smem + 4 * S::CHUNK_BYTES);
+    if constexpr (KB) {
+        static_assert(REL == 0 || REL == 2, "key bias: plain and Sw == 64 forms");
+        float* w = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
+        const float* kbg = p.key_bias + (size_t)b * p.Nk;
+        const int padded = (p.Nk + SA_CHUNK - 1) / SA_CHUNK * SA_CHUNK;
+        for (int i = threadIdx.x; i < padded; i += SA_THREADS) w[i] = i < p.Nk ? kbg[i] * LOG2E : 0.f;
     }
     const int q0 = blk * SA_BROWS + wave * SA_WROWS;
     if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
@@ -296,7 +339,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
 #pragma unroll
             for (int e = 0; e < RL::ECH; ++e) rf[qt][e] = RL::row_frag(p, bh, q0 + qt * 16 + l15, e * 4 + lg, 1.f / p.scale);
     }
-    float rwreg[2][16];
+    f32x4 rwq[2][4];                                          // REL 2: rel_w[q][kt*16 + lg*4 + 0..3] * log2(e)
     if constexpr (REL == 2) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -305,8 +348,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
             for (int kt = 0; kt < 4; ++kt) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (q < p.Nq) v = *reinterpret_cast<const f32x4*>(p.rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rwreg[qt][kt * 4 + r] = v[r] * LOG2E;
+                rwq[qt][kt] = v * LOG2E;
             }
         }
     }
@@ -324,9 +366,9 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
-    const __amdgpu_buffer_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
+    const sa_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
-    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.v_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.k_rs, 0, p.Nk, wave, lane);
     float rhn[2] = {0.f, 0.f};
     if constexpr (REL == 2) {
 #pragma unroll
@@ -335,17 +377,21 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
             if (q < p.Nq) rhn[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh];
         }
     }
+    sa_settle(qf);
+    if constexpr (EMM) sa_settle(rf);
+    if constexpr (REL == 2) sa_settle(rwq);
 
     for (int k0 = 0; k0 < p.Nk; k0 += SA_CHUNK) {
         const int buf = (k0 / SA_CHUNK) & 1;
         const char* Ks = KV + buf * 2 * S::CHUNK_BYTES;
         const char* Vs = Ks + S::CHUNK_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk has landed (own DMA) ...
+        if constexpr (REL == 2) sa_settle(rhn);
         __syncthreads();                                      // ... for every wavefront; the other buffer is free again
         if (k0 + SA_CHUNK < p.Nk) {                           // next chunk streams in under this one's math
             char* nxt = KV + (buf ^ 1) * 2 * S::CHUNK_BYTES;
             S::dma(k_rsrc, nxt, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
-            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.v_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
         }
         // REL 2: this chunk's rel_h value was fetched during the previous chunk (a load issued here and used
         // right away would also wait for the DMA of the NEXT chunk: vmcnt retires in order)
@@ -382,13 +428,13 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + kt * 16 + lg * 4 + r;
                 float kbv = 0.f;
-                if (kb) kbv = key < p.Nk ? kb[key] * LOG2E : 0.f;
+                if constexpr (KB) kbv = kbs[key];
                 int kh = 0, kw = 0;
                 if constexpr (TAB) sa_split_key(key, inv_sw, p.Sw, kh, kw);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
                     float bias = kbv;
-                    if constexpr (REL == 2) bias += rhc[qt] + rwreg[qt][kt * 4 + r];
+                    if constexpr (REL == 2) bias += rhc[qt] + rwq[qt][kt][r];
                     if constexpr (TAB) bias += rh[(qt * 16 + l15) * (p.Sh + 1) + kh] + rw[(qt * 16 + l15) * (p.Sw + 1) + kw];
                     float s = st[qt][kt][r] * c2 + bias;
                     if (tail && key >= p.Nk) s = -INFINITY;
@@ -492,10 +538,12 @@ DEVINL float sa_lg_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <typename T, int D, int REL>
+template <typename T, int D, int REL, bool KB>
 __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p) {
     using S = SA<T, D>;
-    static_assert(REL == 0 || REL == 2, "r04 forward: no bias / key bias (REL 0) or the 64-wide decomposed bias (REL 2)");
+    static_assert(REL == 0 || (REL <= 2 && !KB), "r04 forward: no bias / key bias (REL 0), window tables on the MFMA (REL 1) or "
+                                                 "the 64-wide decomposed bias (REL 2)");
+    using RL = SARel<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int sa_lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
@@ -504,27 +552,34 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
     constexpr int STAGE = 2 * S::CHUNK_BYTES;                 // K chunk | V chunk
     char* KV = smem;                                          // [SA_RING][K | V]
     float* aux = reinterpret_cast<float*>(smem + SA_RING * STAGE);      // REL 2: rel_h rows [128 queries][Sh] * log2(e); REL 0: key bias
+    char* Es = smem + SA_RING * STAGE;                        // REL 1: key -> (kh, kw) indicator matrix [256][32] (SARel)
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
     const int q0 = blk * SA_BROWS + wave * SA_WROWS;
-    const __amdgpu_buffer_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
+    const sa_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     const int nchunk = (p.Nk + SA_CHUNK - 1) / SA_CHUNK;
     // ring prologue first: the two chunks stream in under the rest of the set-up
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
-    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.v_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.k_rs, 0, p.Nk, wave, lane);
     if (nchunk > 1) {
         S::dma(k_rsrc, KV + STAGE, p.k_rs, SA_CHUNK, p.Nk, wave, lane);
-        S::dma(v_rsrc, KV + STAGE + S::CHUNK_BYTES, p.v_rs, SA_CHUNK, p.Nk, wave, lane);
+        S::dma(v_rsrc, KV + STAGE + S::CHUNK_BYTES, p.k_rs, SA_CHUNK, p.Nk, wave, lane);
     }
-    const float* kb = nullptr;
-    if constexpr (REL == 0) {
-        if (p.key_bias != nullptr) {                          // host: Nk <= SA_KB_LDS on this path
-            const float* kbg = p.key_bias + (size_t)b * p.Nk;
-            for (int i = threadIdx.x; i < p.Nk; i += SA_THREADS) aux[i] = kbg[i] * LOG2E;
-            kb = aux;
-        }
-    } else {
+    const float* kb = aux;
+    if constexpr (KB) {                                       // host: Nk <= SA_KB_LDS on this path
+        const float* kbg = p.key_bias + (size_t)b * p.Nk;
+        for (int i = threadIdx.x; i < nchunk * SA_CHUNK; i += SA_THREADS) aux[i] = i < p.Nk ? kbg[i] * LOG2E : 0.f;
+    }
+    u32x4 rf[2][RL::ECH];
+    if constexpr (REL == 1) {
+        RL::build_E(Es, p);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int e = 0; e < RL::ECH; ++e) rf[qt][e] = RL::row_frag(p, bh, q0 + qt * 16 + l15, e * 4 + lg, 1.f / p.scale);
+    }
+    if constexpr (REL == 2) {
         // rel_h[q][kh] of the block's queries, TRANSPOSED [kh][128 queries]: a chunk reads one row, 16 consecutive floats per
         // lane group (conflict free), and two workgroups still share a CU (3 x 16 KiB ring + 32 KiB = 80 KiB each)
         const int rows = min(SA_BROWS, p.Nq - blk * SA_BROWS);
@@ -534,7 +589,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
             aux[c * SA_BROWS + r] = r < rows ? rg[(size_t)r * p.Sh + c] * LOG2E : 0.f;
         }
     }
-    float rwreg[2][16];
+    f32x4 rwq[2][4];                                          // REL 2: rel_w[q][kt*16 + lg*4 + 0..3] * log2(e)
     if constexpr (REL == 2) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -543,15 +598,15 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
             for (int kt = 0; kt < 4; ++kt) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (q < p.Nq) v = *reinterpret_cast<const f32x4*>(p.rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rwreg[qt][kt * 4 + r] = v[r] * LOG2E;
+                rwq[qt][kt] = v * LOG2E;
             }
         }
     }
     u32x4 qf[2][S::STEPS];
     S::gmem_frags(qf[0], qg, p.q_rs, q0, p.Nq, l15, lg);
     S::gmem_frags(qf[1], qg, p.q_rs, q0 + 16, p.Nq, l15, lg);
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY};
+    f32x4 l_run[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 o[2][S::DT];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
@@ -560,7 +615,11 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
     const float c2 = p.scale * LOG2E;
     const float* rhcol = aux + wave * SA_WROWS + l15;          // REL 2: + ci * SA_BROWS (+ 16 for the second query tile)
     // every ordinary load of the prologue has been consumed into registers / LDS before the first counted wait below
+    sa_settle(qf);
+    if constexpr (REL == 1) sa_settle(rf);
+    if constexpr (REL == 2) sa_settle(rwq);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (REL != 0 || KB) __syncthreads();            // the LDS tables written above are complete for every wavefront
 
     int slot = 0;                                             // ring slot of the chunk being consumed
     for (int ci = 0; ci < nchunk; ++ci) {
@@ -574,7 +633,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
         if (ci + 2 < nchunk) {
             const int ns = slot == 0 ? 2 : slot - 1;          // (slot + 2) % 3
             S::dma(k_rsrc, KV + ns * STAGE, p.k_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
-            S::dma(v_rsrc, KV + ns * STAGE + S::CHUNK_BYTES, p.v_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, KV + ns * STAGE + S::CHUNK_BYTES, p.k_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
         }
         f32x4 st[2][4];
 #pragma unroll
@@ -583,30 +642,56 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
             S::lds_frags(kf, Ks, kt * 16, l15, lg);
             st[0][kt] = S::tile(kf, qf[0]);
             st[1][kt] = S::tile(kf, qf[1]);
+            if constexpr (REL == 1) {                         // + R[q] . E[key]: the table values join the same accumulator
+#pragma unroll
+                for (int e = 0; e < RL::ECH; ++e) {
+                    const u32x4 ef = ld_chunk(Es + sa_off<RL::EROWB>(k0 + kt * 16 + l15, e * 4 + lg));
+                    Mma<T>::run(st[0][kt], ef, rf[0][e]);
+                    Mma<T>::run(st[1][kt], ef, rf[1][e]);
+                }
+            }
         }
-        const bool tail = k0 + SA_CHUNK > p.Nk;
+        const bool tail = REL != 2 && k0 + SA_CHUNK > p.Nk;   // wave-uniform: only the last chunk pays for the key mask (REL 2: Nk = Sh * 64)
         float rowb[2] = {0.f, 0.f};                           // REL 2: the chunk is one kh row -> one bias value per query
         if constexpr (REL == 2) {
             rowb[0] = rhcol[ci * SA_BROWS];
             rowb[1] = rhcol[ci * SA_BROWS + 16];
         }
+        // The elementwise work between the two MFMA groups is what the kernel is bound by (one VALU instruction is four
+        // cycles per wavefront, an MFMA sixteen): it is written on float4 values so that the multiply-adds, the running sum
+        // and the exponent offsets issue as packed fp32 instructions (two elements each), and the log2-domain scale rides
+        // on the instruction that adds the bias / the offset instead of being a pass of its own.
+        constexpr bool plain = REL != 2 && !KB;               // logits stay unscaled until the exponent's fma
+        const f32x4 c2v = {c2, c2, c2, c2};
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            // logits in the log2 domain WITHOUT the per-row constant rowb (it joins the exponent's offset below)
-            float mx = -INFINITY;
+            if (!plain) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sv = st[qt][kt][r] * c2;
-                    if constexpr (REL == 2) sv += rwreg[qt][kt * 4 + r];
-                    if constexpr (REL == 0) {
-                        if (kb) sv += kb[min(k0 + kt * 16 + lg * 4 + r, p.Nk - 1)];
-                    }
-                    if (tail && k0 + kt * 16 + lg * 4 + r >= p.Nk) sv = -INFINITY;
-                    st[qt][kt][r] = sv;
-                    mx = fmaxf(mx, sv);
+                for (int kt = 0; kt < 4; ++kt) {
+                    f32x4 bq;
+                    if constexpr (REL == 2) bq = rwq[qt][kt];
+                    else bq = *reinterpret_cast<const f32x4*>(kb + k0 + kt * 16 + lg * 4);      // (aux is padded to the chunk)
+                    st[qt][kt] = st[qt][kt] * c2v + bq;
                 }
+            }
+            if (tail) {                                       // a real branch: the other chunks pay neither selects nor indices
+                int kb0 = k0 + lg * 4;
+                asm volatile("" : "+v"(kb0));                 // (opaque: keeps the index arithmetic inside the branch)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb0 + kt * 16 + r >= p.Nk) st[qt][kt][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(st[qt][0][0], st[qt][0][1]), st[qt][0][2]);       // v_max3_f32 chain
+            mx = fmaxf(fmaxf(mx, st[qt][0][3]), st[qt][1][0]);
+            mx = fmaxf(fmaxf(mx, st[qt][1][1]), st[qt][1][2]);
+            mx = fmaxf(fmaxf(mx, st[qt][1][3]), st[qt][2][0]);
+            mx = fmaxf(fmaxf(mx, st[qt][2][1]), st[qt][2][2]);
+            mx = fmaxf(fmaxf(mx, st[qt][2][3]), st[qt][3][0]);
+            mx = fmaxf(fmaxf(mx, st[qt][3][1]), st[qt][3][2]);
+            mx = fmaxf(mx, st[qt][3][3]);
+            if (plain) mx *= c2;                              // c2 > 0: the maximum commutes with the scale
             mx = sa_lg_max(mx) + rowb[qt];
             // deferred rescale: the reference point moves only when this row's maximum outgrew it by 2^8
             const bool grow = mx > m_run[qt] + SA_RESCALE_LOG2;
@@ -623,16 +708,14 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
                 }
             }
             const float off = rowb[qt] - m_run[qt];
-            float psum = 0.f;
+            const f32x4 offv = {off, off, off, off};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = fast_exp2(st[qt][kt][r] + off);
-                    st[qt][kt][r] = e;
-                    psum += e;
-                }
-            l_run[qt] += psum;                                // per-lane partial; combined over the lane groups at the end
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 x = plain ? st[qt][kt] * c2v + offv : st[qt][kt] + offv;
+                const f32x4 e = {fast_exp2(x[0]), fast_exp2(x[1]), fast_exp2(x[2]), fast_exp2(x[3])};
+                st[qt][kt] = e;
+                l_run[qt] += e;                               // per-lane partials (four of them); combined at the end
+            }
         }
         {
             const f32x4 a0[2] = {st[0][0], st[1][0]}, a1[2] = {st[0][1], st[1][1]};
@@ -645,7 +728,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
     T* og = (T*)p.out + (size_t)b * p.o_bs + h * D;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        const float l = sa_lg_sum(l_run[qt]);
+        const float l = sa_lg_sum((l_run[qt][0] + l_run[qt][1]) + (l_run[qt][2] + l_run[qt][3]));
         const int qrow = q0 + qt * 16 + l15;
         if (lg == 0 && qrow < p.Nq) p.lse[(size_t)bh * p.Nq + qrow] = (m_run[qt] + log2f(l)) * LN2;
         const float inv = 1.f / l;
@@ -663,10 +746,17 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
 
 // ------------------------------------------------------------------------------------ backward: dQ (+ D, d rel-pos)
 // LDS: K chunk | V chunk | REL 1: indicator [256][32] | REL 1/3: per-wave tables | REL 3: per-wave gradient tables
-template <typename T, int D, int REL, bool DROP>
-// (256, 2): every instantiation fits 256 VGPRs -- two workgroups per CU and VGPR-form MFMAs (no AGPR <-> VGPR copies
-// around the short-lived S / dP tiles)
-__global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams p) {
+//
+// r04: the chunk's elementwise work (32 logits per lane) was what the kernel waited for -- 417 vector instructions per chunk
+// against 48 MFMAs (4 vs 16 cycles each).  Now: -D rides in the C operand of the dO.V^T MFMAs; the log2-domain scale, the
+// row's -lse and the bias are ONE packed fma per two logits; the key mask is a branch only the last chunk takes; rows past
+// Nq need no mask at all (their Q / dO fragments, D and lse are zeros: P = exp2(bias) is finite and dS = P * (0 - 0) = 0);
+// the key bias is a template switch instead of a pointer test per logit.
+template <typename T, int D, int REL, bool DROP, bool KB>
+// every instantiation fits 256 VGPRs -- two workgroups per CU and VGPR-form MFMAs (no AGPR <-> VGPR copies around the
+// short-lived S / dP tiles); the plain form is held to 168 so that THREE wavefronts share a SIMD: the loop is bound by the
+// vector issue port (an MFMA holds it four slots, anything else one), and a third wavefront is what keeps the port fed
+__global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) == 2 && D == 64) ? 3 : 2) void sa_bwd_dq_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 3;         // per-wave LDS tables + VALU adds
     constexpr bool EMM = REL == 1;         // bias on the MFMA (SARel), gradients through the same indicator matrix
@@ -679,7 +769,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
     const int sa_lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, lg = lane >> 4;
     char* KV = smem;                                      // [2 buffers][K chunk | V chunk], filled by DMA
     char* Es = smem + 4 * S::CHUNK_BYTES;
     const int tabw = SA_WROWS * (p.Sh + p.Sw + 2);
@@ -688,22 +778,20 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
     float* rw = rh + SA_WROWS * (p.Sh + 1);
     float* gh = rh + tabw;                                // REL 3 only
     float* gw = gh + SA_WROWS * (p.Sh + 1);
-    // REL 2: d rel_w accumulates in LDS ([32 queries][64 kw], pitch 68 floats) -- every lane owns its own
-    // 16-byte slots, so plain ds_read_b128 / ds_write_b128 pairs do (LDS float atomics are far slower); keeping
-    // the 32 accumulators in registers held the kernel at one wavefront per SIMD
-    float* gws = tabs + wave * SA_WROWS * 68;
+    // REL 2: d rel_w accumulates in 32 registers per lane (the kernel sits at two wavefronts per SIMD with or without them;
+    // the r03 LDS read-modify-write of the same tile doubled the kernel's LDS traffic -- SQ_LDS_IDX_ACTIVE 203 vs 101 M)
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
     const T* og = (const T*)p.out + (size_t)b * p.o_bs + h * D;
     const T* dog = (const T*)p.dout + (size_t)b * p.o_bs + h * D;
-    const float* kb = p.key_bias ? p.key_bias + (size_t)b * p.Nk : nullptr;
-    if constexpr (REL == 0) {        // key-bias row in LDS (see the forward kernel)
-        if (kb != nullptr && p.Nk <= SA_KB_LDS) {
-            float* kbs = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
-            for (int i = threadIdx.x; i < p.Nk; i += SA_THREADS) kbs[i] = kb[i];
-            kb = kbs;
-        }
+    const float* kbs = reinterpret_cast<const float*>(smem + 4 * S::CHUNK_BYTES);
+    if constexpr (KB) {              // key-bias row (* log2 e, zero-padded to whole chunks) in LDS (see the forward kernel)
+        static_assert(REL == 0 || REL == 2, "key bias: plain and Sw == 64 forms");
+        float* w = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
+        const float* kbg = p.key_bias + (size_t)b * p.Nk;
+        const int padded = (p.Nk + SA_CHUNK - 1) / SA_CHUNK * SA_CHUNK;
+        for (int i = threadIdx.x; i < padded; i += SA_THREADS) w[i] = i < p.Nk ? kbg[i] * LOG2E : 0.f;
     }
     const int q0 = blk * SA_BROWS + wave * SA_WROWS;
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
@@ -719,11 +807,16 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
 #pragma unroll
             for (int e = 0; e < RL::ECH; ++e) rf[qt][e] = RL::row_frag(p, bh, q0 + qt * 16 + l15, e * 4 + lg, 1.f / p.scale);
     }
-    float rwreg[2][16];
+    f32x4 rwq[2][4];                                          // REL 2: rel_w[q][kt*16 + lg*4 + 0..3] * log2(e)
+    f32x4 gwq[2][4];                                          // REL 2: d rel_w of the same positions
+    f32x2 ghq[2];                                             // REL 2: d rel_h of 8 chunks: lane group c >> 1 keeps chunk c in [c & 1]
     if constexpr (REL == 2) {
-        for (int i = lane; i < SA_WROWS * 68; i += 64) gws[i] = 0.f;
-    }
-    if constexpr (REL == 2) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            ghq[qt] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) gwq[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int q = q0 + qt * 16 + l15;
@@ -731,8 +824,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
             for (int kt = 0; kt < 4; ++kt) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (q < p.Nq) v = *reinterpret_cast<const f32x4*>(p.rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rwreg[qt][kt * 4 + r] = v[r] * LOG2E;
+                rwq[qt][kt] = v * LOG2E;
             }
         }
     }
@@ -772,43 +864,67 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
         ge[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float c2 = p.scale * LOG2E;
+    const f32x4 c2v = {c2, c2, c2, c2};
     constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
-    const __amdgpu_buffer_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
+    // C operand of the dO.V^T tiles: -D (without dropout, which masks dP before D is subtracted)
+    f32x4 dinit[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float v = drop ? 0.f : -dsum[qt];
+        dinit[qt] = f32x4{v, v, v, v};
+    }
+    const sa_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
-    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.v_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.k_rs, 0, p.Nk, wave, lane);
+    // REL 2: rel_h[q][kh] of the two rows this lane owns, read one chunk ahead; rows past Nq read row Nq - 1 (any finite bias
+    // does: their dS is zero, see above) so that the load needs no branch
+    const float* rhp[2] = {nullptr, nullptr};
     float rhn[2] = {0.f, 0.f};
     if constexpr (REL == 2) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const int q = q0 + qt * 16 + l15;
-            if (q < p.Nq) rhn[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh];
+            rhp[qt] = p.rel_h + ((size_t)bh * p.Nq + min(q0 + qt * 16 + l15, p.Nq - 1)) * p.Sh;
+            rhn[qt] = rhp[qt][0];
         }
     }
+    const int nchunk = (p.Nk + SA_CHUNK - 1) / SA_CHUNK;
+    sa_settle(qf);
+    sa_settle(dof);
+    sa_settle(dinit);
+    sa_settle(lq2);
+    if constexpr (EMM) sa_settle(rf);
+    if constexpr (REL == 2) { sa_settle(rwq); sa_settle(rhn); }
 
-    for (int k0 = 0; k0 < p.Nk; k0 += SA_CHUNK) {
-        const int buf = (k0 / SA_CHUNK) & 1;
+    for (int ci = 0; ci < nchunk; ++ci) {
+        const int k0 = ci * SA_CHUNK;
+        const int buf = ci & 1;
         const char* Ks = KV + buf * 2 * S::CHUNK_BYTES;
         const char* Vs = Ks + S::CHUNK_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk has landed (own DMA) ...
+        if constexpr (REL == 2) sa_settle(rhn);               // (the compiler's wait for last chunk's rel_h loads belongs HERE, not behind the DMA issue)
         __syncthreads();                                      // ... for every wavefront; the other buffer is free again
-        if (k0 + SA_CHUNK < p.Nk) {                           // next chunk streams in under this one's math
+        if (ci + 1 < nchunk) {                                // next chunk streams in under this one's math
             char* nxt = KV + (buf ^ 1) * 2 * S::CHUNK_BYTES;
             S::dma(k_rsrc, nxt, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
-            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.v_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
         }
-        float rhc[2] = {rhn[0] * LOG2E, rhn[1] * LOG2E}, ghc[2] = {0.f, 0.f};     // fetched one chunk ahead (see forward)
-        if constexpr (REL == 2) {
-            if (k0 + SA_CHUNK < p.Nk) {
+        // exponent offset of the chunk: -lse (+ the chunk's rel_h value, REL 2), log2 domain
+        f32x4 offv[2];
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    const int q = q0 + qt * 16 + l15;
-                    if (q < p.Nq) rhn[qt] = p.rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6) + 1];
-                }
-            }
+        for (int qt = 0; qt < 2; ++qt) {
+            const float v = (REL == 2 ? rhn[qt] * LOG2E : 0.f) - lq2[qt];
+            offv[qt] = f32x4{v, v, v, v};
         }
+        if constexpr (REL == 2) {                             // fetched one chunk ahead (see forward)
+            const int nx = min(ci + 1, nchunk - 1);
+            rhn[0] = rhp[0][nx];
+            rhn[1] = rhp[1][nx];
+        }
+        const bool tail = REL != 2 && k0 + SA_CHUNK > p.Nk;   // wave-uniform (REL 2: Nk = Sh * 64, no partial chunk)
         f32x4 g[2][4];
+        f32x2 ghc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};    // REL 2: partial row sums of the chunk's d logits
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             u32x4 kf[S::STEPS], vf[S::STEPS];
@@ -818,7 +934,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 sv2[qt] = S::tile(kf, qf[qt]);
-                dp[qt] = S::tile(vf, dof[qt]);
+                dp[qt] = S::tile_c(vf, dof[qt], dinit[qt]);
             }
             if constexpr (EMM) {
 #pragma unroll
@@ -828,31 +944,62 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
                     Mma<T>::run(sv2[1], ef, rf[1][e]);
                 }
             }
+            f32x4 kbq = {0.f, 0.f, 0.f, 0.f};                 // key bias of keys k0 + kt*16 + lg*4 + 0..3
+            if constexpr (KB) kbq = *reinterpret_cast<const f32x4*>(kbs + k0 + kt * 16 + lg * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + kt * 16 + lg * 4 + r;
-                const bool kok = key < p.Nk;
-                float kbv = 0.f;
-                if (kb) kbv = kok ? kb[key] * LOG2E : 0.f;
-                int kh = 0, kw = 0;
-                if constexpr (TAB) sa_split_key(key, inv_sw, p.Sw, kh, kw);
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 bq = offv[qt];
+                if constexpr (REL == 2) bq += rwq[qt][kt];
+                if constexpr (KB) bq += kbq;
+                if constexpr (TAB) {
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    float bias = kbv;
-                    if constexpr (REL == 2) bias += rhc[qt] + rwreg[qt][kt * 4 + r];
-                    if constexpr (TAB) bias += rh[(qt * 16 + l15) * (p.Sh + 1) + kh] + rw[(qt * 16 + l15) * (p.Sw + 1) + kw];
-                    const float pr = fast_exp2(sv2[qt][r] * c2 + bias - lq2[qt]);
-                    float dpe = dp[qt][r];
-                    if (drop) dpe = sa_keep(p.seed, bh, q0 + qt * 16 + l15, key, p.Nk, dthresh) ? dpe * inv_keep : 0.f;
-                    const float gv = (kok && qok[qt]) ? pr * (dpe - dsum[qt]) : 0.f;      // d logits
-                    g[qt][kt][r] = gv;
-                    if constexpr (REL == 2) ghc[qt] += gv;
-                    if constexpr (REL == 3) {
-                        if (kok && qok[qt]) {
-                            atomicAdd(&gh[(qt * 16 + l15) * (p.Sh + 1) + kh], gv);
-                            atomicAdd(&gw[(qt * 16 + l15) * (p.Sw + 1) + kw], gv);
+                    for (int r = 0; r < 4; ++r) {
+                        int kh, kw;
+                        sa_split_key(min(k0 + kt * 16 + lg * 4 + r, p.Nk - 1), inv_sw, p.Sw, kh, kw);
+                        bq[r] += rh[(qt * 16 + l15) * (p.Sh + 1) + kh] + rw[(qt * 16 + l15) * (p.Sw + 1) + kw];
+                    }
+                }
+                const f32x4 x = sv2[qt] * c2v + bq;
+                const f32x4 pr = {fast_exp2(x[0]), fast_exp2(x[1]), fast_exp2(x[2]), fast_exp2(x[3])};
+                f32x4 gv;                                     // d logits
+                if constexpr (drop) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool keep = sa_keep(p.seed, bh, q0 + qt * 16 + l15, k0 + kt * 16 + lg * 4 + r, p.Nk, dthresh);
+                        gv[r] = pr[r] * ((keep ? dp[qt][r] * inv_keep : 0.f) - dsum[qt]);
+                    }
+                } else {
+                    gv = pr * dp[qt];
+                }
+                g[qt][kt] = gv;
+                if constexpr (REL == 2) ghc[qt] += f32x2{gv[0], gv[1]} + f32x2{gv[2], gv[3]};
+                if constexpr (REL == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + kt * 16 + lg * 4 + r;
+                        if (key < p.Nk && qok[qt]) {
+                            int kh, kw;
+                            sa_split_key(key, inv_sw, p.Sw, kh, kw);
+                            atomicAdd(&gh[(qt * 16 + l15) * (p.Sh + 1) + kh], gv[r]);
+                            atomicAdd(&gw[(qt * 16 + l15) * (p.Sw + 1) + kw], gv[r]);
                         }
                     }
+                }
+            }
+        }
+        if (tail) {                                           // a real branch: the other chunks pay neither selects nor indices
+            int kb0 = k0 + lg * 4;
+            asm volatile("" : "+v"(kb0));                     // (opaque: keeps the index arithmetic inside the branch)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb0 + kt * 16 + r >= p.Nk) g[qt][kt][r] = 0.f;
+                if constexpr (REL == 2) {
+                    const f32x4 t4 = (g[qt][0] + g[qt][1]) + (g[qt][2] + g[qt][3]);
+                    ghc[qt] = f32x2{t4[0], t4[1]} + f32x2{t4[2], t4[3]};
                 }
             }
         }
@@ -860,19 +1007,32 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    f32x4* slot = reinterpret_cast<f32x4*>(gws + (qt * 16 + l15) * 68 + kt * 16 + lg * 4);
-                    *slot += g[qt][kt];
-                }
-        }
-        if constexpr (REL == 2) {       // the whole chunk is one kh row
+                for (int kt = 0; kt < 4; ++kt) gwq[qt][kt] += g[qt][kt];
+            // the whole chunk is one kh row: d rel_h[q][ci] = the row sum.  Stores inside the loop would be waited for by the
+            // next chunk's vmcnt(0) (stores count there on gfx9): eight chunks are collected in registers -- every lane group
+            // gets the sum, group c >> 1 keeps it -- and leave as one 8-byte store per lane (32 contiguous bytes per row)
+            const int c8 = ci & 7;
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                float v = ghc[qt];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                const int q = q0 + qt * 16 + l15;
-                if (lg == 0 && q < p.Nq) p.d_rel_h[((size_t)bh * p.Nq + q) * p.Sh + (k0 >> 6)] = v;
+                const float v = sa_lg_sum(ghc[qt][0] + ghc[qt][1]);
+                ghq[qt][0] = (c8 == lg * 2) ? v : ghq[qt][0];
+                ghq[qt][1] = (c8 == lg * 2 + 1) ? v : ghq[qt][1];
+            }
+            if (c8 == 7 || ci == nchunk - 1) {
+                asm volatile("" ::: "memory");
+                const int base = ci - c8 + lg * 2;            // first kh column of this lane's two
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const int q = q0 + qt * 16 + l15;
+                    if (q < p.Nq) {
+                        float* dst = p.d_rel_h + ((size_t)bh * p.Nq + q) * p.Sh + base;
+                        if ((p.Sh & 1) == 0 && base + 1 < p.Sh) *reinterpret_cast<f32x2*>(dst) = ghq[qt];
+                        else {
+                            if (base < p.Sh) dst[0] = ghq[qt][0];
+                            if (base + 1 < p.Sh) dst[1] = ghq[qt][1];
+                        }
+                    }
+                }
             }
         }
         {
@@ -905,12 +1065,15 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
                 }
             }
         }
-    if constexpr (REL == 2) {       // each lane only ever touched its own slots; the wave reads them all back here
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < SA_WROWS * 64; i += 64) {
-            const int r = i >> 6, c = i & 63;
-            if (q0 + r < p.Nq) p.d_rel_w[((size_t)bh * p.Nq + q0 + r) * 64 + c] = gws[r * 68 + c];
+    if constexpr (REL == 2) {       // 16 bytes per lane, the four lane groups x four key tiles of a row are its 256 bytes
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = q0 + qt * 16 + l15;
+            if (q < p.Nq) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    *reinterpret_cast<f32x4*>(p.d_rel_w + ((size_t)bh * p.Nq + q) * 64 + kt * 16 + lg * 4) = gwq[qt][kt];
+            }
         }
     }
     if constexpr (REL == 3) {       // this wavefront's LDS atomics are complete once its own counters drain
@@ -934,7 +1097,12 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dq_kernel(const SAParams
 // groups (rows lg*4 + r) on disjoint banks.  Everything for chunk i+1 is fetched into registers during chunk i.
 DEVINL int sa_rw_off(int row, int kw) { return row * 64 + ((((kw >> 2) ^ (((row >> 2) & 3) << 2))) << 2) + (kw & 3); }
 
-template <typename T, int D, int REL, bool DROP>
+// r04: as in the dQ kernel the chunk's elementwise work is packed: -lse (REL 2: + the key row's rel_h value) and -D come out
+// of LDS as float4 row constants -- the first as the addend of the one fma that also applies the log2-domain scale, the
+// second as the C operand of the dO.V^T MFMAs -- and nothing is masked: rows of the chunk past Nq are zero rows of Q / dO with
+// D = lse = 0 (finite P, zero dS, zero dO), keys past Nk only ever touch their own (unstored) output rows.
+template <typename T, int D, int REL, bool DROP, bool KB>
+// (two wavefronts per SIMD: held to 168 registers for three, the plain form ran 841 -> 974 us -- more wavefronts parked)
 __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParams p) {
     using S = SA<T, D>;
     constexpr bool TAB = REL == 3;         // per-chunk LDS tables + VALU adds
@@ -948,7 +1116,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
     const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
     const int b = bh / p.H, h = bh - b * p.H;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lg = lane >> 4;
     char* QO = smem;                                       // [2 buffers][Q chunk | dO chunk], filled by DMA
     float* Dq = reinterpret_cast<float*>(smem + 4 * S::CHUNK_BYTES);
     float* Ls = Dq + SA_CHUNK;
@@ -970,7 +1138,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
     for (int t = 0; t < 2; ++t) {
         const int key = key0 + t * 16 + l15;
         kok[t] = key < p.Nk;
-        kbias[t] = (p.key_bias && kok[t]) ? p.key_bias[(size_t)b * p.Nk + key] * LOG2E : 0.f;
+        kbias[t] = (KB && kok[t]) ? p.key_bias[(size_t)b * p.Nk + key] * LOG2E : 0.f;
         khl[t] = kwl[t] = 0;
         if constexpr (TAB) {
             if (kok[t]) sa_split_key(key, 1.f / (float)p.Sw, p.Sw, khl[t], kwl[t]);
@@ -993,25 +1161,24 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
 #pragma unroll
         for (int dt = 0; dt < S::DT; ++dt) { dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float c2 = p.scale * LOG2E;
+    const f32x4 c2v = {c2, c2, c2, c2};
     constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
-    const __amdgpu_buffer_rsrc_t q_rsrc = S::rsrc(qg, p.q_rs, p.Nq), o_rsrc = S::rsrc(dog, p.o_rs, p.Nq);
-    float pf_stat = 0.f, pf_rh = 0.f;                      // D / lse (tid < 128), rel_h column (tid < 128)
+    const sa_rsrc_t q_rsrc = S::rsrc(qg, p.q_rs, p.Nq), o_rsrc = S::rsrc(dog, p.o_rs, p.Nq);
+    float pf_d = 0.f, pf_l = 0.f, pf_rh = 0.f;             // D (tid < 64), lse * log2(e) and the rel_h column tid >> 6 (tid < 128)
     // REL 2: the [64 queries][64 kw] fp32 tile of rel_w goes global -> LDS by DMA (no registers, double buffered);
     // the DMA writes wave-linear 16-byte slots, so the XOR swizzle is applied to the SOURCE address
-    typedef __attribute__((address_space(3))) void lds_void;
     const float* rwg = REL == 2 ? p.rel_w + (size_t)bh * p.Nq * 64 : nullptr;
-    const __amdgpu_buffer_rsrc_t rw_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(REL == 2 ? rwg : p.lse), 0, REL == 2 ? (int)((size_t)p.Nq * 64 * sizeof(float)) : 0, 0x00020000);
+    const sa_rsrc_t rw_rs = sa_make_rsrc(REL == 2 ? (const void*)rwg : (const void*)p.lse,
+                                         REL == 2 ? (unsigned)((size_t)p.Nq * 64 * sizeof(float)) : 0u);      // rows past Nq: out of bounds -> zeros
     auto dma_rw = [&](int q0, int buf) {
+        const unsigned dst = sa_lds_addr(rws + buf * SA_CHUNK * 64) + wave * 1024;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int slot = (j * SA_WAVES + wave) * 64 + lane, row = slot >> 4, pos = slot & 15;
             const int c4 = pos ^ (((row >> 2) & 3) << 2);
-            const unsigned off = (q0 + row) < p.Nq ? (unsigned)(((q0 + row) * 64 + c4 * 4) * (int)sizeof(float)) : 0xfffffff0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_rs, (lds_void*)((char*)(rws + buf * SA_CHUNK * 64) + (j * SA_WAVES + wave) * 1024),
-                                                     16, (int)off, 0, 0, 0);
+            sa_dma16(rw_rs, dst + j * SA_WAVES * 1024, (unsigned)(((q0 + row) * 64 + c4 * 4) * (int)sizeof(float)));
         }
     };
     const float* rhg = REL == 2 ? p.rel_h + (size_t)bh * p.Nq * p.Sh + 2 * blk : nullptr;
@@ -1019,10 +1186,15 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
         char* nxt = QO + ((q0 / SA_CHUNK) & 1) * 2 * S::CHUNK_BYTES;
         S::dma(q_rsrc, nxt, p.q_rs, q0, p.Nq, wave, lane);
         S::dma(o_rsrc, nxt + S::CHUNK_BYTES, p.o_rs, q0, p.Nq, wave, lane);
-        if (tid < 2 * SA_CHUNK) {
+        {                                                  // (every wavefront: no branch, no merge of old and new values)
             const int r = q0 + (tid & 63);
-            pf_stat = r < p.Nq ? (tid < SA_CHUNK ? dsg[r] : lsg[r] * LOG2E) : 0.f;
-            if constexpr (REL == 2) pf_rh = r < p.Nq ? rhg[(size_t)r * p.Sh + (tid >> 6)] * LOG2E : 0.f;
+            // RAW loads only (rows past Nq re-read row Nq - 1 and are zeroed when the chunk becomes current): any arithmetic on
+            // the values here makes the compiler wait vmcnt(0) on the spot -- behind the DMA pieces issued just above, i.e. a
+            // full L2 round trip exposed in every chunk (r04 trace: 54 % of the wavefront cycles parked)
+            const int rc = min(r, p.Nq - 1);
+            pf_l = lsg[rc];
+            pf_d = dsg[rc];
+            if constexpr (REL == 2) pf_rh = rhg[(size_t)rc * p.Sh + ((tid >> 6) & 1)];
         }
         if constexpr (EMM) {                               // converted and stored when the chunk becomes current
 #pragma unroll
@@ -1041,6 +1213,10 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
             }
         }
     };
+    sa_settle(kf);
+    sa_settle(vf);
+    sa_settle(kbias);
+    if constexpr (EMM) sa_settle(ek);
     prefetch(0);
     if constexpr (REL == 2) dma_rw(0, 0);
 
@@ -1048,10 +1224,15 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
         const char* Qs = QO + ((q0 / SA_CHUNK) & 1) * 2 * S::CHUNK_BYTES;
         const char* Os = Qs + S::CHUNK_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk's Q / dO (and rel_w) tiles have landed
+        sa_settle(pf_l);
+        sa_settle(pf_d);
+        if constexpr (REL == 2) sa_settle(pf_rh);
         __syncthreads();
-        if (tid < 2 * SA_CHUNK) {
-            Dq[tid] = pf_stat;                             // Dq[0..63] then Ls[0..63] (contiguous)
-            if constexpr (REL == 2) rhs[tid] = pf_rh;
+        if (tid < 2 * SA_CHUNK) {                          // the row constants, negated / combined once per row here
+            const bool rok = q0 + (tid & 63) < p.Nq;
+            const float l2 = rok ? pf_l * LOG2E : 0.f;
+            if (tid < SA_CHUNK) { Dq[tid] = rok ? -pf_d : 0.f; Ls[tid] = -l2; }
+            if constexpr (REL == 2) rhs[tid] = (rok ? pf_rh * LOG2E : 0.f) - l2;   // [2 kh rows of the block][64 queries]
         }
         if constexpr (EMM) {
             const float mul = 1.f / p.scale;
@@ -1089,27 +1270,45 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
                 u32x4 qf[S::STEPS], dof[S::STEPS];
                 S::lds_frags(qf, Qs, qt * 16, l15, lg);
                 S::lds_frags(dof, Os, qt * 16, l15, lg);
+                const int ql0 = qt * 16 + lg * 4;          // this lane's four query rows of the tile
+                const f32x4 nd = *reinterpret_cast<const f32x4*>(Dq + ql0);
+                f32x4 rowc;                                // -lse (+ rel_h), log2 domain
+                if constexpr (REL == 2) rowc = *reinterpret_cast<const f32x4*>(rhs + (wave >> 1) * SA_CHUNK + ql0);
+                else rowc = *reinterpret_cast<const f32x4*>(Ls + ql0);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     f32x4 sv2 = S::tile(qf, kf[t]);        // rows queries, col key
-                    const f32x4 dp = S::tile(dof, vf[t]);
+                    f32x4 dp;
+                    if constexpr (drop) dp = S::tile(dof, vf[t]);
+                    else dp = S::tile_c(dof, vf[t], nd);   // dP - D
                     if constexpr (EMM) {
 #pragma unroll
                         for (int e = 0; e < RL::ECH; ++e)
                             Mma<T>::run(sv2, ld_chunk(Rs + sa_off<RL::EROWB>(qt * 16 + l15, e * 4 + lg)), ek[t][e]);
                     }
+                    f32x4 bq = rowc;
+                    if constexpr (KB) bq += f32x4{kbias[t], kbias[t], kbias[t], kbias[t]};
+                    if constexpr (TAB) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ql = qt * 16 + lg * 4 + r;
-                        float bias = kbias[t];
-                        if constexpr (TAB) bias += rhs[ql * (p.Sh + 1) + khl[t]] + rws[ql * (p.Sw + 1) + kwl[t]];
-                        if constexpr (REL == 2) bias += rhs[(wave >> 1) * SA_CHUNK + ql] + rwc[sa_rw_off(ql, kwl[t])] * LOG2E;
-                        float pr = fast_exp2(sv2[r] * c2 + bias - Ls[ql]);
-                        if (!(kok[t] && q0 + ql < p.Nq)) pr = 0.f;
-                        float keepf = 1.f;
-                        if (drop) keepf = sa_keep(p.seed, bh, q0 + ql, key0 + t * 16 + l15, p.Nk, dthresh) ? inv_keep : 0.f;
-                        pt[t][qq][r] = pr * keepf;
-                        dst[t][qq][r] = pr * (dp[r] * keepf - Dq[ql]);
+                        for (int r = 0; r < 4; ++r) bq[r] += rhs[(ql0 + r) * (p.Sh + 1) + khl[t]] + rws[(ql0 + r) * (p.Sw + 1) + kwl[t]];
+                    }
+                    if constexpr (REL == 2) {
+                        const f32x4 rwv = {rwc[sa_rw_off(ql0, kwl[t])], rwc[sa_rw_off(ql0 + 1, kwl[t])],
+                                           rwc[sa_rw_off(ql0 + 2, kwl[t])], rwc[sa_rw_off(ql0 + 3, kwl[t])]};
+                        bq = rwv * f32x4{LOG2E, LOG2E, LOG2E, LOG2E} + bq;
+                    }
+                    const f32x4 x = sv2 * c2v + bq;
+                    const f32x4 pr = {fast_exp2(x[0]), fast_exp2(x[1]), fast_exp2(x[2]), fast_exp2(x[3])};
+                    if constexpr (drop) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float keepf = sa_keep(p.seed, bh, q0 + ql0 + r, key0 + t * 16 + l15, p.Nk, dthresh) ? inv_keep : 0.f;
+                            pt[t][qq][r] = pr[r] * keepf;
+                            dst[t][qq][r] = pr[r] * (dp[r] * keepf + nd[r]);
+                        }
+                    } else {
+                        pt[t][qq] = pr;
+                        dst[t][qq] = pr * dp;
                     }
                 }
             }
@@ -1141,44 +1340,53 @@ void sa_allow_lds(K k) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <typename T, int D, int REL, bool DROP = false>
+template <typename T, int D, int REL, bool DROP = false, bool KB = false>
 int sa_launch(const SAParams& p, int which, hipStream_t st) {
     const size_t chunk = (size_t)SA_CHUNK * D * sizeof(T);
     const size_t tab = (REL == 1 || REL == 3) ? (size_t)SA_WAVES * SA_WROWS * (p.Sh + p.Sw + 2) * sizeof(float) : 0;
-    const size_t kbl = (REL == 0 && p.key_bias && p.Nk <= SA_KB_LDS) ? (size_t)p.Nk * sizeof(float) : 0;
+    const size_t kbl = KB ? (size_t)((p.Nk + SA_CHUNK - 1) / SA_CHUNK) * SA_CHUNK * sizeof(float) : 0;      // key-bias row, whole chunks
     if (which == 0) {
-        if constexpr (!DROP && (REL == 0 || REL == 2) && sizeof(T) == 2) {
+        if constexpr (!DROP && REL <= 2 && sizeof(T) == 2) {
             // r04 forward (three-slot ring, in-register reductions, deferred rescale); SAICV_SA_FWD2=0 selects the r03 kernel
             // measured (r04e, one box, us r03 -> r04): SAM global N = 4096 with rel-pos 985 -> 838; plain d64 N = 4096 709 -> 689;
             // ViT N = 197 level; DETR d32 N = 1764 100 -> 107 -- so by default the decomposed-bias launches take it, SAICV_SA_FWD2=2
             // sends every eligible launch there, =0 none
             static const int fwd2_env = getenv("SAICV_SA_FWD2") ? atoi(getenv("SAICV_SA_FWD2")) : 1;
-            const bool fwd2 = fwd2_env == 2 || (fwd2_env == 1 && REL == 2);
-            const size_t aux = REL == 2 ? (size_t)SA_BROWS * p.Sh * sizeof(float) : (p.key_bias ? (size_t)p.Nk * sizeof(float) : 0);
-            if (fwd2 && (REL == 2 ? p.key_bias == nullptr : (p.key_bias == nullptr || p.Nk <= SA_KB_LDS))) {
-                auto k2 = sa_fwd2_kernel<T, D, REL>;
-                static bool once2 = (sa_allow_lds(k2), true);
-                (void)once2;
-                hipLaunchKernelGGL(k2, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
-                                   SA_RING * 2 * chunk + aux, st, p);
+            const bool fwd2 = fwd2_env == 2 || (fwd2_env == 1 && REL != 1);
+            const size_t aux = REL == 2 ? (size_t)SA_BROWS * p.Sh * sizeof(float)
+                             : REL == 1 ? (size_t)SARel<T>::EBYTES
+                                        : (p.key_bias ? (size_t)((p.Nk + SA_CHUNK - 1) / SA_CHUNK) * SA_CHUNK * sizeof(float) : 0);   // padded to whole chunks
+            if (fwd2 && (REL == 0 || !KB)) {
+                const dim3 grid((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H);
+                if constexpr (REL == 0 && KB) {
+                    auto k2 = sa_fwd2_kernel<T, D, 0, true>;
+                    static bool once2 = (sa_allow_lds(k2), true);
+                    (void)once2;
+                    hipLaunchKernelGGL(k2, grid, dim3(SA_THREADS), SA_RING * 2 * chunk + aux, st, p);
+                } else {
+                    auto k2 = sa_fwd2_kernel<T, D, REL, false>;
+                    static bool once2 = (sa_allow_lds(k2), true);
+                    (void)once2;
+                    hipLaunchKernelGGL(k2, grid, dim3(SA_THREADS), SA_RING * 2 * chunk + aux, st, p);
+                }
                 return saicv::check_launch("attention_stream");
             }
         }
-        auto k = sa_fwd_kernel<T, D, REL, DROP>;
+        auto k = sa_fwd_kernel<T, D, REL, DROP, KB>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
         hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
                            4 * chunk + (REL == 1 ? (size_t)SARel<T>::EBYTES : tab) + kbl, st, p);
     } else if (which == 1) {
-        auto k = sa_bwd_dq_kernel<T, D, REL, DROP>;
+        auto k = sa_bwd_dq_kernel<T, D, REL, DROP, KB>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
         const size_t e = REL == 1 ? (size_t)256 * 32 * sizeof(T) : 0;
-        const size_t g2 = REL == 2 ? (size_t)SA_WAVES * SA_WROWS * 68 * sizeof(float) : 0;
+        const size_t g2 = 0;          // (REL 2 kept d rel_w in LDS until r04)
         hipLaunchKernelGGL(k, dim3((p.Nq + SA_BROWS - 1) / SA_BROWS, p.B * p.H), dim3(SA_THREADS),
                            4 * chunk + e + g2 + kbl + (REL == 3 ? 2 * tab : 0), st, p);
     } else {
-        auto k = sa_bwd_dkv_kernel<T, D, REL, DROP>;
+        auto k = sa_bwd_dkv_kernel<T, D, REL, DROP, KB>;
         static bool once = (sa_allow_lds(k), true);
         (void)once;
         const size_t rel = REL == 2 ? (size_t)(2 * SA_CHUNK + 2 * SA_CHUNK * 64) * sizeof(float)
@@ -1192,13 +1400,17 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
 
 template <typename T>
 int sa_dispatch(int D, const SAParams& p, int which, hipStream_t st) {
+    // the additive key bias is a template switch of the backward kernels (a pointer test per logit otherwise): instantiated
+    // for the plain kernels (DETR) and for the Sw == 64 relative-position form
+    const bool kb = p.key_bias != nullptr;
     if (p.dropout_p > 0.f) {
-        if (D == 32) return sa_launch<T, 32, 0, true>(p, which, st);
-        return sa_launch<T, 64, 0, true>(p, which, st);
+        if (D == 32) return kb ? sa_launch<T, 32, 0, true, true>(p, which, st) : sa_launch<T, 32, 0, true, false>(p, which, st);
+        return kb ? sa_launch<T, 64, 0, true, true>(p, which, st) : sa_launch<T, 64, 0, true, false>(p, which, st);
     }
-    if (D == 32) return sa_launch<T, 32, 0>(p, which, st);
-    if (!p.rel_h) return sa_launch<T, 64, 0>(p, which, st);
-    if (p.Sw == 64) return sa_launch<T, 64, 2>(p, which, st);
+    if (D == 32) return kb ? sa_launch<T, 32, 0, false, true>(p, which, st) : sa_launch<T, 32, 0>(p, which, st);
+    if (!p.rel_h) return kb ? sa_launch<T, 64, 0, false, true>(p, which, st) : sa_launch<T, 64, 0>(p, which, st);
+    if (p.Sw == 64) return kb ? sa_launch<T, 64, 2, false, true>(p, which, st) : sa_launch<T, 64, 2>(p, which, st);
+    SAICV_REQUIRE(!kb, "attention_stream: a key bias together with relative-position tables is instantiated for Sw == 64 only");
     if (p.Sh + p.Sw <= 32 && p.Nk <= 256) return sa_launch<T, 64, 1>(p, which, st);
     return sa_launch<T, 64, 3>(p, which, st);
 }
@@ -1215,6 +1427,14 @@ int attention_stream(int dtype, int D, int which, const void* desc_ptr, hipStrea
     SAICV_REQUIRE(p.q_rs % e == 0 && p.k_rs % e == 0 && p.v_rs % e == 0 && p.o_rs % e == 0 &&
                       p.q_bs % e == 0 && p.k_bs % e == 0 && p.v_bs % e == 0 && p.o_bs % e == 0,
                   "attention_stream: strides must be multiples of %d elements (16-byte rows)", e);
+    {
+        const size_t es = dtype == SAICV_DTYPE_BF16 ? 2 : 4, lim = (size_t)1 << 31;      // 32-bit buffer offsets inside one (batch, head) view
+        SAICV_REQUIRE(((size_t)p.Nq * p.q_rs + D) * es < lim && ((size_t)p.Nk * p.k_rs + D) * es < lim &&
+                          ((size_t)p.Nk * p.v_rs + D) * es < lim && ((size_t)p.Nq * p.o_rs + D) * es < lim,
+                      "attention_stream: one batch element of an operand spans 2 GiB or more");
+    }
+    SAICV_REQUIRE(p.key_bias == nullptr || p.Nk <= SA_KB_LDS, "attention_stream: a key bias row of %d entries does not fit its LDS stage (%d)", p.Nk, SA_KB_LDS);
+    SAICV_REQUIRE(p.k_rs == p.v_rs, "attention_stream: k and v must share their row stride (%ld vs %ld)", (long)p.k_rs, (long)p.v_rs);
     SAICV_REQUIRE(p.dropout_p >= 0.f && p.dropout_p < 1.f, "attention_stream: dropout_p=%f outside [0, 1)", (double)p.dropout_p);
     SAICV_REQUIRE((p.rel_h == nullptr) == (p.rel_w == nullptr), "attention_stream: rel_h and rel_w come together");
     if (p.rel_h) {
