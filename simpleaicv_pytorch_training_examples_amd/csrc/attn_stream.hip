@@ -368,7 +368,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
     const sa_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
-    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.k_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), 0, p.Nk, wave, lane);
     float rhn[2] = {0.f, 0.f};
     if constexpr (REL == 2) {
 #pragma unroll
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
         if (k0 + SA_CHUNK < p.Nk) {                           // next chunk streams in under this one's math
             char* nxt = KV + (buf ^ 1) * 2 * S::CHUNK_BYTES;
             S::dma(k_rsrc, nxt, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
-            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), k0 + SA_CHUNK, p.Nk, wave, lane);
         }
         // REL 2: this chunk's rel_h value was fetched during the previous chunk (a load issued here and used
         // right away would also wait for the DMA of the NEXT chunk: vmcnt retires in order)
@@ -561,10 +561,10 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
     const int nchunk = (p.Nk + SA_CHUNK - 1) / SA_CHUNK;
     // ring prologue first: the two chunks stream in under the rest of the set-up
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
-    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.k_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), 0, p.Nk, wave, lane);
     if (nchunk > 1) {
         S::dma(k_rsrc, KV + STAGE, p.k_rs, SA_CHUNK, p.Nk, wave, lane);
-        S::dma(v_rsrc, KV + STAGE + S::CHUNK_BYTES, p.k_rs, SA_CHUNK, p.Nk, wave, lane);
+        S::dma(v_rsrc, KV + STAGE + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), SA_CHUNK, p.Nk, wave, lane);
     }
     const float* kb = aux;
     if constexpr (KB) {                                       // host: Nk <= SA_KB_LDS on this path
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
         if (ci + 2 < nchunk) {
             const int ns = slot == 0 ? 2 : slot - 1;          // (slot + 2) % 3
             S::dma(k_rsrc, KV + ns * STAGE, p.k_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
-            S::dma(v_rsrc, KV + ns * STAGE + S::CHUNK_BYTES, p.k_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, KV + ns * STAGE + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
         }
         f32x4 st[2][4];
 #pragma unroll
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
     }
     const sa_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
-    S::dma(v_rsrc, KV + S::CHUNK_BYTES, p.k_rs, 0, p.Nk, wave, lane);
+    S::dma(v_rsrc, KV + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), 0, p.Nk, wave, lane);
     // REL 2: rel_h[q][kh] of the two rows this lane owns, read one chunk ahead; rows past Nq read row Nq - 1 (any finite bias
     // does: their dS is zero, see above) so that the load needs no branch
     const float* rhp[2] = {nullptr, nullptr};
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
         if (ci + 1 < nchunk) {                                // next chunk streams in under this one's math
             char* nxt = KV + (buf ^ 1) * 2 * S::CHUNK_BYTES;
             S::dma(k_rsrc, nxt, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
-            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, p.k_rs, k0 + SA_CHUNK, p.Nk, wave, lane);
+            S::dma(v_rsrc, nxt + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), k0 + SA_CHUNK, p.Nk, wave, lane);
         }
         // exponent offset of the chunk: -lse (+ the chunk's rel_h value, REL 2), log2 domain
         f32x4 offv[2];
@@ -1434,7 +1434,9 @@ int attention_stream(int dtype, int D, int which, const void* desc_ptr, hipStrea
                       "attention_stream: one batch element of an operand spans 2 GiB or more");
     }
     SAICV_REQUIRE(p.key_bias == nullptr || p.Nk <= SA_KB_LDS, "attention_stream: a key bias row of %d entries does not fit its LDS stage (%d)", p.Nk, SA_KB_LDS);
-    SAICV_REQUIRE(p.k_rs == p.v_rs, "attention_stream: k and v must share their row stride (%ld vs %ld)", (long)p.k_rs, (long)p.v_rs);
+    // head dim 64 (packed qkv projections: ViT, SAM): the K and V pieces of a chunk share their per-lane offsets (two registers
+    // the 168-register forms do not have); head dim 32 (DETR: k from the [q | k] projection, v from its own) keeps both strides
+    SAICV_REQUIRE(D == 32 || p.k_rs == p.v_rs, "attention_stream: head dim 64 needs k and v with one row stride (%ld vs %ld)", (long)p.k_rs, (long)p.v_rs);
     SAICV_REQUIRE(p.dropout_p >= 0.f && p.dropout_p < 1.f, "attention_stream: dropout_p=%f outside [0, 1)", (double)p.dropout_p);
     SAICV_REQUIRE((p.rel_h == nullptr) == (p.rel_w == nullptr), "attention_stream: rel_h and rel_w come together");
     if (p.rel_h) {
