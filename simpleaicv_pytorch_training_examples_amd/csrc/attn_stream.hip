@@ -147,6 +147,33 @@ template <typename V, int N> DEVINL void sa_settle(V (&v)[N]) {
     for (int i = 0; i < N; ++i) sa_settle(v[i]);
 }
 
+// A wavefront's [32 rows][D] result tile (C layout: a[t][dt][r] = row t*16 + lg*4 + r, column dt*16 + l15) to global rows of
+// stride rs.  Straight from the accumulators that is 8 * D/16 stores of ONE element per lane (16 lanes = 32 contiguous
+// bytes): store-issue bound, and for the 3-4 chunk problems (ViT, SAM windows, DETR decoder) a visible share of a workgroup's
+// life.  Through a wave-private LDS tile (pitch D * sizeof(T) + 16 bytes: the four row groups of a write land on different
+// banks) every lane stores 16 bytes, a row's bytes contiguous: D * sizeof(T) / 32 store instructions per wavefront.
+template <typename T, int D>
+DEVINL void sa_store_tile(const f32x4 (&a)[2][D / 16], char* stage, T* g, long rs, int row0, int nvalid, int lane) {
+    constexpr int ROWB = D * (int)sizeof(T), PITCH = ROWB + 16, CPR = ROWB / 16;      // 16-byte chunks per row
+    const int l15 = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<T*>(stage + (t * 16 + lg * 4 + r) * PITCH + (dt * 16 + l15) * (int)sizeof(T)) = from_f32<T>(a[t][dt][r]);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): the wavefront's own writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 * CPR / 64; ++it) {
+        const int i = it * 64 + lane, row = i / CPR, c = i - row * CPR;
+        const u32x4 v = ld_chunk(stage + row * PITCH + c * 16);
+        if (row0 + row < nvalid) st_chunk(reinterpret_cast<char*>(g + (size_t)(row0 + row) * rs) + c * 16, v);
+    }
+}
+template <typename T, int D> constexpr int sa_stage_bytes() { return 32 * (D * (int)sizeof(T) + 16); }      // per wavefront; 4 of them fit every kernel's K / V (Q / dO) buffers
+
 template <typename T, int D>
 struct SA {
     static constexpr int EPC = ElemTraits<T>::EPC;
@@ -329,6 +356,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
         for (int i = threadIdx.x; i < padded; i += SA_THREADS) w[i] = i < p.Nk ? kbg[i] * LOG2E : 0.f;
     }
     const int q0 = blk * SA_BROWS + wave * SA_WROWS;
+    const bool live = q0 < p.Nq;                              // wave-uniform: a wavefront without a valid row only feeds the stream
     if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
     char* Es = smem + 4 * S::CHUNK_BYTES;                 // EMM: indicator matrix, published by the loop's first barrier
     u32x4 rf[2][RL::ECH];
@@ -405,6 +433,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
                 }
             }
         }
+        if (live) {
         f32x4 st[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -485,6 +514,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
             const f32x4 b0[2] = {st[0][2], st[1][2]}, b1[2] = {st[0][3], st[1][3]};
             pvN<T, S::ROWB, S::DT, 2>(o, b0, b1, Vs, 32, l15, lg);
         }
+        }
     }
     T* og = (T*)p.out + (size_t)b * p.o_bs + h * D;
 #pragma unroll
@@ -557,6 +587,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
     const T* vg = (const T*)p.v + (size_t)b * p.v_bs + h * D;
     const int q0 = blk * SA_BROWS + wave * SA_WROWS;
+    const bool live = q0 < p.Nq;                              // wave-uniform
     const sa_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     const int nchunk = (p.Nk + SA_CHUNK - 1) / SA_CHUNK;
     // ring prologue first: the two chunks stream in under the rest of the set-up
@@ -635,6 +666,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
             S::dma(k_rsrc, KV + ns * STAGE, p.k_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
             S::dma(v_rsrc, KV + ns * STAGE + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
         }
+        if (live) {                                           // (a wavefront whose 32 rows all lie past Nq only feeds the ring)
         f32x4 st[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -723,6 +755,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
             const f32x4 b0[2] = {st[0][2], st[1][2]}, b1[2] = {st[0][3], st[1][3]};
             pvN<T, S::ROWB, S::DT, 2>(o, b0, b1, Vs, 32, l15, lg);
         }
+        }
         slot = slot == 2 ? 0 : slot + 1;
     }
     T* og = (T*)p.out + (size_t)b * p.o_bs + h * D;
@@ -735,13 +768,12 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float iq = __shfl(inv, lg * 4 + r, 64);
-            const int q = q0 + qt * 16 + lg * 4 + r;
-            if (q < p.Nq) {
 #pragma unroll
-                for (int dt = 0; dt < S::DT; ++dt) og[(size_t)q * p.o_rs + dt * 16 + l15] = from_f32<T>(o[qt][dt][r] * iq);
-            }
+            for (int dt = 0; dt < S::DT; ++dt) o[qt][dt][r] *= iq;
         }
     }
+    __syncthreads();                                          // every wavefront is done with the ring: it becomes the output stage
+    if (live) sa_store_tile<T, D>(o, smem + wave * sa_stage_bytes<T, D>(), og, p.o_rs, q0, p.Nq, lane);
 }
 
 // ------------------------------------------------------------------------------------ backward: dQ (+ D, d rel-pos)
@@ -794,6 +826,7 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
         for (int i = threadIdx.x; i < padded; i += SA_THREADS) w[i] = i < p.Nk ? kbg[i] * LOG2E : 0.f;
     }
     const int q0 = blk * SA_BROWS + wave * SA_WROWS;
+    const bool live = q0 < p.Nq;                              // wave-uniform: a wavefront without a valid row only feeds the stream
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
     if constexpr (TAB) sa_load_tables(rh, rw, p, bh, q0, lane);
     if constexpr (REL == 3) {
@@ -922,6 +955,7 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
             rhn[0] = rhp[0][nx];
             rhn[1] = rhp[1][nx];
         }
+        if (live) {
         const bool tail = REL != 2 && k0 + SA_CHUNK > p.Nk;   // wave-uniform (REL 2: Nk = Sh * 64, no partial chunk)
         f32x4 g[2][4];
         f32x2 ghc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};    // REL 2: partial row sums of the chunk's d logits
@@ -1045,6 +1079,7 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
                 pvN<T, EROWB, 2, 2>(ge, b0, b1, Es, k0 + 32, l15, lg);
             }
         }
+        }
     }
     T* dqg = (T*)p.dq + (size_t)b * p.q_bs + h * D;
 #pragma unroll
@@ -1130,6 +1165,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
     const float* dsg = p.dsum + (size_t)bh * p.Nq;
     const float* lsg = p.lse + (size_t)bh * p.Nq;
     const int key0 = blk * SA_BROWS + wave * SA_WROWS;
+    const bool live = key0 < p.Nk;                            // wave-uniform: a wavefront without a valid key only feeds the stream
     u32x4 kf[2][S::STEPS], vf[2][S::STEPS];
     float kbias[2];
     int khl[2], kwl[2];
@@ -1261,6 +1297,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
             if constexpr (REL == 2) dma_rw(q0 + SA_CHUNK, ((q0 >> 6) + 1) & 1);
         }
         const float* rwc = rws + ((q0 >> 6) & 1) * SA_CHUNK * 64;      // REL 2: this chunk's tile
+        if (live) {
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair) {             // 32 queries at a time
             f32x4 pt[2][2], dst[2][2];                     // [key tile][query tile of the pair]
@@ -1316,6 +1353,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
             const f32x4 d0[2] = {dst[0][0], dst[1][0]}, d1[2] = {dst[0][1], dst[1][1]};
             pvN<T, S::ROWB, S::DT, 2>(dv, p0, p1, Os, pair * 32, l15, lg);      // dV += P^T dO
             pvN<T, S::ROWB, S::DT, 2>(dk, d0, d1, Qs, pair * 32, l15, lg);      // dK += dS^T Q  (scale at the end)
+        }
         }
     }
     T* dkg = (T*)p.dk + (size_t)b * p.k_bs + h * D;
