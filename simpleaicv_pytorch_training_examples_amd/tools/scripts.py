@@ -6,6 +6,7 @@
   compute_voc_ap / compute_ious / evaluate_voc_detection / test_detection   (reference :503-739, :884-897; the COCO
                                                variant needs pycocotools, which the bench image does not have)
   train_detection                              (reference :900-1092)
+  train_mae_self_supervised_learning           (reference :1774-1934)
 
 Loop semantics are kept -- skip a batch when ANY rank saw inf/nan input or a zero/inf/nan loss,
 gradient accumulation with `no_sync()`, optional clipping, GradScaler step/update, EMA, mean-
@@ -241,7 +242,7 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
 
 
 def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, total_name, iter_width,
-                graph_inputs=None):
+                graph_inputs=None, log_terms=True):
     """Shared iteration engine of the dict-loss loops (detection here; the SAM loop in
     interactive_segmentation_scripts.py follows the same scheme): `step_fn(data)` runs forward + loss and
     returns (bad flag tensor, {name: loss tensor}, batch size).  Everything else -- accumulation, the single
@@ -282,7 +283,7 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
             losses.update(loss, n)
             if log_fmt is not None and main:
                 terms = ''.join(f'{k}: {v / float(config.gpus_num) * acc_steps:.4f}, ' for k, v in zip(keys, vals[2:]))
-                logger.info(log_fmt.format(loss=loss * acc_steps) + terms)
+                logger.info(log_fmt.format(loss=loss * acc_steps) + (terms if log_terms else ''))
 
     def forward_backward(data, boundary):
         """forward, criterion, (scaled) backward; -> (packed [skip, total, terms...] reduced over the ranks, batch size)"""
@@ -369,7 +370,7 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
             if iter_index % int(config.print_interval * acc_steps) == 0:
                 log_fmt = (f'train: epoch {epoch:0>4d}, iter [{int(iter_index // acc_steps):0>{iter_width}d}, '
                            f'{int(iters // acc_steps):0>{iter_width}d}], lr: {scheduler.current_lr:.6f}, ' +
-                           total_name + ': {loss:.4f}, ')
+                           total_name + (': {loss:.4f}, ' if log_terms else ': {loss:.4f}'))
             pending.append((packed, n, log_fmt))
         drain(lag)
         iter_index += 1
@@ -410,6 +411,37 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
         def graph_inputs(data):
             return (data['image'].to(device, non_blocking=True), data['annots'].to(device, non_blocking=True))
     return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5, graph_inputs)
+
+
+def train_mae_self_supervised_learning(train_loader, model, criterion, optimizer, scheduler, epoch, logger, config):
+    '''train mae self supervised model for one epoch (reference tools/scripts.py:1774-1934): `outputs, masks = model(images)`,
+    `loss = criterion(outputs, labels, masks)` (the per-patch regression target comes from MAESelfSupervisedPretrainCollater),
+    the reference's skip / accumulation / clipping / scaler / EMA / scheduler semantics and its log line
+    `train: epoch 0001, iter [00100, 01251], lr: 0.000150, loss: 0.7523`.  The iteration has no host read and static shapes
+    (the mask is an argsort of device noise, the kept-patch count is fixed by mask_ratio): with config.use_step_graph it is
+    captured whole and replayed, as the classification loop is.'''
+    model.train()
+    device = _device_of(model)
+    amp_type = get_amp_type(model)
+    if config.local_rank == 0 and getattr(config, 'total_rank', 0) == 0:
+        logger.info(f'use_amp: {config.use_amp}, amp_type: {amp_type}!')
+
+    def step_fn(data):
+        if isinstance(data, tuple):                      # captured step: static device buffers
+            images, labels = data
+        else:
+            images = data['image'].to(device, non_blocking=True)
+            labels = data['label'].to(device, non_blocking=True)
+        bad = any_nonfinite(images, labels)
+        with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
+            outputs, masks = model(images)
+            loss = criterion(outputs, labels, masks)
+        return bad, {'loss': loss}, images.size(0)
+
+    def graph_inputs(data):
+        return (data['image'].to(device, non_blocking=True), data['label'].to(device, non_blocking=True))
+    return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'loss', 5, graph_inputs,
+                       log_terms=False)
 
 
 # ---------------------------------------------------------------------------------------------- detection evaluation

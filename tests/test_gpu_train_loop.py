@@ -580,3 +580,91 @@ def test_detection_step_graph_replays_the_same_training_as_eager_launches():
     spread = max(abs(a - c) for a, c in zip(eager, eager2))
     for i, (a, b, c) in enumerate(zip(eager, graph, eager2)):
         assert abs(a - b) < max(3 * abs(a - c), 3 * spread, 0.05 * max(abs(a), 0.1)), (i, a, b, c)
+
+
+@pytest.mark.parametrize('graphed', [False, True], ids=['eager', 'step_graph'])
+def test_mae_loop_follows_the_reference_loop(graphed):
+    """12 fp32 iterations of the tiny MAE model through THIS package's train_mae_self_supervised_learning / AdamW (betas 0.9,
+    0.95) / CosineLR warm-up against the per-iteration losses the reference's own tools/scripts.py:1774-1934 produced on CPU for
+    the same weights, batches (through the collater) and masking noise (oracle/make_golden_mae.py: the i-th torch.rand(B, L) after
+    torch.manual_seed(77), replayed here).  The reference's two runs agree to 1e-7 per iteration: the gate is 1e-4 on the first two
+    iterations and 1e-3 (north_star) afterwards.  'step_graph': the same loop with the iteration captured and replayed -- the
+    noise then has to live in a static device buffer the closure refills before every replay."""
+    import numpy as np
+    from conftest import load_golden, rel_err
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.masked_image_modeling.common import MAESelfSupervisedPretrainCollater
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.masked_image_modeling.losses import MSELoss
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.masked_image_modeling.models.vit_mae import VITMAEPretrainModel
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts, utils
+    fx = load_golden('traj_mae_tiny')
+    c = fx['config']
+    steps, batch = c['steps'], c['batch']
+
+    class config:
+        pass
+    config.optimizer, config.scheduler, config.epochs = tuple(c['optimizer']), tuple(c['scheduler']), c['epochs']
+    config.batch_size, config.accumulation_steps, config.print_interval = batch, 1, 4
+    config.use_amp, config.use_ema_model, config.local_rank, config.gpus_num, config.group = False, False, 0, 1, None
+    config.host_sync_lag, config.use_step_graph, config.step_graph_warmup = 2, graphed, 2
+    torch.manual_seed(c['model_seed'])
+    model = VITMAEPretrainModel(**c['kwargs']).cuda()
+    optimizer, _ = utils.build_optimizer(config, model)
+    scheduler = utils.Scheduler(config, optimizer)
+    model, config.ema_model, config.scaler = utils.build_training_mode(config, model)
+    coll = MAESelfSupervisedPretrainCollater(image_size=64, patch_size=16, norm_label=True)
+    batches = []
+    for i in range(steps):
+        rng = np.random.default_rng(c['data_seed0'] + i)
+        batches.append(coll([{'image': rng.standard_normal((64, 64, 3), dtype=np.float32) * 0.7 + 0.1, 'label': 0} for _ in range(batch)]))
+    torch.manual_seed(c['noise_seed'])
+    noises = [torch.rand(batch, (64 // 16) ** 2) for _ in range(steps)]      # the reference's CPU draws, in order
+    enc = model.module.encoder
+    original = enc.random_masking
+    static_noise = torch.empty(batch, 16, device='cuda')
+    fed = [0]
+
+    class Loader(list):
+        dataset = [None] * (steps * batch)
+
+        def __iter__(self):                                # the next iteration's noise is in place before the loop issues it
+            for item in list.__iter__(self):
+                static_noise.copy_(noises[fed[0]])
+                fed[0] += 1
+                yield item
+
+    enc.random_masking = lambda x, noise=None: original(x, static_noise)
+    got, restore = _spy_average_meter()
+    logs = []
+
+    class Rec(logging.Handler):
+        def emit(self, record):
+            logs.append(record.getMessage())
+
+    logger = logging.getLogger('saicv_traj_mae_' + ('g' if graphed else 'e'))
+    logger.setLevel(logging.INFO)
+    logger.handlers = [Rec()]
+    try:
+        avg = scripts.train_mae_self_supervised_learning(Loader(batches), model, MSELoss(), optimizer, scheduler, 1, logger, config)
+    finally:
+        restore()
+        enc.random_masking = original
+    ref = fx['losses']
+    assert len(got) == len(ref) == steps and fed[0] == steps
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(got, ref)):
+        err = abs(a - b) / abs(b)
+        assert err < (1e-4 if i < 2 else 1e-3), (i, a, b, err)
+        worst = max(worst, err)
+    print(f'[mae trajectory, {"graph" if graphed else "eager"}] worst relative loss error {worst:.2e}')
+    assert abs(avg - fx['avg_loss']) / fx['avg_loss'] < 1e-3
+    assert abs(scheduler.current_lr - fx['lr']) < 1e-12
+    # the reference's own log lines: same text up to the last printed digit of the loss
+    ref_lines = [l for l in fx['log'] if l.startswith('train: epoch')]
+    mine = [l for l in logs if l.startswith('train: epoch')]
+    assert len(mine) == len(ref_lines) == steps // 4
+    for a, b in zip(mine, ref_lines):
+        assert a.rsplit('loss: ', 1)[0] == b.rsplit('loss: ', 1)[0], (a, b)
+        assert abs(float(a.rsplit('loss: ', 1)[1]) - float(b.rsplit('loss: ', 1)[1])) <= 2e-3, (a, b)
+    sd = model.module.state_dict()
+    for k, v in fx['final_state'].items():
+        assert rel_err(sd[k].float().cpu(), v) < 5e-3, k

@@ -157,6 +157,8 @@ def test_benchmark_configs_import_like_reference_configs_and_collate():
         '00.classification_training/imagenet/resnet50': ('resnet50', {'image': (2, 3, 224, 224), 'label': (2,)}),
         '00.classification_training/imagenet/vit_base_patch16_for_self_train_mae_pretrain':
             ('vit_base_patch16', {'image': (2, 3, 224, 224), 'label': (2, 1000)}),
+        '02.masked_image_modeling_training/imagenet/mae_vit_base_patch16_224':
+            ('vit_base_patch16_224_mae_pretrain_model', {'image': (2, 3, 224, 224), 'label': (2, 196, 768)}),
         '03.detection_training/coco/res50_detr_yoloresize1024':
             ('resnet50_detr', {'image': (2, 3, 1024, 1024), 'mask': (2, 1024, 1024), 'scaled_annots': (2, 100, 5)}),
         '03.detection_training/coco/res50_retinanet_yoloresize1024':
