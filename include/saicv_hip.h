@@ -395,6 +395,19 @@ int saicv_mixup_cutmix(int src_is_u8, const void* src, const saicv_mix_plan* pla
  * (the smoothed one-hot of the same collater, :262-284) */
 int saicv_soft_labels(const long long* labels, const saicv_mix_plan* plan, float off_value, float on_value, float* out, int B,
                       int num_classes, void* stream);
+/* The dataset normalisation on the uint8 batch the loader shipped (reference SimpleAICV/classification/common.py:228-248,
+ * TorchMeanStdNormalize = torchvision ToTensor + Normalize, there per sample on a CPU worker): src u8 [n] in NHWC order (n =
+ * B*H*W*C), dst fp32 [n]: ((float)v / 255 - mean[c]) / std[c], each step rounded as the tensor expressions round. */
+int saicv_u8_normalize(const unsigned char* src, const float* mean, const float* stdv, float* dst, size_t n, int C, void* stream);
+/* RandomErasing on the device batch (reference common.py:561-640): the host draws the boxes (and, for the 'const' / 'rand'
+ * modes, the colour) with the reference's numpy calls; x fp32 [B][H][W][C] is filled in place.  mode 0: color[c]; mode 1
+ * ('pixel'): every element its own N(0, 1) value from a counter-based generator keyed by (seed, box index, element).  Boxes of
+ * one call must not overlap within an image (the reference applies a sample's boxes in sequence: one call per round). */
+typedef struct saicv_erase_box {
+    int b, top, left, h, w, mode;
+    float color[4];
+} saicv_erase_box;
+int saicv_random_erase(float* x, const saicv_erase_box* boxes, int nboxes, int B, int H, int W, int C, unsigned int seed, void* stream);
 /* One click per sample, uniform over the error region of a mask prediction (reference tools/interactive_segmentation_scripts.py:
  * 202-228): label 1 on a false-negative pixel, label 0 on a false-positive one -- or on a background pixel when the
  * prediction is exact.  gt: fp32 [B][H][W], a pixel is foreground where gt > gt_threshold; pred: [B][pred_channels][H][W]

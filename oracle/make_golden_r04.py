@@ -5,6 +5,8 @@ Build container only:   python oracle/make_golden_r04.py [names...]
 convbnact_variants        reference classification ConvBnActBlock (resnet.py:19-48) in the forms round 3 refused:
                           has_bn=False (biased convolution, with and without ReLU) and a depthwise block (groups == channels,
                           BatchNorm + ReLU): state_dict, output, input / parameter gradients, BatchNorm buffers after the step.
+random_erasing            reference RandomErasing (classification/common.py:561-640), modes const / rand / pixel, seeded numpy
+                          draws: the erased images (the loader-side transform the ViT fine-tuning configs use).
 sam_block_relpos_resized  reference segment_anything Block (image_encoder.py:201-239) whose relative-position tables were built
                           for an 8 x 8 grid, run on a 16 x 16 grid: get_rel_pos interpolates the 15-row tables to 31 rows
                           (image_encoder.py:96-103) -- the path ops_tfm.resize_rel_pos restates; output, input gradient and
@@ -71,6 +73,36 @@ def sam_block_relpos_resized(name='sam_block_relpos_resized'):
           f'({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
+def random_erasing(name='random_erasing'):
+    """reference RandomErasing (SimpleAICV/classification/common.py:561-640) on seeded float32 HWC images: all three modes, prob
+    0.7 (both branches over the seeds), one configuration with up to three boxes; per case the numpy seed, the constructor
+    arguments and the erased image (the input is regenerated from the seed by the test)."""
+    import types
+    import numpy as np
+    for mod in ('cv2', 'torchvision', 'torchvision.transforms'):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    tv = sys.modules['torchvision.transforms']
+    for attr in ('ToTensor', 'Normalize', 'Compose'):
+        if not hasattr(tv, attr):
+            setattr(tv, attr, lambda *a, **k: None)
+    sys.modules['torchvision'].transforms = tv
+    from SimpleAICV.classification.common import RandomErasing
+    cases = []
+    for mode in ('const', 'rand', 'pixel'):
+        for kw in (dict(prob=0.7, mode=mode), dict(prob=0.7, mode=mode, min_count=1, max_count=4, max_area=0.2)):
+            for seed in range(6):
+                np.random.seed(1000 + seed)
+                image = np.random.standard_normal((40, 48, 3)).astype(np.float32)
+                before = image.copy()
+                out = RandomErasing(**kw)({'image': image, 'label': 3})
+                cases.append({'kwargs': kw, 'seed': 1000 + seed, 'image': torch.from_numpy(out['image'].copy()),
+                              'changed': int((out['image'] != before).any(axis=-1).sum())})
+    print(name, len(cases), 'cases; erased pixels per case', [c['changed'] for c in cases])
+    path = os.path.join(OUT, name + '.pt')
+    torch.save({'name': name, 'cases': cases}, path)
+    print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit(f'{REF} not present: golden fixtures can only be (re)generated in the build container')
@@ -81,6 +113,8 @@ def main():
         convbnact_variants()
     if not only or 'sam_block_relpos_resized' in only:
         sam_block_relpos_resized()
+    if not only or 'random_erasing' in only:
+        random_erasing()
 
 
 if __name__ == '__main__':

@@ -64,6 +64,11 @@ class MixPlan(Structure):
                 ('one_minus_lam', ctypes.c_float), ('label_lam', ctypes.c_float), ('label_one_minus_lam', ctypes.c_float)]
 
 
+class EraseBox(Structure):
+    """saicv_erase_box (include/saicv_hip.h)"""
+    _fields_ = [('b', c_int), ('top', c_int), ('left', c_int), ('h', c_int), ('w', c_int), ('mode', c_int), ('color', ctypes.c_float * 4)]
+
+
 # name -> (restype, argtypes); mirrors include/saicv_hip.h one to one
 SIGNATURES = {
     'saicv_version': (c_int, []),
@@ -143,6 +148,8 @@ SIGNATURES = {
     'saicv_upsample4_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_mask_loss_stats_up4': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
     'saicv_mask_loss_grad_up4': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
+    'saicv_u8_normalize': (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
+    'saicv_random_erase': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, _P]),
     'saicv_mixup_cutmix': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'saicv_soft_labels': (c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, c_int, c_int, _P]),
     'saicv_detr_sine_pe': (c_int, [_P, _P, c_int, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, _P]),

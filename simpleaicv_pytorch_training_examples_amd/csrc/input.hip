@@ -11,6 +11,13 @@
 //                          materialises (168 MB at batch 20, four times per step): a counter-based generator gives every
 //                          (pixel, label) slot its own 32-bit draw and the arg-max travels as a packed 64-bit key.
 //
+//   saicv_u8_normalize     reference SimpleAICV/classification/common.py:228-248 (TorchMeanStdNormalize = torchvision ToTensor +
+//                          Normalize) on the uint8 NHWC batch the loader shipped: float(v) / 255, - mean[c], / std[c], every step
+//                          rounded like the tensor expressions (a quarter of the fp32 batch's PCIe / HBM traffic on the way in).
+//   saicv_random_erase     reference common.py:561-640 (RandomErasing): boxes and colours drawn by the HOST with the reference's
+//                          numpy calls, pixels filled on the device; mode 'pixel' takes its N(0, 1) values from a counter-based
+//                          generator instead of shipping h * w * c host draws.
+//
 // Arithmetic of the first two is written to be BIT-IDENTICAL to the reference's fp32 tensor expressions (separately rounded
 // products and sum, no fused multiply-add): tests compare with the fixture the reference collater produced.
 #include "common.h"
@@ -137,6 +144,49 @@ __global__ void sample_point_pick_kernel(const unsigned long long* __restrict__ 
     points[b * 3 + 0] = (float)(idx % (unsigned)W);
     points[b * 3 + 1] = (float)(idx / (unsigned)W);
     points[b * 3 + 2] = label;
+}
+
+// uint8 NHWC -> fp32 NHWC: ((float)v / 255 - mean[c]) / std[c], three separately rounded steps (torchvision's
+// img.to(float32).div(255) followed by tensor.sub_(mean).div_(std))
+__global__ __launch_bounds__(256) void u8_normalize_kernel(const uint8_t* __restrict__ src, const float* __restrict__ mean,
+                                                           const float* __restrict__ stdv, float* __restrict__ dst, size_t n, int C) {
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
+        const int c = (int)(i % (size_t)C);
+        float v = (float)src[i] / 255.f;
+        v = v - mean[c];
+        dst[i] = v / stdv[c];
+    }
+}
+
+DEVINL unsigned erase_hash(unsigned a, unsigned b, unsigned c) {
+    unsigned h = a * 0x9E3779B9u + b;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    h += c * 0x27d4eb2fu;
+    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+    return h;
+}
+
+// one workgroup row (blockIdx.y) per box; mode 0: the box takes color[c]; mode 1: every element its own N(0, 1) draw
+// (Box-Muller on two 24-bit uniforms of a counter-based hash of (seed, box, element))
+__global__ __launch_bounds__(256) void random_erase_kernel(float* __restrict__ x, const saicv_erase_box* __restrict__ boxes, int H,
+                                                           int W, int C, unsigned seed) {
+    const saicv_erase_box bx = boxes[blockIdx.y];
+    const int n = bx.h * bx.w * C;
+    float* base = x + (((size_t)bx.b * H + bx.top) * W + bx.left) * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = i % C, px = i / C, xx = px % bx.w, yy = px / bx.w;
+        float v;
+        if (bx.mode == 0) {
+            v = bx.color[c];
+        } else {
+            const unsigned k1 = erase_hash(seed, (unsigned)blockIdx.y, (unsigned)i * 2u), k2 = erase_hash(seed ^ 0x68bc21ebu, (unsigned)blockIdx.y, (unsigned)i * 2u + 1u);
+            const float u1 = ((float)(k1 >> 8) + 1.f) * (1.f / 16777216.f);        // (0, 1]
+            const float u2 = (float)(k2 >> 8) * (1.f / 16777216.f);                // [0, 1)
+            v = sqrtf(-2.f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+        }
+        base[((size_t)yy * W + xx) * C + c] = v;
+    }
 }
 
 int sgrid(size_t n) {
@@ -324,6 +374,20 @@ int saicv_sam_grid_pe(const float* gauss, int F, int S, float* out, void* stream
     SAICV_REQUIRE(gauss && out && F > 0 && S > 0, "saicv_sam_grid_pe: bad arguments");
     hipLaunchKernelGGL(grid_pe_kernel, dim3((F * S * S + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gauss, F, S, out);
     return saicv::check_launch("sam_grid_pe");
+}
+
+int saicv_u8_normalize(const unsigned char* src, const float* mean, const float* stdv, float* dst, size_t n, int C, void* stream) {
+    SAICV_REQUIRE(src && mean && stdv && dst && n > 0 && C >= 1 && C <= 4, "saicv_u8_normalize: bad arguments");
+    hipLaunchKernelGGL(u8_normalize_kernel, dim3(sgrid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), (const uint8_t*)src, mean, stdv,
+                       dst, n, C);
+    return saicv::check_launch("u8_normalize");
+}
+
+int saicv_random_erase(float* x, const saicv_erase_box* boxes, int nboxes, int B, int H, int W, int C, unsigned int seed, void* stream) {
+    SAICV_REQUIRE(x && boxes && nboxes > 0 && B > 0 && H > 0 && W > 0 && C >= 1 && C <= 4, "saicv_random_erase: bad arguments");
+    // (the caller orders overlapping boxes of one image into separate calls: within a call boxes are disjoint or of different images)
+    hipLaunchKernelGGL(random_erase_kernel, dim3(16, nboxes), dim3(256), 0, static_cast<hipStream_t>(stream), x, boxes, H, W, C, seed);
+    return saicv::check_launch("random_erase");
 }
 
 int saicv_detr_sine_pe(const unsigned char* mask, float* out, int B, int H, int W, int F, float temperature, float eps, void* stream) {
