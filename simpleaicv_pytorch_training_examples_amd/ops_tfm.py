@@ -198,9 +198,8 @@ def gelu_bwd(dy, x):
 def attn_fwd(qkv, b, n, heads, scale):
     c = qkv.shape[1] // 3
     if c // heads == 32 or n > 256 or (qkv.dtype == torch.bfloat16 and c // heads == 64):
-        # bf16: the streaming kernel's forward is ~1.9x faster than the whole-head one at N = 197 (102 vs 192 us at
-        # b256), its backward slower (335 vs 283 us): forward from here, backward stays saicv_attention_bwd -- both
-        # keep the same natural-log lse [B, heads, N]
+        # bf16: the streaming kernels are faster than the whole-head ones at N = 197, b256 both ways since r04 (forward 92 vs
+        # 192 us, backward 255 vs 283 us: csrc/attn_stream.hip); both families keep the same natural-log lse [B, heads, N]
         q3 = qkv.view(b, n, 3 * c)
         out, lse = sattn_fwd(q3[:, :, :c], q3[:, :, c:2 * c], q3[:, :, 2 * c:], heads, scale)
         return out.view(b * n, c), lse.view(b, heads, n)
@@ -216,8 +215,8 @@ def attn_fwd(qkv, b, n, heads, scale):
 def attn_bwd(qkv, out, dout, lse, b, n, heads, scale):
     c = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
-    if c // heads != 64 or n > 256:
-        # head dim 32 (the MAE decoder: 512 planes / 16 heads) or long sequences: the streaming kernels both ways
+    if c // heads != 64 or n > 256 or qkv.dtype == torch.bfloat16:
+        # head dim 32 (the MAE decoder: 512 planes / 16 heads), long sequences, or bf16: the streaming kernels both ways
         q3, g3 = qkv.view(b, n, 3 * c), dqkv.view(b, n, 3 * c)
         sattn_bwd(q3[:, :, :c], q3[:, :, c:2 * c], q3[:, :, 2 * c:], out.view(b, n, c), dout.contiguous().view(b, n, c),
                   lse.view(b * heads, n), heads, scale, g3[:, :, :c], g3[:, :, c:2 * c], g3[:, :, 2 * c:])
