@@ -454,6 +454,15 @@ int saicv_act_bwd(int dtype, int kind, double slope, const void* dy, const void*
 /* out = a * b on tensors of one dense layout (van.py:91 `u * attn`); da = dy * b, db = dy * a (either may be NULL) */
 int saicv_mul_fwd(int dtype, const void* a, const void* b, void* out, size_t n, void* stream);
 int saicv_mul_bwd(int dtype, const void* dy, const void* a, const void* b, void* da, void* db, size_t n, void* stream);
+/* DINOv3 blocks (reference SimpleAICV/detection/models/backbones/dinov3vit.py).  saicv_rope_apply: rotary position embedding on
+ * the q and k thirds of a packed projection qkv [B][N][3][heads][D] -> out (same layout; v and the first `prefix` tokens copied):
+ * y = x * cos + rot(x) * sin, rot(x) = [-x2, x1] over the halves of D (:262-276, :331-353), sin / cos fp32 [N - prefix][D];
+ * transpose = 1 is the gradient map dx = g * cos + rot^T(g * sin).  fp32 arithmetic, one rounding.  D a multiple of 16 (bf16) / 8.
+ * saicv_swiglu_*: hidden = silu(x1) * x2 (:137-140) and (dx1, dx2) from dy in one pass each. */
+int saicv_rope_apply(int dtype, const void* qkv, const float* sin_t, const float* cos_t, void* out, int B, int N, int heads, int D,
+                     int prefix, int transpose, void* stream);
+int saicv_swiglu_fwd(int dtype, const void* x1, const void* x2, void* out, size_t n, void* stream);
+int saicv_swiglu_bwd(int dtype, const void* dy, const void* x1, const void* x2, void* dx1, void* dx2, size_t n, void* stream);
 /* out[m][c] = x[m][c] + s[c] * y[m][c] on [M][C] (NHWC) tensors, s fp32 [C]; x NULL: s * y; s NULL: x + y.
  * van.py:181-185 (x + layer_scale * branch), the residual joins of darknet.py (Darknet53Block) and convformer.py:157-163.
  * Backward of the branch: dy = s * dout (dy NULL: skipped; s NULL: ones), ds[c] += sum_m dout * y (ds NULL: skipped; fp32 atomics). */

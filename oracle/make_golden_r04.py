@@ -5,6 +5,8 @@ Build container only:   python oracle/make_golden_r04.py [names...]
 convbnact_variants        reference classification ConvBnActBlock (resnet.py:19-48) in the forms round 3 refused:
                           has_bn=False (biased convolution, with and without ReLU) and a depthwise block (groups == channels,
                           BatchNorm + ReLU): state_dict, output, input / parameter gradients, BatchNorm buffers after the step.
+dinov3_tiny               reference DinoVisionTransformer (detection/models/backbones/dinov3vit.py): GELU-MLP form in training mode
+                          (RoPE rescale draw) and SwiGLU form in eval mode; outputs, input and parameter gradients.
 random_erasing            reference RandomErasing (classification/common.py:561-640), modes const / rand / pixel, seeded numpy
                           draws: the erased images (the loader-side transform the ViT fine-tuning configs use).
 sam_block_relpos_resized  reference segment_anything Block (image_encoder.py:201-239) whose relative-position tables were built
@@ -103,6 +105,52 @@ def random_erasing(name='random_erasing'):
     print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
+def dinov3_tiny(name='dinov3_tiny'):
+    """reference DinoVisionTransformer (SimpleAICV/detection/models/backbones/dinov3vit.py:453-571) in two tiny geometries
+    (embedding 128 = 2 heads of 64, 2 blocks, patch 16): 'mlp_train' -- GELU MLP, training mode with the RoPE rescale augmentation
+    (one host draw: torch.manual_seed(5) right before the forward), image 64 x 48; 'swiglu_eval' -- SwiGLU FFN (ratio 6), eval
+    mode, image 96 x 64.  LayerScale gammas (1e-5 at init: the branches would vanish) are redrawn around 1, biases around 0.  Per
+    case: parameter checksums (the test rebuilds the weights from the seeds), output [B, C, H, W], input gradient, norm + first 64
+    entries of every parameter gradient for a random probe (all from generator 21 in a fixed order)."""
+    import types
+    for mod in ('cv2', 'torchvision', 'torchvision.transforms'):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    from SimpleAICV.detection.models.backbones.dinov3vit import DinoVisionTransformer
+    cases = {}
+    for key, kw, train, hw in (('mlp_train', dict(embedding_planes=128, head_nums=2, block_nums=2, ffn_layer='mlp', ffn_ratio=4,
+                                                   pos_embed_rope_rescale_coords=2), True, (64, 48)),
+                               ('swiglu_eval', dict(embedding_planes=128, head_nums=2, block_nums=2, ffn_layer='swiglu', ffn_ratio=6,
+                                                    pos_embed_rope_rescale_coords=2), False, (96, 64))):
+        torch.manual_seed(0)
+        m = DinoVisionTransformer(**kw)
+        g = torch.Generator().manual_seed(21)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith('.gamma'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.3 + 1.0)
+                elif n.endswith('.bias'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        m.train(train)
+        x = torch.randn(2, 3, hw[0], hw[1], generator=g, requires_grad=True)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        torch.manual_seed(5)                      # the rope augmentation's draw (training mode only)
+        out = m(x)
+        probe = torch.randn(out.shape, generator=g)
+        (out * probe).sum().backward()
+        # the weights are NOT stored: the test rebuilds them from the same seeds (construction draw order is part of the contract);
+        # per-parameter checksums pin that, gradients are stored as norm + first 64 entries
+        cases[key] = {'kwargs': kw, 'train': train, 'hw': hw, 'param_sum': {k: float(v.double().sum()) for k, v in sd.items()},
+                      'param_abs_sum': {k: float(v.double().abs().sum()) for k, v in sd.items()},
+                      'out': out.detach().clone(), 'dx': x.grad.clone(), 'input_checksum': float(x.detach().double().sum()),
+                      'grad_norm': {n: float(p.grad.norm()) for n, p in m.named_parameters()},
+                      'grad_sample': {n: p.grad.flatten()[:64].clone() for n, p in m.named_parameters()}}
+        print(key, tuple(out.shape), float(out.norm()), 'qkv bias grad (k third must be 0):',
+              float(m.blocks[0].attn.qkv.bias.grad[128:256].abs().max()))
+    path = os.path.join(OUT, name + '.pt')
+    torch.save({'name': name, 'cases': cases, 'torch_version': torch.__version__}, path)
+    print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit(f'{REF} not present: golden fixtures can only be (re)generated in the build container')
@@ -115,6 +163,8 @@ def main():
         sam_block_relpos_resized()
     if not only or 'random_erasing' in only:
         random_erasing()
+    if not only or 'dinov3_tiny' in only:
+        dinov3_tiny()
 
 
 if __name__ == '__main__':

@@ -148,6 +148,9 @@ SIGNATURES = {
     'saicv_upsample4_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_mask_loss_stats_up4': (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, _P]),
     'saicv_mask_loss_grad_up4': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
+    'saicv_rope_apply': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_swiglu_fwd': (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
+    'saicv_swiglu_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     'saicv_u8_normalize': (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
     'saicv_random_erase': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, _P]),
     'saicv_mixup_cutmix': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

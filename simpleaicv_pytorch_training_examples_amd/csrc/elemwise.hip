@@ -197,6 +197,82 @@ inline int ew_check(const char* what, int dtype, size_t n) {
     return 0;
 }
 
+// DINOv3 blocks (reference SimpleAICV/detection/models/backbones/dinov3vit.py).
+// Rotary position embedding on the q and k thirds of a packed [B][N][3][heads][D] projection (:262-276 rope_rotate_half /
+// rope_apply, :331-353 apply_rope): for tokens n >= prefix, y = x * cos + rot(x) * sin with rot(x) = [-x2, x1] over the two
+// halves of the head dimension, computed in fp32 and rounded once (the reference casts q / k to the fp32 of sin / cos and back);
+// v and the prefix tokens are copied.  TRANSPOSE: the gradient, dx = g * cos + rot^T(g * sin), rot^T(u) = [u2, -u1].
+// One thread per 16-byte chunk of the LOWER half and its partner chunk in the upper half.
+template <typename T, bool TRANSPOSE>
+__global__ __launch_bounds__(EW_THREADS) void rope_kernel(const T* __restrict__ in, const float* __restrict__ sn, const float* __restrict__ cs,
+                                                          T* __restrict__ out, size_t rows, int N, int heads, int D, int prefix) {
+    constexpr int NE = Chunk<T>::N;
+    const int half = D / 2, cph = half / NE;               // chunks per half head
+    const size_t C3 = (size_t)3 * heads * D;
+    const size_t items = rows * (size_t)3 * heads * cph;    // rows = B * N
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < items; i += (size_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % cph);
+        size_t t = i / cph;
+        const int h = (int)(t % heads); t /= heads;
+        const int part = (int)(t % 3);
+        const size_t row = t / 3;
+        const int n = (int)(row % N);
+        const size_t off = row * C3 + ((size_t)part * heads + h) * D + (size_t)c * NE;
+        const u32x4 lo = ld_chunk(in + off), hi = ld_chunk(in + off + half);
+        if (part == 2 || n < prefix) {
+            st_chunk(out + off, lo);
+            st_chunk(out + off + half, hi);
+            continue;
+        }
+        float a[NE], b[NE], s1[NE], s2[NE], c1[NE], c2[NE], o1[NE], o2[NE];
+        Chunk<T>::unpack(lo, a);
+        Chunk<T>::unpack(hi, b);
+        const float* sp = sn + (size_t)(n - prefix) * D + c * NE;
+        const float* cp = cs + (size_t)(n - prefix) * D + c * NE;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) { s1[j] = sp[j]; s2[j] = sp[j + half]; c1[j] = cp[j]; c2[j] = cp[j + half]; }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            if (TRANSPOSE) {
+                o1[j] = a[j] * c1[j] + b[j] * s2[j];
+                o2[j] = b[j] * c2[j] - a[j] * s1[j];
+            } else {
+                o1[j] = a[j] * c1[j] - b[j] * s1[j];
+                o2[j] = b[j] * c2[j] + a[j] * s2[j];
+            }
+        }
+        st_chunk(out + off, Chunk<T>::pack(o1));
+        st_chunk(out + off + half, Chunk<T>::pack(o2));
+    }
+}
+
+// SwiGLU gate (dinov3vit.py:137-140: hidden = silu(x1) * x2) and its backward in one pass each: the silu output is never written
+template <typename T, bool BWD>
+__global__ __launch_bounds__(EW_THREADS) void swiglu_kernel(const T* __restrict__ dy, const T* __restrict__ x1, const T* __restrict__ x2,
+                                                            T* __restrict__ o1, T* __restrict__ o2, size_t chunks) {
+    constexpr int N = Chunk<T>::N;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < chunks; i += (size_t)gridDim.x * EW_THREADS) {
+        float a[N], b[N], r1[N], r2[N];
+        Chunk<T>::unpack(ld_chunk(x1 + i * N), a);
+        Chunk<T>::unpack(ld_chunk(x2 + i * N), b);
+        if (BWD) {
+            float g[N];
+            Chunk<T>::unpack(ld_chunk(dy + i * N), g);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                r1[j] = g[j] * b[j] * act_der<ACT_SILU>(a[j], 0.f);
+                r2[j] = g[j] * act_val<ACT_SILU>(a[j], 0.f);
+            }
+            st_chunk(o1 + i * N, Chunk<T>::pack(r1));
+            st_chunk(o2 + i * N, Chunk<T>::pack(r2));
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) r1[j] = act_val<ACT_SILU>(a[j], 0.f) * b[j];
+            st_chunk(o1 + i * N, Chunk<T>::pack(r1));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -299,6 +375,49 @@ int saicv_channel_scale_add_bwd(int dtype, const void* dout, const void* y, cons
 // per-channel sum and sum of squares of x[M][C], ADDED into sum[C] / sq[C] (fp32, zeroed by the caller): the statistics of a
 // BatchNorm2d whose input is not a convolution output (van.py:176,178 norm1 / norm2, :260 stage norm; convformer.py:143,149);
 // saicv_bn_finalize_fwd(rows = 1) turns them into mean / invstd / scale / shift as for the convolution epilogues' rows
+int saicv_rope_apply(int dtype, const void* qkv, const float* sin_t, const float* cos_t, void* out, int B, int N, int heads, int D,
+                     int prefix, int transpose, void* stream) {
+    SAICV_REQUIRE(qkv && sin_t && cos_t && out && B > 0 && N > 0 && heads > 0 && prefix >= 0 && prefix <= N, "saicv_rope_apply: bad arguments");
+    const int ne = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(dtype == SAICV_DTYPE_BF16 || dtype == SAICV_DTYPE_F32, "saicv_rope_apply: dtype %d", dtype);
+    SAICV_REQUIRE(D % (2 * ne) == 0, "saicv_rope_apply: head dim %d must be a multiple of %d", D, 2 * ne);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = (size_t)B * N, items = rows * 3 * heads * (D / 2 / ne);
+#define ROPE(T, TR) hipLaunchKernelGGL((rope_kernel<T, TR>), dim3(ew_grid(items)), dim3(EW_THREADS), 0, st, (const T*)qkv, sin_t, cos_t, (T*)out, rows, N, heads, D, prefix)
+    if (dtype == SAICV_DTYPE_BF16) { if (transpose) ROPE(bf16_t, true); else ROPE(bf16_t, false); }
+    else { if (transpose) ROPE(float, true); else ROPE(float, false); }
+#undef ROPE
+    return saicv::check_launch("rope_apply");
+}
+
+int saicv_swiglu_fwd(int dtype, const void* x1, const void* x2, void* out, size_t n, void* stream) {
+    if (ew_check("swiglu_fwd", dtype, n)) return -1;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t chunks = n / (dtype == SAICV_DTYPE_BF16 ? 8 : 4);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL((swiglu_kernel<bf16_t, false>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const bf16_t*)nullptr, (const bf16_t*)x1,
+                           (const bf16_t*)x2, (bf16_t*)out, (bf16_t*)nullptr, chunks);
+    else
+        hipLaunchKernelGGL((swiglu_kernel<float, false>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const float*)nullptr, (const float*)x1,
+                           (const float*)x2, (float*)out, (float*)nullptr, chunks);
+    return saicv::check_launch("swiglu_fwd");
+}
+
+int saicv_swiglu_bwd(int dtype, const void* dy, const void* x1, const void* x2, void* dx1, void* dx2, size_t n, void* stream) {
+    if (ew_check("swiglu_bwd", dtype, n)) return -1;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t chunks = n / (dtype == SAICV_DTYPE_BF16 ? 8 : 4);
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL((swiglu_kernel<bf16_t, true>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const bf16_t*)dy, (const bf16_t*)x1,
+                           (const bf16_t*)x2, (bf16_t*)dx1, (bf16_t*)dx2, chunks);
+    else
+        hipLaunchKernelGGL((swiglu_kernel<float, true>), dim3(ew_grid(chunks)), dim3(EW_THREADS), 0, st, (const float*)dy, (const float*)x1,
+                           (const float*)x2, (float*)dx1, (float*)dx2, chunks);
+    return saicv::check_launch("swiglu_bwd");
+}
+
 int saicv_bn_stats(int dtype, const void* x, size_t M, int C, float* sum, float* sq, void* stream) {
     if (ew_check("bn_stats", dtype, (size_t)C)) return -1;
     if (M == 0) return 0;

@@ -1126,7 +1126,7 @@ class ScaleAddFn(torch.autograd.Function):
     def forward(ctx, x, y, s):
         require_gpu(x, y)
         y = _nhwc(y)
-        x = _like(y, x)
+        x = _like(y, x) if x is not None else None            # None: s[c] * y alone (a layer scale outside a residual join)
         n, c, h, w = y.shape
         sf = s.detach().reshape(-1).float().contiguous() if s is not None else None
         if sf is not None and sf.numel() != c:
@@ -1145,7 +1145,7 @@ class ScaleAddFn(torch.autograd.Function):
         dout = _nhwc(dout)
         if dout.dtype != dt:
             dout = dout.to(dt)
-        dx = dout if ctx.needs_input_grad[0] else None
+        dx = dout if ctx.needs_input_grad[0] else None        # (needs_input_grad[0] is False for x = None)
         if s is None:
             return dx, (dout if ctx.needs_input_grad[1] else None), None
         dy = torch.empty_like(dout) if ctx.needs_input_grad[1] else None

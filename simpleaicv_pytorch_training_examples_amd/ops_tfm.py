@@ -822,3 +822,66 @@ class Upsample4Fn(torch.autograd.Function):
 
 def upsample4_bilinear(low):
     return Upsample4Fn.apply(low)
+
+
+# ---------------------------------------------------------------------------------------------- DINOv3 block pieces
+class RopeFn(torch.autograd.Function):
+    """Rotary position embedding on the q / k thirds of a packed projection [B, N, 3*C] (reference detection/models/backbones/
+    dinov3vit.py:262-276, :331-353): one pass, v and the `prefix` leading tokens copied; the backward is the transposed map."""
+
+    @staticmethod
+    def forward(ctx, qkv, sin, cos, heads, prefix):
+        require_gpu(qkv, sin, cos)
+        b, n, c3 = qkv.shape
+        d = c3 // 3 // heads
+        qkv = qkv.contiguous()
+        sin, cos = sin.float().contiguous(), cos.float().contiguous()
+        if tuple(sin.shape) != (n - prefix, d) or tuple(cos.shape) != (n - prefix, d):
+            raise ValueError(f'rope tables {tuple(sin.shape)} for {n - prefix} tokens of head dim {d}')
+        out = torch.empty_like(qkv)
+        check(lib().saicv_rope_apply(dtype_code(qkv.dtype), ptr(qkv), ptr(sin), ptr(cos), ptr(out), b, n, heads, d, prefix, 0,
+                                     stream()), 'rope_apply')
+        ctx.save_for_backward(sin, cos)
+        ctx.cfg = (b, n, heads, d, prefix)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sin, cos = ctx.saved_tensors
+        b, n, heads, d, prefix = ctx.cfg
+        dout = dout.contiguous()
+        dx = torch.empty_like(dout)
+        check(lib().saicv_rope_apply(dtype_code(dout.dtype), ptr(dout), ptr(sin), ptr(cos), ptr(dx), b, n, heads, d, prefix, 1,
+                                     stream()), 'rope_apply')
+        return dx, None, None, None, None
+
+
+def rope(qkv, sin, cos, heads, prefix=0):
+    return RopeFn.apply(qkv, sin, cos, heads, prefix)
+
+
+class SwiGluFn(torch.autograd.Function):
+    """silu(x1) * x2 (reference dinov3vit.py:137-140) and its gradients, one pass each."""
+
+    @staticmethod
+    def forward(ctx, x1, x2):
+        require_gpu(x1, x2)
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        out = torch.empty_like(x1)
+        check(lib().saicv_swiglu_fwd(dtype_code(x1.dtype), ptr(x1), ptr(x2), ptr(out), x1.numel(), stream()), 'swiglu_fwd')
+        ctx.save_for_backward(x1, x2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != x1.dtype:
+            dy = dy.to(x1.dtype)
+        d1, d2 = torch.empty_like(x1), torch.empty_like(x2)
+        check(lib().saicv_swiglu_bwd(dtype_code(x1.dtype), ptr(dy), ptr(x1), ptr(x2), ptr(d1), ptr(d2), x1.numel(), stream()), 'swiglu_bwd')
+        return d1, d2
+
+
+def swiglu(x1, x2):
+    return SwiGluFn.apply(x1, x2)
