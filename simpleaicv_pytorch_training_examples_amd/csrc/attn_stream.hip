@@ -174,6 +174,11 @@ DEVINL void sa_store_tile(const f32x4 (&a)[2][D / 16], char* stage, T* g, long r
 }
 template <typename T, int D> constexpr int sa_stage_bytes() { return 32 * (D * (int)sizeof(T) + 16); }      // per wavefront; 4 of them fit every kernel's K / V (Q / dO) buffers
 
+// the 4-byte form: one dword per lane (256 bytes per wavefront piece) -- a strided column of an fp32 table into LDS
+DEVINL void sa_dma4(const sa_rsrc_t& rs, unsigned lds_dst, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rs) : "memory", "m0");
+}
+
 template <typename T, int D>
 struct SA {
     static constexpr int EPC = ElemTraits<T>::EPC;
@@ -569,7 +574,7 @@ DEVINL float sa_lg_sum(float v) {
 }
 
 template <typename T, int D, int REL, bool KB>
-__global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p) {
+__global__ __launch_bounds__(SA_THREADS, 3) void sa_fwd2_kernel(const SAParams p) {      // (<= 168 registers: three workgroups per CU)
     using S = SA<T, D>;
     static_assert(REL == 0 || (REL <= 2 && !KB), "r04 forward: no bias / key bias (REL 0), window tables on the MFMA (REL 1) or "
                                                  "the 64-wide decomposed bias (REL 2)");
@@ -579,9 +584,13 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
     const int bh = sa_lid / (int)gridDim.x, blk = sa_lid - bh * (int)gridDim.x;
     const int b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, lg = lane >> 4;
-    constexpr int STAGE = 2 * S::CHUNK_BYTES;                 // K chunk | V chunk
-    char* KV = smem;                                          // [SA_RING][K | V]
-    float* aux = reinterpret_cast<float*>(smem + SA_RING * STAGE);      // REL 2: rel_h rows [128 queries][Sh] * log2(e); REL 0: key bias
+    // ring stage: K chunk | V chunk | REL 2: the chunk's rel_h column of the block's 128 queries (1 KiB: every wavefront moves one
+    // 256-byte piece so that all four count the same number of transfers; wavefronts 2, 3 deposit duplicates nobody reads)
+    constexpr int RHB = REL == 2 ? 4 * 256 : 0;
+    constexpr int STAGE = 2 * S::CHUNK_BYTES + RHB;
+    constexpr int PIECES = 2 * S::NLD + (REL == 2 ? 1 : 0);   // transfers per wavefront and chunk
+    char* KV = smem;                                          // [SA_RING][K | V | rel_h column]
+    float* aux = reinterpret_cast<float*>(smem + SA_RING * STAGE);      // REL 0: key bias
     char* Es = smem + SA_RING * STAGE;                        // REL 1: key -> (kh, kw) indicator matrix [256][32] (SARel)
     const T* qg = (const T*)p.q + (size_t)b * p.q_bs + h * D;
     const T* kg = (const T*)p.k + (size_t)b * p.k_bs + h * D;
@@ -590,12 +599,23 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
     const bool live = q0 < p.Nq;                              // wave-uniform
     const sa_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
     const int nchunk = (p.Nk + SA_CHUNK - 1) / SA_CHUNK;
+    // REL 2: rel_h[q][kh] travels with the ring -- column ci of the block's rows, one dword per lane (rows past Nq: out of bounds
+    // -> zeros).  r04 first staged all 64 columns of the 128 rows in LDS (32 KiB: 80 KiB per workgroup, two per CU); with the column
+    // in the ring the workgroup needs 51 KiB and a third one fits (the kernel holds 167 registers)
+    const sa_rsrc_t rh_rsrc = sa_make_rsrc(REL == 2 ? (const void*)(p.rel_h + (size_t)bh * p.Nq * p.Sh) : (const void*)p.lse,
+                                           REL == 2 ? (unsigned)((size_t)p.Nq * p.Sh * sizeof(float)) : 0u);
+    const unsigned rh_lane = (unsigned)(((size_t)(blk * SA_BROWS + (wave & 1) * 64 + lane) * p.Sh) * sizeof(float));
+    auto dma_rh = [&](int ci, int s) {
+        if constexpr (REL == 2) sa_dma4(rh_rsrc, sa_lds_addr(KV + s * STAGE + 2 * S::CHUNK_BYTES) + wave * 256, rh_lane + (unsigned)ci * 4u);
+    };
     // ring prologue first: the two chunks stream in under the rest of the set-up
     S::dma(k_rsrc, KV, p.k_rs, 0, p.Nk, wave, lane);
     S::dma(v_rsrc, KV + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), 0, p.Nk, wave, lane);
+    dma_rh(0, 0);
     if (nchunk > 1) {
         S::dma(k_rsrc, KV + STAGE, p.k_rs, SA_CHUNK, p.Nk, wave, lane);
         S::dma(v_rsrc, KV + STAGE + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), SA_CHUNK, p.Nk, wave, lane);
+        dma_rh(1, 1);
     }
     const float* kb = aux;
     if constexpr (KB) {                                       // host: Nk <= SA_KB_LDS on this path
@@ -609,16 +629,6 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int e = 0; e < RL::ECH; ++e) rf[qt][e] = RL::row_frag(p, bh, q0 + qt * 16 + l15, e * 4 + lg, 1.f / p.scale);
-    }
-    if constexpr (REL == 2) {
-        // rel_h[q][kh] of the block's queries, TRANSPOSED [kh][128 queries]: a chunk reads one row, 16 consecutive floats per
-        // lane group (conflict free), and two workgroups still share a CU (3 x 16 KiB ring + 32 KiB = 80 KiB each)
-        const int rows = min(SA_BROWS, p.Nq - blk * SA_BROWS);
-        const float* rg = p.rel_h + ((size_t)bh * p.Nq + (size_t)blk * SA_BROWS) * p.Sh;
-        for (int i = threadIdx.x; i < SA_BROWS * p.Sh; i += SA_THREADS) {
-            const int r = i / p.Sh, c = i - r * p.Sh;
-            aux[c * SA_BROWS + r] = r < rows ? rg[(size_t)r * p.Sh + c] * LOG2E : 0.f;
-        }
     }
     f32x4 rwq[2][4];                                          // REL 2: rel_w[q][kt*16 + lg*4 + 0..3] * log2(e)
     if constexpr (REL == 2) {
@@ -644,13 +654,12 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
 #pragma unroll
         for (int dt = 0; dt < S::DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c2 = p.scale * LOG2E;
-    const float* rhcol = aux + wave * SA_WROWS + l15;          // REL 2: + ci * SA_BROWS (+ 16 for the second query tile)
     // every ordinary load of the prologue has been consumed into registers / LDS before the first counted wait below
     sa_settle(qf);
     if constexpr (REL == 1) sa_settle(rf);
     if constexpr (REL == 2) sa_settle(rwq);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (REL != 0 || KB) __syncthreads();            // the LDS tables written above are complete for every wavefront
+    if constexpr (REL == 1 || KB) __syncthreads();            // the LDS tables written above are complete for every wavefront
 
     int slot = 0;                                             // ring slot of the chunk being consumed
     for (int ci = 0; ci < nchunk; ++ci) {
@@ -658,13 +667,14 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
         const char* Ks = KV + slot * STAGE;
         const char* Vs = Ks + S::CHUNK_BYTES;
         // chunk ci has landed: behind it at most chunk ci + 1 (2 * NLD loads per thread) is still in flight
-        if (ci + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S::NLD) : "memory");
+        if (ci + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // ... for every wavefront; chunk ci - 1's slot is free again
         if (ci + 2 < nchunk) {
             const int ns = slot == 0 ? 2 : slot - 1;          // (slot + 2) % 3
             S::dma(k_rsrc, KV + ns * STAGE, p.k_rs, k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
             S::dma(v_rsrc, KV + ns * STAGE + S::CHUNK_BYTES, (D == 32 ? p.v_rs : p.k_rs), k0 + 2 * SA_CHUNK, p.Nk, wave, lane);
+            dma_rh(ci + 2, ns);
         }
         if (live) {                                           // (a wavefront whose 32 rows all lie past Nq only feeds the ring)
         f32x4 st[2][4];
@@ -686,8 +696,9 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd2_kernel(const SAParams p
         const bool tail = REL != 2 && k0 + SA_CHUNK > p.Nk;   // wave-uniform: only the last chunk pays for the key mask (REL 2: Nk = Sh * 64)
         float rowb[2] = {0.f, 0.f};                           // REL 2: the chunk is one kh row -> one bias value per query
         if constexpr (REL == 2) {
-            rowb[0] = rhcol[ci * SA_BROWS];
-            rowb[1] = rhcol[ci * SA_BROWS + 16];
+            const float* rhs = reinterpret_cast<const float*>(Ks + 2 * S::CHUNK_BYTES) + wave * SA_WROWS + l15;
+            rowb[0] = rhs[0] * LOG2E;
+            rowb[1] = rhs[16] * LOG2E;
         }
         // The elementwise work between the two MFMA groups is what the kernel is bound by (one VALU instruction is four
         // cycles per wavefront, an MFMA sixteen): it is written on float4 values so that the multiply-adds, the running sum
@@ -1391,7 +1402,7 @@ int sa_launch(const SAParams& p, int which, hipStream_t st) {
             // sends every eligible launch there, =0 none
             static const int fwd2_env = getenv("SAICV_SA_FWD2") ? atoi(getenv("SAICV_SA_FWD2")) : 1;
             const bool fwd2 = fwd2_env == 2 || (fwd2_env == 1 && REL != 1);
-            const size_t aux = REL == 2 ? (size_t)SA_BROWS * p.Sh * sizeof(float)
+            const size_t aux = REL == 2 ? (size_t)SA_RING * 4 * 256               // the ring's rel_h column pieces
                              : REL == 1 ? (size_t)SARel<T>::EBYTES
                                         : (p.key_bias ? (size_t)((p.Nk + SA_CHUNK - 1) / SA_CHUNK) * SA_CHUNK * sizeof(float) : 0);   // padded to whole chunks
             if (fwd2 && (REL == 0 || !KB)) {
