@@ -56,6 +56,7 @@ struct NTParams {
     float* stat_sq;
     const void* addend;         // epilogue: out = addend + row_scale * (acc + bias)   (act_mode 2: the GELU pre-activation)
     void* out2;                 // act_mode 1: second output, gelu(out)
+    int lean_gelu;              // 1: act modes 1 / 3 without addend / row scale take the lean epilogue row loop (SAICV_GELU_EPI=0: the general one)
     int act_mode;               // 0 none | 1 out2 = gelu(out) | 2 out = (acc + bias) * gelu'(addend) | 3 out = gelu'(pre), out2 = gelu(pre) | 4 out = (acc + bias) * addend
     const float* row_scale;
     int rows_per_scale;
@@ -624,13 +625,7 @@ void igemm_nt_kernel(const NTParams p) {
                             Chunk<TO>::unpack(v, f);
                             if (p.act_mode == 1 || p.act_mode == 3) {   // fc1 of an MLP: emit gelu() beside the pre-activation (1) or gelu'() (3)
                                 float gl[OEPC], gr[OEPC];
-#pragma unroll
-                                for (int k = 0; k < OEPC; ++k) {
-                                    float c, d;
-                                    gelu_cdf_pdf(f[k], c, d);
-                                    gl[k] = f[k] * c;
-                                    gr[k] = fmaf(f[k], d, c);
-                                }
+                                gelu_and_grad8(f, gl, gr);
                                 st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)mo * p.ldo + ncol, Chunk<TO>::pack(gl));
                                 if (p.act_mode == 3) v = Chunk<TO>::pack(gr);
                             } else if (p.act_mode == 2 || p.act_mode == 4) {     // dgrad of fc2: times gelu'(pre) (2) or times the stored derivative (4)
@@ -1452,6 +1447,31 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
                 }
             }
         }
+    } else if (p.lean_gelu && aligned && !remap && (p.act_mode == 1 || p.act_mode == 3) && p.addend == nullptr && p.row_scale == nullptr && !bstats &&
+               (p.Nn % OEPC) == 0) {   // uniform
+        // fc1 of an MLP (r04): out = the pre-activation (1) or gelu'(pre) (3), out2 = gelu(pre).  Nothing but the staged tile is read,
+        // so the row loop is just unpack -> packed-fp32 GELU pieces -> two packs -> two 16-byte stores: 322 -> ~150 vector
+        // instructions per row of eight against the general rolled loop below (an epilogue instruction competes with the other
+        // workgroup's MFMAs for the issue port)
+        if (ncol < p.Nn) {
+            const int mrow0 = tile_m * BM_T + orow0;
+            const char* ls = smem + orow0 * OPITCH + oc * 16;
+            TO* const o2 = reinterpret_cast<TO*>(p.out2);
+            const bool emit_grad = p.act_mode == 3;
+#pragma unroll 2
+            for (int g = 0; g < NIT; ++g) {
+                const int mrow = mrow0 + g * RPP;
+                if (mrow < Mc) {
+                    const u32x4 v = ld_chunk(ls + g * RPP * OPITCH);
+                    float f[OEPC], gl[OEPC], gr[OEPC];
+                    Chunk<TO>::unpack(v, f);
+                    gelu_and_grad8(f, gl, gr);
+                    const size_t off = (size_t)mrow * p.ldo + ncol;
+                    st_chunk(o2 + off, Chunk<TO>::pack(gl));
+                    st_chunk(outp + off, emit_grad ? Chunk<TO>::pack(gr) : v);
+                }
+            }
+        }
     } else if (ncol < p.Nn) {
         // one copy of the fused-mode code in a ROLLED loop; the staged chunk and the addend chunk of the NEXT row are
         // fetched before the current row is processed, so a row's global-load latency hides under its predecessor
@@ -1500,16 +1520,10 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
             }
             TO* o = outp + (size_t)m * p.ldo + ncol;
             if (p.act_mode == 1 || p.act_mode == 3) {   // fc1 of an MLP: emit gelu() beside the pre-activation (1) or beside gelu'() (3)
-                float f[OEPC], gr[OEPC];
+                float f[OEPC], gl[OEPC], gr[OEPC];
                 Chunk<TO>::unpack(v, f);
-#pragma unroll
-                for (int j = 0; j < OEPC; ++j) {
-                    float c, d;
-                    gelu_cdf_pdf(f[j], c, d);
-                    gr[j] = fmaf(f[j], d, c);
-                    f[j] *= c;
-                }
-                st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(f));
+                gelu_and_grad8(f, gl, gr);
+                st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(gl));
                 if (p.act_mode == 3) v = Chunk<TO>::pack(gr);
             } else if (p.act_mode == 2 || p.act_mode == 4) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre) (2) or * the stored derivative (4)
                 float f[OEPC], a[OEPC];
@@ -2358,6 +2372,8 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.rows_per_scale = ex ? ex->rows_per_scale : 1;
     p.out2 = ex ? ex->out2 : nullptr;
     p.act_mode = ex ? ex->act_mode : 0;
+    static const int lean_gelu_env = getenv("SAICV_GELU_EPI") ? atoi(getenv("SAICV_GELU_EPI")) : 1;
+    p.lean_gelu = lean_gelu_env;
     p.addend_gate = ex ? ex->addend_gate : nullptr;
     p.bs_y = ex ? ex->bs_y : nullptr;
     p.bs_mask = ex ? ex->bs_mask : nullptr;
