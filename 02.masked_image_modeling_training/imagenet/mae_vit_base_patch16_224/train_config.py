@@ -22,46 +22,25 @@ class config:
     input_image_size = 224
     scale = 256 / 224
 
-    model = models.__dict__[network](**{
-        'mask_ratio': 0.75,
-    })
+    model = models.__dict__[network](**{'mask_ratio': 0.75})
 
-    # load pretrained model or not
     trained_model_path = ''
     load_state_dict(trained_model_path, model)
 
     train_criterion = losses.__dict__['MSELoss']()
 
-    train_dataset = SyntheticClassificationDataset(int(os.environ.get('SAICV_MAE_TRAIN', 1281167)), input_image_size, 1000,
-                                                   seed=0)
+    train_dataset = SyntheticClassificationDataset(int(os.environ.get('SAICV_MAE_TRAIN', 1281167)), input_image_size, 1000, seed=0)
     train_collater = MAESelfSupervisedPretrainCollater(image_size=input_image_size, patch_size=16, norm_label=True)
 
     seed = 0
-    # batch_size is total size
-    batch_size = int(os.environ.get('SAICV_MAE_BATCH', 1024))
-    # num_workers is total workers
-    num_workers = int(os.environ.get('SAICV_MAE_WORKERS', 32))
+    batch_size = int(os.environ.get('SAICV_MAE_BATCH', 1024))       # total over all GPUs
+    num_workers = int(os.environ.get('SAICV_MAE_WORKERS', 32))     # total over all GPUs
     accumulation_steps = 1
 
-    optimizer = (
-        'AdamW',
-        {   # lr = base_lr:1.5e-4 * batch_size * accumulation_steps / 256
-            'lr': 6e-4,
-            'global_weight_decay': False,
-            'weight_decay': 5e-2,
-            'no_weight_decay_layer_name_list': [],
-            'beta1': 0.9,
-            'beta2': 0.95,
-        },
-    )
-
-    scheduler = (
-        'CosineLR',
-        {
-            'warm_up_epochs': 40,
-            'min_lr': 1e-6,
-        },
-    )
+    # lr = 1.5e-4 * batch_size * accumulation_steps / 256; 1-d parameters (biases, norms, tokens) at weight decay 0
+    optimizer = ('AdamW', {'lr': 6e-4, 'global_weight_decay': False, 'weight_decay': 5e-2, 'no_weight_decay_layer_name_list': [],
+                           'beta1': 0.9, 'beta2': 0.95})
+    scheduler = ('CosineLR', {'warm_up_epochs': 40, 'min_lr': 1e-6})
 
     epochs = int(os.environ.get('SAICV_MAE_EPOCHS', 400))
     print_interval = int(os.environ.get('SAICV_MAE_PRINT', 100))
