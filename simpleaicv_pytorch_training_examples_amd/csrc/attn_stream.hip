@@ -25,6 +25,7 @@
 //     registers per tile and rel_h is one value per chunk; gradients accumulate in registers;
 //   3 anything else: LDS tables + LDS atomics (slow, kept for generality).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "saicv_internal.h"
 #include "../../include/saicv_hip.h"
@@ -968,10 +969,20 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
         }
         if (live) {
         const bool tail = REL != 2 && k0 + SA_CHUNK > p.Nk;   // wave-uniform (REL 2: Nk = Sh * 64, no partial chunk)
+        // The chunk's math exists twice: the copy for the (one) partial chunk skips the 16-key tiles that hold no valid key at all --
+        // for the short sequences (ViT N = 197, SAM windows N = 196: four chunks, the last with 4-5 keys) that is 3/16 of the S / dP
+        // work and 1/8 of dS.K -- and pays for the key mask; the copy every other chunk runs has neither branch nor select.
+        auto compute = [&](auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        const int nkt = TAIL ? (p.Nk - k0 + 15) >> 4 : 4;     // key tiles of this chunk with a valid key
         f32x4 g[2][4];
         f32x2 ghc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};    // REL 2: partial row sums of the chunk's d logits
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
+            if (TAIL && kt >= nkt) {
+                g[0][kt] = g[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             u32x4 kf[S::STEPS], vf[S::STEPS];
             S::lds_frags(kf, Ks, kt * 16, l15, lg);
             S::lds_frags(vf, Vs, kt * 16, l15, lg);
@@ -1032,21 +1043,15 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
                 }
             }
         }
-        if (tail) {                                           // a real branch: the other chunks pay neither selects nor indices
-            int kb0 = k0 + lg * 4;
-            asm volatile("" : "+v"(kb0));                     // (opaque: keeps the index arithmetic inside the branch)
+        if constexpr (TAIL) {
+            const int kb0 = k0 + lg * 4;
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (kb0 + kt * 16 + r >= p.Nk) g[qt][kt][r] = 0.f;
-                if constexpr (REL == 2) {
-                    const f32x4 t4 = (g[qt][0] + g[qt][1]) + (g[qt][2] + g[qt][3]);
-                    ghc[qt] = f32x2{t4[0], t4[1]} + f32x2{t4[2], t4[3]};
-                }
-            }
         }
         if constexpr (REL == 2) {
 #pragma unroll
@@ -1084,12 +1089,15 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
             const f32x4 a0[2] = {g[0][0], g[1][0]}, a1[2] = {g[0][1], g[1][1]};
             const f32x4 b0[2] = {g[0][2], g[1][2]}, b1[2] = {g[0][3], g[1][3]};
             pvN<T, S::ROWB, S::DT, 2>(o, a0, a1, Ks, 0, l15, lg);          // dQ += dS K   (scale applied at the end)
-            pvN<T, S::ROWB, S::DT, 2>(o, b0, b1, Ks, 32, l15, lg);
+            if (!TAIL || nkt > 2) pvN<T, S::ROWB, S::DT, 2>(o, b0, b1, Ks, 32, l15, lg);
             if constexpr (REL == 1) {
                 pvN<T, EROWB, 2, 2>(ge, a0, a1, Es, k0, l15, lg);          // d rel += dS E
-                pvN<T, EROWB, 2, 2>(ge, b0, b1, Es, k0 + 32, l15, lg);
+                if (!TAIL || nkt > 2) pvN<T, EROWB, 2, 2>(ge, b0, b1, Es, k0 + 32, l15, lg);
             }
         }
+        };
+        if (tail) compute(std::true_type{});
+        else compute(std::false_type{});
         }
     }
     T* dqg = (T*)p.dq + (size_t)b * p.q_bs + h * D;
@@ -1309,12 +1317,21 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
         }
         const float* rwc = rws + ((q0 >> 6) & 1) * SA_CHUNK * 64;      // REL 2: this chunk's tile
         if (live) {
+        // the partial query chunk (N = 196 / 197: the last chunk has 4-5 rows) skips the 32-row pair and the 16-row tile that hold no
+        // valid query: two wave-uniform compares per chunk (a second copy of the chunk's math, as in the dQ kernel, costs this kernel
+        // its registers: 256 + spills)
+        const int nvq = p.Nq - q0;                         // valid rows of this chunk (>= 64 except in the last one)
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair) {             // 32 queries at a time
+            if (pair * 32 >= nvq) continue;
             f32x4 pt[2][2], dst[2][2];                     // [key tile][query tile of the pair]
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int qt = pair * 2 + qq;
+                if (qt * 16 >= nvq) {
+                    pt[0][qq] = pt[1][qq] = dst[0][qq] = dst[1][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    continue;
+                }
                 u32x4 qf[S::STEPS], dof[S::STEPS];
                 S::lds_frags(qf, Qs, qt * 16, l15, lg);
                 S::lds_frags(dof, Os, qt * 16, l15, lg);
