@@ -13,10 +13,17 @@
 //
 // Structure.  A workgroup is 4 wavefronts; each wavefront owns 32 rows (queries in the forward
 // and dQ kernels, keys in the dK/dV kernel) as two 16-row MFMA tiles that share every LDS
-// fragment read; the other operand streams through LDS in 64-row chunks, the next chunk being
-// fetched into registers while the current one is consumed.  Scores live in the S^T accumulator
-// layout (query on the lane, keys on lane-group / register), so softmax row reductions are two
-// shuffles; P.V and dS.K use transposing LDS reads.  Softmax runs in the log2 domain (v_exp_f32).
+// fragment read; the other operand streams through LDS in 64-row chunks, moved by the DMA engine
+// (`buffer_load ... lds` as an assembly statement, sa_dma16) one or two chunks ahead of the one
+// being consumed.  Scores live in the S^T accumulator layout (query on the lane, keys on
+// lane-group / register), so softmax row reductions are two lane swaps; P.V and dS.K use
+// transposing LDS reads.  Softmax runs in the log2 domain (v_exp_f32).
+//
+// What bounds these kernels (r04, rocprofv3 SQ counters + the instruction streams): the vector
+// issue port -- an MFMA holds it four slots, every other vector instruction one -- and any s_waitcnt vmcnt the compiler places
+// inside a chunk (it drains the DMA pieces in flight).  Hence: packed fp32 elementwise math with the row constants folded into
+// one fma / the MFMA C operand, masks only in the partial chunk, no compiler-visible VMEM operation between the kernels' own
+// waits at the top of a chunk (sa_settle), registers instead of LDS read-modify-write for the rel-pos gradients.
 // Relative-position modes (template REL):
 //   0 none;
 //   1 small tables (Sh + Sw <= 32, Nk <= 256: SAM windows): rows of rel_h / rel_w in LDS, gradients
