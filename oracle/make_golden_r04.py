@@ -5,6 +5,9 @@ Build container only:   python oracle/make_golden_r04.py [names...]
 convbnact_variants        reference classification ConvBnActBlock (resnet.py:19-48) in the forms round 3 refused:
                           has_bn=False (biased convolution, with and without ReLU) and a depthwise block (groups == channels,
                           BatchNorm + ReLU): state_dict, output, input / parameter gradients, BatchNorm buffers after the step.
+det_van_convformer        reference detection VANBackbone / MetaFormerBackbone / Dinov3ConvNeXtBackbone
+                          (detection/models/backbones/{van,convformer,dinov3convnext}.py) in tiny
+                          geometries, training mode: the four stage outputs, parameter gradients, BatchNorm buffers after the step.
 dinov3_tiny               reference DinoVisionTransformer (detection/models/backbones/dinov3vit.py): GELU-MLP form in training mode
                           (RoPE rescale draw) and SwiGLU form in eval mode; outputs, input and parameter gradients.
 random_erasing            reference RandomErasing (classification/common.py:561-640), modes const / rand / pixel, seeded numpy
@@ -151,6 +154,51 @@ def dinov3_tiny(name='dinov3_tiny'):
     print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
+def det_van_convformer(name='det_van_convformer'):
+    """reference VANBackbone (SimpleAICV/detection/models/backbones/van.py:32-130) and MetaFormerBackbone
+    (.../convformer.py:29-117) and Dinov3ConvNeXtBackbone (.../dinov3convnext.py:120-199), four stages of widths 16..128 / 32..128,
+    depths [1, 1, 2, 1], drop-path 0, training mode, image 2 x 3 x 64 x 96.  Layer scales (1e-2 at init in VAN, 1e-6 gammas in
+    ConvNeXt) are redrawn around 0.5 and biases around 0 from generator 33 so every branch
+    carries gradient.  Per net: parameter checksums (the test rebuilds the weights from the seeds), the four stage outputs, norm +
+    first 64 entries of every parameter gradient for one random probe per output, BatchNorm buffers after the forward."""
+    import types
+    for mod in ('cv2', 'torchvision', 'torchvision.transforms'):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    from SimpleAICV.detection.models.backbones.van import VANBackbone
+    from SimpleAICV.detection.models.backbones.convformer import MetaFormerBackbone
+    from SimpleAICV.detection.models.backbones.dinov3convnext import Dinov3ConvNeXtBackbone
+    cases = {}
+    for key, cls, kw in (('van', VANBackbone, dict(embedding_planes=[16, 32, 64, 128], mlp_ratios=[8, 8, 4, 4], block_nums=[1, 1, 2, 1])),
+                         ('convformer', MetaFormerBackbone, dict(embedding_planes=[32, 64, 96, 128], block_nums=[1, 1, 2, 1])),
+                         ('dinov3convnext', Dinov3ConvNeXtBackbone, dict(embedding_planes=[32, 64, 96, 128], block_nums=[1, 1, 2, 1]))):
+        torch.manual_seed(0)
+        m = cls(**kw)
+        g = torch.Generator().manual_seed(33)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if 'layer_scale' in n or n.endswith('.scale') or n.endswith('.gamma'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.2 + 0.5)
+                elif n.endswith('.bias'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        m.train()
+        x = torch.randn(2, 3, 64, 96, generator=g)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        outs = m(x)
+        probes = [torch.randn(o.shape, generator=g) for o in outs]
+        sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+        after = m.state_dict()
+        cases[key] = {'kwargs': kw, 'param_sum': {k: float(v.double().sum()) for k, v in sd.items()},
+                      'param_abs_sum': {k: float(v.double().abs().sum()) for k, v in sd.items()},
+                      'input_checksum': float(x.double().sum()), 'outs': [o.detach().clone() for o in outs],
+                      'buffers_after': {k: after[k].detach().clone() for k in after if 'running_' in k},
+                      'grad_norm': {n: float(p.grad.norm()) for n, p in m.named_parameters()},
+                      'grad_sample': {n: p.grad.flatten()[:64].clone() for n, p in m.named_parameters()}}
+        print(key, [tuple(o.shape) for o in outs], [round(float(o.norm()), 3) for o in outs], len(sd), 'state entries')
+    path = os.path.join(OUT, name + '.pt')
+    torch.save({'name': name, 'cases': cases, 'torch_version': torch.__version__}, path)
+    print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit(f'{REF} not present: golden fixtures can only be (re)generated in the build container')
@@ -165,6 +213,8 @@ def main():
         random_erasing()
     if not only or 'dinov3_tiny' in only:
         dinov3_tiny()
+    if not only or 'det_van_convformer' in only:
+        det_van_convformer()
 
 
 if __name__ == '__main__':

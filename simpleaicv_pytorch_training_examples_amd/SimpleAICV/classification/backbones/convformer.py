@@ -112,6 +112,48 @@ class MetaFormerBlock(nn.Module):
         return x
 
 
+def _register_stages(net, inplanes, embedding_planes, block_nums, dropout_prob, drop_path_prob):
+    """downsample_layers / stages in the reference's registration order (convformer.py:185-222; the detection backbone builds the
+    same tree, detection/models/backbones/convformer.py:43-84)."""
+    widths = [inplanes] + list(embedding_planes)
+    # stem: 7x7 stride 4 (padding 2) with a BatchNorm after it; later stages: BatchNorm, then 3x3 stride 2
+    net.downsample_layers = nn.ModuleList([
+        Downsampling(widths[i], widths[i + 1], kernel_size=7 if i == 0 else 3, stride=4 if i == 0 else 2, padding=2 if i == 0 else 1,
+                     pre_norm=i > 0, post_norm=i == 0) for i in range(len(block_nums))])
+    rates = list(np.linspace(0, drop_path_prob, sum(block_nums)))
+    offsets = np.cumsum([0] + list(block_nums))
+    net.stages = nn.ModuleList([
+        nn.Sequential(*[MetaFormerBlock(inplanes=embedding_planes[i], dropout_prob=dropout_prob, drop_path_prob=rates[offsets[i] + j])
+                        for j in range(block_nums[i])]) for i in range(len(block_nums))])
+
+
+def _init_like_reference(net):
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d) and m.groups == 1:
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+
+
+def _stage_outputs(net, x):
+    """Every stage's output (NHWC, compute dtype): the classifier pools the last, the detection backbone returns all four."""
+    outs = []
+    x = ops.pack_input(x)
+    for down, stage in zip(net.downsample_layers, net.stages):
+        if net.use_gradient_checkpoint:
+            x = checkpoint(stage, checkpoint(down, x, use_reentrant=False), use_reentrant=False)
+        else:
+            x = stage(down(x))
+        outs.append(x)
+    return outs
+
+
 class MetaFormer(nn.Module):
 
     def __init__(self, inplanes=3, embedding_planes=[64, 128, 320, 512], block_nums=[2, 2, 6, 2], dropout_prob=0., drop_path_prob=0.,
@@ -121,38 +163,13 @@ class MetaFormer(nn.Module):
         self.block_nums = block_nums
         self.num_classes = num_classes
         self.use_gradient_checkpoint = use_gradient_checkpoint
-        widths = [inplanes] + list(embedding_planes)
-        # stem: 7x7 stride 4 (padding 2) with a BatchNorm after it; later stages: BatchNorm, then 3x3 stride 2
-        self.downsample_layers = nn.ModuleList([
-            Downsampling(widths[i], widths[i + 1], kernel_size=7 if i == 0 else 3, stride=4 if i == 0 else 2, padding=2 if i == 0 else 1,
-                         pre_norm=i > 0, post_norm=i == 0) for i in range(len(block_nums))])
-        rates = list(np.linspace(0, drop_path_prob, sum(block_nums)))
-        offsets = np.cumsum([0] + list(block_nums))
-        self.stages = nn.ModuleList([
-            nn.Sequential(*[MetaFormerBlock(inplanes=embedding_planes[i], dropout_prob=dropout_prob, drop_path_prob=rates[offsets[i] + j])
-                            for j in range(block_nums[i])]) for i in range(len(block_nums))])
+        _register_stages(self, inplanes, embedding_planes, block_nums, dropout_prob, drop_path_prob)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         self.head = nn.Linear(embedding_planes[3], num_classes)
-        for m in self.modules():
-            if isinstance(m, (nn.Conv2d, nn.Linear)):
-                nn.init.trunc_normal_(m.weight, std=.02)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d) and m.groups == 1:
-                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        _init_like_reference(self)
 
     def forward(self, x):
-        x = ops.pack_input(x)
-        for down, stage in zip(self.downsample_layers, self.stages):
-            if self.use_gradient_checkpoint:
-                x = checkpoint(stage, checkpoint(down, x, use_reentrant=False), use_reentrant=False)
-            else:
-                x = stage(down(x))
-        x = ops.global_avg_pool(x)
+        x = ops.global_avg_pool(_stage_outputs(self, x)[-1])
         return ops.linear(x, self.head.weight, self.head.bias, out_f32=True)
 
 

@@ -142,6 +142,57 @@ class OverlapPatchEmbed(nn.Module):
         return ops.batch_norm2d(_pointwise(self.proj, x), self.norm)
 
 
+def _register_stages(net, inplanes, embedding_planes, mlp_ratios, block_nums, dropout_prob, drop_path_prob):
+    """patch_embed{i} / block{i} / norm{i} for the four stages, in the reference's registration order (van.py:232-260; the detection
+    backbone builds the same tree, detection/models/backbones/van.py:52-80)."""
+    rates = list(np.linspace(0, drop_path_prob, sum(block_nums)))
+    width_in, first = inplanes, 0
+    for i, (width, ratio, depth) in enumerate(zip(embedding_planes, mlp_ratios, block_nums)):
+        setattr(net, f'patch_embed{i + 1}', OverlapPatchEmbed(patch_size=7 if i == 0 else 3, stride=4 if i == 0 else 2,
+                                                               inplanes=width_in, embedding_planes=width))
+        setattr(net, f'block{i + 1}', nn.ModuleList([
+            Block(inplanes=width, mlp_ratio=ratio, dropout_prob=dropout_prob, drop_path_prob=rates[first + j]) for j in range(depth)]))
+        setattr(net, f'norm{i + 1}', nn.BatchNorm2d(width))
+        width_in, first = width, first + depth
+
+
+def _init_like_reference(net):
+    for m in net.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.Conv2d):
+            fan_out = (m.kernel_size[0] * m.kernel_size[1] * m.out_channels) // m.groups
+            m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
+            if m.bias is not None:
+                m.bias.data.zero_()
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d) and m.groups == 1:
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+
+
+def _stage_outputs(net, x):
+    """The normalised output of every stage (NHWC, compute dtype); the classifier pools the last one, the detection backbone
+    returns all four."""
+    def run(fn, t):
+        return checkpoint(fn, t, use_reentrant=False) if net.use_gradient_checkpoint else fn(t)
+
+    outs = []
+    x = ops.pack_input(x)
+    for i in range(len(net.block_nums)):
+        x = run(getattr(net, f'patch_embed{i + 1}'), x)
+        for blk in getattr(net, f'block{i + 1}'):
+            x = run(blk, x)
+        norm = getattr(net, f'norm{i + 1}')
+        x = run(lambda t, bn=norm: ops.batch_norm2d(t, bn), x)
+        outs.append(x)
+    return outs
+
+
 class VAN(nn.Module):
 
     def __init__(self, inplanes=3, embedding_planes=[64, 128, 256, 512], mlp_ratios=[4, 4, 4, 4], block_nums=[3, 4, 6, 3],
@@ -151,49 +202,13 @@ class VAN(nn.Module):
         self.block_nums = block_nums
         self.num_classes = num_classes
         self.use_gradient_checkpoint = use_gradient_checkpoint
-        rates = list(np.linspace(0, drop_path_prob, sum(block_nums)))
-        width_in, first = inplanes, 0
-        for i, (width, ratio, depth) in enumerate(zip(embedding_planes, mlp_ratios, block_nums)):
-            setattr(self, f'patch_embed{i + 1}', OverlapPatchEmbed(patch_size=7 if i == 0 else 3, stride=4 if i == 0 else 2,
-                                                                    inplanes=width_in, embedding_planes=width))
-            setattr(self, f'block{i + 1}', nn.ModuleList([
-                Block(inplanes=width, mlp_ratio=ratio, dropout_prob=dropout_prob, drop_path_prob=rates[first + j]) for j in range(depth)]))
-            setattr(self, f'norm{i + 1}', nn.BatchNorm2d(width))
-            width_in, first = width, first + depth
+        _register_stages(self, inplanes, embedding_planes, mlp_ratios, block_nums, dropout_prob, drop_path_prob)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         self.head = nn.Linear(embedding_planes[3], num_classes)
-        self._init_like_reference()
-
-    def _init_like_reference(self):
-        for m in self.modules():
-            if isinstance(m, nn.Linear):
-                nn.init.trunc_normal_(m.weight, std=.02)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
-            elif isinstance(m, nn.Conv2d):
-                fan_out = (m.kernel_size[0] * m.kernel_size[1] * m.out_channels) // m.groups
-                m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
-                if m.bias is not None:
-                    m.bias.data.zero_()
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d) and m.groups == 1:
-                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
-
-    def _run(self, fn, x):
-        return checkpoint(fn, x, use_reentrant=False) if self.use_gradient_checkpoint else fn(x)
+        _init_like_reference(self)
 
     def forward(self, x):
-        x = ops.pack_input(x)
-        for i in range(len(self.block_nums)):
-            x = self._run(getattr(self, f'patch_embed{i + 1}'), x)
-            for blk in getattr(self, f'block{i + 1}'):
-                x = self._run(blk, x)
-            norm = getattr(self, f'norm{i + 1}')
-            x = self._run(lambda t, bn=norm: ops.batch_norm2d(t, bn), x)
-        x = ops.global_avg_pool(x)
+        x = ops.global_avg_pool(_stage_outputs(self, x)[-1])
         return ops.linear(x, self.head.weight, self.head.bias, out_f32=True)
 
 

@@ -508,18 +508,21 @@ class AttnSubLayerFn(torch.autograd.Function):
 
 
 class MlpSubLayerFn(torch.autograd.Function):
-    """out = x + s * fc2(gelu(fc1(LN(x))))   -- one node (reference vit.py:161)."""
+    """out = x + s * fc2(gelu(fc1(LN(x))))   -- one node (reference vit.py:161).  residual=False: the branch alone,
+    fc2(gelu(fc1(LN(x)))) -- the token half of a ConvNeXt block, whose shortcut joins after the layer scale
+    (reference detection/models/backbones/dinov3convnext.py:103-117)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, drop_scale, eps):
+    def forward(ctx, x, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, drop_scale, eps, residual=True):
         require_gpu(x, fc1_w)
         b, n, c = x.shape
         x2 = _as2d(x)
         h, mean, rstd = ln_fwd(x2, ln_w, ln_b, eps)
         f1, g, f1_is_dact = lin_gelu_fwd(h, fc1_w, fc1_b, aux=True)      # f1 = gelu'(pre) when the aux form ran, else pre
-        out = lin_fwd(g, fc2_w, fc2_b, addend=x2, row_scale=drop_scale, rows_per_scale=n)
+        out = lin_fwd(g, fc2_w, fc2_b, addend=x2 if residual else None, row_scale=drop_scale, rows_per_scale=n)
         ctx.save_for_backward(x2, ln_w, ln_b, mean, rstd, h, fc1_w, fc1_b, f1, g, fc2_w, fc2_b, drop_scale)
         ctx.cfg = (b, n, c)
+        ctx.residual = residual
         ctx.f1_is_dact = f1_is_dact
         return out.view(b, n, c)
 
@@ -533,8 +536,8 @@ class MlpSubLayerFn(torch.autograd.Function):
         dys = row_scale(dy, drop_scale, n) if drop_scale is not None else dy
         df1, d2w, d2b = lin_bwd(g, fc2_w, fc2_b, dys, **({'gelu_dact': f1} if ctx.f1_is_dact else {'gelu_pre': f1}))      # dgrad epilogue applies gelu'
         dh, d1w, d1b = lin_bwd(h, fc1_w, fc1_b, df1)
-        dx, dlw, dlb = ln_bwd(dh, x2, ln_w, ln_b, mean, rstd, addend=dy)
-        return dx.view(b, n, c), dlw, dlb, d1w, d1b, d2w, d2b, None, None
+        dx, dlw, dlb = ln_bwd(dh, x2, ln_w, ln_b, mean, rstd, addend=dy if ctx.residual else None)
+        return dx.view(b, n, c), dlw, dlb, d1w, d1b, d2w, d2b, None, None, None
 
 
 def attn_sublayer(x, norm, attn, drop_scale):
@@ -545,6 +548,11 @@ def attn_sublayer(x, norm, attn, drop_scale):
 def mlp_sublayer(x, norm, mlp, drop_scale):
     return MlpSubLayerFn.apply(x, norm.weight, norm.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias,
                                drop_scale, norm.eps)
+
+
+def norm_mlp_branch(x, norm, fc1, fc2):
+    """fc2(gelu(fc1(norm(x)))) on [B, N, C] tokens as one node: no shortcut, no drop-path factor"""
+    return MlpSubLayerFn.apply(x, norm.weight, norm.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, None, norm.eps, False)
 
 
 # ------------------------------------------------------------------------------ SAM encoder block (windows + rel-pos)

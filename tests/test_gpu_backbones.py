@@ -10,7 +10,7 @@ import os
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -99,3 +99,79 @@ def test_van_stochastic_depth_and_eval_run():
     with torch.no_grad():
         a, b = model(x), model(x)
     assert torch.equal(a, b)
+
+
+def _det_backbone(case):
+    """The detection backbone of `case` rebuilt from the fixture's seeds (oracle/make_golden_r04.py det_van_convformer)."""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models.backbones import convformer, dinov3convnext, van
+    fx = load_golden('det_van_convformer')['cases'][case]
+    torch.manual_seed(0)
+    m = {'van': van.VANBackbone, 'convformer': convformer.MetaFormerBackbone,
+         'dinov3convnext': dinov3convnext.Dinov3ConvNeXtBackbone}[case](**fx['kwargs'])
+    g = torch.Generator().manual_seed(33)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'layer_scale' in n or n.endswith('.scale') or n.endswith('.gamma'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2 + 0.5)
+            elif n.endswith('.bias'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    return fx, m, x, g
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('case', ['van', 'convformer', 'dinov3convnext'])
+def test_detection_van_convformer_backbones_match_reference(case, dtype):
+    """VANBackbone / MetaFormerBackbone (reference detection/models/backbones/van.py:32-130, convformer.py:29-117): the four stage
+    outputs, every parameter gradient and the BatchNorm buffers after a training-mode step against what the reference produced.
+    Tolerances as for the classification forms above (BatchNorm over 12..768 samples per channel); bf16 is held to the fp32
+    reference at bf16 resolution."""
+    fx, m, x, g = _det_backbone(case)
+    assert m.out_channels == fx['kwargs']['embedding_planes']
+    assert abs(float(x.double().sum()) - fx['input_checksum']) < 1e-6
+    m = m.cuda().train()
+    f32 = dtype == torch.float32
+    if f32:
+        outs = m(x.cuda())
+    else:
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            outs = m(x.cuda())
+    assert len(outs) == 4
+    probes = [torch.randn(o.shape, generator=g) for o in fx['outs']]
+    for o, ref in zip(outs, fx['outs']):
+        assert tuple(o.shape) == tuple(ref.shape)
+        assert rel_err(o.float().cpu(), ref) < (1e-3 if f32 else 4e-2)
+    sum((o.float() * p.cuda()).sum() for o, p in zip(outs, probes)).backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p in m.named_parameters():
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(p.shape), n
+        ref_n = fx['grad_norm'][n]
+        gn = float(p.grad.float().norm())
+        assert abs(gn - ref_n) <= (2e-2 if f32 else 1e-1) * ref_n + 1e-4, (n, gn, ref_n)
+        ref = fx['grad_sample'][n]
+        got = p.grad.flatten()[:64].float().cpu()
+        scale = max(float(ref.abs().max()), 1e-2 * ref_n)
+        err = float((got - ref).abs().max()) / (scale + 1e-6)
+        worst = max(worst, err) if ref_n > 1e-4 else worst
+        assert err <= (4e-2 if f32 else 2e-1) or ref_n <= 1e-4, (n, err)
+    sd = m.state_dict()
+    for k, v in fx['buffers_after'].items():
+        assert float((sd[k].float().cpu() - v).abs().max()) <= (1e-3 if f32 else 2e-2) * float(v.abs().max()) + 1e-5, k
+    print(f'detection {case} backbone {"fp32" if f32 else "bf16"}: worst gradient-sample error {worst:.2e}')
+
+
+def test_detection_van_convformer_feed_the_retinanet_family():
+    """The factories are reachable the way the detectors reach them (backbones.__dict__[backbone_type], reference
+    detection/models/retinanet.py:43-47) and a RetinaNet on a VAN-B0 trunk runs a training step."""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import backbones
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models.retinanet import RetinaNet
+    for name in ('vanb0backbone', 'vanb6backbone', 'convformers18backbone', 'convformerb36backbone'):
+        assert callable(backbones.__dict__[name])
+    torch.manual_seed(0)
+    net = RetinaNet('vanb0backbone', planes=64, num_classes=8).cuda().train()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        cls_heads, reg_heads = net(torch.randn(2, 3, 128, 160, device='cuda'))
+    assert len(cls_heads) == 5 and cls_heads[0].shape[-1] == 8
+    (sum(c.float().sum() for c in cls_heads) + sum(r.float().sum() for r in reg_heads)).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.backbone.parameters())

@@ -1,5 +1,6 @@
 """Round-4 host-side logic (CPU): the relative-position table resampling against torch's own linear interpolation, and the
 ConvBnActBlock switches' parameter contract against the reference-generated fixture (no kernels run here)."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -223,3 +224,29 @@ def test_random_erasing_host_call_reproduces_the_reference_bit_for_bit():
                 mask[top:top + h, left:left + w] = True
                 assert (changed <= mask).all() and changed.sum() >= 0.97 * mask.sum()       # (a drawn value may equal the old one)
                 assert (value is None) == (c['kwargs']['mode'] == 'pixel')
+
+
+@pytest.mark.parametrize('case', ['van', 'convformer', 'dinov3convnext'])
+def test_detection_van_convformer_trees_and_init_draws_are_the_references(case):
+    """state_dict keys in registration order and every initial tensor (checksums of the reference's own construction under the same
+    seed; oracle/make_golden_r04.py det_van_convformer) -- reference detection/models/backbones/van.py:52-105, convformer.py:43-97.
+    Host-only: construction runs no kernel."""
+    import os
+    import torch
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models.backbones import convformer, dinov3convnext, van
+    fx = load_golden('det_van_convformer')['cases'][case]
+    torch.manual_seed(0)
+    m = {'van': van.VANBackbone, 'convformer': convformer.MetaFormerBackbone,
+         'dinov3convnext': dinov3convnext.Dinov3ConvNeXtBackbone}[case](**fx['kwargs'])
+    g = torch.Generator().manual_seed(33)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'layer_scale' in n or n.endswith('.scale') or n.endswith('.gamma'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2 + 0.5)
+            elif n.endswith('.bias'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(fx['param_sum'].keys())
+    for k, v in sd.items():
+        assert abs(float(v.double().sum()) - fx['param_sum'][k]) <= 1e-6 * max(1.0, fx['param_abs_sum'][k]), k
+    assert m.out_channels == fx['kwargs']['embedding_planes']
