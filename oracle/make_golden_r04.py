@@ -2,6 +2,9 @@
 
 Build container only:   python oracle/make_golden_r04.py [names...]
 
+auto_rand_augment         reference AutoAugment / RandAugment (classification/auto_rand_augment.py) on seeded uint8 images: every op of
+                          the table at two magnitudes, the four AutoAugment policies, RandAugment (uniform / weighted choice,
+                          magnitude noise and cap) -- SHA-256 of the output bytes under fixed `random` / numpy seeds.
 convbnact_variants        reference classification ConvBnActBlock (resnet.py:19-48) in the forms round 3 refused:
                           has_bn=False (biased convolution, with and without ReLU) and a depthwise block (groups == channels,
                           BatchNorm + ReLU): state_dict, output, input / parameter gradients, BatchNorm buffers after the step.
@@ -199,6 +202,69 @@ def det_van_convformer(name='det_van_convformer'):
     print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
+def _augment_image(seed, h=48, w=64):
+    """a uint8 RGB test card: smooth ramps + a bright box + noise, so that geometric, histogram and colour ops all change it"""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([xx * 255 // (w - 1), yy * 255 // (h - 1), (xx + yy) * 255 // (h + w - 2)], axis=-1).astype(np.int64)
+    img[h // 4:h // 2, w // 3:w // 2] = (240, 30, 120)
+    return np.clip(img + rng.randint(-20, 21, size=img.shape), 0, 255).astype(np.uint8)
+
+
+def auto_rand_augment(name='auto_rand_augment'):
+    """reference SimpleAICV/classification/auto_rand_augment.py (loaded from its file: no package imports needed).  Cases:
+    'ops'   every entry of NAME_TO_OP as AugmentOp(name, prob=1, magnitude m, hparams{translate_const 28, img_mean, magnitude_std .5})
+            for m in (3, 9), random.seed(100 + index) before the call;
+    'auto'  AutoAugment(policy, resize=64) for the four policies x 6 samples, random.seed(200 + k);
+    'rand'  RandAugment in four configurations x 6 samples, random.seed(300 + k), np.random.seed(400 + k).
+    Stored per case: SHA-256 of the output image bytes + its mean (a mismatch then says how far off)."""
+    import hashlib
+    import importlib.util
+    import random
+    import numpy as np
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location('ref_auto_rand_augment', os.path.join(REF, 'SimpleAICV/classification/auto_rand_augment.py'))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+
+    def digest(img):
+        a = np.asarray(img)
+        return {'sha256': hashlib.sha256(a.tobytes()).hexdigest(), 'mean': float(a.mean()), 'shape': list(a.shape)}
+
+    out = {'ops': [], 'auto': [], 'rand': []}
+    hp = dict(translate_const=28, img_mean=(124, 116, 104), magnitude_std=0.5)
+    for i, opname in enumerate(sorted(ref.NAME_TO_OP)):
+        for m in (3, 9):
+            random.seed(100 + i)
+            res = ref.AugmentOp(opname, prob=1.0, magnitude=m, hparams=hp)(Image.fromarray(_augment_image(i)))
+            out['ops'].append({'name': opname, 'magnitude': m, 'image_seed': i, 'seed': 100 + i, **digest(res)})
+    for policy in ('original', 'originalr', 'v0', 'v0r'):
+        aug = ref.AutoAugment(policy, resize=64, magnitude_std=0.5 if policy.endswith('r') else None)
+        for k in range(6):
+            random.seed(200 + k)
+            res = aug({'image': Image.fromarray(_augment_image(50 + k)), 'label': k})
+            out['auto'].append({'policy': policy, 'image_seed': 50 + k, 'seed': 200 + k, **digest(res['image'])})
+    for kw in (dict(), dict(integer=False, weight_idx=0, num_layers=3), dict(magnitude=14, magnitude_max=20, magnitude_std=float('inf')),
+               dict(magnitude=5, magnitude_std=0, num_layers=4)):
+        aug = ref.RandAugment(resize=64, **kw)
+        for k in range(6):
+            random.seed(300 + k)
+            np.random.seed(400 + k)
+            res = aug({'image': Image.fromarray(_augment_image(80 + k)), 'label': k})
+            out['rand'].append({'kwargs': {a: (str(b) if isinstance(b, float) and b == float('inf') else b) for a, b in kw.items()},
+                                'image_seed': 80 + k, 'seed': 300 + k, 'np_seed': 400 + k, **digest(res['image'])})
+    import json
+    import PIL
+    out['pil_version'] = PIL.__version__
+    path = os.path.join(OUT, name + '.json')
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=0)
+    base = [hashlib.sha256(_augment_image(i).tobytes()).hexdigest() for i in range(100)]
+    changed = sum(c['sha256'] not in base for grp in ('ops', 'auto', 'rand') for c in out[grp])
+    print(name, {g: len(out[g]) for g in ('ops', 'auto', 'rand')}, f'{changed} outputs differ from their input', f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit(f'{REF} not present: golden fixtures can only be (re)generated in the build container')
@@ -207,6 +273,8 @@ def main():
     only = sys.argv[1:]
     if not only or 'convbnact_variants' in only:
         convbnact_variants()
+    if not only or 'auto_rand_augment' in only:
+        auto_rand_augment()
     if not only or 'sam_block_relpos_resized' in only:
         sam_block_relpos_resized()
     if not only or 'random_erasing' in only:

@@ -5,7 +5,10 @@ load_state_dict (:758-840), get_amp_type (:843-881) and the Mixup / CutMix colla
 Of the dataset side (CPU worker processes in the reference) the two steps that can move to the device batch are here
 (SURVEY.md section 8f rank 3): the mean / std normalisation of TorchMeanStdNormalize (:228-248) on the uint8 batch
 (Uint8ClassificationCollater + normalize_on_device) and RandomErasing (:561-640, host call and plan / erase_on_device).
-The cv2 / PIL / torchvision geometric transforms stay out of scope.
+The PIL policy transforms the fine-tuning configs put in front of them are host code and stay host code: Opencv2PIL (:22-37),
+PIL2Opencv (:40-55) and AutoAugment / RandAugment (auto_rand_augment.py, re-exported here as the reference does at :18).
+The torchvision-backed Torch* transforms and the cv2 ones stay out of scope (neither library is in the image, so neither their
+parameter draws nor their resampling could be pinned).
 """
 import math
 
@@ -13,10 +16,29 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .auto_rand_augment import AutoAugment, RandAugment
 from .mixupcutmixclassificationcollator import MixupCutmixClassificationCollater
 
 __all__ = ['ClassificationCollater', 'MixupCutmixClassificationCollater', 'Uint8ClassificationCollater', 'normalize_on_device',
-           'RandomErasing', 'AverageMeter', 'AccMeter', 'load_state_dict', 'get_amp_type']
+           'RandomErasing', 'AutoAugment', 'RandAugment', 'Opencv2PIL', 'PIL2Opencv', 'AverageMeter', 'AccMeter', 'load_state_dict',
+           'get_amp_type']
+
+
+class Opencv2PIL:
+    """sample['image'] (HWC array, any real dtype in 0..255) -> PIL image, for the PIL policy transforms"""
+
+    def __call__(self, sample):
+        from PIL import Image
+        sample['image'] = Image.fromarray(np.uint8(sample['image']))
+        return sample
+
+
+class PIL2Opencv:
+    """sample['image'] (PIL) -> float32 HWC array, the form the rest of the pipeline and the collaters take"""
+
+    def __call__(self, sample):
+        sample['image'] = np.asarray(sample['image']).astype(np.float32)
+        return sample
 
 
 class ClassificationCollater:
