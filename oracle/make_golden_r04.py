@@ -11,6 +11,8 @@ convbnact_variants        reference classification ConvBnActBlock (resnet.py:19-
 det_van_convformer        reference detection VANBackbone / MetaFormerBackbone / Dinov3ConvNeXtBackbone
                           (detection/models/backbones/{van,convformer,dinov3convnext}.py) in tiny
                           geometries, training mode: the four stage outputs, parameter gradients, BatchNorm buffers after the step.
+dinov3_detectors          reference dinov3_vit_retinanet.RetinaNet / dinov3_vit_fcos.FCOS (detection/models/) on a two-block DINOv3 trunk
+                          registered under a test name: per-level head outputs, parameter gradients.
 dinov3_tiny               reference DinoVisionTransformer (detection/models/backbones/dinov3vit.py): GELU-MLP form in training mode
                           (RoPE rescale draw) and SwiGLU form in eval mode; outputs, input and parameter gradients.
 random_erasing            reference RandomErasing (classification/common.py:561-640), modes const / rand / pixel, seeded numpy
@@ -265,6 +267,55 @@ def auto_rand_augment(name='auto_rand_augment'):
     print(name, {g: len(out[g]) for g in ('ops', 'auto', 'rand')}, f'{changed} outputs differ from their input', f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
+TINY_DINOV3 = dict(embedding_planes=128, head_nums=2, block_nums=2, ffn_layer='mlp', ffn_ratio=4, pos_embed_rope_rescale_coords=2)
+
+
+def dinov3_detectors(name='dinov3_detectors'):
+    """reference RetinaNet (SimpleAICV/detection/models/dinov3_vit_retinanet.py:28-112) and FCOS (dinov3_vit_fcos.py:28-101) with
+    planes 64, 6 classes, on a DINOv3 trunk of two blocks (TINY_DINOV3) registered in the backbones namespace as
+    'tiny_dinov3_backbone' (the shipped factories start at 384 channels x 12 blocks), training mode, image 2 x 3 x 128 x 96;
+    torch.manual_seed(5) right before the forward (the trunk's RoPE rescale draw).  LayerScale gammas redrawn around 1 and biases
+    around 0 from generator 44.  Stored: parameter checksums, every level's outputs, norm + first 64 entries of every parameter
+    gradient for one random probe per output."""
+    import types
+    for mod in ('cv2', 'torchvision', 'torchvision.transforms'):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    from SimpleAICV.detection.models import backbones, dinov3_vit_fcos, dinov3_vit_retinanet
+    from SimpleAICV.detection.models.backbones.dinov3vit import DinoVisionTransformer
+    backbones.__dict__['tiny_dinov3_backbone'] = lambda pretrained_path='', **kw: DinoVisionTransformer(**TINY_DINOV3, **kw)
+    cases = {}
+    for key, build in (('retinanet', lambda: dinov3_vit_retinanet.RetinaNet('tiny_dinov3_backbone', planes=64, num_classes=6)),
+                       ('fcos', lambda: dinov3_vit_fcos.FCOS('tiny_dinov3_backbone', planes=64, num_classes=6))):
+        torch.manual_seed(0)
+        m = build()
+        g = torch.Generator().manual_seed(44)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith('.gamma'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.3 + 1.0)
+                elif n.endswith('.bias') and 'cls_out' not in n and 'cls_head' not in n:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        m.train()
+        x = torch.randn(2, 3, 128, 96, generator=g)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        torch.manual_seed(5)
+        outs = m(x)
+        flat = [o for group in outs for o in group]
+        probes = [torch.randn(o.shape, generator=g) for o in flat]
+        sum((o * p).sum() for o, p in zip(flat, probes)).backward()
+        cases[key] = {'param_sum': {k: float(v.double().sum()) for k, v in sd.items()},
+                      'param_abs_sum': {k: float(v.double().abs().sum()) for k, v in sd.items()},
+                      'input_checksum': float(x.double().sum()), 'groups': [len(group) for group in outs],
+                      'outs': [o.detach().clone() for o in flat],
+                      'grad_norm': {n: float(p.grad.norm()) for n, p in m.named_parameters() if p.grad is not None},
+                      'grad_sample': {n: p.grad.flatten()[:64].clone() for n, p in m.named_parameters() if p.grad is not None},
+                      'no_grad': [n for n, p in m.named_parameters() if p.grad is None]}
+        print(key, [tuple(o.shape) for o in flat][:5], len(sd), 'state entries; without gradient:', cases[key]['no_grad'])
+    path = os.path.join(OUT, name + '.pt')
+    torch.save({'name': name, 'cases': cases, 'trunk': TINY_DINOV3}, path)
+    print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit(f'{REF} not present: golden fixtures can only be (re)generated in the build container')
@@ -283,6 +334,8 @@ def main():
         dinov3_tiny()
     if not only or 'det_van_convformer' in only:
         det_van_convformer()
+    if not only or 'dinov3_detectors' in only:
+        dinov3_detectors()
 
 
 if __name__ == '__main__':

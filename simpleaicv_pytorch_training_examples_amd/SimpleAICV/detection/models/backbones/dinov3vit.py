@@ -23,6 +23,7 @@ from torch.utils.checkpoint import checkpoint
 
 from ..... import ops, ops_tfm
 from ...common import load_state_dict
+from .vit import VitPyramidNeck  # noqa: F401  (re-exported as in the reference, :21: the DINOv3 detectors import it from here)
 
 __all__ = [
     'dinov3_vit_small_patch16_backbone',
