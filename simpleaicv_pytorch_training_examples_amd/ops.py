@@ -575,7 +575,9 @@ class ConvBnActFn(torch.autograd.Function):
                                               float(bn.eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                               ptr(ws), ptr(nbt), st), 'bn_finalize_fwd')      # also num_batches_tracked += 1
         else:
+            t0 = KernelTimer.begin('igemm_nt')
             check(L.saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), 0, ptr(y), 0, 0, 0, st), 'conv2d_fwd')
+            KernelTimer.end(t0, 'igemm_nt', 2.0 * M * k * r * s * min(c, ci), 0)
             check(L.saicv_bn_eval_coeffs(k, ptr(gamma), ptr(beta), ptr(bn.running_mean),
                                          ptr(bn.running_var), float(bn.eps), ptr(scale), ptr(shift), st),
                   'bn_eval_coeffs')
@@ -1010,8 +1012,10 @@ class DepthwiseConvFn(torch.autograd.Function):
         wt = weight.detach().reshape(c, k * k).t().contiguous().to(dt)        # tap-major [k*k][C]
         y = _empty_nhwc(n, c, oh, ow, dt, x.device)
         bf = bias.detach().float() if bias is not None else None
+        t0 = KernelTimer.begin('dwconv_fwd')
         check(lib().saicv_dwconv2d_fwd(dtype_code(dt), ptr(x), ptr(wt), ptr(bf), ptr(y), n, h, w, c, oh, ow, k, stride, pad, dilation,
                                        stream()), 'dwconv2d_fwd')
+        KernelTimer.end(t0, 'dwconv_fwd', 2.0 * n * oh * ow * c * k * k, float(n) * (h * w + oh * ow) * c * x.element_size())
         ctx.save_for_backward(x, weight, bias, wt)
         ctx.cfg = (n, h, w, c, oh, ow, k, stride, pad, dilation)
         return y
@@ -1353,8 +1357,10 @@ class LinearFn(torch.autograd.Function):
         if bias is not None and op != o:
             bp = torch.zeros(op, dtype=torch.float32, device=x.device)
             bp[:o] = bias.detach()
+        t0 = KernelTimer.begin('linear_head')
         check(lib().saicv_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(wf), ptr(bp), ptr(y),
                                      int(odt == torch.float32), 0, 0, stream()), 'linear_fwd')
+        KernelTimer.end(t0, 'linear_head', 2.0 * b * ci * o, 0)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (d, wd, bias is not None, o, op)
         return y if op == o else y[:, :o]

@@ -739,8 +739,10 @@ class PatchEmbedFn(torch.autograd.Function):
         wf, _ = packed_weight(weight, dt, cp, False)
         d = _desc(b, h, w, cp, k, r, s, stride, 0, dt)
         y = torch.empty((b, d.OH, d.OW, k), dtype=dt, device=x.device)
+        t0 = KernelTimer.begin('patch_embed')
         check(lib().saicv_conv2d_fwd(ctypes.byref(d), ptr(xp), ptr(wf), ptr(bias), ptr(y), 0, 0, 0, stream()),
               'patch_embed_fwd')
+        KernelTimer.end(t0, 'patch_embed', 2.0 * b * d.OH * d.OW * k * r * s * ci, 0)
         ctx.save_for_backward(xp, weight, bias)
         ctx.cfg = (d, cp)
         return y.view(b, d.OH * d.OW, k)

@@ -3,7 +3,7 @@
 Same names, arguments and return values as the reference (file:line cited per function) so a
 reference tools/train_*.py only changes its import root:
   get_logger (:66-92), set_seed (:95-107), worker_seed_init_fn (:110-116), EmaModel (:145-172),
-  build_training_mode (:175-202), Scheduler (:205-289), build_optimizer (:292-679).
+  compute_macs_and_params (:119-142), build_training_mode (:175-202), Scheduler (:205-289), build_optimizer (:292-679).
 What changes underneath: build_training_mode wraps the model in the flat-arena RCCL engine
 (engine.DistributedDataParallel) and returns the sync-free GradScaler; build_optimizer returns
 the fused flat SGD / AdamW.  Everything is device agnostic (CPU + gloo works for plumbing runs).
@@ -62,6 +62,45 @@ def worker_seed_init_fn(worker_id, num_workers, local_rank, seed):
     worker_seed = num_workers * local_rank + worker_id + seed + int(time.time())
     np.random.seed(worker_seed)
     random.seed(worker_seed)
+
+
+def _with_unit(value, suffix):
+    """calflops' number_to_string form: 4089184256 -> '4.089 G' + suffix (three decimals, trailing zeros dropped)"""
+    for mag, unit in ((1e12, 'T'), (1e9, 'G'), (1e6, 'M'), (1e3, 'K')):
+        if value >= mag:
+            return f'{round(value / mag, 3):g} {unit}{suffix}'
+    return f'{round(value, 3):g} {suffix}'
+
+
+def compute_macs_and_params(config, model):
+    """-> (flops, macs, params) as strings, for the test entry scripts' `model: ..., flops: ..., macs: ..., params: ...` line
+    (reference tools/utils.py:119-142: calflops on a CPU copy of the model with one random image of config.input_image_size).
+
+    calflops is not in the image and the HIP modules do not run on the CPU; the count comes from the engine's own accounting
+    instead: one eval-mode forward of a single random image on the GPU with ops.KernelTimer bracketing every matrix-product launch
+    (convolutions incl. depthwise, linears, patch embedding, attention products) -- each site reports its algorithmic flops from
+    the LOGICAL shapes (unpadded channels).  macs = flops / 2; normalisation / activation / pooling arithmetic is not counted (on
+    ResNet-50 calflops reports 8.21 GFLOPS / 4.09 GMACs, this 8.18 / 4.09).  The model is left on the GPU (the entry scripts move
+    it there next anyway) in the mode it came in."""
+    from .. import ops
+    size = config.input_image_size
+    assert isinstance(size, (int, list)), 'Illegal input_image_size type!'
+    h, w = (size, size) if isinstance(size, int) else (size[0], size[1])
+    params = sum(p.numel() for p in model.parameters())
+    was_training = model.training
+    model = model.cuda().eval()
+    timer = ops.KernelTimer
+    saved = (timer.enabled, timer.only, timer.records)
+    timer.enabled, timer.only, timer.records = True, None, []
+    try:
+        with torch.no_grad():
+            model(torch.randn(1, 3, h, w, device='cuda'))
+        torch.cuda.synchronize()
+        flops = float(sum(r[3] for r in timer.records))
+    finally:
+        timer.enabled, timer.only, timer.records = saved
+        model.train(was_training)
+    return _with_unit(flops, 'FLOPS'), _with_unit(flops / 2, 'MACs'), _with_unit(params, '')
 
 
 class EmaModel(nn.Module):

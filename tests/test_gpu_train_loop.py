@@ -668,3 +668,25 @@ def test_mae_loop_follows_the_reference_loop(graphed):
     sd = model.module.state_dict()
     for k, v in fx['final_state'].items():
         assert rel_err(sd[k].float().cpu(), v) < 5e-3, k
+
+
+def test_compute_macs_and_params_counts_the_matrix_products():
+    """tools.utils.compute_macs_and_params (reference tools/utils.py:119-142, calflops there): the engine's own accounting on one
+    eval forward.  Known values: ResNet-50 at 224 has 25 557 032 parameters and 4.089 G multiply-accumulates in its convolutions
+    + classifier (torchvision's published 4.09 GFLOPs-as-MACs figure); ViT-B/16 at 224 has 86 567 656 parameters and about
+    17.5 GMACs (projections + MLPs 16.8, attention products 0.36 x 2, patch embedding 0.116)."""
+    from types import SimpleNamespace
+    from simpleaicv_pytorch_training_examples_amd import ops
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones
+    from simpleaicv_pytorch_training_examples_amd.tools.utils import compute_macs_and_params
+    torch.manual_seed(0)
+    model = backbones.resnet50(num_classes=1000).train()
+    flops, macs, params = compute_macs_and_params(SimpleNamespace(input_image_size=224), model)
+    assert params == '25.557 M' and macs.endswith(' GMACs') and flops.endswith(' GFLOPS'), (flops, macs, params)
+    assert abs(float(macs.split()[0]) - 4.089) < 0.02 and abs(float(flops.split()[0]) - 2 * 4.089) < 0.04, (flops, macs)
+    assert model.training and next(model.parameters()).is_cuda and not ops.KernelTimer.enabled and ops.KernelTimer.records == []
+    vit = backbones.vit_base_patch16(image_size=224, num_classes=1000)
+    flops, macs, params = compute_macs_and_params(SimpleNamespace(input_image_size=[224, 224]), vit)
+    assert params == '86.568 M', params
+    assert 17.2 < float(macs.split()[0]) < 17.8 and macs.endswith(' GMACs'), macs
+    print(f'compute_macs_and_params: resnet50 ok, vit_base_patch16 {flops} / {macs} / {params}')

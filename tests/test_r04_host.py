@@ -339,3 +339,38 @@ def test_dinov3_vit_detector_trees_and_init_draws_are_the_references(case):
         for head in ('retinanet', 'fcos'):
             assert callable(models.__dict__[f'dinov3_vit_{trunk}_patch16_{head}'])
             assert f'dinov3_vit_{trunk}_patch16_backbone' in backbones.__dict__
+
+
+def test_test_entry_scripts_and_configs_follow_the_reference_surface():
+    """tools.test_classification_model / tools.test_detection_model (reference tools/test_classification_model.py:31-103,
+    test_detection_model.py:29-98) exist under the reference's names with main / parse_args, tools.utils exposes
+    compute_macs_and_params(config, model), and the two benchmark test_config.py files import and collate."""
+    import importlib
+    import importlib.util
+    import inspect
+    import os
+    from conftest import ROOT
+    for name in ('test_classification_model', 'test_detection_model'):
+        m = importlib.import_module(f'simpleaicv_pytorch_training_examples_amd.tools.{name}')
+        assert callable(m.main) and callable(m.parse_args)
+        assert importlib.import_module(f'tools.{name}') is m
+    from simpleaicv_pytorch_training_examples_amd.tools import utils
+    assert list(inspect.signature(utils.compute_macs_and_params).parameters) == ['config', 'model']
+    assert utils._with_unit(4089184256, 'MACs') == '4.089 GMACs' and utils._with_unit(25557032, '') == '25.557 M'
+    assert utils._with_unit(8.2e9, 'FLOPS') == '8.2 GFLOPS' and utils._with_unit(512, 'MACs') == '512 MACs'
+    os.environ.update(SAICV_CLS_TEST='8', SAICV_DET_TEST='4', SAICV_DET_TRAIN='4')
+    try:
+        for d, keys in (('00.classification_training/imagenet/resnet50', {'image': (2, 3, 224, 224), 'label': (2,)}),
+                        ('03.detection_training/coco/res50_retinanet_yoloresize1024', {'image': (2, 3, 1024, 1024), 'annots': (2, 100, 5)})):
+            spec = importlib.util.spec_from_file_location('test_cfg_' + d.split('/')[-1], os.path.join(ROOT, d, 'test_config.py'))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            c = mod.config
+            assert c.batch_size in (256, 32) and c.seed == 0 and hasattr(c, 'test_criterion')
+            batch = c.test_collater([c.test_dataset[i] for i in range(2)])
+            for k, shp in keys.items():
+                assert tuple(batch[k].shape) == shp, (d, k)
+        assert c.eval_type == 'COCO' and c.decoder is not None
+    finally:
+        for k in ('SAICV_CLS_TEST', 'SAICV_DET_TEST', 'SAICV_DET_TRAIN'):
+            os.environ.pop(k, None)
