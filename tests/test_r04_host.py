@@ -374,3 +374,31 @@ def test_test_entry_scripts_and_configs_follow_the_reference_surface():
     finally:
         for k in ('SAICV_CLS_TEST', 'SAICV_DET_TEST', 'SAICV_DET_TRAIN'):
             os.environ.pop(k, None)
+
+
+def test_every_environment_switch_is_documented_and_every_documented_switch_exists():
+    """INTEGRATION.md's switch table is the spec of what runs by default (hygiene): every SAICV_* name read through
+    getenv / os.environ anywhere in the product (csrc, package, bench.py, benchmark configs) has a row there, and no row names a
+    switch the code no longer reads."""
+    import glob
+    import os
+    import re
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, 'simpleaicv_pytorch_training_examples_amd')
+    files = [os.path.join(ROOT, 'bench.py')] + glob.glob(os.path.join(pkg, 'csrc', '*.hip')) + glob.glob(os.path.join(pkg, 'csrc', '*.h'))
+    files += glob.glob(os.path.join(pkg, '**', '*.py'), recursive=True) + glob.glob(os.path.join(ROOT, '[0-9][0-9].*', '**', '*_config.py'), recursive=True)
+    read = set()
+    for f in files:
+        text = open(f, errors='replace').read()
+        read |= set(re.findall(r'getenv\(\s*"(SAICV_[A-Z0-9_]+)"', text))
+        read |= set(re.findall(r"""environ(?:\.get\(|\[|\.pop\(|\.setdefault\()\s*['"](SAICV_[A-Z0-9_]+)['"]""", text))
+        read |= set(re.findall(r'env_(?:int|flag|float|str)\(\s*"(SAICV_[A-Z0-9_]+)"', text))
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    documented = set(re.findall(r'SAICV_[A-Z0-9_]+', doc))
+    prefixes = {m[:-1] for m in re.findall(r'SAICV_[A-Z0-9_]+_\*', doc)}           # families written as SAICV_DET_*
+    missing = sorted(n for n in read if n not in documented and not any(n.startswith(p) for p in prefixes))
+    assert not missing, f'switches read by the code without a row in INTEGRATION.md: {missing}'
+    assert len(read) > 40
+    rows = set(re.findall(r'^\| `(SAICV_[A-Z0-9_]+)`', doc, flags=re.M))
+    stale = sorted(rows - read)
+    assert not stale, f'INTEGRATION.md rows for switches nothing reads: {stale}'
