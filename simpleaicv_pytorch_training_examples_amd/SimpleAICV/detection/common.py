@@ -51,6 +51,16 @@ class DETRDetectionCollater:
         }
 
 
+def pad_mask_on_device(scaled_size, resize, device):
+    """The DETR padding mask built where it is used: [B, S, S] bool, True outside each image's (h, w) top-left rectangle -- what
+    DETRDetectionCollater fills on the host (reference detection/common.py:315-322) and the loop would otherwise copy to the device
+    (S * S bytes per image, 8 MiB per batch of eight 1024-pixel canvases) -- from the [B, 2] `scaled_size` array the collater
+    returns anyway.  Two broadcast compares; `config.device_pad_mask = True` makes train_detection use it."""
+    hw = torch.as_tensor(scaled_size, dtype=torch.float32).to(device, non_blocking=True)
+    idx = torch.arange(resize, device=device, dtype=torch.float32)
+    return (idx.view(1, -1, 1) >= hw[:, 0].view(-1, 1, 1)) | (idx.view(1, 1, -1) >= hw[:, 1].view(-1, 1, 1))
+
+
 class DetectionCollater:
     """images at the top-left of a zero [B, S, S, 3] canvas handed over as its NCHW view, annotations [B, max_annots_num, 5]
     (xyxy + class) padded with -1 rows, per-image scale / size arrays (reference :243-288)."""

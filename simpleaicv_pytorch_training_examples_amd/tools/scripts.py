@@ -35,6 +35,7 @@ from torch.amp.autocast_mode import autocast
 
 from ..engine import any_nonfinite
 from ..SimpleAICV.classification.common import AccMeter, AverageMeter, get_amp_type
+from ..SimpleAICV.detection.common import pad_mask_on_device
 
 
 def _device_of(model):
@@ -399,7 +400,12 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
                 targets._saicv_host = host_targets       # DETRLoss selects the valid rows on the host (no per-image device sync)
         bad = any_nonfinite(images, targets)
         with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
-            outs = model(images, data['mask'].to(device, non_blocking=True)) if is_detr else model(images)
+            if not is_detr:
+                outs = model(images)
+            elif getattr(config, 'device_pad_mask', False):      # f3: the mask from the [B, 2] sizes instead of a [B, S, S] copy
+                outs = model(images, pad_mask_on_device(data['scaled_size'], images.shape[-1], device))
+            else:
+                outs = model(images, data['mask'].to(device, non_blocking=True))
             loss_value = criterion(outs, targets)
         return bad, loss_value, images.size(0)
 

@@ -402,3 +402,24 @@ def test_every_environment_switch_is_documented_and_every_documented_switch_exis
     rows = set(re.findall(r'^\| `(SAICV_[A-Z0-9_]+)`', doc, flags=re.M))
     stale = sorted(rows - read)
     assert not stale, f'INTEGRATION.md rows for switches nothing reads: {stale}'
+
+
+def test_detr_pad_mask_from_sizes_equals_the_collaters_mask():
+    """pad_mask_on_device(scaled_size, S, device) == the mask DETRDetectionCollater fills on the host (reference
+    detection/common.py:315-322) for ragged image sizes, including a full-canvas image and a one-pixel one; the detection loop takes it
+    when config.device_pad_mask is set."""
+    import numpy as np
+    import torch
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.common import DETRDetectionCollater, pad_mask_on_device
+    rng = np.random.default_rng(0)
+    sizes = [(64, 64), (1, 1), (37, 64), (64, 5), (20, 33)]
+    data = [{'image': rng.random((h, w, 3), dtype=np.float32), 'annots': np.zeros((0, 5), dtype=np.float32),
+             'scale': np.float32(1.0), 'size': np.array([h, w], dtype=np.float32)} for h, w in sizes]
+    batch = DETRDetectionCollater(resize=64, resize_type='yolo_style', max_annots_num=4)(data)
+    got = pad_mask_on_device(batch['scaled_size'], 64, torch.device('cpu'))
+    assert got.dtype == torch.bool and got.shape == batch['mask'].shape
+    assert torch.equal(got, batch['mask'])
+    assert int((~got[1]).sum()) == 1 and not bool(got[0].any())
+    import inspect
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts
+    assert 'device_pad_mask' in inspect.getsource(scripts.train_detection)
