@@ -181,6 +181,173 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* 
     }
 }
 
+// ---- experimental (SAICV_LN_HALF=1, off by default; not yet measured): two rows per wavefront, 32 lanes each
+// C = 768 in bf16 is 96 chunks of 16 bytes: one row per wavefront leaves 32 of 128 chunk slots empty (NCH = 2), and the SQ counters
+// of the backward kernel say it is bound by instruction issue, not by bandwidth (profiles/r04_layernorm_sq_counters.json) -- so idle
+// lanes cost time.  With 32 lanes per row and NCH = 3 every lane works, and the row reductions lose their last cross-half step.
+DEVINL float half32_sum(float v) {          // sum over the 32 lanes of this lane's half of the wavefront
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_half_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, T* __restrict__ y,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, int M, int C, float eps) {
+    constexpr int N = Chunk<T>::N;
+    const int lane = threadIdx.x & 63, sl = lane & 31;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool live = row < M;                       // (the other half of the wavefront may still hold a row: no early return)
+    const int cpr = C / N;                           // == 32 * NCH (launcher)
+    float v[NCH][N];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = sl + 32 * j;
+        if (live) Chunk<T>::unpack(ld_chunk(x + (size_t)row * C + c * N), v[j]);
+        else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[j][k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) s += v[j][k];
+    }
+    const float mu = half32_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int k = 0; k < N; ++k) { const float d = v[j][k] - mu; q += d * d; }
+    const float rs = rsqrtf(half32_sum(q) / (float)C + eps);
+    if (!live) return;
+    if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = sl + 32 * j;
+        float o[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) o[k] = (v[j][k] - mu) * rs * gamma[c * N + k] + beta[c * N + k];
+        st_chunk(y + (size_t)row * C + c * N, Chunk<T>::pack(o));
+    }
+    (void)cpr;
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_half_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const T* __restrict__ addend,
+                                                                 T* __restrict__ dx, float* __restrict__ part_g,
+                                                                 float* __restrict__ part_b, int M, int C, int rows_per) {
+    // rows_per counts ROW PAIRS per wavefront here: a block covers rows_per * LNB_WAVES * 2 rows
+    constexpr int N = Chunk<T>::N;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sl = lane & 31, sub = lane >> 5;
+    float gam[NCH][N], ag[NCH][N], ab[NCH][N];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = sl + 32 * j;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            gam[j][k] = gamma[c * N + k];
+            ag[j][k] = 0.f;
+            ab[j][k] = 0.f;
+        }
+    }
+    const int r0 = blockIdx.x * rows_per * LNB_WAVES * 2;
+    u32x4 nd[NCH], nx[NCH], na[NCH];
+    float nmu = 0.f, nrs = 0.f;
+    auto fetch = [&](int row) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = sl + 32 * j;
+            nd[j] = ld_chunk(dy + (size_t)row * C + c * N);
+            nx[j] = ld_chunk(x + (size_t)row * C + c * N);
+            if (addend != nullptr) na[j] = ld_chunk(addend + (size_t)row * C + c * N);
+        }
+        nmu = mean[row];
+        nrs = rstd[row];
+    };
+    auto zero_next = [&]() {                   // a half without a row contributes zeros (d = 0 => nothing reaches the sums)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { nd[j] = u32x4{0u, 0u, 0u, 0u}; nx[j] = u32x4{0u, 0u, 0u, 0u}; na[j] = u32x4{0u, 0u, 0u, 0u}; }
+        nmu = 0.f;
+        nrs = 0.f;
+    };
+    const int first = r0 + wave * 2 + sub;
+    if (first < M) fetch(first); else zero_next();
+    for (int i = 0; i < rows_per; ++i) {
+        const int pair = r0 + (i * LNB_WAVES + wave) * 2;         // wave-uniform
+        if (pair >= M) break;
+        const int row = pair + sub;
+        const bool live = row < M;
+        const float mu = nmu, rs = nrs;
+        u32x4 cd[NCH], cx[NCH], ca[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { cd[j] = nd[j]; cx[j] = nx[j]; ca[j] = na[j]; }
+        if (i + 1 < rows_per) {
+            const int nrow = row + LNB_WAVES * 2;
+            if (nrow < M) fetch(nrow); else zero_next();
+        }
+        float g[NCH][N], xh[NCH][N];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float d[N], xv[N];
+            Chunk<T>::unpack(cd[j], d);
+            Chunk<T>::unpack(cx[j], xv);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                xh[j][k] = (xv[k] - mu) * rs;
+                g[j][k] = d[k] * gam[j][k];
+                s1 += g[j][k];
+                s2 += g[j][k] * xh[j][k];
+                ag[j][k] += d[k] * xh[j][k];
+                ab[j][k] += d[k];
+            }
+        }
+        s1 = half32_sum(s1) / (float)C;
+        s2 = half32_sum(s2) / (float)C;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c = sl + 32 * j;
+                float o[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) o[k] = rs * (g[j][k] - s1 - xh[j][k] * s2);
+                if (addend != nullptr) {
+                    float a[N];
+                    Chunk<T>::unpack(ca[j], a);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) o[k] += a[k];
+                }
+                st_chunk(dx + (size_t)row * C + c * N, Chunk<T>::pack(o));
+            }
+        }
+    }
+    // combine the two halves of every wavefront and the wavefronts of the block through LDS, one accumulator set at a time
+    __shared__ float red[LNB_WAVES][64 * 8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = sl + 32 * j;
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) red[wave][lane * N + k] = pass == 0 ? ag[j][k] : ab[j][k];
+            __syncthreads();
+            if (wave == 0 && sub == 0) {
+                float* dst = (pass == 0 ? part_g : part_b) + (size_t)blockIdx.x * C + c * N;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < LNB_WAVES; ++w) v += red[w][sl * N + k] + red[w][(sl + 32) * N + k];
+                    dst[k] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // out[c] (=|+=) sum_p part[p][c]; blockIdx.y selects one of two (partials, output) pairs, so dgamma and dbeta of a LayerNorm
 // backward leave in ONE launch (ViT-B: 25 launches of ~7 us per step less)
 __global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int P, int C,
@@ -827,11 +994,22 @@ void allow_lds(K k, size_t bytes) {
 
 namespace saicv {
 
+// SAICV_LN_HALF=1 routes rows of exactly 96 chunks (C = 768 in bf16, C = 384 in fp32) to the two-rows-per-wavefront kernels
+static bool ln_half_rows(int cpr) {
+    const char* e = getenv("SAICV_LN_HALF");
+    return cpr == 96 && e != nullptr && atoi(e) == 1;
+}
+
 template <typename T>
 static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                            float* rstd, int M, int C, double eps, hipStream_t st) {
     constexpr int N = Chunk<T>::N;
     const int nch = (C / N + 63) / 64;
+    if (ln_half_rows(C / N)) {              // experimental, off by default: 32 lanes per row, no idle chunk slots at 96 chunks
+        hipLaunchKernelGGL((layernorm_fwd_half_kernel<T, 3>), dim3((M + 7) / 8), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
+                           rstd, M, C, (float)eps);
+        return check_launch("layernorm_fwd");
+    }
     dim3 grid((M + 3) / 4), block(256);
 #define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), grid, block, 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, M, C, (float)eps)
     if (nch <= 1) LN_LAUNCH(1);
@@ -878,6 +1056,12 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
     float* pb = ws + (size_t)nb * C;
     dim3 grid(nb), block(64 * LNB_WAVES);
 #define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)addend, (T*)dx, pg, pb, M, C, rp)
+    if (ln_half_rows(C / N)) {
+        // the same nb blocks (the workspace is sized for them), each covering 2 * rp2 * LNB_WAVES rows with rp2 row PAIRS per wavefront
+        const int rp2 = (rp + 1) / 2;
+        hipLaunchKernelGGL((layernorm_bwd_half_kernel<T, 3>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
+                           (const T*)addend, (T*)dx, pg, pb, M, C, rp2);
+    } else
     if (nch <= 1) LN_LAUNCH(1);
     else if (nch <= 2) LN_LAUNCH(2);
     else if (nch <= 4) LN_LAUNCH(4);
