@@ -1889,7 +1889,11 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_kernel(const TNParams
 DEVINL int tn_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 template <int CPR> DEVINL int tn_g(int r) { return CPR >= 16 ? tn_key(r) : (tn_key(r) >> 1); }
 
-template <int BA, int BB, int NWA, int NWB, bool PLAIN>
+// INCR (experimental, SAICV_TN_INCR=1, off by default, not yet run on a GPU): the gathered operand's byte offset and its (ih, iw) are
+// carried from step to step with adds and selects instead of being rebuilt from (img, oh, ow) with three 32-bit multiplies per DMA
+// instruction.  Static count of the 128 x 128 convolution form: 58 full-rate + 10 quarter-rate (v_mad_u64_u32 / v_mul_lo_u32) vector
+// instructions per 16 MFMAs in the K loop -- more issue slots than the MFMAs themselves (profiles/r04_nt_experiments.md section 6).
+template <int BA, int BB, int NWA, int NWB, bool PLAIN, bool INCR = false>
 __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNParams p) {
     typedef bf16_t T;
     constexpr int NWAVES = NWA * NWB;
@@ -1946,10 +1950,16 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
         a_off[i] = (uint32_t)((m_begin + row) * p.Cout + n) * 2u;
     }
     const uint32_t a_step = (uint32_t)(BR * p.Cout) * 2u;
-    uint32_t b_off[NIB];                 // PLAIN: byte offset, advanced per step
+    uint32_t b_off[NIB];                 // PLAIN / INCR: byte offset, advanced per step
     int b_m[NIB], g_img[NIB], g_oh[NIB], g_ow[NIB], b_fr[NIB], b_fs[NIB], b_c0[NIB];
     bool b_ok[NIB];
     const int ohw = p.OH * p.OW;
+    // INCR: a step moves every DMA row by BR output pixels = (d_img, d_oh, d_ow) in mixed radix; a carry out of the column digit
+    // takes OW columns back and adds a row, a carry out of the row digit takes OH rows back and adds an image (wave-uniform scalars)
+    const int st_dow = p.stride * p.d_ow, st_ow = p.stride * p.OW, st_doh = p.stride * p.d_oh, st_oh = p.stride * p.OH;     // in input pixels
+    const uint32_t inc_base = (uint32_t)(((p.d_img * p.H + st_doh) * p.W + st_dow) * p.C) * 2u;
+    const uint32_t inc_cy1 = (uint32_t)((p.stride * p.W - st_ow) * p.C) * 2u;
+    const uint32_t inc_cy2 = (uint32_t)(((p.H - st_oh) * p.W) * p.C) * 2u;
 #pragma unroll
     for (int j = 0; j < NIB; ++j) {
         const int row = (j * NWAVES + wave) * RPI_B + lane / CPR_B;
@@ -1972,6 +1982,11 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
             g_oh[j] = (int)fdiv((uint32_t)rem, p.fd_ow);
             g_ow[j] = rem - g_oh[j] * p.OW;
             b_off[j] = 0;
+            if (INCR) {
+                const int ih0 = g_oh[j] * p.stride + b_fr[j], iw0 = g_ow[j] * p.stride + b_fs[j];
+                // (wraps like the rebuilt form when ih / iw are negative: such an offset is never used, `ok` is false there)
+                b_off[j] = (uint32_t)(((img * p.H + ih0) * p.W + iw0) * p.C + b_c0[j]) * 2u;
+            }
         }
     }
     const uint32_t b_step = (uint32_t)(BR * p.C) * 2u;
@@ -1992,6 +2007,21 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
                 const bool ok = b_ok[j] & (b_m[j] < m_end);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + A_BYTES + j * NWAVES * 1024), 16, (int)(ok ? b_off[j] : OOB), 0, 0, 0);
                 b_off[j] += b_step;
+            } else if (INCR) {
+                // (ih, iw) for the bounds test only: one 24-bit multiply-add each (full rate; oh, ow and the stride are far below 2^24)
+                const int ih = __mul24(g_oh[j], p.stride) + b_fr[j];
+                const int iw = __mul24(g_ow[j], p.stride) + b_fs[j];
+                const bool ok = b_ok[j] & (b_m[j] < m_end) & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + A_BYTES + j * NWAVES * 1024), 16, (int)(ok ? b_off[j] : OOB), 0, 0, 0);
+                int ow = g_ow[j] + p.d_ow;
+                const bool c1 = ow >= p.OW;
+                ow -= c1 ? p.OW : 0;
+                int oh = g_oh[j] + p.d_oh + (c1 ? 1 : 0);
+                const bool c2 = oh >= p.OH;
+                oh -= c2 ? p.OH : 0;
+                g_ow[j] = ow;
+                g_oh[j] = oh;
+                b_off[j] += inc_base + (c1 ? inc_cy1 : 0u) + (c2 ? inc_cy2 : 0u);
             } else {
                 const int ih = g_oh[j] * p.stride + b_fr[j];
                 const int iw = g_ow[j] * p.stride + b_fs[j];
@@ -2321,6 +2351,11 @@ int launch_tn_dma(const TNParams& p, int splits, bool plain, hipStream_t st) {
     dim3 grid(p.tiles_a * p.tiles_b, splits), block(64 * NWA * NWB);
     if (plain) {
         auto k = igemm_tn_dma_kernel<BA, BB, NWA, NWB, true>;
+        static bool once = (allow_lds(k, smem), true);
+        (void)once;
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    } else if (const char* e = getenv("SAICV_TN_INCR"); e != nullptr && atoi(e) == 1) {
+        auto k = igemm_tn_dma_kernel<BA, BB, NWA, NWB, false, true>;      // experimental: carried offsets (see the kernel's header)
         static bool once = (allow_lds(k, smem), true);
         (void)once;
         hipLaunchKernelGGL(k, grid, block, smem, st, p);

@@ -423,3 +423,46 @@ def test_detr_pad_mask_from_sizes_equals_the_collaters_mask():
     import inspect
     from simpleaicv_pytorch_training_examples_amd.tools import scripts
     assert 'device_pad_mask' in inspect.getsource(scripts.train_detection)
+
+
+def test_wgrad_carried_offsets_equal_rebuilt_offsets():
+    """Host emulation of the offset recurrence of igemm_tn_dma_kernel<..., INCR> (csrc/igemm.hip, SAICV_TN_INCR=1): walking a DMA row
+    32 output pixels at a time, offset += inc_base + carry1 * inc_cy1 + carry2 * inc_cy2 (mod 2^32) equals the offset rebuilt from
+    (img, oh, ow) at every step, for random geometries / strides / paddings / taps -- the kernel itself has not run on a GPU yet."""
+    import random
+    rnd = random.Random(7)
+    mask = 0xffffffff
+    checked = 0
+    for _ in range(1500):
+        n, h, w = rnd.randint(1, 9), rnd.randint(3, 40), rnd.randint(3, 40)
+        c, k, stride, pad = rnd.choice([8, 16, 64]), rnd.choice([1, 3, 7]), rnd.choice([1, 2, 4]), rnd.choice([0, 1, 3])
+        oh_n, ow_n = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        if oh_n < 1 or ow_n < 1:
+            continue
+        br = 32
+        d_img = br // (oh_n * ow_n)
+        d_oh, d_ow = divmod(br - d_img * oh_n * ow_n, ow_n)
+        m_total = n * oh_n * ow_n
+        m, tap, c0 = rnd.randrange(m_total), rnd.randrange(k * k), rnd.randrange(0, c, 8)
+        fr, fs = tap // k - pad, tap % k - pad
+        img, rem = divmod(m, oh_n * ow_n)
+        oh, ow = divmod(rem, ow_n)
+        inc_base = ((((d_img * h + stride * d_oh) * w + stride * d_ow) * c) * 2) & mask
+        inc_cy1 = (((stride * w - stride * ow_n) * c) * 2) & mask
+        inc_cy2 = ((((h - stride * oh_n) * w) * c) * 2) & mask
+        off = ((((img * h + oh * stride + fr) * w + ow * stride + fs) * c + c0) * 2) & mask
+        step = 0
+        while m + step * br < m_total:
+            rebuilt = ((((img * h + oh * stride + fr) * w + ow * stride + fs) * c + c0) * 2) & mask
+            assert rebuilt == off, (n, h, w, c, k, stride, pad, m, tap, step)
+            ow += d_ow
+            c1 = ow >= ow_n
+            ow -= ow_n if c1 else 0
+            oh += d_oh + (1 if c1 else 0)
+            c2 = oh >= oh_n
+            oh -= oh_n if c2 else 0
+            img += d_img + (1 if c2 else 0)
+            off = (off + inc_base + (inc_cy1 if c1 else 0) + (inc_cy2 if c2 else 0)) & mask
+            step += 1
+            checked += 1
+    assert checked > 5000
