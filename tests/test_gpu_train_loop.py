@@ -563,10 +563,19 @@ def test_detection_step_graph_replays_the_same_training_as_eager_launches():
         got, restore = _spy_average_meter()
         try:
             scripts.train_detection(Loader(batches), model, crit, optimizer, scheduler, 1, logging.getLogger('saicv_det_graph'), config)
+            params = model.arena.flat_param.clone()
+            if use_graph:
+                # a SECOND epoch in the same process replays the cached graph from its first iteration: the loop must still know
+                # the loss-term names it logs with (print_interval = 1; ADVICE r04: they were per-call state and the first logged
+                # iteration of epoch 2 raised on rank 0)
+                n1 = len(got)
+                scripts.train_detection(Loader(batches[:3]), model, crit, optimizer, scheduler, 2, logging.getLogger('saicv_det_graph'), config)
+                assert len(got) == n1 + 3
+                del got[n1:]
         finally:
             restore()
         torch.cuda.synchronize()
-        return got, model.arena.flat_param.clone(), getattr(config, '_saicv_step_graphs', {})
+        return got, params, getattr(config, '_saicv_step_graphs', {})
 
     eager, p_eager, _ = run(False)
     eager2, p_eager2, _ = run(False)
