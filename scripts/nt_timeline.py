@@ -41,7 +41,7 @@ def main():
     raw.saicv_debug_nt_timeline.restype = None
     bf = torch.bfloat16
     cap = 1 << 17
-    buf = torch.zeros(cap * 12, dtype=torch.int64, device='cuda')
+    buf = torch.zeros(cap * 16, dtype=torch.int64, device='cuda')
 
     def measure(name, fn, flops):
         for _ in range(2):
@@ -56,7 +56,7 @@ def main():
         torch.cuda.synchronize()
         raw.saicv_debug_nt_timeline(ctypes.c_void_p(0))
         wall = e0.elapsed_time(e1) * 1e3
-        r = buf.view(cap, 12).cpu()
+        r = buf.view(cap, 16).cpu()
         r = r[r[:, 0] != 0]
         n = r.shape[0]
         if n == 0:
@@ -91,6 +91,10 @@ def main():
                'tflops': round(flops / wall / 1e6, 1), 'mean_lifetime_us': round(float(life.mean()), 2),
                'mean_resident_per_cu': round(busy, 2), 'cu_idle_frac': round(idle / (ncu * span_us), 3),
                'phase_us': {k: round(float(d[:, i].mean()), 2) for i, k in enumerate(names)},
+               'setup_split_us': {'to_tile_known': round(float(((r[:, 11].double() - t[:, 0]) / mhz).mean()), 2),
+                                  'rows_decomposed': round(float(((r[:, 12].double() - r[:, 11].double()) / mhz).mean()), 2),
+                                  'walker_ready': round(float(((r[:, 13].double() - r[:, 12].double()) / mhz).mean()), 2),
+                                  'bias_and_dma_issue': round(float(((t[:, 1] - r[:, 13].double()) / mhz).mean()), 2)},
                'phase_p90_us': {k: round(float(d[:, i].quantile(0.9)), 2) for i, k in enumerate(names)},
                'first_round_entry_spread_us': round(float(first[min(n, 2 * ncu) - 1] - first[0]), 2)}
         print(json.dumps(rec), flush=True)
@@ -129,7 +133,7 @@ def show(path):
             continue
         ph = d['phase_us']
         print(f"{d['launch']:44s} wall {d['wall_us']:7.1f} TF {d['tflops']:6.1f} life {d['mean_lifetime_us']:6.2f} res/cu {d['mean_resident_per_cu']:4.2f} | "
-              + ' '.join(f'{k} {v:5.2f}' for k, v in ph.items()))
+              + ' '.join(f'{k} {v:5.2f}' for k, v in ph.items()) + ' || setup: ' + ' '.join(f'{k} {v:4.2f}' for k, v in d.get('setup_split_us', {}).items()))
 
 
 if __name__ == '__main__':

@@ -18,6 +18,28 @@
 
 namespace {
 
+// cache policy of the streaming kernels' accesses (library variants for A/B runs, scripts/build_variant_lib.py)
+#ifdef SAICV_BN_FWD_LD_NT
+#define BNF_LD ld_chunk_nt
+#else
+#define BNF_LD ld_chunk
+#endif
+#ifdef SAICV_BN_FWD_ST_NT
+#define BNF_ST st_chunk_nt
+#else
+#define BNF_ST st_chunk
+#endif
+#ifdef SAICV_BN_BWD_LD_NT
+#define BNB_LD ld_chunk_nt
+#else
+#define BNB_LD ld_chunk
+#endif
+#ifdef SAICV_BN_BWD_ST_NT
+#define BNB_ST st_chunk_nt
+#else
+#define BNB_ST st_chunk
+#endif
+
 constexpr int kMaxBlocks = 1024;        // four 256-thread blocks per CU (sweep 512..16384: flat within 1 %, 2048 the slowest)
 
 // ---------------------------------------------------------------- partial reduce [P][C] -> [Y][C]
@@ -216,9 +238,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     for (size_t i = first; i < nchunks; i += stride) {
         if (!HOIST) load_coeffs((int)((i * N) % (size_t)C));
         float v[N];
-        Chunk<T>::unpack(ld_chunk(y + i * N), v);
+        Chunk<T>::unpack(BNF_LD(y + i * N), v);
         float rr[N];
-        if (RES) Chunk<T>::unpack(ld_chunk(res + i * N), rr);
+        if (RES) Chunk<T>::unpack(BNF_LD(res + i * N), rr);
         unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
             }
             v[j] = o;
         }
-        st_chunk(z + i * N, Chunk<T>::pack(v));
+        BNF_ST(z + i * N, Chunk<T>::pack(v));
         if (RELU && mask != nullptr) mask[i] = (uint8_t)bits;     // one bit per element: all backward needs of z
     }
 }
@@ -411,8 +433,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (size_t i = first; i < nchunks; i += stride) {
         if (!HOIST) load_coeffs((int)((i * N) % (size_t)C));
         float g[N], yy[N], zz[N], o[N];
-        Chunk<T>::unpack(ld_chunk(dz + i * N), g);
-        Chunk<T>::unpack(ld_chunk(y + i * N), yy);
+        Chunk<T>::unpack(BNB_LD(dz + i * N), g);
+        Chunk<T>::unpack(BNB_LD(y + i * N), yy);
         unsigned bits = 0xffu;
         if (RELU) {
             if (mask != nullptr) {
@@ -430,8 +452,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             g[j] = gj;
             o[j] = fmaf(ka[j], gj, fmaf(kb[j], yy[j], kc[j]));
         }
-        st_chunk(dy + i * N, Chunk<T>::pack(o));
-        if (RES) st_chunk(dres + i * N, Chunk<T>::pack(g));
+        BNB_ST(dy + i * N, Chunk<T>::pack(o));
+        if (RES) BNB_ST(dres + i * N, Chunk<T>::pack(g));
     }
 }
 

@@ -47,6 +47,8 @@ DEVINL void st_chunk(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 // streaming store: the line is not kept in L2 for a reader that will not come before it is evicted anyway (the vendor
 // library's GEMMs store their output this way, "NTD" in its kernel names)
 DEVINL void st_chunk_nt(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
+// streaming load: an operand read exactly once does not displace the lines other workgroups are about to re-read
+DEVINL u32x4 ld_chunk_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 
 DEVINL float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
 

@@ -99,6 +99,23 @@ static unsigned long long* g_nt_timeline = nullptr;
 #else
 #define NT_STAMP(i) do { } while (0)
 #endif
+// r05 -- output stores of igemm_nt1_kernel's epilogue are STREAMING stores ("nt": the line is not kept in L2 / MALL).  A training step's
+// outputs are read by a LATER kernel and are 25-411 MB each against 32 MB of L2 and 256 MB of MALL; written with the default policy
+// they evict what the neighbouring kernels re-read (the operand panels other tiles of this launch share, the dy a weight-gradient
+// kernel reads right after the data-gradient kernel did).  Same box, library A/B (profiles/r05_nt_experiments.md): ResNet-50 21.85 ->
+// 21.27 ms per step (igemm_nt 10.82 -> 10.60, igemm_tn 4.51 -> 4.30, bn_act_fwd 2.63 -> 2.55), ViT-B 40.04 -> 39.34 ms (igemm_nt 21.39 -> 20.43).
+// -DSAICV_NT_PLAIN_STORES builds the default-policy variant (scripts/build_variant_lib.py).
+#ifdef SAICV_NT_PLAIN_STORES
+#define NT_OUT_ST st_chunk
+#else
+#define NT_OUT_ST st_chunk_nt
+#endif
+// the data gradient's fused epilogue operands (shortcut gradient, pre-BatchNorm output, two mask bytes per chunk) are read exactly once
+#ifdef SAICV_DGRAD_EPI_LD_NT
+#define NT_EPI_LD ld_chunk_nt
+#else
+#define NT_EPI_LD ld_chunk
+#endif
 
 // NT kernel LDS image: one K tile = 64-byte rows = 4 chunks; chunk c of row r lives at slot
 // c ^ f((r>>2)&3), f = {0,2,3,1}.  ds_read_b128 is served in 16-lane groups that mix rows 0-3 /
@@ -954,7 +971,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     const int wn = wave / WM_;
 #ifdef SAICV_NT_TIMELINE
     const bool tl_on = p.timeline != nullptr;
-    unsigned long long tl_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // 8..10: inside the set-up (tile known | rows decomposed | walker ready)
     const unsigned long long tl_rt0 = tl_on ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz, the same on every XCD
     NT_STAMP(0);
 #endif
@@ -994,6 +1011,9 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     const int bid = xcd_remap(tix, nblk);
     const int tile_n = bid % p.tiles_n;
     const int tile_m = bid / p.tiles_n;
+#ifdef SAICV_NT_TIMELINE
+    if (tl_on) { int t_ = tile_m; asm volatile("" : "+s"(t_)); NT_STAMP(8); }
+#endif
 
     const __amdgpu_buffer_rsrc_t src_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
@@ -1067,6 +1087,9 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
             b0[i] = -(1 << 24);
         }
     }
+#ifdef SAICV_NT_TIMELINE
+    if (tl_on) { int t_ = rowc[0]; asm volatile("" : "+v"(t_)); NT_STAMP(9); }
+#endif
     int wrow[WROWS];                    // weight row base [elements], or -1
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
@@ -1201,6 +1224,9 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
         }
     };
 
+#ifdef SAICV_NT_TIMELINE
+    if (tl_on) { int t_ = kpos + fa0; asm volatile("" : "+v"(t_)); NT_STAMP(10); }
+#endif
     const int nkt = (Kc + BK - 1) / BK;        // 0 for a class without taps: the output is zero
     // r05 -- the bias starts the accumulators: out = bias + sum, and the epilogue's 16 masked loads + adds per thread behind the K loop
     // (1.5 us of a 27 us ViT-B tile, profiles/r05_nt_timeline.md) are gone.  The four values per 16-column fragment were requested
@@ -1432,11 +1458,11 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
             for (int j = 0; j < GRP; ++j) v[j] = ld_chunk(ls + (g + j) * RPP * OPITCH);
             if (full) {
 #pragma unroll
-                for (int j = 0; j < GRP; ++j) st_chunk(o + (g + j) * ostep, v[j]);
+                for (int j = 0; j < GRP; ++j) NT_OUT_ST(o + (g + j) * ostep, v[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < GRP; ++j)
-                    if (mrow0 + (g + j) * RPP < Mc) st_chunk(o + (g + j) * ostep, v[j]);
+                    if (mrow0 + (g + j) * RPP < Mc) NT_OUT_ST(o + (g + j) * ostep, v[j]);
             }
         }
     } else if (aligned && !remap && (p.act_mode == 0 || p.act_mode == 4) && (p.Nn % OEPC) == 0) {   // uniform
@@ -1470,8 +1496,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
                     sc[j] = 1.f;
                     if (ok) {
                         if (scalep) sc[j] = p.row_scale[mrow / p.rows_per_scale];
-                        if (addp) av[j] = ld_chunk(addend + off);
-                        if (bstats) yv[j] = ld_chunk(ybn + off);
+                        if (addp) av[j] = NT_EPI_LD(addend + off);
+                        if (bstats) yv[j] = NT_EPI_LD(ybn + off);
                         if (gatep) gb[j] = p.addend_gate[off / OEPC];
                         if (bstats && maskp) mb[j] = p.bs_mask[off / OEPC];
                     }
@@ -1505,7 +1531,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
                                 bax[e] = fmaf(ge, yy[e], bax[e]);
                             }
                         }
-                        st_chunk(outp + (size_t)mrow * p.ldo + ncol, v[j]);
+                        NT_OUT_ST(outp + (size_t)mrow * p.ldo + ncol, v[j]);
                     }
                 }
             }
@@ -1530,8 +1556,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
                     Chunk<TO>::unpack(v, f);
                     gelu_and_grad8(f, gl, gr);
                     const size_t off = (size_t)mrow * p.ldo + ncol;
-                    st_chunk(o2 + off, Chunk<TO>::pack(gl));
-                    st_chunk(outp + off, emit_grad ? Chunk<TO>::pack(gr) : v);
+                    NT_OUT_ST(o2 + off, Chunk<TO>::pack(gl));
+                    NT_OUT_ST(outp + off, emit_grad ? Chunk<TO>::pack(gr) : v);
                 }
             }
         }
@@ -1586,7 +1612,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
                 float f[OEPC], gl[OEPC], gr[OEPC];
                 Chunk<TO>::unpack(v, f);
                 gelu_and_grad8(f, gl, gr);
-                st_chunk(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(gl));
+                NT_OUT_ST(reinterpret_cast<TO*>(p.out2) + (size_t)m * p.ldo + ncol, Chunk<TO>::pack(gl));
                 if (p.act_mode == 3) v = Chunk<TO>::pack(gr);
             } else if (p.act_mode == 2 || p.act_mode == 4) {     // dgrad of fc2: d pre-activation = d act * gelu'(pre) (2) or * the stored derivative (4)
                 float f[OEPC], a[OEPC];
@@ -1631,7 +1657,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
                 }
             }
             if (whole) {
-                st_chunk(o, v);
+                NT_OUT_ST(o, v);
             } else {                          // N tail, or a leading dimension without 16-byte alignment
                 const TO* e = reinterpret_cast<const TO*>(&v);
                 for (int j = 0; j < OEPC; ++j)
@@ -1672,7 +1698,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the workgroup's stores are acknowledged
         NT_STAMP(7);
         if (tid == 0) {
-            unsigned long long* rec = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12;
+            unsigned long long* rec = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
             unsigned int hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1681,6 +1707,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
             rec[8] = ((unsigned long long)xcc << 32) | hw;
             rec[9] = __builtin_amdgcn_s_memrealtime();
             rec[10] = tl_rt0;
+            rec[11] = tl_t[8]; rec[12] = tl_t[9]; rec[13] = tl_t[10];
         }
     }
 #endif
@@ -2280,7 +2307,17 @@ void launch_nt1_inst(const NTParams& p, size_t smem, hipStream_t st) {
     auto k = igemm_nt1_kernel<T, BM_T, BN_T, WM_, WN_, MODE, OUT_F32, PLAIN, KC>;
     static bool once = (allow_lds(k, 160 * 1024), true);
     (void)once;
-    dim3 grid(p.nblk, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
+    // SAICV_NT1_ROUNDS=r (tuning aid, default 0 = one tile per workgroup): at most r resident rounds of workgroups, each walking the
+    // tiles tix, tix + grid, ... -- the launch-invariant part of the set-up (kernel arguments, divisions: 1.1-2.5 us of a 9-13 us
+    // ResNet-50 tile, profiles/r05_nt_timeline.md) is then paid once per workgroup instead of once per tile
+    int gx = p.nblk;
+    static const int rounds = getenv("SAICV_NT1_ROUNDS") ? atoi(getenv("SAICV_NT1_ROUNDS")) : 0;
+    if (rounds > 0) {
+        const int per_cu = KC == 8 ? 1 : (int)(160 * 1024 / (smem + 1024)) < 1 ? 1 : (int)(160 * 1024 / (smem + 1024));
+        const int cap = 256 * (per_cu > 4 ? 4 : per_cu) * rounds;
+        if (gx > cap) gx = cap;
+    }
+    dim3 grid(gx, (MODE == 1 && p.stride > 1) ? p.stride * p.stride : 1), block(64 * WM_ * WN_);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
 }
 
@@ -2687,6 +2724,6 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
 }  // namespace saicv
 
 #ifdef SAICV_NT_TIMELINE
-// debug build only (scripts/nt_timeline.py): 12 u64 per workgroup of the NEXT igemm_nt launches (one tile per workgroup kernels)
+// debug build only (scripts/nt_timeline.py): 16 u64 per workgroup of the NEXT igemm_nt launches (one tile per workgroup kernels)
 extern "C" void saicv_debug_nt_timeline(unsigned long long* buf) { g_nt_timeline = buf; }
 #endif

@@ -92,7 +92,7 @@ def test_linear_forward_and_input_gradient_with_bias_match_torch(mkn, dtype):
     b = torch.randn(n, generator=g)
     dy = torch.randn(m, n, generator=g).to(dtype)
     xg = x.cuda().requires_grad_(True)
-    wg = w.cuda().requires_grad_(True)
+    wg = w.float().cuda().requires_grad_(True)       # parameters are fp32 masters (packed to the compute dtype by the op)
     bg = b.cuda().requires_grad_(True)
     y = ops_tfm.linear_nd(xg, wg, bg)
     y.backward(dy.cuda())
