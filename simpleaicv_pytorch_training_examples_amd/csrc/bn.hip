@@ -18,21 +18,26 @@
 
 namespace {
 
-// cache policy of the streaming kernels' accesses (library variants for A/B runs, scripts/build_variant_lib.py)
-#ifdef SAICV_BN_FWD_LD_NT
-#define BNF_LD ld_chunk_nt
-#else
+// r05 -- cache policy of the two big streaming kernels.  Their INPUTS (the convolution's raw output y and the residual in the forward
+// pass; dz, y and the mask in the backward pass) are read exactly once by these kernels: streaming loads ("nt") keep them from
+// displacing what the neighbouring kernels re-read.  Their OUTPUTS (z; dy, dres) are read by the very next kernel and keep the default
+// policy.  Same box, library A/B on the ResNet-50 step (profiles/r05_nt_experiments.md): streaming loads 21.39 -> 21.22 ms (forward) and
+// -> 21.21 ms (backward); streaming STORES lose (21.55 / 21.50 ms).  -DSAICV_BN_FWD_LD_PLAIN / _BWD_LD_PLAIN / _FWD_ST_NT / _BWD_ST_NT
+// build the other policies (scripts/build_variant_lib.py).
+#ifdef SAICV_BN_FWD_LD_PLAIN
 #define BNF_LD ld_chunk
+#else
+#define BNF_LD ld_chunk_nt
 #endif
 #ifdef SAICV_BN_FWD_ST_NT
 #define BNF_ST st_chunk_nt
 #else
 #define BNF_ST st_chunk
 #endif
-#ifdef SAICV_BN_BWD_LD_NT
-#define BNB_LD ld_chunk_nt
-#else
+#ifdef SAICV_BN_BWD_LD_PLAIN
 #define BNB_LD ld_chunk
+#else
+#define BNB_LD ld_chunk_nt
 #endif
 #ifdef SAICV_BN_BWD_ST_NT
 #define BNB_ST st_chunk_nt

@@ -104,7 +104,8 @@ static unsigned long long* g_nt_timeline = nullptr;
 // they evict what the neighbouring kernels re-read (the operand panels other tiles of this launch share, the dy a weight-gradient
 // kernel reads right after the data-gradient kernel did).  Same box, library A/B (profiles/r05_nt_experiments.md): ResNet-50 21.85 ->
 // 21.27 ms per step (igemm_nt 10.82 -> 10.60, igemm_tn 4.51 -> 4.30, bn_act_fwd 2.63 -> 2.55), ViT-B 40.04 -> 39.34 ms (igemm_nt 21.39 -> 20.43).
-// -DSAICV_NT_PLAIN_STORES builds the default-policy variant (scripts/build_variant_lib.py).
+// -DSAICV_NT_PLAIN_STORES builds the default-policy variant (scripts/build_variant_lib.py).  (A run-time choice between the two store
+// forms does not survive the compiler: `if (flag) nontemporal_store else store` is merged into one plain store.)
 #ifdef SAICV_NT_PLAIN_STORES
 #define NT_OUT_ST st_chunk
 #else

@@ -8,6 +8,16 @@
 #include "common.h"
 #include "saicv_internal.h"
 
+// cache policy of the fused optimizer kernels (library variant for A/B runs: -DSAICV_OPT_NT = streaming loads and stores: every
+// value is read once and written once per step)
+#ifdef SAICV_OPT_NT
+#define OPT_LD(ptr) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr))
+#define OPT_ST(ptr, v) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ptr))
+#else
+#define OPT_LD(ptr) (*reinterpret_cast<const f32x4*>(ptr))
+#define OPT_ST(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
+#endif
+
 namespace {
 
 constexpr int kHyper = 8;   // floats per group: lr, wd, momentum|beta1, beta2, eps, 1-beta1, 1-beta2, flags
@@ -34,9 +44,9 @@ __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, co
     const float is = inv_scale ? inv_scale[0] : 1.f;
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
-    f32x4 mv = *reinterpret_cast<f32x4*>(mom + i);
+    f32x4 pv = OPT_LD(p + i);
+    const f32x4 gv = OPT_LD(g + i);
+    f32x4 mv = OPT_LD(mom + i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float d = gv[k] * is;
@@ -47,8 +57,8 @@ __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, co
         }
         pv[k] = fmaf(-lr, d, pv[k]);
     }
-    *reinterpret_cast<f32x4*>(p + i) = pv;
-    *reinterpret_cast<f32x4*>(mom + i) = mv;
+    OPT_ST(p + i, pv);
+    OPT_ST(mom + i, mv);
 }
 
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -77,10 +87,10 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     const float is = inv_scale ? inv_scale[0] : 1.f;
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
-    f32x4 mv = *reinterpret_cast<f32x4*>(m + i);
-    f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+    f32x4 pv = OPT_LD(p + i);
+    const f32x4 gv = OPT_LD(g + i);
+    f32x4 mv = OPT_LD(m + i);
+    f32x4 vv = OPT_LD(v + i);
     const float step = lr / bc1;
     const float rs2 = rsqrtf(bc2);
 #pragma unroll
@@ -92,9 +102,9 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
         const float denom = sqrtf(vv[k]) * rs2 + eps;
         pv[k] = fmaf(-step, mv[k] / denom, pv[k]);
     }
-    *reinterpret_cast<f32x4*>(p + i) = pv;
-    *reinterpret_cast<f32x4*>(m + i) = mv;
-    *reinterpret_cast<f32x4*>(v + i) = vv;
+    OPT_ST(p + i, pv);
+    OPT_ST(m + i, mv);
+    OPT_ST(v + i, vv);
 }
 
 // found_inf[0] = 1 if any gradient is inf/nan;  sumsq[0] += sum(g^2)  (for clip_grad_norm_)

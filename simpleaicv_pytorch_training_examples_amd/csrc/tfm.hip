@@ -15,6 +15,13 @@
 #include "common.h"
 #include "saicv_internal.h"
 
+// cache policy of the LayerNorm kernels' loads (library variant for A/B runs: -DSAICV_LN_LD_NT = streaming loads)
+#ifdef SAICV_LN_LD_NT
+#define LN_LD ld_chunk_nt
+#else
+#define LN_LD ld_chunk
+#endif
+
 namespace {
 
 // ======================================================================== LayerNorm
@@ -36,7 +43,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     for (int j = 0; j < NCH; ++j) {
         const int c = lane + 64 * j;
         if (c < cpr) {
-            Chunk<T>::unpack(ld_chunk(x + (size_t)row * C + c * N), v[j]);
+            Chunk<T>::unpack(LN_LD(x + (size_t)row * C + c * N), v[j]);
 #pragma unroll
             for (int k = 0; k < N; ++k) s += v[j][k];
         } else {
@@ -101,9 +108,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* 
         for (int j = 0; j < NCH; ++j) {
             const int c = lane + 64 * j;
             if (c < cpr) {
-                nd[j] = ld_chunk(dy + (size_t)row * C + c * N);
-                nx[j] = ld_chunk(x + (size_t)row * C + c * N);
-                if (addend != nullptr) na[j] = ld_chunk(addend + (size_t)row * C + c * N);
+                nd[j] = LN_LD(dy + (size_t)row * C + c * N);
+                nx[j] = LN_LD(x + (size_t)row * C + c * N);
+                if (addend != nullptr) na[j] = LN_LD(addend + (size_t)row * C + c * N);
             }
         }
         nmu = mean[row];
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_half_kernel(const T* __rest
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = sl + 32 * j;
-        if (live) Chunk<T>::unpack(ld_chunk(x + (size_t)row * C + c * N), v[j]);
+        if (live) Chunk<T>::unpack(LN_LD(x + (size_t)row * C + c * N), v[j]);
         else {
 #pragma unroll
             for (int k = 0; k < N; ++k) v[j][k] = 0.f;
@@ -260,9 +267,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_half_kernel(cons
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = sl + 32 * j;
-            nd[j] = ld_chunk(dy + (size_t)row * C + c * N);
-            nx[j] = ld_chunk(x + (size_t)row * C + c * N);
-            if (addend != nullptr) na[j] = ld_chunk(addend + (size_t)row * C + c * N);
+            nd[j] = LN_LD(dy + (size_t)row * C + c * N);
+            nx[j] = LN_LD(x + (size_t)row * C + c * N);
+            if (addend != nullptr) na[j] = LN_LD(addend + (size_t)row * C + c * N);
         }
         nmu = mean[row];
         nrs = rstd[row];
