@@ -88,6 +88,7 @@ def parse():
     ap.add_argument('--dominant-only', action='store_true',
                     help='bracket only the dominant kernel with HIP events in the eager pricing pass (default: every instrumented family)')
     ap.add_argument('--no-sam', action='store_true', help='skip the sam_b_encoder object of the default line')
+    ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi power / clock sample after the timed windows')
     return ap.parse_args()
 
 
@@ -382,6 +383,11 @@ def measure(name, args, world, rank, device, use_graph, primary):
         'allreduce_bytes_per_step': int(sum(b['end'] - b['start'] for b in model.buckets) * 4) if (world > 1 and hasattr(model, 'buckets')) else 0,
         'gradient_bytes': int(arena.total * 4) if arena is not None else None,
     }
+    # ---- socket power and shader clock while the same steps replay (rocm-smi polled from a thread for ~1.5 s, AFTER the timed windows).
+    # r05 finding: the GEMM kernels of these steps run AT the 1 400 W socket limit on random operands and the shader clock gives way
+    # (2.0-2.2 of 2.4 GHz): `power` says how close the whole step sits to that limit.
+    if world == 1 and not getattr(args, 'no_power', False):
+        res['power'] = sample_power(lambda: run(args.steps), fence)
     # ---- price the dominant kernel: an eager pass of the same steps with HIP events on the launch stream
     if not args.no_kernel_timer:
         cfg_graph = name in CONFIG_DIR and use_graph
@@ -426,7 +432,8 @@ def measure(name, args, world, rank, device, use_graph, primary):
                 if t == 'igemm_nt':
                     continue            # priced against the MFMA peak in `roofline` (its bytes are in roofline.shape_bound)
                 fam = {'kernel': FAMILY_KERNELS.get(t, t), 'ms_per_step': round(v['ms'] / k, 3), 'launches_per_step': round(v['calls'] / k, 1)}
-                if v['bytes'] > 0:
+                hbm_bound = v['bytes'] > 0 and v['bytes'] / 8e12 >= v['flops'] / (PEAK_BF16_TFLOPS * 1e12)
+                if hbm_bound:
                     # memory-bound families: algorithmic bytes (tensors read + written once) / measured time against HBM3E
                     fam.update({'bound': 'hbm', 'algorithmic_GB_per_step': round(v['bytes'] / k / 1e9, 2),
                                 'GB/s': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
@@ -440,6 +447,44 @@ def measure(name, args, world, rank, device, use_graph, primary):
                                 'frac_of_mfma_peak': round(v['flops'] / (v['ms'] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)})
                     res.setdefault('mfma_kernels', {})[t] = fam
     return res
+
+
+def sample_power(run_steps, fence, seconds=1.5):
+    """-> {'socket_w', 'sclk_mhz', 'samples', 'limit_w'} averaged over `seconds` of replayed steps, or None when rocm-smi is not usable."""
+    import re
+    import shutil
+    import threading
+    exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    if not os.path.exists(exe):
+        return None
+    stop, got = threading.Event(), []
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run([exe, '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=5).stdout
+                w = re.search(r'Power \(W\)": "([0-9.]+)', out)
+                c = re.search(r'sclk clock speed:": "\((\d+)Mhz', out)
+                if w and c:
+                    got.append((float(w.group(1)), int(c.group(1))))
+            except Exception:      # noqa: BLE001  (a missing / hanging tool must not fail the bench)
+                return
+            time.sleep(0.1)
+    th = threading.Thread(target=poll, daemon=True)
+    fence()
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        run_steps()
+    fence()
+    stop.set()
+    th.join(timeout=6)
+    got = got[1:] if len(got) > 2 else got          # the first sample may predate the load
+    if not got:
+        return None
+    return {'socket_w': round(sum(g[0] for g in got) / len(got), 1), 'sclk_mhz': round(sum(g[1] for g in got) / len(got)),
+            'samples': len(got), 'limit_w': 1400, 'max_sclk_mhz': 2400,
+            'note': 'rocm-smi --showpower --showclocks polled while the timed workload replays (after the timed windows)'}
 
 
 def want_step_graph(eager, force_graph, world, env):

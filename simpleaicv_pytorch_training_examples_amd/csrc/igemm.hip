@@ -86,6 +86,7 @@ struct NTParams {
     int nblk;
     int grid_x;         // resident workgroups (256 CUs x workgroups per CU)
     int kc8;            // host: launch the 128-byte-K-slice instantiation (pointwise bf16, 256-row tiles)
+    int stream_out;     // host: the output is written with streaming stores (see NT_OUT_ST)
     FastDiv fd_ohw, fd_ow;   // for OH*OW and OW (unit-stride row decomposition)
 #ifdef SAICV_NT_TIMELINE
     unsigned long long* timeline;       // debug build only (scripts/nt_timeline.py): 8 shader-clock stamps per workgroup
@@ -106,10 +107,17 @@ static unsigned long long* g_nt_timeline = nullptr;
 // 21.27 ms per step (igemm_nt 10.82 -> 10.60, igemm_tn 4.51 -> 4.30, bn_act_fwd 2.63 -> 2.55), ViT-B 40.04 -> 39.34 ms (igemm_nt 21.39 -> 20.43).
 // -DSAICV_NT_PLAIN_STORES builds the default-policy variant (scripts/build_variant_lib.py).  (A run-time choice between the two store
 // forms does not survive the compiler: `if (flag) nontemporal_store else store` is merged into one plain store.)
+// Which launches stream: outputs of at least SAICV_NT_STREAM_MIN_MB MiB (p.stream_out).  The streaming form is an assembly statement --
+// a run-time choice between __builtin_nontemporal_store and a plain store does not survive the compiler (both arms are merged into ONE
+// plain store; the first build of this switch measured exactly like plain stores).  `s_nop 1`: the statement's data registers may be
+// rewritten right behind it (guide section 5.7).
+DEVINL void st_chunk_stream(void* q, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+}
 #ifdef SAICV_NT_PLAIN_STORES
 #define NT_OUT_ST st_chunk
 #else
-#define NT_OUT_ST st_chunk_nt
+#define NT_OUT_ST(ptr, v) do { if (stream_out) st_chunk_stream(ptr, v); else st_chunk(ptr, v); } while (0)
 #endif
 // the data gradient's fused epilogue operands (shortcut gradient, pre-BatchNorm output, two mask bytes per chunk) are read exactly once
 #ifdef SAICV_DGRAD_EPI_LD_NT
@@ -1430,6 +1438,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
         }
     }
     NT_STAMP(5);
+    const bool stream_out = p.stream_out != 0;      // uniform
     const int oc = tid % OCPR;               // chunk within the tile row
     const int orow0 = tid / OCPR;
     constexpr int RPP = NTHREADS / OCPR;     // tile rows per pass
@@ -2575,6 +2584,12 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
     // per CU: ViT-B step 42.57 ms off, 42.95 with them, 42.31 without.
     const char* ke = getenv("SAICV_NT_KC8");             // read per call
     const int kc8_mode = ke ? atoi(ke) : 2;
+    {
+        // streaming output stores from SAICV_NT_STREAM_MIN_MB MiB of output on (0: always; a huge value: never)
+        static const long min_mb = getenv("SAICV_NT_STREAM_MIN_MB") ? atol(getenv("SAICV_NT_STREAM_MIN_MB")) : 0;
+        const size_t out_bytes = (size_t)M * Nn * ((out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2);
+        p.stream_out = out_bytes >= (size_t)min_mb * 1024 * 1024 ? 1 : 0;
+    }
     p.kc8 = 0;
     {
         const bool pointwise = R == 1 && S == 1 && pad == 0 && (mode == 0 || stride == 1);

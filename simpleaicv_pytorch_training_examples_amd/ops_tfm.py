@@ -41,7 +41,10 @@ def lin_fwd(x2, weight, bias, out_f32=False, addend=None, row_scale=None, rows_p
     t0 = KernelTimer.begin('igemm_nt')
     check(lib().saicv_linear_fwd(dtype_code(dt), ptr(x2), ptr(wf), ptr(bp), ptr(y), m, k, op, int(odt == torch.float32),
                                  ptr(addend), ptr(row_scale), rows_per_scale, stream()), 'linear_fwd')
-    KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, 0)
+    # algorithmic bytes: each operand once, the output once, the fused addend once
+    es = x2.element_size()
+    KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o,
+                    float(m) * k * es + float(o) * k * es + float(m) * o * y.element_size() * (2 if addend is not None else 1))
     return y if op == o else y[:, :o]
 
 
@@ -70,7 +73,8 @@ def lin_gelu_fwd(x2, weight, bias, aux=False):
     else:
         check(lib().saicv_linear_gelu_fwd(dtype_code(dt), ptr(x2), ptr(wf), ptr(bias), ptr(pre), ptr(act), m, k, o, stream()),
               'linear_gelu_fwd')
-    KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, 0)
+    es = x2.element_size()
+    KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, float(m) * k * es + float(o) * k * es + 2.0 * m * o * es)      # two outputs
     return (pre, act, GELU_AUX) if aux else (pre, act)
 
 
@@ -114,7 +118,9 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None, grad
                   'linear_dgrad_gelu')
         else:
             check(L.saicv_linear_dgrad(dtype_code(dt), ptr(dy), ptr(wd), ptr(dx), m, k, op, ptr(addend), st), 'linear_dgrad')
-        KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, 0)
+        es = dy.element_size()
+        fused_in = 1 if (gelu_dact is not None or gelu_pre is not None or addend is not None) else 0
+        KernelTimer.end(t0, 'igemm_nt', 2.0 * m * k * o, float(m) * o * es + float(o) * k * es + float(m) * k * es * (1 + fused_in))
     want_b = (bias is not None and bias.requires_grad) if want_bias is None else (bias is not None and want_bias)
     want_w = weight.requires_grad if want_w is None else want_w
     if grad_b is _AUTO:
@@ -133,11 +139,11 @@ def lin_bwd(x2, weight, bias, dy, need_dx=True, addend=None, gelu_pre=None, grad
             with ops._SideStream(dy, x2):
                 t0 = KernelTimer.begin('igemm_tn')
                 check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), ptr(tb), m, k, op, stream()), 'linear_wgrad')
-                KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, 0)
+                KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, float(m) * (k + o) * dy.element_size() + 4.0 * o * k)
         else:
             t0 = KernelTimer.begin('igemm_tn')
             check(L.saicv_linear_wgrad(dtype_code(dt), ptr(dy), ptr(x2), ptr(tgt), ptr(tb), m, k, op, st), 'linear_wgrad')
-            KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, 0)
+            KernelTimer.end(t0, 'igemm_tn', 2.0 * m * k * o, float(m) * (k + o) * dy.element_size() + 4.0 * o * k)
         if gw is None:
             dw = tgt[:o]
     elif want_b:
