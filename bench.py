@@ -211,8 +211,11 @@ def loop_workload(name, args, world, rank, device, use_graph=False):
     config.use_ema_model = getattr(config, 'use_ema_model', False)
     # whole-step capture where the loop allows it (r04): a criterion without host reads and with static shapes (RetinaLoss with
     # SmoothL1); DETR (Hungarian assignment on the host), FCOS (positive-only IoU terms) and the SAM loop (prompt draws) stay eager
-    graphed = bool(use_graph and LOOP_MODELS[name][0].endswith('train_detection') and 'detr' not in getattr(config, 'network', '')
-                   and getattr(config.train_criterion, 'capturable', False))
+    is_det = LOOP_MODELS[name][0].endswith('train_detection')
+    is_detr = 'detr' in getattr(config, 'network', '')
+    # r05: DETR as two captured graphs around the host-side assignment (engine.TwoPhaseStepGraph)
+    graphed = bool(use_graph and is_det and ((not is_detr and getattr(config.train_criterion, 'capturable', False)) or
+                                             (is_detr and getattr(config.train_criterion, 'two_phase', False))))
     config.use_step_graph = graphed
     model = config.model.to(device)
     optimizer, _ = utils.build_optimizer(config, model)

@@ -112,6 +112,103 @@ class DETRLoss(nn.Module):
         giou = _giou(_cxcywh_to_xyxy(matched_preds), _cxcywh_to_xyxy(target_boxes))
         return l1, (1 - giou).sum() / target_num
 
+    # ------------------------------------------------------------------ static-shape form (r05: the step as TWO captured graphs)
+    # The Hungarian assignment needs the cost matrices on the host, so a DETR step cannot be ONE hipGraph.  It can be two, with the
+    # assignment between them (engine.TwoPhaseStepGraph; tools.scripts.train_detection): graph 1 = forward + match_inputs(), host =
+    # assign_host(), graph 2 = forward_static() + backward + optimizer.  Everything the graphs touch has a fixed shape: the
+    # ground truth is the collater's [B, T, 5] tensor itself (rows with class < 0 are padding), the matched pairs are [B, T] index /
+    # weight buffers this module owns (weight 0 = no pair), the number of boxes is a device scalar.
+    two_phase = True
+
+    @torch.no_grad()
+    def match_inputs(self, preds, gt_pad):
+        """-> (cost [B, Q, T] fp32, valid [B, T] bool): the matching cost of the LAST layer against every row of the padded ground
+        truth (the same operations as _match on the valid rows; the columns of padding rows hold garbage nobody reads)."""
+        cls_preds, reg_preds = preds
+        boxes = torch.clamp(reg_preds[-1], min=1e-4, max=1. - 1e-4).float()                     # [B, Q, 4]
+        prob = torch.clamp(F.softmax(cls_preds[-1].float(), dim=-1), min=1e-4, max=1. - 1e-4)   # [B, Q, C + 1]
+        gt = gt_pad.float()
+        valid = gt[:, :, 4] >= 0
+        b, q, t = boxes.shape[0], boxes.shape[1], gt.shape[1]
+        cls_idx = gt[:, :, 4].clamp(min=0).long()
+        cls_cost = -prob.gather(2, cls_idx[:, None, :].expand(b, q, t))
+        box_cost = torch.cdist(boxes, gt[:, :, 0:4], p=1)
+        giou_cost = -_giou(_cxcywh_to_xyxy(boxes)[:, :, None, :], _cxcywh_to_xyxy(gt[:, :, 0:4])[:, None, :, :])
+        return self.cls_match_cost * cls_cost + self.box_match_cost * box_cost + self.giou_match_cost * giou_cost, valid
+
+    def _pair_buffers(self, b, t, device):
+        bufs = getattr(self, '_pairs', None)
+        if bufs is None or bufs['src'].shape != (b, t) or bufs['src'].device != device:
+            bufs = {'src': torch.zeros(b, t, dtype=torch.int64, device=device), 'tgt': torch.zeros(b, t, dtype=torch.int64, device=device),
+                    'w': torch.zeros(b, t, dtype=torch.float32, device=device),
+                    'h_src': torch.zeros(b, t, dtype=torch.int64).pin_memory(), 'h_tgt': torch.zeros(b, t, dtype=torch.int64).pin_memory(),
+                    'h_w': torch.zeros(b, t, dtype=torch.float32).pin_memory()}
+            # constants of forward_static, built HERE (outside any capture: a host -> device copy is not capturable)
+            weight = torch.ones(self.num_classes + 1)
+            weight[-1] = self.no_object_cls_weight
+            bufs['cls_weight'] = weight.to(device)
+            bufs['dummy_box'] = torch.tensor([0.5, 0.5, 0.2, 0.2]).to(device)
+            self._pairs = bufs
+        return bufs
+
+    def assign_host(self, cost, valid):
+        """One device -> host copy of (cost, valid), scipy's assignment per image on the valid columns, one host -> device copy of the
+        pairs into the module's static buffers: -> (src [B, T] query index, tgt [B, T] ground-truth row, w [B, T] 1 / 0)."""
+        b, q, t = cost.shape
+        bufs = self._pair_buffers(b, t, cost.device)
+        total = cost.float().cpu().numpy()               # the one synchronising copy of a step
+        ok = valid.cpu().numpy()
+        hs, ht, hw = bufs['h_src'], bufs['h_tgt'], bufs['h_w']
+        hs.zero_(); ht.zero_(); hw.zero_()
+        for i in range(b):
+            cols = np.nonzero(ok[i])[0]
+            if cols.size == 0:
+                continue
+            rows, cj = self.linear_sum_assignment_with_inf(total[i][:, cols])
+            n = len(rows)
+            hs[i, :n] = torch.as_tensor(rows, dtype=torch.int64)
+            ht[i, :n] = torch.as_tensor(cols[cj], dtype=torch.int64)
+            hw[i, :n] = 1.0
+        bufs['src'].copy_(hs, non_blocking=True)
+        bufs['tgt'].copy_(ht, non_blocking=True)
+        bufs['w'].copy_(hw, non_blocking=True)
+        return bufs['src'], bufs['tgt'], bufs['w']
+
+    def forward_static(self, preds, gt_pad, src, tgt, w):
+        """The loss of forward() from static-shape inputs: pairs (src[i, k], tgt[i, k]) of image i count where w[i, k] = 1.  Same
+        per-pair arithmetic; padding pairs are computed on a harmless dummy box and multiplied by 0 (their gradient is exactly 0)."""
+        cls_preds, reg_preds = preds
+        reg_preds = torch.clamp(reg_preds, min=1e-4, max=1. - 1e-4).float()
+        cls_preds = cls_preds.float()
+        gt = gt_pad.float()
+        l, b, q = cls_preds.shape[0], cls_preds.shape[1], cls_preds.shape[2]
+        t = src.shape[1]
+        bidx = torch.arange(b, device=gt.device)[:, None].expand(b, t)
+        on = w > 0
+        m_cls = gt[bidx, tgt, 4]
+        m_box = gt[bidx, tgt, 0:4]
+        # class map [B, Q]: the no-object class everywhere, the matched class at (i, src); padding pairs write column Q of a wider map
+        gmap = torch.full((b, q + 1), self.num_classes, dtype=torch.long, device=gt.device)
+        gmap[bidx, torch.where(on, src, torch.full_like(src, q))] = torch.where(on, m_cls.long(), torch.full_like(src, self.num_classes))
+        gmap = gmap[:, :q]
+        weight = self._pairs['cls_weight']
+        nll = -F.log_softmax(cls_preds, dim=-1).gather(-1, gmap.view(1, b, q, 1).expand(l, b, q, 1)).squeeze(-1)
+        wgt = weight[gmap]
+        cls_l = (nll * wgt).sum(dim=(1, 2)) / wgt.sum()
+        target_num = w.sum().clamp(min=1.0)
+        dummy = self._pairs['dummy_box']
+        pm = torch.where(on[None, :, :, None], reg_preds[:, bidx, src], dummy)                 # [L, B, T, 4]
+        tb = torch.where(on[:, :, None], m_box, dummy)                                          # [B, T, 4]
+        l1_l = ((pm - tb).abs().sum(dim=-1) * w).sum(dim=(1, 2)) / target_num
+        giou = _giou(_cxcywh_to_xyxy(pm), _cxcywh_to_xyxy(tb))
+        iou_l = ((1 - giou) * w).sum(dim=(1, 2)) / target_num
+        loss_dict = {}
+        for idx in range(l):
+            loss_dict[f'layer_{idx}_cls_loss'] = self.cls_loss_weight * cls_l[idx]
+            loss_dict[f'layer_{idx}_box_l1_loss'] = self.box_l1_loss_weight * l1_l[idx]
+            loss_dict[f'layer_{idx}_box_iou_loss'] = self.iou_loss_weight * iou_l[idx]
+        return loss_dict
+
     # reference-named views of the same computations (used by its tests / tools)
     def compute_batch_cls_loss(self, cls_preds, annotations, indices):
         valid = [a[a[:, 4] >= 0] for a in annotations]

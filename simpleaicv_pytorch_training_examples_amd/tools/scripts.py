@@ -243,7 +243,7 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
 
 
 def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, total_name, iter_width,
-                graph_inputs=None, log_terms=True):
+                graph_inputs=None, log_terms=True, two_phase=None):
     """Shared iteration engine of the dict-loss loops (detection here; the SAM loop in
     interactive_segmentation_scripts.py follows the same scheme): `step_fn(data)` runs forward + loss and
     returns (bad flag tensor, {name: loss tensor}, batch size).  Everything else -- accumulation, the single
@@ -292,6 +292,10 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
     def forward_backward(data, boundary):
         """forward, criterion, (scaled) backward; -> (packed [skip, total, terms...] reduced over the ranks, batch size)"""
         bad, loss_value, n = step_fn(data)
+        return loss_tail(bad, loss_value, boundary), n
+
+    def loss_tail(bad, loss_value, boundary):
+        """loss terms -> total, skip flag, (scaled) backward, the packed vector reduced over the ranks"""
         if names['keys'] is None:
             names['keys'] = list(loss_value.keys())
         keys = names['keys']
@@ -307,7 +311,7 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
                 scaled.backward()
         packed = torch.cat([torch.stack([bad.float(), loss.detach().float()]), terms])
         all_reduce_sum_packed(packed, model, config.group)
-        return packed, n
+        return packed
 
     def update(packed):
         if hasattr(model, 'finish_gradient_sync'):
@@ -342,6 +346,17 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
             batch_n[0] = n
             update(packed)
             return packed
+
+        # two_phase = (phase1, host, phase2): a step with host work between forward and loss (DETR's assignment) as two graphs
+        # around it -- phase1(tensors) -> (bad, mid tensors); host(mid); phase2(mid) -> loss terms
+        def first_half(*tensors):
+            bad, mid = two_phase[0](tensors)
+            return (bad,) + tuple(mid)
+
+        def second_half(mid):
+            packed = loss_tail(mid[0], two_phase[2](mid[1:]), True)
+            update(packed)
+            return packed
         cache = getattr(config, '_saicv_step_graphs', None)
         if cache is None:
             cache = {}
@@ -349,8 +364,12 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
         key = (id(model), id(optimizer))
         step_graph = cache.get(key)
         if step_graph is None:
-            step_graph = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3),
-                                          before_replay=(optimizer.refresh_hyper,))
+            if two_phase is not None:
+                step_graph = engine.TwoPhaseStepGraph(first_half, lambda mid: two_phase[1](mid[1:]), second_half,
+                                                      warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,))
+            else:
+                step_graph = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3),
+                                              before_replay=(optimizer.refresh_hyper,))
             step_graph.loss_term_names = names      # the captured closure writes into THIS holder
             cache[key] = step_graph
         else:
@@ -360,8 +379,8 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
     for data in train_loader:
         micro += 1
         boundary = micro % acc_steps == 0
-        if step_graph is not None:
-            tensors = graph_inputs(data)
+        tensors = graph_inputs(data) if step_graph is not None else None     # None: this batch does not fit the captured shapes
+        if tensors is not None:
             packed = step_graph(*tensors).clone()
             n = tensors[0].size(0)
         else:
@@ -370,7 +389,7 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
             packed = torch.cat([torch.maximum(packed[0:1], carried_bad), packed[1:]])
         carried_bad = None if boundary else packed[0:1]
         if boundary:
-            if step_graph is None:
+            if tensors is None:
                 update(packed)
             scheduler.step(optimizer, iter_index / iters + (epoch - 1))
             log_fmt = None
@@ -418,11 +437,50 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
     # the dense detectors' step has no host read (anchor assignment, focal loss and SmoothL1 are decided on the device): it can be
     # captured whole.  DETR's Hungarian assignment runs on the host between forward and loss, and criteria that index by a
     # data-dependent positive mask (`capturable = False`, e.g. the IoU branches) have dynamic shapes: those stay eager.
-    graph_inputs = None
+    graph_inputs, two_phase = None, None
     if not is_detr and getattr(criterion, 'capturable', False):
         def graph_inputs(data):
             return (data['image'].to(device, non_blocking=True), data['annots'].to(device, non_blocking=True))
-    return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5, graph_inputs)
+    elif is_detr and getattr(criterion, 'two_phase', False) and getattr(config, 'use_step_graph', False):
+        # r05: the DETR step as TWO captured graphs around the host-side assignment (engine.TwoPhaseStepGraph; DETRLoss.match_inputs /
+        # assign_host / forward_static).  Static shapes: the collater's annotations padded (class -1 rows) to config.max_annots rows
+        # (default 100 = the reference's query count); a batch with more boxes in one image takes the eager step.
+        max_annots = int(getattr(config, 'max_annots', 100))
+
+        def graph_inputs(data):
+            ann = data['scaled_annots']
+            if ann.shape[1] > max_annots:
+                if bool((ann[:, max_annots:, 4] >= 0).any()):
+                    return None
+                ann = ann[:, :max_annots]
+            ann = ann.to(device, non_blocking=True).float()
+            if ann.shape[1] < max_annots:
+                ann = torch.cat([ann, ann.new_full((ann.shape[0], max_annots - ann.shape[1], ann.shape[2]), -1.0)], dim=1)
+            if getattr(config, 'device_pad_mask', False):
+                mask = pad_mask_on_device(data['scaled_size'], data['image'].shape[-1], device)
+            else:
+                mask = data['mask'].to(device, non_blocking=True)
+            return (data['image'].to(device, non_blocking=True), mask, ann)
+
+        def phase1(tensors):
+            images, mask, ann = tensors
+            bad = any_nonfinite(images, ann)
+            with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
+                cls_preds, reg_preds = model(images, mask)
+                cost, valid = criterion.match_inputs((cls_preds, reg_preds), ann)
+            return bad, (cls_preds, reg_preds, cost, valid, ann)
+
+        def host(mid):
+            criterion.assign_host(mid[2], mid[3])
+
+        def phase2(mid):
+            cls_preds, reg_preds, _, _, ann = mid
+            pairs = criterion._pairs
+            with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
+                return criterion.forward_static((cls_preds, reg_preds), ann, pairs['src'], pairs['tgt'], pairs['w'])
+        two_phase = (phase1, host, phase2)
+    return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5, graph_inputs,
+                       two_phase=two_phase)
 
 
 def train_mae_self_supervised_learning(train_loader, model, criterion, optimizer, scheduler, epoch, logger, config):

@@ -405,12 +405,16 @@ def _spy_average_meter():
     return got, lambda: setattr(common.AverageMeter, 'update', orig)
 
 
-def test_detection_loop_follows_the_reference_loop():
+@pytest.mark.parametrize('graphed', [False, True], ids=['eager', 'two_graphs'])
+def test_detection_loop_follows_the_reference_loop(graphed):
     """8 fp32 iterations of resnet18_detr (dropout 0) through THIS package's train_detection / AdamW / Scheduler / norm clip
     against the per-iteration total losses the reference's own tools/scripts.py:900-1092 produced on CPU for the same weights
     and batches (oracle/make_golden_traj_det_sam.py).  Gate: 1e-3 on the first iteration (north_star), afterwards
     max(2e-3, 4 x how far the reference moved from ITSELF by then under another thread count -- the Hungarian assignment
-    makes the trajectory chaotic: 6.6e-3 by iteration 7)."""
+    makes the trajectory chaotic: 6.6e-3 by iteration 7).
+    'two_graphs' (r05): the same iterations with config.use_step_graph -- two eager warm-up steps, then the step as two captured
+    hipGraphs around the host-side assignment (engine.TwoPhaseStepGraph, DETRLoss.match_inputs / assign_host / forward_static):
+    the same gates against the reference's trajectory, and the graphs must really have been replayed."""
     from conftest import load_golden
     from oracle.make_golden_detr import detr_inputs, zero_dropout
     from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
@@ -427,6 +431,7 @@ def test_detection_loop_follows_the_reference_loop():
     config.epochs, config.batch_size, config.accumulation_steps, config.print_interval = 1, batch, 1, 1
     config.use_amp, config.use_ema_model, config.local_rank, config.gpus_num, config.group = False, False, 0, 1, None
     config.clip_max_norm, config.sync_bn, config.host_sync_lag = 0.1, False, 2
+    config.use_step_graph, config.step_graph_warmup = graphed, 2
     torch.manual_seed(0)
     model = detr.resnet18_detr(hidden_inplanes=256, query_nums=20, num_classes=20)
     zero_dropout(model)
@@ -448,6 +453,10 @@ def test_detection_loop_follows_the_reference_loop():
                                       logging.getLogger('saicv_traj_detr'), config)
     finally:
         restore()
+    if graphed:
+        graphs = getattr(config, '_saicv_step_graphs', {})
+        g = next(iter(graphs.values()))
+        assert len(graphs) == 1 and g.graph is not None and g.graph2 is not None and g.replays >= steps - 3, (len(graphs), g.replays)
     worst = _gate_trajectory(got, fx, 1e-3, 2e-3)
     print(f'[detection trajectory] worst relative loss error {worst:.2e}; reference self-noise up to '
           f'{max(fx["reference_noise"]["loss_rel"]):.2e}')
