@@ -193,8 +193,8 @@ def classification_workload(name, args, world, rank, device, use_graph):
 
 
 def loop_workload(name, args, world, rank, device, use_graph=False):
-    """DETR / full SAM through the reference's own config and loop (eager launches: both loops have host-side work per
-    iteration -- the Hungarian assignment, the prompt-type draw)."""
+    """DETR / full SAM through the reference's own config and loop.  DETR (r05) runs as ONE captured step when `use_graph`: its
+    Hungarian assignment is a device kernel (saicv_detr_assign).  The SAM loop stays eager (host-side prompt-type draw)."""
     import numpy as np
     import torch
     from simpleaicv_pytorch_training_examples_amd.tools import interactive_segmentation_scripts, scripts, utils
@@ -210,12 +210,12 @@ def loop_workload(name, args, world, rank, device, use_graph=False):
     config.print_interval = 10 ** 9
     config.use_ema_model = getattr(config, 'use_ema_model', False)
     # whole-step capture where the loop allows it (r04): a criterion without host reads and with static shapes (RetinaLoss with
-    # SmoothL1); DETR (Hungarian assignment on the host), FCOS (positive-only IoU terms) and the SAM loop (prompt draws) stay eager
+    # SmoothL1); FCOS (positive-only IoU terms) and the SAM loop (prompt draws) stay eager
     is_det = LOOP_MODELS[name][0].endswith('train_detection')
     is_detr = 'detr' in getattr(config, 'network', '')
-    # r05: DETR as two captured graphs around the host-side assignment (engine.TwoPhaseStepGraph)
+    # r05: DETR captured whole -- its Hungarian assignment runs on the device (DETRLoss.assign_device, saicv_detr_assign)
     graphed = bool(use_graph and is_det and ((not is_detr and getattr(config.train_criterion, 'capturable', False)) or
-                                             (is_detr and getattr(config.train_criterion, 'two_phase', False))))
+                                             (is_detr and getattr(config.train_criterion, 'static_form', False))))
     config.use_step_graph = graphed
     model = config.model.to(device)
     optimizer, _ = utils.build_optimizer(config, model)
@@ -795,6 +795,26 @@ def worker(args):
             sam['steps'], sam['warmup'] = a2.steps, a2.warmup
         except Exception as e:      # noqa: BLE001 -- the headline must not die with the third object
             sam = {'error': f'{type(e).__name__}: {e}'}
+    detr = None
+    if args.model == 'resnet50' and not args.no_secondary and not args.no_sam and world == 1:
+        # BASELINE.json configs[3] on the driver line (r05): the reference's DETR-R50 config through tools.scripts.train_detection,
+        # per-GPU batch 8, the whole step captured (Hungarian assignment on the device); ONE window of 5 steps
+        import argparse as _ap
+        import gc
+        for cfg in _CONFIGS.values():
+            for attr in ('_saicv_step_graphs', 'model', 'ema_model'):
+                if hasattr(cfg, attr):
+                    setattr(cfg, attr, None)
+        _CONFIGS.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+        a3 = _ap.Namespace(**vars(args))
+        a3.batch, a3.steps, a3.warmup, a3.max_windows, a3.min_gpu_seconds, a3.no_kernel_timer = 8, 5, 5, 1, 0.0, True
+        try:
+            detr = measure('resnet50_detr_config', a3, world, rank, device, want_step_graph(args.eager, args.graph, world, os.environ.get('SAICV_STEP_GRAPH')), False)
+            detr['steps'], detr['warmup'] = a3.steps, a3.warmup
+        except Exception as e:      # noqa: BLE001
+            detr = {'error': f'{type(e).__name__}: {e}'}
 
     if rank == 0:
         out = {'metric': 'training images/sec/node', 'value': primary['value'], 'unit': 'images/s', 'n_gpus': world,
@@ -810,6 +830,8 @@ def worker(args):
             out['secondary'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **secondary}
         if sam is not None:
             out['sam_b_encoder'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **sam}
+        if detr is not None:
+            out['resnet50_detr_config'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **detr}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model)
         line = json.dumps(out)

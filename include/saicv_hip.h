@@ -432,6 +432,14 @@ int saicv_sam_grid_pe(const float* gauss, int F, int S, float* out, void* stream
  * padding) -> out fp32 [B][2F][H][W]; H * W <= 8192. */
 int saicv_detr_sine_pe(const unsigned char* mask, float* out, int B, int H, int W, int F, float temperature, float eps, void* stream);
 
+/* DETR Hungarian assignment on the device (r05; replaces the host-side scipy.optimize.linear_sum_assignment call of reference
+ * SimpleAICV/detection/losses.py:1009-1090, which put a device -> host copy and a synchronisation between forward and loss of every
+ * step): cost fp32 [B][Q][T] = matching cost of every query against every row of the padded ground truth, valid u8 [B][T] = rows that
+ * are boxes.  Per image the minimum-cost assignment over the valid columns, scipy's algorithm and tie rules in double precision
+ * (nan -> 1e5, one-signed infinities -> a finite value beyond any total, as the reference's wrapper).  Output: src / tgt int64 [B][T],
+ * w fp32 [B][T]: slot k < min(n, Q) holds the pair (query src, ground-truth row tgt) with w = 1, the other slots 0.  Q, T <= 2048. */
+int saicv_detr_assign(const float* cost, const unsigned char* valid, int B, int Q, int T, long long* src, long long* tgt, float* w, void* stream);
+
 /* ---- depthwise convolution ---------------------------------
  * nn.Conv2d(C, C, K, stride, padding, dilation, groups=C) and its backward: reference
  * SimpleAICV/classification/backbones/van.py:30,68,75 (3x3 / 5x5 / dilated 7x7 of the LKA block) and convformer.py (7x7 of the

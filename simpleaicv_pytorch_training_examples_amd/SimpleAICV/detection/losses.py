@@ -112,13 +112,14 @@ class DETRLoss(nn.Module):
         giou = _giou(_cxcywh_to_xyxy(matched_preds), _cxcywh_to_xyxy(target_boxes))
         return l1, (1 - giou).sum() / target_num
 
-    # ------------------------------------------------------------------ static-shape form (r05: the step as TWO captured graphs)
-    # The Hungarian assignment needs the cost matrices on the host, so a DETR step cannot be ONE hipGraph.  It can be two, with the
-    # assignment between them (engine.TwoPhaseStepGraph; tools.scripts.train_detection): graph 1 = forward + match_inputs(), host =
-    # assign_host(), graph 2 = forward_static() + backward + optimizer.  Everything the graphs touch has a fixed shape: the
-    # ground truth is the collater's [B, T, 5] tensor itself (rows with class < 0 are padding), the matched pairs are [B, T] index /
-    # weight buffers this module owns (weight 0 = no pair), the number of boxes is a device scalar.
-    two_phase = True
+    # ------------------------------------------------------------------ static-shape form (r05: the whole step as ONE captured graph)
+    # The reference runs the Hungarian assignment on the host between forward and loss (scipy), which puts a device -> host copy and
+    # a synchronisation into every step and keeps the step from being captured.  Here the assignment can run ON THE DEVICE
+    # (assign_device: saicv_detr_assign, scipy's algorithm and tie rules restated in csrc/detloss.hip) and everything around it has a
+    # fixed shape: match_inputs() -> assign_device() -> forward_static().  The ground truth is the collater's [B, T, 5] tensor itself
+    # (rows with class < 0 are padding), the matched pairs are [B, T] index / weight buffers this module owns (weight 0 = no pair),
+    # the number of boxes is a device scalar.  tools.scripts.train_detection takes this path with config.use_step_graph.
+    static_form = True
 
     @torch.no_grad()
     def match_inputs(self, preds, gt_pad):
@@ -150,6 +151,17 @@ class DETRLoss(nn.Module):
             bufs['dummy_box'] = torch.tensor([0.5, 0.5, 0.2, 0.2]).to(device)
             self._pairs = bufs
         return bufs
+
+    def assign_device(self, cost, valid):
+        """The assignment of every image on the device, no host read: -> (src, tgt, w) [B, T] (the module's static buffers)."""
+        from ... import _lib
+        b, q, t = cost.shape
+        bufs = self._pair_buffers(b, t, cost.device)
+        cost = cost.float().contiguous()
+        valid = valid.contiguous()
+        _lib.check(_lib.lib().saicv_detr_assign(_lib.ptr(cost), _lib.ptr(valid), b, q, t, _lib.ptr(bufs['src']), _lib.ptr(bufs['tgt']),
+                                                _lib.ptr(bufs['w']), _lib.stream()), 'detr_assign')
+        return bufs['src'], bufs['tgt'], bufs['w']
 
     def assign_host(self, cost, valid):
         """One device -> host copy of (cost, valid), scipy's assignment per image on the valid columns, one host -> device copy of the

@@ -156,6 +156,7 @@ SIGNATURES = {
     'saicv_mixup_cutmix': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'saicv_soft_labels': (c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, c_int, c_int, _P]),
     'saicv_detr_sine_pe': (c_int, [_P, _P, c_int, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, _P]),
+    'saicv_detr_assign': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     'saicv_sam_prompt_tokens': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, ctypes.c_float, _P, _P, c_int, _P]),
     'saicv_sam_prompt_tokens_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P]),
     'saicv_sam_grid_pe': (c_int, [_P, c_int, c_int, _P, _P]),

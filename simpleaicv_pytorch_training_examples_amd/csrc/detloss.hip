@@ -264,6 +264,161 @@ inline int dl_grid(size_t items) {
     return (int)g;
 }
 
+
+// ---------------------------------------------------------------- DETR: the Hungarian assignment on the device (r05)
+// Reference SimpleAICV/detection/losses.py:1009-1090 runs scipy.optimize.linear_sum_assignment per image on the host, between forward
+// and loss: a device -> host copy, a synchronisation and a host -> device copy in the middle of every step -- and the reason the step
+// could not be ONE captured graph.  This kernel is scipy's algorithm itself (scipy/optimize/rectangular_lsap/rectangular_lsap.cpp,
+// v1.15: Crouse's shortest augmenting path, the `remaining` list filled in reverse and swap-removed, ties towards a new sink) restated
+// in double precision, one workgroup per image, the scan over the remaining columns spread over the 64 lanes of one wavefront with the
+// sequential scan's tie rule reproduced exactly (among equal minima: the LAST unassigned column in scan order if there is one, else the
+// FIRST).  cost [B][Q][T] fp32 (queries x padded ground truth), valid [B][T]: the assignment is over the valid columns only;
+// a tall matrix (fewer targets than queries, the usual case) is transposed as scipy does.  nan -> 1e5 and one-signed infinities -> a
+// finite value beyond any achievable total, as the reference's wrapper (losses.py:1063-1090) does.
+// Output, per image: pairs (src = query, tgt = ground-truth row of the padded tensor) in slots [0, min(n, Q)), weight 1; 0 elsewhere.
+__global__ __launch_bounds__(64) void detr_assign_kernel(const float* __restrict__ cost, const unsigned char* __restrict__ valid, int Q, int T,
+                                                         long long* __restrict__ src, long long* __restrict__ tgt, float* __restrict__ wgt) {
+    extern __shared__ __attribute__((aligned(16))) char lsa_smem[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int NMAX = Q > T ? Q : T;
+    double* u = reinterpret_cast<double*>(lsa_smem);           // [NMAX] row duals
+    double* v = u + NMAX;                                       // [NMAX] column duals
+    double* spc = v + NMAX;                                     // [NMAX] shortest path costs
+    int* path = reinterpret_cast<int*>(spc + NMAX);             // [NMAX]
+    int* col4row = path + NMAX;
+    int* row4col = col4row + NMAX;
+    int* remaining = row4col + NMAX;
+    int* cols = remaining + NMAX;                               // [T] valid ground-truth rows
+    unsigned char* SR = reinterpret_cast<unsigned char*>(cols + NMAX);
+    unsigned char* SC = SR + NMAX;
+    __shared__ int sh_n;
+    const float* cb = cost + (size_t)b * Q * T;
+    if (lane == 0) {
+        int n = 0;
+        for (int t = 0; t < T; ++t)
+            if (valid[(size_t)b * T + t]) cols[n++] = t;
+        sh_n = n;
+    }
+    for (int t = lane; t < T; t += 64) { src[(size_t)b * T + t] = 0; tgt[(size_t)b * T + t] = 0; wgt[(size_t)b * T + t] = 0.f; }
+    __syncthreads();
+    const int n = sh_n;
+    if (n == 0) return;
+    // ---- the reference wrapper's clean-up of nan / inf (per image block, over the valid columns)
+    double lo = INFINITY, hi = -INFINITY;
+    int has_neg = 0, has_pos = 0;
+    for (int e = lane; e < Q * n; e += 64) {
+        double c = (double)cb[(size_t)(e / n) * T + cols[e % n]];
+        if (c != c) c = 1e5;
+        if (c == INFINITY) has_pos = 1;
+        else if (c == -INFINITY) has_neg = 1;
+        else { lo = fmin(lo, c); hi = fmax(hi, c); }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, o));
+        hi = fmax(hi, __shfl_xor(hi, o));
+        has_pos |= __shfl_xor(has_pos, o);
+        has_neg |= __shfl_xor(has_neg, o);
+    }
+    double inf_fix = 0.0;
+    if (has_pos || has_neg) {                                   // (both at once raise in the reference; here the positive rule wins)
+        const double m = (double)(Q < n ? Q : n);
+        const double positive = m * (hi - lo + fabs(hi) + fabs(lo) + 1.0);
+        inf_fix = has_pos ? (hi + (m - 1.0) * (hi - lo)) + positive : (lo + (m - 1.0) * (lo - hi)) - positive;
+    }
+    const bool transpose = n < Q;                               // scipy: a tall matrix is transposed (rows = the smaller side)
+    const int nr = transpose ? n : Q, nc = transpose ? Q : n;
+    auto C = [&](int i, int j) -> double {                      // cost of (row i, column j) of the matrix being solved
+        const int q = transpose ? j : i, k = transpose ? i : j;
+        double c = (double)cb[(size_t)q * T + cols[k]];
+        if (c != c) c = 1e5;
+        if (c == INFINITY || c == -INFINITY) c = inf_fix;
+        return c;
+    };
+    for (int i = lane; i < NMAX; i += 64) { u[i] = 0.0; v[i] = 0.0; path[i] = -1; col4row[i] = -1; row4col[i] = -1; }
+    __syncthreads();
+    for (int cur = 0; cur < nr; ++cur) {
+        // ---- augmenting_path(cur)
+        for (int j = lane; j < nc; j += 64) { remaining[j] = nc - j - 1; SC[j] = 0; spc[j] = INFINITY; }
+        for (int i = lane; i < nr; i += 64) SR[i] = 0;
+        __syncthreads();
+        double minVal = 0.0;
+        int num_remaining = nc, sink = -1, i = cur;
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            // scan of the remaining columns, 64 at a time; per lane: the winner among its own positions under the sequential rule
+            double best = INFINITY;
+            int best_it = -1, best_free = 0;                    // best_free: the winner is an unassigned column
+            const double ui = u[i];
+            for (int it = lane; it < num_remaining; it += 64) {
+                const int j = remaining[it];
+                const double r = minVal + C(i, j) - ui - v[j];
+                double sj = spc[j];
+                if (r < sj) { path[j] = i; spc[j] = r; sj = r; }
+                const int free_ = row4col[j] == -1;
+                // sequential rule: take j if strictly lower, or equal and unassigned (a later unassigned column replaces an earlier one)
+                if (sj < best || (sj == best && free_)) { best = sj; best_it = it; best_free = free_; }
+            }
+            // combine the lanes: lower value wins; among equal values an unassigned winner beats an assigned one; two unassigned:
+            // the LATER position; two assigned: the EARLIER position -- what one sequential scan over all positions yields
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o);
+                const int oi = __shfl_xor(best_it, o), of = __shfl_xor(best_free, o);
+                bool take = false;
+                if (oi >= 0) {
+                    if (best_it < 0 || ob < best) take = true;
+                    else if (ob == best) {
+                        if (of && !best_free) take = true;
+                        else if (of == best_free) take = of ? (oi > best_it) : (oi < best_it);
+                    }
+                }
+                if (take) { best = ob; best_it = oi; best_free = of; }
+            }
+            minVal = best;
+            if (!(minVal < INFINITY)) break;                    // infeasible (cannot happen after the clean-up): leave unassigned
+            const int j = remaining[best_it];
+            __syncthreads();                                    // every lane has read remaining[] / spc[] of this scan
+            if (row4col[j] == -1) sink = j;
+            else i = row4col[j];
+            if (lane == 0) {
+                SC[j] = 1;
+                remaining[best_it] = remaining[num_remaining - 1];
+            }
+            --num_remaining;
+            __syncthreads();
+        }
+        if (sink < 0) break;
+        // ---- dual update, augmentation (serial parts: short)
+        if (lane == 0) u[cur] += minVal;
+        __syncthreads();
+        for (int r_ = lane; r_ < nr; r_ += 64)
+            if (SR[r_] && r_ != cur) u[r_] += minVal - spc[col4row[r_]];
+        for (int j = lane; j < nc; j += 64)
+            if (SC[j]) v[j] -= minVal - spc[j];
+        __syncthreads();
+        if (lane == 0) {
+            int j = sink;
+            while (true) {
+                const int ii = path[j];
+                row4col[j] = ii;
+                const int tmp = col4row[ii];
+                col4row[ii] = j;
+                j = tmp;
+                if (ii == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- pairs.  transposed: row k = valid target k -> query col4row[k]; else row q = query -> target cols[col4row[q]]
+    for (int r_ = lane; r_ < nr; r_ += 64) {
+        const int c_ = col4row[r_];
+        if (c_ < 0) continue;
+        const size_t o = (size_t)b * T + r_;
+        src[o] = transpose ? c_ : r_;
+        tgt[o] = transpose ? cols[r_] : cols[c_];
+        wgt[o] = 1.f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -327,6 +482,16 @@ int saicv_det_best_class(const float* probs, const float* centerness, float* sco
     hipLaunchKernelGGL(best_class_kernel, dim3(dl_grid(rows)), dim3(DL_THREADS), 0, (hipStream_t)stream, probs, centerness, scores, classes,
                        rows, Al, At, off, C);
     return saicv::check_launch("det_best_class");
+}
+
+// cost fp32 [B][Q][T], valid u8 / bool [B][T] -> src, tgt int64 [B][T], w fp32 [B][T]  (see detr_assign_kernel)
+int saicv_detr_assign(const float* cost, const unsigned char* valid, int B, int Q, int T, long long* src, long long* tgt, float* w, void* stream) {
+    SAICV_REQUIRE(cost && valid && src && tgt && w && B > 0 && Q > 0 && T > 0, "saicv_detr_assign: bad arguments");
+    const int nmax = Q > T ? Q : T;
+    SAICV_REQUIRE(nmax <= 2048, "saicv_detr_assign: %d queries / %d ground-truth rows (at most 2048)", Q, T);
+    const size_t smem = (size_t)nmax * (3 * sizeof(double) + 5 * sizeof(int) + 2);
+    hipLaunchKernelGGL(detr_assign_kernel, dim3(B), dim3(64), smem, static_cast<hipStream_t>(stream), cost, valid, Q, T, src, tgt, w);
+    return saicv::check_launch("detr_assign");
 }
 
 }  // extern "C"

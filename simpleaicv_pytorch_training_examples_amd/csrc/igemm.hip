@@ -2491,6 +2491,10 @@ int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dt
     return ((M_tile + g.bm - 1) / g.bm) * stride * stride * (pl.persist ? g.wm : 1);
 }
 
+// r05, measured and NOT kept: cutting a badly quantised linear GEMM (ViT-B's 768-wide outputs: 1 182 tiles of 256 x 128 on 512 slots
+// = 2.31 rounds of work in 3 rounds of time) into whole rounds of 256 x 128 tiles + one round of 128 x 128 tiles.  Correct (torch fp32
+// parity on the row-addressed fused operands), but the ViT-B step went 39.44 -> 40.11 ms on the same box: the second launch pays its
+// own ramp, and at the socket power limit the idle CUs of the third round are not lost time (profiles/r05_nt_experiments.md).
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
              int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st,

@@ -541,70 +541,6 @@ class StepGraph:
         torch.cuda.synchronize()
 
 
-class TwoPhaseStepGraph(StepGraph):
-    """A training step with ONE piece of host work in the middle, as two hipGraphs around it (r05; DETR: the Hungarian assignment
-    needs the cost matrices on the host between forward and loss):
-
-        mid = fn1(*inputs)      graph 1   forward, everything the host needs (tuple of tensors, static buffers on replay)
-        host(mid)               eager     may synchronise; writes ONLY into device buffers that exist before the capture
-        out = fn2(mid)          graph 2   loss, backward, optimizer -- same memory pool as graph 1: the autograd tape of fn1
-                                          (saved activations) is consumed by fn2's backward, on replay the pool replays both
-    The two graphs are always replayed in this order, which is what sharing a capture pool requires."""
-
-    def __init__(self, fn1, host, fn2, warmup=3, before_replay=()):
-        super().__init__(None, warmup, before_replay)
-        self.fn1, self.host, self.fn2 = fn1, host, fn2
-        self.graph2 = None
-        self.mid = None
-
-    def __call__(self, *inputs):
-        if self.graph is None:
-            if self.calls < self.warmup:
-                self.calls += 1
-                mid = self.fn1(*inputs)
-                self.host(mid)
-                return self.fn2(mid)
-            self._capture(inputs)
-        t0 = time.perf_counter()
-        for s, x in zip(self.static_in, inputs):
-            if s is not None and s.data_ptr() != x.data_ptr():
-                s.copy_(x, non_blocking=True)
-        for cb in self.before_replay:
-            cb()
-        self.graph.replay()
-        self.host(self.mid)
-        self.graph2.replay()
-        ops.bump_weights_epoch()
-        self.replays += 1
-        self.replay_host_s += time.perf_counter() - t0
-        return self.static_out
-
-    def _capture(self, inputs):
-        self.static_in = [x.clone() if torch.is_tensor(x) else None for x in inputs]
-        args = [s if s is not None else x for s, x in zip(self.static_in, inputs)]
-        for cb in self.before_replay:
-            cb()
-        torch.cuda.synchronize()
-        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            ops._ZeroPool.zero_all()
-            mid = self.fn1(*args)
-            ops.join_side_stream()
-        # nothing of graph 1 has RUN yet (a capture only records): its outputs are uninitialised memory.  They are zeroed (a plain
-        # launch into the live buffers) so that the host step between the captures is well defined; the first real replay below
-        # overwrites everything it derives from them
-        for t in mid:
-            if torch.is_tensor(t) and not t.requires_grad:      # (what the host reads carries no gradient; autograd's outputs stay untouched)
-                t.zero_()
-        torch.cuda.synchronize()
-        self.host(mid)
-        with torch.cuda.graph(g2, pool=g1.pool()):
-            out = self.fn2(mid)
-            ops.join_side_stream()
-        self.graph, self.graph2, self.mid, self.static_out = g1, g2, mid, out
-        torch.cuda.synchronize()
-
-
 # ------------------------------------------------------------------------------ DDP engine
 class NativeComm:
     """The library's RCCL communicator (include/saicv_hip.h, saicv_comm_*) for one process group member.

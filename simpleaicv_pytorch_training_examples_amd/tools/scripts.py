@@ -243,7 +243,7 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
 
 
 def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, total_name, iter_width,
-                graph_inputs=None, log_terms=True, two_phase=None):
+                graph_inputs=None, log_terms=True):
     """Shared iteration engine of the dict-loss loops (detection here; the SAM loop in
     interactive_segmentation_scripts.py follows the same scheme): `step_fn(data)` runs forward + loss and
     returns (bad flag tensor, {name: loss tensor}, batch size).  Everything else -- accumulation, the single
@@ -347,16 +347,6 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
             update(packed)
             return packed
 
-        # two_phase = (phase1, host, phase2): a step with host work between forward and loss (DETR's assignment) as two graphs
-        # around it -- phase1(tensors) -> (bad, mid tensors); host(mid); phase2(mid) -> loss terms
-        def first_half(*tensors):
-            bad, mid = two_phase[0](tensors)
-            return (bad,) + tuple(mid)
-
-        def second_half(mid):
-            packed = loss_tail(mid[0], two_phase[2](mid[1:]), True)
-            update(packed)
-            return packed
         cache = getattr(config, '_saicv_step_graphs', None)
         if cache is None:
             cache = {}
@@ -364,12 +354,8 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
         key = (id(model), id(optimizer))
         step_graph = cache.get(key)
         if step_graph is None:
-            if two_phase is not None:
-                step_graph = engine.TwoPhaseStepGraph(first_half, lambda mid: two_phase[1](mid[1:]), second_half,
-                                                      warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,))
-            else:
-                step_graph = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3),
-                                              before_replay=(optimizer.refresh_hyper,))
+            step_graph = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3),
+                                          before_replay=(optimizer.refresh_hyper,))
             step_graph.loss_term_names = names      # the captured closure writes into THIS holder
             cache[key] = step_graph
         else:
@@ -414,7 +400,20 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
         logger.info(f'use_amp: {config.use_amp}, amp_type: {amp_type}!')
     is_detr = 'detr' in config.network
 
+    static_detr = is_detr and getattr(criterion, 'static_form', False) and getattr(config, 'use_step_graph', False)
+
     def step_fn(data):
+        if isinstance(data, tuple) and static_detr:
+            # captured DETR step (r05): fixed shapes and no host read -- the cost matrices, the Hungarian assignment (saicv_detr_assign)
+            # and the loss over the padded ground truth all stay on the device
+            images, mask, ann = data
+            bad = any_nonfinite(images, ann)
+            with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
+                outs = model(images, mask)
+                cost, valid = criterion.match_inputs(outs, ann)
+                src, tgt, w = criterion.assign_device(cost, valid)
+                loss_value = criterion.forward_static(outs, ann, src, tgt, w)
+            return bad, loss_value, images.size(0)
         if isinstance(data, tuple):                      # captured step: (images, targets) already on the device, static buffers
             images, targets = data
         else:
@@ -435,16 +434,15 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
         return bad, loss_value, images.size(0)
 
     # the dense detectors' step has no host read (anchor assignment, focal loss and SmoothL1 are decided on the device): it can be
-    # captured whole.  DETR's Hungarian assignment runs on the host between forward and loss, and criteria that index by a
-    # data-dependent positive mask (`capturable = False`, e.g. the IoU branches) have dynamic shapes: those stay eager.
-    graph_inputs, two_phase = None, None
+    # captured whole.  So can DETR's since r05: its Hungarian assignment runs on the device (DETRLoss.assign_device) over the
+    # annotations padded (class -1 rows) to config.max_annots rows (default 100 = the reference's query count; a batch with more boxes
+    # in one image takes the eager step with the host-side assignment).  Criteria that index by a data-dependent positive mask
+    # (`capturable = False`, e.g. the IoU branches) have dynamic shapes and stay eager.
+    graph_inputs = None
     if not is_detr and getattr(criterion, 'capturable', False):
         def graph_inputs(data):
             return (data['image'].to(device, non_blocking=True), data['annots'].to(device, non_blocking=True))
-    elif is_detr and getattr(criterion, 'two_phase', False) and getattr(config, 'use_step_graph', False):
-        # r05: the DETR step as TWO captured graphs around the host-side assignment (engine.TwoPhaseStepGraph; DETRLoss.match_inputs /
-        # assign_host / forward_static).  Static shapes: the collater's annotations padded (class -1 rows) to config.max_annots rows
-        # (default 100 = the reference's query count); a batch with more boxes in one image takes the eager step.
+    elif static_detr:
         max_annots = int(getattr(config, 'max_annots', 100))
 
         def graph_inputs(data):
@@ -461,26 +459,7 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
             else:
                 mask = data['mask'].to(device, non_blocking=True)
             return (data['image'].to(device, non_blocking=True), mask, ann)
-
-        def phase1(tensors):
-            images, mask, ann = tensors
-            bad = any_nonfinite(images, ann)
-            with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
-                cls_preds, reg_preds = model(images, mask)
-                cost, valid = criterion.match_inputs((cls_preds, reg_preds), ann)
-            return bad, (cls_preds, reg_preds, cost, valid, ann)
-
-        def host(mid):
-            criterion.assign_host(mid[2], mid[3])
-
-        def phase2(mid):
-            cls_preds, reg_preds, _, _, ann = mid
-            pairs = criterion._pairs
-            with autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp)):
-                return criterion.forward_static((cls_preds, reg_preds), ann, pairs['src'], pairs['tgt'], pairs['w'])
-        two_phase = (phase1, host, phase2)
-    return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5, graph_inputs,
-                       two_phase=two_phase)
+    return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5, graph_inputs)
 
 
 def train_mae_self_supervised_learning(train_loader, model, criterion, optimizer, scheduler, epoch, logger, config):
