@@ -388,7 +388,7 @@ def measure(name, args, world, rank, device, use_graph, primary):
     }
     # ---- socket power and shader clock while the same steps replay (rocm-smi polled from a thread for ~1.5 s, AFTER the timed windows).
     # r05 finding: the GEMM kernels of these steps run AT the 1 400 W socket limit on random operands and the shader clock gives way
-    # (2.0-2.2 of 2.4 GHz): `power` says how close the whole step sits to that limit (DESIGN.md section 3a).
+    # (2.0-2.2 of 2.4 GHz): `power` says how close the whole step sits to that limit (DESIGN.md section 3g).
     if world == 1 and not getattr(args, 'no_power', False):
         res['power'] = sample_power(lambda: run(args.steps), fence)
     # ---- price the dominant kernel: an eager pass of the same steps with HIP events on the launch stream

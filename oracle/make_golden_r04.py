@@ -162,20 +162,26 @@ def dinov3_tiny(name='dinov3_tiny'):
 def det_van_convformer(name='det_van_convformer'):
     """reference VANBackbone (SimpleAICV/detection/models/backbones/van.py:32-130) and MetaFormerBackbone
     (.../convformer.py:29-117) and Dinov3ConvNeXtBackbone (.../dinov3convnext.py:120-199), four stages of widths 16..128 / 32..128,
-    depths [1, 1, 2, 1], drop-path 0, training mode, image 2 x 3 x 64 x 96.  Layer scales (1e-2 at init in VAN, 1e-6 gammas in
-    ConvNeXt) are redrawn around 0.5 and biases around 0 from generator 33 so every branch
-    carries gradient.  Per net: parameter checksums (the test rebuilds the weights from the seeds), the four stage outputs, norm +
-    first 64 entries of every parameter gradient for one random probe per output, BatchNorm buffers after the forward."""
+    depths [1, 1, 2, 1], drop-path 0, training mode, image 4 x 3 x 256 x 256: the LAST stage then normalises over 4 x 8 x 8 = 256
+    samples per BatchNorm channel (r05; the r04 fixture had 12, where one rounded activation moves a channel's statistics and the
+    bf16 gates had to be opened to 50 %).  Layer scales (1e-2 at init in VAN, 1e-6 gammas in ConvNeXt) are redrawn around 0.5 and
+    biases around 0 from generator 33 so every branch carries gradient.  Per net: parameter checksums (the test rebuilds the weights
+    from the seeds), norm + a strided sample (<= 16384 entries) of the four stage outputs, norm + first 64 entries of every
+    parameter gradient for one random probe per output, BatchNorm buffers after the forward, and -- `bf16_drift` -- how far the
+    REFERENCE ITSELF moves under torch.autocast('cpu', bfloat16) on the same weights, input and probes (outputs, gradient norms,
+    gradient samples, buffers): the yardstick the bf16 test of the HIP path is held to."""
     import types
     for mod in ('cv2', 'torchvision', 'torchvision.transforms'):
         sys.modules.setdefault(mod, types.ModuleType(mod))
     from SimpleAICV.detection.models.backbones.van import VANBackbone
     from SimpleAICV.detection.models.backbones.convformer import MetaFormerBackbone
     from SimpleAICV.detection.models.backbones.dinov3convnext import Dinov3ConvNeXtBackbone
-    cases = {}
-    for key, cls, kw in (('van', VANBackbone, dict(embedding_planes=[16, 32, 64, 128], mlp_ratios=[8, 8, 4, 4], block_nums=[1, 1, 2, 1])),
-                         ('convformer', MetaFormerBackbone, dict(embedding_planes=[32, 64, 96, 128], block_nums=[1, 1, 2, 1])),
-                         ('dinov3convnext', Dinov3ConvNeXtBackbone, dict(embedding_planes=[32, 64, 96, 128], block_nums=[1, 1, 2, 1]))):
+
+    def sample(t):
+        f = t.detach().flatten()
+        return f[::max(1, f.numel() // 16384)][:16384].clone()
+
+    def build(cls, kw):
         torch.manual_seed(0)
         m = cls(**kw)
         g = torch.Generator().manual_seed(33)
@@ -186,19 +192,48 @@ def det_van_convformer(name='det_van_convformer'):
                 elif n.endswith('.bias'):
                     p.copy_(torch.randn(p.shape, generator=g) * 0.1)
         m.train()
-        x = torch.randn(2, 3, 64, 96, generator=g)
+        x = torch.randn(4, 3, 256, 256, generator=g)
+        return m, x, g
+
+    cases = {}
+    for key, cls, kw in (('van', VANBackbone, dict(embedding_planes=[16, 32, 64, 128], mlp_ratios=[8, 8, 4, 4], block_nums=[1, 1, 2, 1])),
+                         ('convformer', MetaFormerBackbone, dict(embedding_planes=[32, 64, 96, 128], block_nums=[1, 1, 2, 1])),
+                         ('dinov3convnext', Dinov3ConvNeXtBackbone, dict(embedding_planes=[32, 64, 96, 128], block_nums=[1, 1, 2, 1]))):
+        m, x, g = build(cls, kw)
         sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
         outs = m(x)
         probes = [torch.randn(o.shape, generator=g) for o in outs]
         sum((o * p).sum() for o, p in zip(outs, probes)).backward()
         after = m.state_dict()
+        # the reference's own bf16 drift: same weights / input / probes under CPU autocast
+        mb, xb, _ = build(cls, kw)
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            outs_b = mb(xb)
+        sum((o.float() * p).sum() for o, p in zip(outs_b, probes)).backward()
+        after_b = mb.state_dict()
+        gn = {n: float(p.grad.norm()) for n, p in m.named_parameters()}
+        top = max(gn.values())
+        drift = {'outs': [float((ob.float() - o).norm() / o.norm()) for ob, o in zip(outs_b, outs)], 'grad_norm': {}, 'grad_sample': {},
+                 'buffers': {k: float((after_b[k].float() - after[k]).abs().max() / (after[k].abs().max() + 1e-12)) for k in after if 'running_' in k}}
+        for (n, p), (_, pb) in zip(m.named_parameters(), mb.named_parameters()):
+            drift['grad_norm'][n] = abs(float(pb.grad.float().norm()) - gn[n]) / max(gn[n], 1e-12)
+            ref = p.grad.flatten()[:64]
+            scale = max(float(ref.abs().max()), 1e-2 * gn[n])
+            drift['grad_sample'][n] = float((pb.grad.float().flatten()[:64] - ref).abs().max()) / max(scale, 1e-12)
         cases[key] = {'kwargs': kw, 'param_sum': {k: float(v.double().sum()) for k, v in sd.items()},
                       'param_abs_sum': {k: float(v.double().abs().sum()) for k, v in sd.items()},
-                      'input_checksum': float(x.double().sum()), 'outs': [o.detach().clone() for o in outs],
+                      'input_shape': tuple(x.shape), 'input_checksum': float(x.double().sum()),
+                      'out_shapes': [tuple(o.shape) for o in outs], 'out_norm': [float(o.norm()) for o in outs],
+                      'out_sample': [sample(o) for o in outs],
                       'buffers_after': {k: after[k].detach().clone() for k in after if 'running_' in k},
-                      'grad_norm': {n: float(p.grad.norm()) for n, p in m.named_parameters()},
-                      'grad_sample': {n: p.grad.flatten()[:64].clone() for n, p in m.named_parameters()}}
-        print(key, [tuple(o.shape) for o in outs], [round(float(o.norm()), 3) for o in outs], len(sd), 'state entries')
+                      'grad_norm': gn, 'grad_sample': {n: p.grad.flatten()[:64].clone() for n, p in m.named_parameters()},
+                      'bf16_drift': drift}
+        live = [n for n in gn if gn[n] > 1e-3]
+        print(key, [tuple(o.shape) for o in outs], [round(float(o.norm()), 3) for o in outs], len(sd), 'state entries;',
+              'reference bf16 drift: outs', [f'{v:.1e}' for v in drift['outs']],
+              'grad norm max %.2e median %.2e' % (max(drift['grad_norm'][n] for n in live), sorted(drift['grad_norm'][n] for n in live)[len(live) // 2]),
+              'grad sample max %.2e median %.2e' % (max(drift['grad_sample'][n] for n in live), sorted(drift['grad_sample'][n] for n in live)[len(live) // 2]),
+              'buffers max %.2e' % max(drift['buffers'].values(), default=0.0))
     path = os.path.join(OUT, name + '.pt')
     torch.save({'name': name, 'cases': cases, 'torch_version': torch.__version__}, path)
     print(f'-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')

@@ -10,8 +10,10 @@ the CIFAR-100 python format); torchvision / PIL are not in the image, so the con
 chain is replaced by the one transform that matters to the loop's arithmetic (mean / std normalisation, same constants as
 cifar100/resnet18cifar/train_config.py:55-60).  As in oracle/make_golden_traj.py the loop's `.cuda()` calls are made identity,
 the per-iteration barrier a no-op (single gloo rank) and get_amp_type a constant; nothing else of the reference is touched.
-The log (the loop's own logger lines + wall time per 50 iterations) goes to profiles/r04_cfg1_reference_cpu_epoch.log; the
-engine's run of the same configuration through its entry script is profiles/r03_entry_cifar_epoch1.log."""
+The log (the loop's own logger lines + wall time per 50 iterations) goes to profiles/r05_cfg1_reference_cpu_epoch.log; the
+engine's run of the SAME experiment (same pickle bytes from scripts/cifar_synthetic_pickles.py, same seed-0 weights, same
+DistributedSampler order, fp32) through its entry script is profiles/r05_cfg1_engine_gpu_epoch.log (scripts/gpu_cfg1_r05.sh), and
+profiles/r05_cfg1_loss_columns.md puts the two loss columns side by side."""
 import logging
 import os
 import pickle
@@ -26,33 +28,15 @@ import torch.distributed as dist
 
 REF = '/root/reference'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_TRAIN, BATCH, CLASSES = 50000, 64, 100
+BATCH, CLASSES = 64, 100
 
 
-def write_pickles(d):
-    rng = np.random.RandomState(0)
-    labels = rng.randint(0, CLASSES, size=N_TRAIN)
-    # class-dependent means so that one epoch has something to learn (the loss must fall below ln 100)
-    base = rng.randint(40, 216, size=(CLASSES, 3072)).astype(np.int16)
-    data = np.clip(base[labels] + rng.randint(-48, 49, size=(N_TRAIN, 3072)), 0, 255).astype(np.uint8)
-    with open(os.path.join(d, 'train'), 'wb') as f:
-        pickle.dump({'data': data, 'fine_labels': labels.tolist()}, f)
-    with open(os.path.join(d, 'meta'), 'wb') as f:
-        pickle.dump({'fine_label_names': [f'class_{i}' for i in range(CLASSES)]}, f)
-
-
-class Normalize:
-    """[H, W, 3] float32 0..255 -> (x / 255 - mean) / std, the constants of the reference config"""
-    mean = np.array([0.5071, 0.4865, 0.4409], dtype=np.float32)
-    std = np.array([0.2673, 0.2564, 0.2762], dtype=np.float32)
-
-    def __call__(self, sample):
-        sample['image'] = (sample['image'] / 255.0 - self.mean) / self.std
-        return sample
+sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+from cifar_synthetic_pickles import Normalize, write_pickles  # noqa: E402  (the same bytes the engine's entry script reads)
 
 
 def main():
-    log_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r04_cfg1_reference_cpu_epoch.log')
+    log_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r05_cfg1_reference_cpu_epoch.log')
     sys.path.insert(0, REF)
     for name in ['calflops', 'cv2', 'torchvision', 'torchvision.transforms', 'pycocotools', 'pycocotools.mask',
                  'pycocotools.cocoeval', 'PIL', 'PIL.Image']:
@@ -83,7 +67,7 @@ def main():
         optimizer = ('SGD', {'lr': 0.1, 'momentum': 0.9, 'global_weight_decay': False, 'weight_decay': 5e-4,
                              'no_weight_decay_layer_name_list': []})
         scheduler = ('MultiStepLR', {'warm_up_epochs': 0, 'gamma': 0.2, 'milestones': [60, 120, 160]})
-        epochs, batch_size, accumulation_steps, print_interval = 200, BATCH, 1, 50
+        epochs, batch_size, accumulation_steps, print_interval = 200, BATCH, 1, 10
         use_amp = use_ema_model = False
         local_rank, gpus_num, group = 0, 1, None
 
@@ -95,8 +79,12 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         write_pickles(d)
         ds = CIFAR100Dataset(root_dir=d, set_name='train', transform=Normalize())
-        loader = torch.utils.data.DataLoader(ds, batch_size=BATCH, shuffle=True, num_workers=4, drop_last=True,
-                                             collate_fn=ClassificationCollater(), generator=torch.Generator().manual_seed(0))
+        # the entry script's own loader (tools/train_classification_model.py:72-82): DistributedSampler(shuffle=True), set_epoch(1)
+        # -- the engine's entry script builds the same one, so both runs see the same batches in the same order
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=True)
+        sampler.set_epoch(1)
+        loader = torch.utils.data.DataLoader(ds, batch_size=BATCH, shuffle=False, num_workers=4, drop_last=True,
+                                             collate_fn=ClassificationCollater(), sampler=sampler)
         torch.manual_seed(0)
         model = backbones.resnet18cifar(num_classes=CLASSES)
         model.no_sync = None

@@ -21,6 +21,48 @@ import torch.nn.functional as F
 
 
 # ------------------------------------------------------------------------------ ResNet
+class relu_gates:
+    """Context: the ResNet ReLUs below take their open / closed decision from a recorded list of boolean masks (one per ReLU, in
+    call order) instead of from the sign of their own input, and report how the two differ.  Purpose (r05, __graft_entry__.smoke):
+    two correct fp32 evaluations of a ReLU network disagree on the few gates whose pre-activation is within rounding distance of
+    zero (4.5 M gates in ResNet18Cifar at batch 8, ~1e-6 relative arithmetic noise -> a handful), and ONE flipped gate moves the
+    relative L2 distance of the gradients by ~1 / sqrt(elements per layer) ~ 1e-3 -- so a gradient comparison tighter than that has
+    to be made AT THE SAME GATES.  The report (`flips`: [(relu index, flipped count, max |pre-activation| / rms among the flipped)])
+    lets the caller insist that only knife-edge elements were overridden."""
+    active = None
+
+    def __init__(self, masks=None):
+        """masks: the recorded decisions to impose; None = record this evaluation's own decisions into `.masks` instead."""
+        self.record = masks is None
+        self.masks, self.k, self.flips = ([] if masks is None else list(masks)), 0, []
+
+    def __enter__(self):
+        relu_gates.active = self
+        return self
+
+    def __exit__(self, *exc):
+        relu_gates.active = None
+
+    def apply(self, y):
+        if self.record:
+            self.masks.append(y.detach() > 0)
+            self.k += 1
+            return F.relu(y)
+        m = self.masks[self.k].to(y.device)
+        assert m.shape == y.shape, (self.k, tuple(m.shape), tuple(y.shape))
+        diff = m != (y > 0)
+        n = int(diff.sum())
+        if n:
+            self.flips.append((self.k, n, float(y.detach()[diff].abs().max() / y.detach().pow(2).mean().sqrt())))
+        self.k += 1
+        return y * m.to(y.dtype)
+
+
+def _relu(y):
+    g = relu_gates.active
+    return F.relu(y) if g is None else g.apply(y)
+
+
 def conv_bn_act(x, sd, prefix, stride, padding, act, training, bn_updates=None, momentum=0.1, eps=1e-5):
     """ConvBnActBlock.forward: Conv2d(bias=False) -> BatchNorm2d -> [ReLU].
     reference SimpleAICV/classification/backbones/resnet.py:19-48."""
@@ -32,7 +74,7 @@ def conv_bn_act(x, sd, prefix, stride, padding, act, training, bn_updates=None, 
     if training and bn_updates is not None:
         bn_updates[prefix + '.layer.1.running_mean'] = rm
         bn_updates[prefix + '.layer.1.running_var'] = rv
-    return F.relu(y) if act else y
+    return _relu(y) if act else y
 
 
 def basic_block(x, sd, prefix, stride, downsample, training, bn_updates=None):
@@ -41,7 +83,7 @@ def basic_block(x, sd, prefix, stride, downsample, training, bn_updates=None):
     out = conv_bn_act(out, sd, prefix + '.conv2', 1, 1, False, training, bn_updates)
     if downsample:
         x = conv_bn_act(x, sd, prefix + '.downsample_conv', stride, 0, False, training, bn_updates)
-    return F.relu(out + x)
+    return _relu(out + x)
 
 
 def bottleneck(x, sd, prefix, stride, downsample, training, bn_updates=None):
@@ -51,7 +93,7 @@ def bottleneck(x, sd, prefix, stride, downsample, training, bn_updates=None):
     out = conv_bn_act(out, sd, prefix + '.conv3', 1, 0, False, training, bn_updates)
     if downsample:
         x = conv_bn_act(x, sd, prefix + '.downsample_conv', stride, 0, False, training, bn_updates)
-    return F.relu(out + x)
+    return _relu(out + x)
 
 
 RESNET_SPECS = {

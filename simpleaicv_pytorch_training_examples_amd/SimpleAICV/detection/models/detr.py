@@ -51,7 +51,9 @@ def _mha(mha, q_in, k_in, v_in, key_bias, same_qk):
     c = mha.embed_dim
     w, b = mha.in_proj_weight, mha.in_proj_bias
     # the packed parameters enter whole (row ranges): their gradients land in the arena rows directly
-    if same_qk:
+    # head dimension 64: the streaming attention kernels stage K and V with ONE row stride (csrc/attn_stream.hip), so K must not
+    # be a column slice of the packed [q | k] projection (row stride 2c against V's c) -- project it on its own
+    if same_qk and c // mha.num_heads != 64:
         qk = ops_tfm.linear_rows(q_in, w, b, 0, 2 * c)
         q, k = qk[..., :c], qk[..., c:]
     else:

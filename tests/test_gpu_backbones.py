@@ -115,66 +115,81 @@ def _det_backbone(case):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.2 + 0.5)
             elif n.endswith('.bias'):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.1)
-    x = torch.randn(2, 3, 64, 96, generator=g)
+    x = torch.randn(*fx['input_shape'], generator=g)
     return fx, m, x, g
+
+
+# bf16 gates of the detection-backbone test: multiples of the REFERENCE'S OWN drift under torch.autocast('cpu', bfloat16) on the same
+# weights / input / probes (fixture key bf16_drift), with floors where that drift is tiny.  r04's fixture normalised its last stage
+# over 12 samples per channel and needed 50 % / 1.0 x / "10 % of tensors" allowances; at 256 samples they are gone.
+BF16_OUT_X, BF16_OUT_FLOOR = 3.0, 1e-2
+BF16_NORM_X, BF16_NORM_FLOOR = 4.0, 6e-2
+BF16_SAMPLE_X, BF16_SAMPLE_FLOOR = 4.0, 1.5e-1
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
 @pytest.mark.parametrize('case', ['van', 'convformer', 'dinov3convnext'])
 def test_detection_van_convformer_backbones_match_reference(case, dtype):
-    """VANBackbone / MetaFormerBackbone (reference detection/models/backbones/van.py:32-130, convformer.py:29-117): the four stage
-    outputs, every parameter gradient and the BatchNorm buffers after a training-mode step against what the reference produced.
-    Tolerances as for the classification forms above (BatchNorm over 12..768 samples per channel); bf16 is held to the fp32
-    reference at bf16 resolution."""
+    """VANBackbone / MetaFormerBackbone / Dinov3ConvNeXtBackbone (reference detection/models/backbones/van.py:32-130,
+    convformer.py:29-117, dinov3convnext.py:120-199): the four stage outputs, every parameter gradient and the BatchNorm buffers
+    after a training-mode step against what the reference produced on 4 x 3 x 256 x 256 (>= 256 samples per BatchNorm channel in
+    every stage).  fp32: 1e-4 on outputs, 1e-3 on gradient norms, 1e-2 on gradient samples.  bf16: each quantity within a small
+    multiple of what the reference itself moves by under CPU autocast (constants above)."""
     fx, m, x, g = _det_backbone(case)
     assert m.out_channels == fx['kwargs']['embedding_planes']
-    assert abs(float(x.double().sum()) - fx['input_checksum']) < 1e-6
+    assert abs(float(x.double().sum()) - fx['input_checksum']) < 1e-5
     m = m.cuda().train()
     f32 = dtype == torch.float32
+    drift = fx['bf16_drift']
     if f32:
         outs = m(x.cuda())
     else:
         with torch.autocast('cuda', dtype=torch.bfloat16):
             outs = m(x.cuda())
     assert len(outs) == 4
-    probes = [torch.randn(o.shape, generator=g) for o in fx['outs']]
-    for o, ref in zip(outs, fx['outs']):
-        assert tuple(o.shape) == tuple(ref.shape)
-        assert rel_err(o.float().cpu(), ref) < (1e-3 if f32 else 4e-2)
+    probes = [torch.randn(sh, generator=g) for sh in fx['out_shapes']]
+    worst_out = 0.0
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == tuple(fx['out_shapes'][i])
+        f = o.detach().float().flatten()
+        got = f[::max(1, f.numel() // 16384)][:16384].cpu()
+        ref = fx['out_sample'][i]
+        err = float((got - ref).norm() / ref.norm())
+        gate = 1e-4 if f32 else max(BF16_OUT_X * drift['outs'][i], BF16_OUT_FLOOR)
+        worst_out = max(worst_out, err / gate)
+        assert err < gate, (i, err, gate)
+        assert abs(float(o.float().norm()) - fx['out_norm'][i]) <= (1e-4 if f32 else 1e-2) * fx['out_norm'][i], i
     sum((o.float() * p.cuda()).sum() for o, p in zip(outs, probes)).backward()
     torch.cuda.synchronize()
-    worst, top, far = 0.0, max(fx['grad_norm'].values()), 0
+    top = max(fx['grad_norm'].values())
+    worst_norm = worst_sample = worst_norm_x = worst_sample_x = 0.0
     for n, p in m.named_parameters():
         assert p.grad is not None and tuple(p.grad.shape) == tuple(p.shape), n
+        assert bool(torch.isfinite(p.grad).all()), n
         ref_n = fx['grad_norm'][n]
         gn = float(p.grad.float().norm())
-        if ref_n <= 1e-3:
-            # the bias of a convolution in front of a BatchNorm: its gradient is exactly zero in real arithmetic, both sides hold the
-            # rounding noise of a sum over every pixel (fp32 ~1e-4, bf16 gradients ~1) -- only its smallness can be checked
-            assert gn <= (1e-5 if f32 else 1e-2) * top, (n, gn, top)
+        if ref_n <= 1e-6 * top:
+            # the bias in front of a normalisation: its gradient is exactly zero in real arithmetic, both sides hold the rounding
+            # noise of a sum over every pixel -- only its smallness can be checked (the reference's own bf16 noise: ~1e-4 of `top`)
+            assert gn <= (1e-6 if f32 else 1e-3) * top, (n, gn, top)
             continue
-        # bf16: the last stage normalises over 12 samples per channel (48 in the one before), where one rounded activation moves a
-        # whole channel's statistics and flips ReLU gates -- the fp32 runs of the same code sit at 1e-6 of the reference, so bf16 is
-        # held to it only as far as that is stable from run to run (BatchNorm statistics are summed with atomics): the last stage's
-        # tensors by norm within 50 %, the others by norm within 15 % and by sample -- a few tensors may hold a sample beyond 0.3 of
-        # the tensor's gradient scale, none beyond the scale itself
-        last = any(tag in n for tag in ('block4.', 'patch_embed4.', 'norm4.', 'stages.3.', 'downsample_layers.3.'))
-        assert abs(gn - ref_n) <= (2e-2 if f32 else 5e-1 if last else 1.5e-1) * ref_n, (n, gn, ref_n)
-        assert bool(torch.isfinite(p.grad).all()), n
-        if last and not f32:
-            continue
+        e_norm = abs(gn - ref_n) / ref_n
+        g_norm = 1e-3 if f32 else max(BF16_NORM_X * drift['grad_norm'][n], BF16_NORM_FLOOR)
+        assert e_norm <= g_norm, (n, 'norm', e_norm, g_norm)
         ref = fx['grad_sample'][n]
         got = p.grad.flatten()[:64].float().cpu()
         scale = max(float(ref.abs().max()), 1e-2 * ref_n)
-        err = float((got - ref).abs().max()) / scale
-        worst = max(worst, err)
-        assert err <= (4e-2 if f32 else 1.0), (n, err)
-        far += err > 3e-1
-    assert far <= 0.1 * len(fx['grad_norm']), far
+        e_s = float((got - ref).abs().max()) / scale
+        g_s = 1e-2 if f32 else max(BF16_SAMPLE_X * drift['grad_sample'][n], BF16_SAMPLE_FLOOR)
+        assert e_s <= g_s, (n, 'sample', e_s, g_s)
+        worst_norm, worst_sample = max(worst_norm, e_norm), max(worst_sample, e_s)
+        worst_norm_x, worst_sample_x = max(worst_norm_x, e_norm / g_norm), max(worst_sample_x, e_s / g_s)
     sd = m.state_dict()
     for k, v in fx['buffers_after'].items():
-        assert float((sd[k].float().cpu() - v).abs().max()) <= (1e-3 if f32 else 2e-2) * float(v.abs().max()) + 1e-5, k
-    print(f'detection {case} backbone {"fp32" if f32 else "bf16"}: worst gradient-sample error {worst:.2e}')
+        gate = 1e-4 if f32 else max(4.0 * drift['buffers'][k], 1e-2)
+        assert float((sd[k].float().cpu() - v).abs().max()) <= gate * float(v.abs().max()) + 1e-6, k
+    print(f'detection {case} backbone {"fp32" if f32 else "bf16"}: outputs at {worst_out:.2f} of their gate; gradient norms worst '
+          f'{worst_norm:.2e} ({worst_norm_x:.2f} of the gate), gradient samples worst {worst_sample:.2e} ({worst_sample_x:.2f} of the gate)')
 
 
 def test_detection_van_convformer_feed_the_retinanet_family():

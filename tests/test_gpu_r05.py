@@ -186,3 +186,43 @@ def test_device_hungarian_assignment_equals_scipy(case):
         got = {(int(s), int(k)) for s, k, ww in zip(src[i], tgt[i], w[i]) if ww > 0}
         assert int((w[i] > 0).sum()) == min(counts[i], q), (case, i)
         assert got == want[i], (case, i, sorted(got ^ want[i])[:6])
+
+
+@pytest.mark.parametrize('heads', [8, 16], ids=['head_dim_64', 'head_dim_32'])
+def test_detr_attention_with_shared_qk_projection_at_both_head_dims(heads):
+    """detr._mha with same_qk (encoder / decoder self-attention: q = k = x + pos, v = x) against nn.MultiheadAttention itself, for
+    head dimension 64 (hidden 512 / 8 heads -- ADVICE r04: K used to be a column slice of the packed [q | k] projection, whose row
+    stride the streaming kernel's single K / V stride rejects) and 32 (the packed projection stays).  fp32: output 1e-4, every
+    gradient (inputs, packed in-projection, out-projection) 1e-3 of its scale; an additive key-padding bias (-30) on the last keys of image 1."""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import detr
+    torch.manual_seed(5)
+    c, b, n = 512, 2, 80
+    mha = torch.nn.MultiheadAttention(c, heads, dropout=0.0).cuda()
+    with torch.no_grad():
+        mha.in_proj_bias.normal_(0, 0.1)
+        mha.out_proj.bias.normal_(0, 0.1)
+    x = torch.randn(b, n, c, device='cuda')
+    pos = torch.randn(b, n, c, device='cuda')
+    pad = torch.zeros(b, n, dtype=torch.bool, device='cuda')
+    pad[1, 70:] = True
+    probe = torch.randn(b, n, c, device='cuda')
+    # torch's own module (sequence-first), fp32
+    xr, pr = x.clone().requires_grad_(True), pos.clone()
+    qk = (xr + pr).transpose(0, 1)
+    key_bias = torch.zeros(b, n, device='cuda').masked_fill(pad, -30.0)      # additive float mask, as DETR hands it over
+    ref = mha(qk, qk, xr.transpose(0, 1), key_padding_mask=key_bias, need_weights=False)[0].transpose(0, 1)
+    (ref * probe).sum().backward()
+    ref_g = {'x': xr.grad.clone(), 'in_w': mha.in_proj_weight.grad.clone(), 'in_b': mha.in_proj_bias.grad.clone(),
+             'out_w': mha.out_proj.weight.grad.clone(), 'out_b': mha.out_proj.bias.grad.clone()}
+    mha.zero_grad(set_to_none=True)
+    xg = x.clone().requires_grad_(True)
+    q_in = xg + pos
+    out = detr._mha(mha, q_in, q_in, xg, key_bias, True)
+    (out.float() * probe).sum().backward()
+    torch.cuda.synchronize()
+    assert float((out.float() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    got = {'x': xg.grad, 'in_w': mha.in_proj_weight.grad, 'in_b': mha.in_proj_bias.grad, 'out_w': mha.out_proj.weight.grad,
+           'out_b': mha.out_proj.bias.grad}
+    for k, r in ref_g.items():
+        assert got[k] is not None, k
+        assert float((got[k].float() - r).abs().max()) <= 1e-3 * float(r.abs().max()), k

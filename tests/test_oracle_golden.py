@@ -64,3 +64,36 @@ def test_losses_match_reference_math():
     assert abs(float(O.ce_loss(pred, label)) - float(torch.nn.CrossEntropyLoss()(pred, label))) < 1e-6
     manual = -(soft * torch.log_softmax(pred, -1)).sum(-1).mean()
     assert abs(float(O.one_hot_ce_loss(pred, soft)) - float(manual)) < 1e-6
+
+
+def test_relu_gates_override_only_knife_edge_decisions():
+    """oracle.torch_oracle.relu_gates (r05, used by __graft_entry__.smoke): the ReLU decisions recorded from the fp32 oracle, imposed on
+    the float64 oracle -- 17 ReLUs in ResNet18Cifar, only a handful of the 4.5 M gates differ, each within 1e-4 rms of zero in
+    float64, and at equal gates the fp32 gradients are the float64 ones to ~1e-6 (at float64's own gates they may be 1e-3 apart)."""
+    import torch
+    from oracle import torch_oracle as O
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones
+    torch.manual_seed(0)
+    model = backbones.resnet18cifar(num_classes=100)
+    sd = {k: v.detach().clone(memory_format=torch.contiguous_format) for k, v in model.state_dict().items()}
+    pnames = [n for n, _ in model.named_parameters()]
+    g = torch.Generator().manual_seed(3)        # a seed where the fp32 oracle is 1.7e-3 from float64 at float64's own gates
+    x = torch.randn(8, 3, 32, 32, generator=g)
+    y = torch.randint(0, 100, (8,), generator=g)
+    fwd = lambda leaves, inp: O.resnet_forward('resnet18cifar', leaves, inp, training=True)     # noqa: E731
+    with O.relu_gates() as rec:
+        _, _, g32 = O.loss_and_grads(fwd, sd, pnames, x, loss_fn=O.ce_loss, label=y)
+    assert rec.k == len(rec.masks) == 17
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    _, _, g64 = O.loss_and_grads(fwd, sd64, pnames, x.double(), loss_fn=O.ce_loss, label=y)
+    with O.relu_gates(rec.masks) as imp:
+        _, _, g64g = O.loss_and_grads(fwd, sd64, pnames, x.double(), loss_fn=O.ce_loss, label=y)
+    assert imp.k == 17 and O.relu_gates.active is None
+    flat = lambda d: torch.cat([d[n].double().flatten() for n in pnames])      # noqa: E731
+    own = float((flat(g32) - flat(g64)).norm() / flat(g64).norm())
+    same = float((flat(g32) - flat(g64g)).norm() / flat(g64g).norm())
+    flipped = sum(n for _, n, _ in imp.flips)
+    margin = max((m for _, _, m in imp.flips), default=0.0)
+    print(f'fp32 oracle vs float64: {own:.2e} at float64\'s own gates, {same:.2e} at equal gates; {flipped} gates differ, margin {margin:.1e}')
+    assert flipped <= 64 and margin <= 1e-4
+    assert same <= 2e-5 and (flipped == 0 or own > same)
