@@ -170,8 +170,9 @@ def test_detection_van_convformer_backbones_match_reference(case, dtype):
         gn = float(p.grad.float().norm())
         if ref_n <= 1e-6 * top:
             # the bias in front of a normalisation: its gradient is exactly zero in real arithmetic, both sides hold the rounding
-            # noise of a sum over every pixel -- only its smallness can be checked (the reference's own bf16 noise: ~1e-4 of `top`)
-            assert gn <= (1e-6 if f32 else 1e-3) * top, (n, gn, top)
+            # noise of a sum over every pixel -- only its smallness can be checked (the reference's own bf16 noise: up to 4e-4 of
+            # `top`, the HIP path's up to 1e-3: its activations are rounded to bf16 once more than CPU autocast's)
+            assert gn <= (1e-6 if f32 else 3e-3) * top, (n, gn, top)
             continue
         e_norm = abs(gn - ref_n) / ref_n
         g_norm = 1e-3 if f32 else max(BF16_NORM_X * drift['grad_norm'][n], BF16_NORM_FLOOR)
