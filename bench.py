@@ -56,9 +56,9 @@ LOOP_MODELS = {'resnet50_detr_config': ('tools.scripts.train_detection', 8, 1024
                'resnet50_fcos': ('tools.scripts.train_detection', 4, 1024, 0.0),
                # full SAM step: one encoder pass (972.1 GFLOP fwd) + 1 + decoder_iters light decoder passes
                'sam_b': ('tools.interactive_segmentation_scripts.train_sam_segmentation', 8, 1024, 3 * 972.1)}
-# HBM bytes per launch per kernel family, from separate rocprofv3 --pmc passes of the same command (scripts/gpu_pmc_r04.sh)
-PMC_FILES = {'resnet50': ['profiles/r04_pmc_hbm_traffic.json', 'profiles/r03_pmc_hbm_traffic.json', 'profiles/r02_pmc_hbm_traffic.json'],
-             'vit_base_patch16': ['profiles/r04_pmc_hbm_traffic_vit_base_patch16.json']}
+# HBM bytes per launch per kernel family, from separate rocprofv3 --pmc passes of the same command (scripts/gpu_r05.sh pmc:<model>)
+PMC_FILES = {'resnet50': ['profiles/r05_pmc_hbm_traffic.json', 'profiles/r04_pmc_hbm_traffic.json', 'profiles/r03_pmc_hbm_traffic.json', 'profiles/r02_pmc_hbm_traffic.json'],
+             'vit_base_patch16': ['profiles/r05_pmc_hbm_traffic_vit_base_patch16.json', 'profiles/r04_pmc_hbm_traffic_vit_base_patch16.json']}
 # what each bracketed family is in the rocprofv3 kernel lists
 FAMILY_KERNELS = {'igemm_nt': 'igemm_nt1_kernel (implicit-GEMM conv / linear: forward + data gradient)',
                   'igemm_tn': 'igemm_tn_dma_kernel (weight gradient)',

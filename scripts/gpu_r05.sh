@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-5 GPU runner.   gpurun --timeout N -- 'bash scripts/gpu_r05.sh <tag> <step> <step> ...'
 # steps (":"-separated arguments; "+" inside an env list separates variables, "|" separates variants):
-#   exp[:<pytest -k>]                  tests/test_gpu_experimental.py with SAICV_TEST_EXPERIMENTAL=1
+#   seeds                              scripts/pick_smoke_seed.py (smoke fixture over data seeds, own gates and equal gates)
+#   cfg1                               BASELINE.json configs[0] through the entry script on the reference run's pickles (scripts/gpu_cfg1_r05.sh)
 #   tests[:<pytest args>] / testsx[:<workers>] / smoke
 #   ab:<model>:<envA>|<envB>|...       same-box A/B of environment variants on one model bench (variants interleaved, REPS rounds, default 2);
 #                                      an empty variant ("-") is the default build
@@ -28,8 +29,9 @@ except Exception as e: print("ERR", e)' 2>&1 | tail -1; }
 for step in "$@"; do
   name=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}
   case $name in
-    exp)    SAICV_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_experimental.py -q ${arg:+-k "$arg"} > $O/pytest_experimental.log 2>&1; tail -3 $O/pytest_experimental.log ;;
-    tests)  timeout 1500 python -m pytest tests -m gpu -q -x ${arg:-} > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log ;;
+    seeds)  timeout 600 python scripts/pick_smoke_seed.py 1 2 3 4 > $O/smoke_seed.txt 2> $O/smoke_seed.err; cut -c1-170 $O/smoke_seed.txt ;;
+    cfg1)   bash scripts/gpu_cfg1_r05.sh ;;
+    tests)  timeout 1500 python -m pytest tests -m gpu -q ${arg:-} > $O/pytest_gpu.log 2>&1; tail -6 $O/pytest_gpu.log | cut -c1-300 ;;
     testsx) timeout 900 python -m pytest tests -m gpu -q -n ${arg:-4} --dist loadfile > $O/pytest_gpu.log 2>&1; tail -15 $O/pytest_gpu.log ;;
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     ab)
@@ -88,7 +90,12 @@ for step in "$@"; do
       python scripts/pmc_fold.py $O/${name}_${model}_1 $O/${name}_${model}_2 > $O/${name}_${model}.json 2> $O/${name}_${model}.err; head -c 3000 $O/${name}_${model}.json; tail -2 $O/${name}_${model}.err ;;
     bench)  timeout 900 python bench.py ${arg:-} > $O/bench_$(echo "${arg:-default}" | tr -c 'a-zA-Z0-9\n' '_').log 2>&1; tail -1 $O/bench_$(echo "${arg:-default}" | tr -c 'a-zA-Z0-9\n' '_').log | cut -c1-900 ;;
     prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$arg -o $arg -- python $GRAFT_REPO_ROOT/bench.py --model $arg --no-secondary --no-cpu-baseline --no-sam --max-windows 2 --steps 5 --warmup 5 > $O/prof_$arg.log 2>&1); f=$(find $O/prof_$arg -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${arg}_rocprofv3_kernel_stats.csv && head -12 $f | cut -c1-200; t=$(find $O/prof_$arg -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python scripts/trace_compact.py $t > $O/${arg}_kernel_trace_compact.csv ;;
-    pmc)    TAGDIR=$O MODEL=$arg bash scripts/gpu_pmc_r04.sh ;;
+    pmc)    # HBM traffic: separate FETCH_SIZE / WRITE_SIZE passes of the eager step, folded per kernel family (MI355X_MICROARCH.md corrections)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$arg -o $c -- python $GRAFT_REPO_ROOT/bench.py --model $arg --steps 2 --warmup 1 --eager --no-cpu-baseline --no-secondary --no-sam --no-power --no-kernel-timer --max-windows 1 > $O/pmc_${arg}_$c.log 2>&1); echo "pmc $arg $c rc=$?"
+      done
+      suffix=""; [ "$arg" != "resnet50" ] && suffix="_$arg"
+      python scripts/make_pmc_summary.py $O/pmc_$arg 3 $O/r05_pmc_hbm_traffic$suffix.json $arg | head -30 ;;
     *) echo "unknown step $step" ;;
   esac
 done
