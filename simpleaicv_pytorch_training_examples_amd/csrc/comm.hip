@@ -123,6 +123,9 @@ bool on_side_stream(const saicv_comm* c, void* stream) {
 
 }  // namespace
 
+// ranks of the largest communicator created in this process (common.h): igemm.hip sizes the weight-gradient round with it
+int g_saicv_comm_world = 1;
+
 extern "C" {
 
 int saicv_comm_available(void) {
@@ -169,6 +172,7 @@ int saicv_comm_create(const void* id128, int world, int rank, saicv_comm** out) 
     }
     const char* mode = getenv("SAICV_COMM_MODE");
     c->overlap_eager = mode && strcmp(mode, "events") == 0;
+    if (world > g_saicv_comm_world) g_saicv_comm_world = world;       // collectives now share this GPU with the step's kernels
     *out = c;
     return 0;
 }

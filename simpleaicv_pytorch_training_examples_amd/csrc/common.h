@@ -221,3 +221,9 @@ DEVINL int xcd_remap(int b, int nblk) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+// Ranks of the largest RCCL communicator this process has created through saicv_comm_create (comm.hip); 1 = this GPU runs the
+// step's kernels only.  The weight-gradient kernel sizes its one resident round for all CU slots then, and for 85 % of them when
+// all-reduce kernels share the GPU (igemm.hip, SAICV_TN_SLOTS_PCT overrides).
+extern int g_saicv_comm_world;
+

@@ -2692,11 +2692,14 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     const int total_rt = (M + BR - 1) / BR;
     // 128-wide tiles: 2 workgroups per CU are resident (73 KiB LDS each); 256-wide: one (139 KiB)
     // rounded DOWN: one full round of resident workgroups beats a second, nearly empty one
-    // The split count is sized for 85 % of the resident slots (SAICV_TN_SLOTS_PCT).  Sizing it for all of them is
-    // exact on an otherwise idle GPU (+0.6 % on the ResNet-50 step), but the one-round design has no slack: under
-    // data-parallel training RCCL's all-reduce kernels hold CU slots (and LDS) during backward, and every workgroup
-    // that cannot start with the others costs this kernel a whole second round.
-    static const int slots_pct = getenv("SAICV_TN_SLOTS_PCT") ? atoi(getenv("SAICV_TN_SLOTS_PCT")) : 85;
+    // The split count is sized for ALL resident slots when this GPU runs nothing else, and for 85 % of them once the process has
+    // created an RCCL communicator over more than one rank (g_saicv_comm_world, comm.hip): the one-round design has no slack -- under
+    // data-parallel training RCCL's all-reduce kernels hold CU slots (and LDS) during backward, and every workgroup that cannot
+    // start with the others costs this kernel a whole second round.  Measured on one GPU (r05, same box, twice each): 100 against
+    // 85 is ViT-B 40.02 -> 39.52 ms (weight gradients 10.0 -> 9.4 ms), ResNet-50 21.00 -> 20.95 ms; 70 is ResNet-50 21.60 ms.
+    // SAICV_TN_SLOTS_PCT overrides (read per call; e.g. 85 for a torch.distributed process group without the native communicator).
+    const char* slots_env = getenv("SAICV_TN_SLOTS_PCT");
+    const int slots_pct = slots_env ? atoi(slots_env) : (g_saicv_comm_world > 1 ? 85 : 100);
     int splits = ((big ? 256 : 512) * slots_pct / 100) / tiles;
     if (splits > total_rt) splits = total_rt;
     if (splits < 1) splits = 1;

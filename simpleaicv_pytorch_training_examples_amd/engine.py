@@ -657,6 +657,10 @@ class DistributedDataParallel(torch.nn.Module):
         self._active = self.world > 1 or os.environ.get('SAICV_DDP_FORCE_SYNC') == '1'
         self.arena = _arena_of(module)
         self.comm = self._native_comm(process_group)
+        if self.world > 1 and self.comm is None and self.arena.device.type == 'cuda':
+            # torch.distributed's own RCCL kernels will share the GPU with backward: the library only knows about communicators
+            # it created itself (g_saicv_comm_world), so tell the weight-gradient kernel to leave CU slots free (csrc/igemm.hip)
+            os.environ.setdefault('SAICV_TN_SLOTS_PCT', '85')
         self._sync = True
         self._works = []
         self._next_bucket = 0           # buckets are launched in list order on every rank
