@@ -501,6 +501,7 @@ class StepGraph:
         self.calls = 0
         self.graph = None
         self.static_in = self.static_out = None
+        self._pack_entries = []          # ops._PackRegistry entries the captured step reads (kept "live" across replays)
         self.replays, self.replay_host_s = 0, 0.0        # host time spent issuing replays (input copies + hipGraphLaunch)
 
     def __call__(self, *inputs):
@@ -517,6 +518,7 @@ class StepGraph:
             cb()
         self.graph.replay()
         ops.bump_weights_epoch()        # the replayed optimizer kernels rewrote the parameters
+        ops._PackRegistry.touch(self._pack_entries)     # ... and the replayed step used its compute-dtype copies
         self.replays += 1
         self.replay_host_s += time.perf_counter() - t0
         return self.static_out
@@ -538,6 +540,7 @@ class StepGraph:
         if dump:
             graph.debug_dump(dump)
         self.graph, self.static_out = graph, out
+        self._pack_entries = ops._PackRegistry.used_now()
         torch.cuda.synchronize()
 
 

@@ -346,6 +346,13 @@ class _PackRegistry:
     BATCH = _os.environ.get('SAICV_PACK_BATCH', '1') == '1'
     entries = {}            # (id(param), dtype, cin_padded, cout_padded) -> dict
     table = None            # (signature, device descriptor tensor, n, total tiles, dtype)
+    # Descriptor tables a CAPTURED step launched with.  The graph keeps the table's device ADDRESS; the table itself was built in the
+    # eager warm-up (a host -> device copy cannot be captured), i.e. in the ordinary allocator pool -- were it dropped when a later
+    # eager step changes the set of live weights (an evaluation between epochs, an EMA model, one eager iteration between replays),
+    # the allocator would hand its memory to the next tensor and the replayed launch would read descriptors out of that: wild
+    # writes, a GPU memory fault (r05, found by tests/test_gpu_train_loop.py::test_detr_batch_beyond_max_annots_...).  Never freed;
+    # one small tensor per capture.
+    pinned_tables = []
 
     @classmethod
     def get(cls, weight, dtype, cin_padded, cout_padded, need_wd):
@@ -417,10 +424,25 @@ class _PackRegistry:
                 dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][1].device)
                 tables.append((dt, dev, len(items), t0))
             cls.table = (sig, tables)
+        if live[0][2].is_cuda and torch.cuda.is_current_stream_capturing() and not any(t is cls.table for t in cls.pinned_tables):
+            cls.pinned_tables.append(cls.table)
         for dt, dev, n, tiles in cls.table[1]:
             check(lib().saicv_pack_weight_batched(dtype_code(dt), ptr(dev), n, tiles, stream()), 'pack_weight_batched')
         for _, e, w in live:
             e['key'] = (w._version, _weights_epoch[0], w.data_ptr())
+
+    @classmethod
+    def used_now(cls):
+        """The live entries (asked for since the weight change before last -- the rule of refresh()): what a step that has just been
+        captured depends on (its own optimizer step has already bumped the epoch once)."""
+        return [e for e in cls.entries.values() if e['used'] >= _weights_epoch[0] - 1]
+
+    @classmethod
+    def touch(cls, entries):
+        """A replayed step used these entries without running get(): keep them among the live ones, so that an eager step between
+        replays refreshes the same set through the same descriptor table (engine.StepGraph calls this after every replay)."""
+        for e in entries:
+            e['used'] = _weights_epoch[0]
 
 
 def packed_weight(weight, dtype, cin_padded, need_wd, cout_padded=None):

@@ -476,19 +476,12 @@ def test_detection_loop_follows_the_reference_loop(graphed):
     assert abs(scheduler.current_lr - fx['lr']) < 1e-12
 
 
-def test_detr_replays_equal_eager_steps_from_the_same_state():
-    """What one replay of the captured DETR step computes, pinned against the SAME step run eagerly from the SAME state: before
-    every replay the weights, the AdamW moments and step counts, the model buffers and the batch are saved; afterwards each saved
-    state is restored and the step function the graph was captured from runs eagerly on it, twice.  The loss terms of the replay
-    must equal the eager ones (5e-4, or 3 x what two eager runs differ by), and the weight update must be the eager update
-    (mean |difference| below 3 x the eager-to-eager difference, floor 2 % of the mean update -- AdamW turns gradient noise on
-    near-zero gradients into +-lr moves, so an element-wise gate cannot hold even between two eager runs)."""
+def _detr_tiny_setup(use_graph, steps, batch, data_seed0, **overrides):
+    """resnet18_detr (hidden 256, 20 queries, 20 classes, dropout 0) + AdamW + the loop's configuration, as the trajectory fixture uses
+    them; `steps` seeded batches in the DETRDetectionCollater contract."""
     from oracle.make_golden_detr import detr_inputs, zero_dropout
-    from simpleaicv_pytorch_training_examples_amd import engine, ops
-    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
     from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import detr
-    from simpleaicv_pytorch_training_examples_amd.tools import scripts, utils
-    steps, batch = 7, 4
+    from simpleaicv_pytorch_training_examples_amd.tools import utils
 
     class config:
         pass
@@ -498,7 +491,9 @@ def test_detr_replays_equal_eager_steps_from_the_same_state():
     config.epochs, config.batch_size, config.accumulation_steps, config.print_interval = 1, batch, 1, 1
     config.use_amp, config.use_ema_model, config.local_rank, config.gpus_num, config.group = False, False, 0, 1, None
     config.clip_max_norm, config.sync_bn, config.host_sync_lag = 0.1, False, 2
-    config.use_step_graph, config.step_graph_warmup = True, 2
+    config.use_step_graph, config.step_graph_warmup = use_graph, 2
+    for k, v in overrides.items():
+        setattr(config, k, v)
     torch.manual_seed(0)
     model = detr.resnet18_detr(hidden_inplanes=256, query_nums=20, num_classes=20)
     zero_dropout(model)
@@ -508,11 +503,27 @@ def test_detr_replays_equal_eager_steps_from_the_same_state():
     model, config.ema_model, config.scaler = utils.build_training_mode(config, model)
     batches = []
     for s in range(steps):
-        images, masks, annots = detr_inputs(batch, 2000 + s)
+        images, masks, annots = detr_inputs(batch, data_seed0 + s)
         batches.append({'image': images, 'annots': annots, 'scaled_annots': annots, 'mask': masks})
 
     class Loader(list):
         dataset = [None] * (steps * batch)
+
+    return config, model, optimizer, scheduler, Loader(batches)
+
+
+def test_detr_replays_equal_eager_steps_from_the_same_state():
+    """What one replay of the captured DETR step computes, pinned against the SAME step run eagerly from the SAME state: before
+    every replay the weights, the AdamW moments and step counts, the model buffers and the batch are saved; afterwards each saved
+    state is restored and the step function the graph was captured from runs eagerly on it, twice.  The loss terms of the replay
+    must equal the eager ones (5e-4, or 3 x what two eager runs differ by), and the weight update must be the eager update
+    (mean |difference| below 3 x the eager-to-eager difference, floor 2 % of the mean update -- AdamW turns gradient noise on
+    near-zero gradients into +-lr moves, so an element-wise gate cannot hold even between two eager runs)."""
+    from simpleaicv_pytorch_training_examples_amd import engine, ops
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts
+    steps, batch = 7, 4
+    config, model, optimizer, scheduler, loader = _detr_tiny_setup(True, steps, batch, 2000)
 
     arena = optimizer.arena
     state_tensors = [arena.flat_param, optimizer.exp_avg, optimizer.exp_avg_sq, optimizer.step_blk] + list(model.buffers())
@@ -532,7 +543,7 @@ def test_detr_replays_equal_eager_steps_from_the_same_state():
 
     engine.StepGraph.__call__ = recording_call
     try:
-        scripts.train_detection(Loader(batches), model, DETRLoss(num_classes=20), optimizer, scheduler, 1,
+        scripts.train_detection(loader, model, DETRLoss(num_classes=20), optimizer, scheduler, 1,
                                 logging.getLogger('saicv_detr_replay'), config)
     finally:
         engine.StepGraph.__call__ = orig_call
@@ -810,3 +821,92 @@ def test_compute_macs_and_params_counts_the_matrix_products():
     assert params == '86.568 M', params
     assert 17.2 < float(macs.split()[0]) < 17.8 and macs.endswith(' GMACs'), macs
     print(f'compute_macs_and_params: resnet50 ok, vit_base_patch16 {flops} / {macs} / {params}')
+
+
+def test_detr_batch_beyond_max_annots_takes_one_eager_step_between_replays():
+    """config.max_annots bounds the static ground-truth buffer of the captured DETR step.  A batch with more boxes in one image does
+    not fit it: that ONE iteration runs eagerly with the host-side assignment (same optimizer state, same arena), the replays go on
+    afterwards.  6 iterations at max_annots = 5 (the seeded images carry 3..5 boxes), iteration 4 gets a sixth box in one image:
+    2 warm-up + 3 replays + 1 eager; every loss finite, and the first three iterations equal the all-eager loop's (1e-2: before the
+    AdamW / assignment bifurcation of DESIGN.md section 3h can set in)."""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts
+    steps, batch = 6, 4
+
+    def run(use_graph):
+        config, model, optimizer, scheduler, loader = _detr_tiny_setup(use_graph, steps, batch, 3000, max_annots=5)
+        extra = loader[4]['annots'].clone()
+        assert float(extra[0, 3, 4]) < 0                                # image 0 carries three boxes: rows 3.. are padding
+        extra[0, 3] = torch.tensor([0.3, 0.3, 0.2, 0.2, 1.0])           # three more -> six boxes, one beyond max_annots
+        extra[0, 4] = torch.tensor([0.7, 0.6, 0.2, 0.3, 2.0])
+        extra[0, 5] = torch.tensor([0.5, 0.5, 0.2, 0.3, 7.0])
+        loader[4]['annots'] = loader[4]['scaled_annots'] = extra
+        got, restore = _spy_average_meter()
+        try:
+            scripts.train_detection(loader, model, DETRLoss(num_classes=20), optimizer, scheduler, 1,
+                                    logging.getLogger('saicv_detr_overflow'), config)
+        finally:
+            restore()
+        return got, config
+
+    eager, _ = run(False)
+    got, config = run(True)
+    g = next(iter(config._saicv_step_graphs.values()))
+    assert g.graph is not None and g.replays == steps - 2 - 1, g.replays
+    assert len(got) == steps and all(np.isfinite(v) for v in got), got
+    for i in range(3):
+        assert abs(got[i] - eager[i]) <= 1e-2 * abs(eager[i]), (i, got, eager)
+    assert got[-1] < got[0] and eager[-1] < eager[0]
+
+
+
+def test_eager_work_between_epochs_does_not_break_the_cached_step_graph():
+    """The step graph is cached on the config across epochs.  Between two epochs the reference's entry scripts evaluate (an eager,
+    eval-mode forward of the same model) and may build other models (EMA copy, a teacher): both change which compute-dtype weight copies
+    are "live", and the batched weight-pack launch then rebuilds its descriptor table.  The captured step keeps the ADDRESS of the
+    table it was captured with, so that table must survive (ops._PackRegistry.pinned_tables) -- before r05 it was freed and the
+    replays of the next epoch read descriptors out of recycled memory (wild writes / a GPU memory fault).  Here: epoch 1 captured,
+    then an eval forward, a second model's training step and 64 MB of allocations that would recycle a freed table, then epoch 2
+    replayed; the run must end where the same two epochs WITHOUT the interlude end (same yardstick as the test above)."""
+    from simpleaicv_pytorch_training_examples_amd import ops
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts, utils
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones
+
+    def run(interlude):
+        config = _config(SyntheticSet(n=640, seed=3), batch=64)
+        config.use_amp = True
+        config.epochs = 4
+        config.use_step_graph = True
+        model = config.model.cuda()
+        optimizer, _ = utils.build_optimizer(config, model)
+        scheduler = utils.Scheduler(config, optimizer)
+        model, config.ema_model, config.scaler = utils.build_training_mode(config, model)
+        for epoch in (1, 2):
+            scripts.train_classification(_loader(config), model, config.train_criterion, optimizer, scheduler, epoch,
+                                         logging.getLogger('saicv_graph_interlude'), config)
+            if interlude and epoch == 1:
+                tables_before = len(ops._PackRegistry.pinned_tables)
+                assert tables_before >= 1
+                x = torch.randn(64, 3, 32, 32, device='cuda')
+                model.eval()
+                with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+                    model(x)
+                model.train()
+                other = backbones.resnet18cifar(num_classes=10).cuda()         # new weights enter the registry: another table
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    other(x).float().sum().backward()
+                del other
+                junk = [torch.full((1 << 20,), float('nan'), device='cuda') for _ in range(16)]     # recycle whatever was freed
+                torch.cuda.synchronize()
+                del junk
+        torch.cuda.synchronize()
+        g = next(iter(config._saicv_step_graphs.values()))
+        assert g.graph is not None and g.replays >= 2 * 10 - 3
+        return model.arena.flat_param.clone()
+
+    plain, plain2, mixed = run(False), run(False), run(True)
+    assert bool(torch.isfinite(mixed).all())
+    noise = float((plain - plain2).norm() / plain.norm())
+    rel = float((plain - mixed).norm() / plain.norm())
+    print(f'[step graph + interlude] parameters after 2 epochs: with interlude vs without {rel:.2e}, two plain runs {noise:.2e}')
+    assert rel < max(3 * noise, 5e-3), (rel, noise)
