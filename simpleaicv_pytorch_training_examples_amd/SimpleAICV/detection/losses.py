@@ -140,10 +140,11 @@ class DETRLoss(nn.Module):
     def _pair_buffers(self, b, t, device):
         bufs = getattr(self, '_pairs', None)
         if bufs is None or bufs['src'].shape != (b, t) or bufs['src'].device != device:
+            pin = (lambda x: x.pin_memory()) if torch.device(device).type == 'cuda' else (lambda x: x)
             bufs = {'src': torch.zeros(b, t, dtype=torch.int64, device=device), 'tgt': torch.zeros(b, t, dtype=torch.int64, device=device),
                     'w': torch.zeros(b, t, dtype=torch.float32, device=device),
-                    'h_src': torch.zeros(b, t, dtype=torch.int64).pin_memory(), 'h_tgt': torch.zeros(b, t, dtype=torch.int64).pin_memory(),
-                    'h_w': torch.zeros(b, t, dtype=torch.float32).pin_memory()}
+                    'h_src': pin(torch.zeros(b, t, dtype=torch.int64)), 'h_tgt': pin(torch.zeros(b, t, dtype=torch.int64)),
+                    'h_w': pin(torch.zeros(b, t, dtype=torch.float32))}
             # constants of forward_static, built HERE (outside any capture: a host -> device copy is not capturable)
             weight = torch.ones(self.num_classes + 1)
             weight[-1] = self.no_object_cls_weight
@@ -164,8 +165,10 @@ class DETRLoss(nn.Module):
         return bufs['src'], bufs['tgt'], bufs['w']
 
     def assign_host(self, cost, valid):
-        """One device -> host copy of (cost, valid), scipy's assignment per image on the valid columns, one host -> device copy of the
-        pairs into the module's static buffers: -> (src [B, T] query index, tgt [B, T] ground-truth row, w [B, T] 1 / 0)."""
+        """The same pairs from scipy on the host (the reference's own assignment through its nan / inf wrapper): one device -> host copy
+        of (cost, valid), one host -> device copy of the pairs into the module's static buffers -> (src [B, T] query index, tgt [B, T]
+        ground-truth row, w [B, T] 1 / 0).  Not on the training path (a synchronising copy per step); it is what the device kernel is
+        checked against (tests/test_gpu_r05.py) and what makes the static-shape loss testable without a GPU (tests/test_detr_host.py)."""
         b, q, t = cost.shape
         bufs = self._pair_buffers(b, t, cost.device)
         total = cost.float().cpu().numpy()               # the one synchronising copy of a step

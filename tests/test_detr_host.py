@@ -114,3 +114,45 @@ def test_detr_loss_selects_valid_rows_on_the_host_copy_of_the_annotations():
     tagged._saicv_host = ann.clone()
     fast = crit([cls.detach(), reg.detach()], tagged)
     assert all(float(plain[k]) == float(fast[k]) for k in plain)
+
+
+def test_detr_static_shape_loss_equals_the_dynamic_loss():
+    """DETRLoss.match_inputs -> assign_host -> forward_static (r05: the form the captured step uses, with the assignment from scipy on
+    the host here) against DETRLoss.forward on the same predictions and annotations: every loss term to 1e-6 and the gradients with
+    respect to both prediction tensors to 1e-6 of their scale.  Images with 0, 1 and several boxes, padding rows INTERLEAVED with
+    boxes, the ground truth padded to 8 rows (the static buffer) against the collater's 100-row tensor on the dynamic side."""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
+    g = torch.Generator().manual_seed(21)
+    layers, b, q, classes, t = 3, 4, 12, 20, 8
+    cls_preds = torch.randn(layers, b, q, classes + 1, generator=g)
+    reg_preds = torch.rand(layers, b, q, 4, generator=g) * 0.8 + 0.1
+    annots = -torch.ones(b, t, 5)
+    rows = {0: [1, 4, 6], 1: [], 2: [0], 3: [0, 1, 2, 3, 5]}
+    for i, rr in rows.items():
+        for r in rr:
+            cxcy = torch.rand(2, generator=g) * 0.5 + 0.25
+            wh = torch.rand(2, generator=g) * 0.3 + 0.1
+            annots[i, r] = torch.cat([cxcy, wh, torch.randint(0, classes, (1,), generator=g).float()])
+    crit = DETRLoss(num_classes=classes)
+
+    def run(static):
+        c, r = cls_preds.clone().requires_grad_(True), reg_preds.clone().requires_grad_(True)
+        if static:
+            cost, valid = crit.match_inputs([c, r], annots)
+            src, tgt, w = crit.assign_host(cost, valid)
+            assert int(w.sum()) == sum(len(v) for v in rows.values())
+            ld = crit.forward_static([c, r], annots, src, tgt, w)
+        else:
+            wide = -torch.ones(b, 100, 5)
+            wide[:, :t] = annots
+            ld = crit([c, r], wide)
+        sum(ld.values()).backward()
+        return {k: float(v) for k, v in ld.items()}, c.grad, r.grad
+
+    dyn, dc, dr = run(False)
+    sta, sc, sr = run(True)
+    assert list(dyn.keys()) == list(sta.keys()) and len(dyn) == 3 * layers
+    for k in dyn:
+        assert abs(dyn[k] - sta[k]) <= 1e-6 * max(1.0, abs(dyn[k])), (k, dyn[k], sta[k])
+    assert float((dc - sc).abs().max()) <= 1e-6 * float(dc.abs().max())
+    assert float((dr - sr).abs().max()) <= 1e-6 * float(dr.abs().max())
