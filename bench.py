@@ -714,6 +714,7 @@ def worker(args):
     # ResNet-50 step) unless --deterministic, and says so in its JSON line (config.bn_statistics)
     if not args.deterministic:
         os.environ.setdefault('SAICV_BN_INLINE', '1')
+        os.environ.setdefault('SAICV_DETERMINISTIC', '0')
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -41,6 +41,19 @@ typedef struct saicv_conv_desc {
 int saicv_version(void);
 const char* saicv_last_error_string(void);
 
+/* ---- deterministic mode ----------------------------------------------------------------
+ * Replaces `torch.backends.cudnn.deterministic = True` of the reference's set_seed (tools/utils.py:95-107).
+ * on != 0: every reduction that otherwise adds workgroup partials with fp32 atomics (weight / bias gradients of the
+ * convolution, linear and depthwise kernels, BatchNorm / GroupNorm statistics of non-convolution inputs, the stem's fused
+ * BatchNorm backward sums, relative-position table gradients, mask-loss sums, focal / SmoothL1 sums, the gradient norm)
+ * parks its partials in a library-owned workspace and folds them in a fixed order: results are bit-identical from run to run
+ * for the same shapes.  The workspace (96 MiB per stream, doubling on demand) is the one exception to "the library allocates
+ * nothing"; saicv_deterministic_prepare(stream) allocates it up front so that no allocation falls into a hipGraph capture.
+ * saicv_set_deterministic returns the previous setting.  Process-global, not thread-local. */
+int saicv_set_deterministic(int on);
+int saicv_get_deterministic(void);
+int saicv_deterministic_prepare(void* stream);
+
 /* ---- layout packing ------------------------------------------------------------------ */
 /* NCHW-shaped fp32 batch with element strides (sN,sC,sH,sW) -> dense NHWC [N,H,W,Cp],
  * channels zero-padded.  Input contract: SimpleAICV/classification/common.py:645-665

@@ -210,7 +210,10 @@ class DETRLoss(nn.Module):
         nll = -F.log_softmax(cls_preds, dim=-1).gather(-1, gmap.view(1, b, q, 1).expand(l, b, q, 1)).squeeze(-1)
         wgt = weight[gmap]
         cls_l = (nll * wgt).sum(dim=(1, 2)) / wgt.sum()
-        target_num = w.sum().clamp(min=1.0)
+        # the number of ground-truth boxes of the batch, as forward() and the reference (losses.py:938-954) divide by it -- NOT the
+        # number of matched pairs (fewer when an image carries more boxes than queries) and not clamped: a batch without any box
+        # gives 0 / 0 = nan here as it does there, and the loop skips the step
+        target_num = (gt[:, :, 4] >= 0).sum().float()
         dummy = self._pairs['dummy_box']
         pm = torch.where(on[None, :, :, None], reg_preds[:, bidx, src], dummy)                 # [L, B, T, 4]
         tb = torch.where(on[:, :, None], m_box, dummy)                                          # [B, T, 4]

@@ -73,6 +73,9 @@ class EraseBox(Structure):
 SIGNATURES = {
     'saicv_version': (c_int, []),
     'saicv_last_error_string': (c_char_p, []),
+    'saicv_set_deterministic': (c_int, [c_int]),
+    'saicv_get_deterministic': (c_int, []),
+    'saicv_deterministic_prepare': (c_int, [_P]),
     'saicv_pack_input': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_pack_weight': (c_int, [c_int, _P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'saicv_unpack_wgrad': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_long, c_long, c_long, c_long, c_int, _P]),

@@ -123,8 +123,17 @@ bool on_side_stream(const saicv_comm* c, void* stream) {
 
 }  // namespace
 
-// ranks of the largest communicator created in this process (common.h): igemm.hip sizes the weight-gradient round with it
+// ranks of the largest LIVE communicator of this process (common.h): igemm.hip sizes the weight-gradient round with it.
+// Recomputed when a communicator is destroyed (it only ever grew, so a single-GPU model trained later in the same
+// process kept the 85 % split).
 int g_saicv_comm_world = 1;
+static int g_live_worlds[64];
+static int g_n_live = 0;
+static void comm_world_changed() {
+    int w = 1;
+    for (int i = 0; i < g_n_live; ++i) w = g_live_worlds[i] > w ? g_live_worlds[i] : w;
+    g_saicv_comm_world = w;
+}
 
 extern "C" {
 
@@ -172,7 +181,8 @@ int saicv_comm_create(const void* id128, int world, int rank, saicv_comm** out) 
     }
     const char* mode = getenv("SAICV_COMM_MODE");
     c->overlap_eager = mode && strcmp(mode, "events") == 0;
-    if (world > g_saicv_comm_world) g_saicv_comm_world = world;       // collectives now share this GPU with the step's kernels
+    if (g_n_live < 64) g_live_worlds[g_n_live++] = world;             // collectives now share this GPU with the step's kernels
+    comm_world_changed();
     *out = c;
     return 0;
 }
@@ -283,6 +293,9 @@ int saicv_comm_destroy(saicv_comm* c) {
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_out) hipEventDestroy(c->ev_out);
     if (c->side) hipStreamDestroy(c->side);
+    for (int i = 0; i < g_n_live; ++i)
+        if (g_live_worlds[i] == c->world) { g_live_worlds[i] = g_live_worlds[--g_n_live]; break; }
+    comm_world_changed();
     delete c;
     return 0;
 }

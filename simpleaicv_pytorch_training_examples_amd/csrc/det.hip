@@ -1,0 +1,125 @@
+// Deterministic accumulation: the per-stream partials workspace and the ordered fold (det.h).
+#include <mutex>
+
+#include "common.h"
+#include "det.h"
+
+namespace saicv {
+
+int g_deterministic = 0;
+
+namespace {
+
+// One workspace per stream that ever ran a deterministic reduction (the step's kernels run on one stream; the optional weight-gradient
+// side stream of ops._SideStream is a second).  A reduction's partials live from its kernel to its fold, both on the same stream, so
+// successive reductions of a stream reuse the same memory in stream order.
+struct StreamWs { hipStream_t st; float* p; size_t floats; };
+constexpr int MAX_STREAMS = 8;
+StreamWs g_ws[MAX_STREAMS] = {};
+int g_nws = 0;
+std::mutex g_mu;
+
+// The weight-gradient kernels need at most 512 resident tiles of 128 x 128 (or 256 of 256 x 256) fp32 partials = 32 / 64 MiB; every
+// other user stays far below.  Allocated up front so that no allocation falls inside a hipGraph capture.
+constexpr size_t kInitialFloats = (size_t)24 << 20;      // 96 MiB
+
+float* ws_for(hipStream_t st, size_t floats, const char* who) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    StreamWs* w = nullptr;
+    for (int i = 0; i < g_nws; ++i)
+        if (g_ws[i].st == st) { w = &g_ws[i]; break; }
+    if (!w) {
+        if (g_nws == MAX_STREAMS) {
+            set_error("%s: deterministic reductions on more than %d streams", who, MAX_STREAMS);
+            return nullptr;
+        }
+        w = &g_ws[g_nws++];
+        *w = StreamWs{st, nullptr, 0};
+    }
+    if (w->floats < floats) {
+        size_t want = w->floats ? w->floats : kInitialFloats;
+        while (want < floats) want *= 2;
+        float* fresh = nullptr;
+        const hipError_t e = hipMalloc(&fresh, want * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("%s: deterministic workspace of %zu MiB: %s (a workspace cannot grow inside a hipGraph capture: run the step "
+                      "eagerly once first)", who, want * sizeof(float) >> 20, hipGetErrorString(e));
+            return nullptr;
+        }
+        // the old block may still be read by a fold in flight on this stream: it is left to the process (growth is rare and doubles)
+        w->p = fresh;
+        w->floats = want;
+    }
+    return w->p;
+}
+
+// dst[i] += part[0][off + i] + part[1][off + i] + ...   (p ascending; one thread per element, four elements when aligned)
+__global__ __launch_bounds__(256) void det_fold_kernel(const float* __restrict__ part, size_t n, int nparts, size_t off, size_t count,
+                                                       float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float* p = part + off + i;
+    float acc = p[0];
+    for (int k = 1; k < nparts; ++k) acc += p[(size_t)k * n];
+    dst[i] += acc;
+}
+__global__ __launch_bounds__(256) void det_fold4_kernel(const float* __restrict__ part, size_t n, int nparts, size_t off, size_t count4,
+                                                        float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    const float* p = part + off + i * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(p);
+    for (int k = 1; k < nparts; ++k) acc += *reinterpret_cast<const f32x4*>(p + (size_t)k * n);
+    f32x4* d = reinterpret_cast<f32x4*>(dst + i * 4);
+    *d = *d + acc;
+}
+
+}  // namespace
+
+int DetParts::begin(hipStream_t stream, int parts, size_t n, const char* who) {
+    s = DetSink{nullptr, n};
+    nparts = parts;
+    st = stream;
+    if (!g_deterministic || parts <= 1 || n == 0) return 0;      // one contributor per element: its atomics are already ordered
+    float* p = ws_for(stream, (size_t)parts * n, who);
+    if (!p) return -1;
+    if (hipMemsetAsync(p, 0, (size_t)parts * n * sizeof(float), stream) != hipSuccess) {
+        set_error("%s: clearing the deterministic workspace failed: %s", who, hipGetErrorString(hipGetLastError()));
+        return -1;
+    }
+    s.part = p;
+    return 0;
+}
+
+int DetParts::fold(float* dst, size_t offset, size_t count) const {
+    if (!s.part || count == 0) return 0;
+    const bool vec = (s.n % 4 == 0) && (offset % 4 == 0) && (count % 4 == 0) && ((uintptr_t)dst % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(det_fold4_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, st, s.part, s.n, nparts, offset, count / 4, dst);
+    else
+        hipLaunchKernelGGL(det_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, s.part, s.n, nparts, offset, count, dst);
+    return check_launch("det_fold");
+}
+
+}  // namespace saicv
+
+extern "C" {
+
+// Reference tools/utils.py:95-107 (set_seed: cudnn.deterministic = True).  on != 0: every reduction of this library is ordered
+// (bit-reproducible run to run on the same shapes); the first call allocates the partials workspace of the calling thread's
+// current use (96 MiB per stream, lazily for further streams).  Returns the previous setting.
+int saicv_set_deterministic(int on) {
+    const int prev = saicv::g_deterministic;
+    saicv::g_deterministic = on ? 1 : 0;
+    return prev;
+}
+
+int saicv_get_deterministic(void) { return saicv::g_deterministic; }
+
+// Allocates the deterministic workspace of `stream` now (outside any capture).  0 on success.
+int saicv_deterministic_prepare(void* stream) {
+    return saicv::ws_for((hipStream_t)stream, saicv::kInitialFloats, "deterministic_prepare") ? 0 : -1;
+}
+
+}  // extern "C"

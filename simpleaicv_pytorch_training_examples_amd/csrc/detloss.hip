@@ -10,6 +10,7 @@
 // Sums are accumulated with one fp32 atomic per workgroup into a zeroed buffer; the host divides by the positive count.
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 namespace {
 
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(DL_THREADS) void retina_assign_kernel(const float* 
 template <bool GAMMA2>
 __global__ __launch_bounds__(DL_THREADS) void focal_level_kernel(const float* __restrict__ probs, const float* __restrict__ targets,
                                                                  float* __restrict__ dprobs, float* __restrict__ loss_sum, size_t total,
-                                                                 int Al, int At, int off, int C, float alpha, float gamma) {
+                                                                 int Al, int At, int off, int C, float alpha, float gamma, const saicv::DetSink det) {
     __shared__ float red[DL_THREADS / 64];
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * DL_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * DL_THREADS) {
@@ -134,13 +135,13 @@ __global__ __launch_bounds__(DL_THREADS) void focal_level_kernel(const float* __
         if (dprobs) dprobs[i] = grad;
     }
     const float t = block_sum(acc, red);
-    if (threadIdx.x == 0 && t != 0.f) atomicAdd(loss_sum, t);
+    if (threadIdx.x == 0 && t != 0.f) saicv::det_add(det, loss_sum, 0, blockIdx.x, t);
 }
 
 // one level: reg [B][Al][4] against targets[..][0:4] on the rows with class > 0
 __global__ __launch_bounds__(DL_THREADS) void smoothl1_level_kernel(const float* __restrict__ reg, const float* __restrict__ targets,
                                                                     float* __restrict__ dreg, float* __restrict__ loss_sum, size_t rows,
-                                                                    int Al, int At, int off, float beta) {
+                                                                    int Al, int At, int off, float beta, const saicv::DetSink det) {
     __shared__ float red[DL_THREADS / 64];
     float acc = 0.f;
     for (size_t row = (size_t)blockIdx.x * DL_THREADS + threadIdx.x; row < rows; row += (size_t)gridDim.x * DL_THREADS) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(DL_THREADS) void smoothl1_level_kernel(const float*
         if (dreg) *reinterpret_cast<f32x4*>(dreg + row * 4) = g;
     }
     const float s = block_sum(acc, red);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss_sum, s);
+    if (threadIdx.x == 0 && s != 0.f) saicv::det_add(det, loss_sum, 0, blockIdx.x, s);
 }
 
 
@@ -441,13 +442,17 @@ int saicv_focal_loss_level(const float* probs, const float* targets, float* dpro
                            int C, double alpha, double gamma, void* stream) {
     SAICV_REQUIRE(B > 0 && Al > 0 && C > 0 && off >= 0 && off + Al <= At, "focal_loss_level: B=%d Al=%d At=%d off=%d C=%d", B, Al, At, off, C);
     const size_t total = (size_t)B * Al * C;
+    // (the positive counts of the assignment kernels stay atomic: sums of small integers are exact in fp32 in any order)
+    saicv::DetParts det;
+    if (det.begin((hipStream_t)stream, dl_grid(total), 1, "focal_loss_level")) return -1;
     if (gamma == 2.0)
         hipLaunchKernelGGL((focal_level_kernel<true>), dim3(dl_grid(total)), dim3(DL_THREADS), 0, (hipStream_t)stream, probs, targets, dprobs,
-                           loss_sum, total, Al, At, off, C, (float)alpha, (float)gamma);
+                           loss_sum, total, Al, At, off, C, (float)alpha, (float)gamma, det.sink());
     else
         hipLaunchKernelGGL((focal_level_kernel<false>), dim3(dl_grid(total)), dim3(DL_THREADS), 0, (hipStream_t)stream, probs, targets, dprobs,
-                           loss_sum, total, Al, At, off, C, (float)alpha, (float)gamma);
-    return saicv::check_launch("focal_loss_level");
+                           loss_sum, total, Al, At, off, C, (float)alpha, (float)gamma, det.sink());
+    if (saicv::check_launch("focal_loss_level")) return -2;
+    return det.fold(loss_sum, 0, 1);
 }
 
 // SmoothL1 box loss of one level's positive anchors: reg [B][Al][4] (16-byte aligned) against targets[..][0:4]; loss_sum[0] +=
@@ -457,9 +462,12 @@ int saicv_smoothl1_level(const float* reg, const float* targets, float* dreg, fl
     SAICV_REQUIRE(B > 0 && Al > 0 && off >= 0 && off + Al <= At && beta > 0., "smoothl1_level: B=%d Al=%d At=%d off=%d", B, Al, At, off);
     SAICV_REQUIRE(((uintptr_t)reg & 15) == 0 && ((uintptr_t)dreg & 15) == 0, "smoothl1_level: box tensors must be 16-byte aligned");
     const size_t rows = (size_t)B * Al;
+    saicv::DetParts det;
+    if (det.begin((hipStream_t)stream, dl_grid(rows), 1, "smoothl1_level")) return -1;
     hipLaunchKernelGGL(smoothl1_level_kernel, dim3(dl_grid(rows)), dim3(DL_THREADS), 0, (hipStream_t)stream, reg, targets, dreg, loss_sum,
-                       rows, Al, At, off, (float)beta);
-    return saicv::check_launch("smoothl1_level");
+                       rows, Al, At, off, (float)beta, det.sink());
+    if (saicv::check_launch("smoothl1_level")) return -2;
+    return det.fold(loss_sum, 0, 1);
 }
 
 // FCOS point assignment (reference losses.py:623-842): points [P][5] fp32 = (x, y, stride, range low, range high) of one image's
@@ -490,6 +498,10 @@ int saicv_detr_assign(const float* cost, const unsigned char* valid, int B, int 
     const int nmax = Q > T ? Q : T;
     SAICV_REQUIRE(nmax <= 2048, "saicv_detr_assign: %d queries / %d ground-truth rows (at most 2048)", Q, T);
     const size_t smem = (size_t)nmax * (3 * sizeof(double) + 5 * sizeof(int) + 2);
+    if (smem > 64 * 1024) {       // 46 bytes per row: beyond 1 424 rows the dynamic LDS passes the 64 KiB a kernel gets without asking
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(detr_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        SAICV_REQUIRE(e == hipSuccess, "saicv_detr_assign: %zu bytes of LDS for %d rows: %s", smem, nmax, hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(detr_assign_kernel, dim3(B), dim3(64), smem, static_cast<hipStream_t>(stream), cost, valid, Q, T, src, tgt, w);
     return saicv::check_launch("detr_assign");
 }

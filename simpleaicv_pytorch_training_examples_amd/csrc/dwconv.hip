@@ -22,6 +22,7 @@
 // the Python wrapper converts from / to PyTorch's [C, 1, k, k].
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 #include "../../include/saicv_hip.h"
 
 namespace {
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(256) void dwconv_s1_kernel(const T* __restrict__ sr
 template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dwt,
                                                            float* __restrict__ dbias, int Nimg, int H, int W, int OH, int OW, int C,
-                                                           int stride, int pad, int dil, int pix_per_block, int chunks_per_block) {
+                                                           int stride, int pad, int dil, int pix_per_block, int chunks_per_block,
+                                                           const saicv::DetSink det) {
     constexpr int N = Chunk<T>::N;
     constexpr int ACC = (K + 1) * N;                        // K column sums + the bias sum, N channels each
     extern __shared__ float red[];                          // [256][ACC]
@@ -250,10 +252,11 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 #pragma unroll
         for (int s = 0; s < K; ++s)
 #pragma unroll
-            for (int e = 0; e < N; ++e) unsafeAtomicAdd(dwt + (size_t)(r * K + s) * C + cb * N + e, acc[s][e]);
+            for (int e = 0; e < N; ++e)      // pixel range blockIdx.y = partial blockIdx.y of [K*K][C] weights (+ [C] bias sums behind them)
+                saicv::det_add(det, dwt + (size_t)(r * K + s) * C + cb * N + e, (size_t)(r * K + s) * C + cb * N + e, blockIdx.y, acc[s][e]);
         if (r == 0 && dbias != nullptr) {
 #pragma unroll
-            for (int e = 0; e < N; ++e) unsafeAtomicAdd(dbias + cb * N + e, bacc[e]);
+            for (int e = 0; e < N; ++e) saicv::det_add(det, dbias + cb * N + e, (size_t)K * K * C + cb * N + e, blockIdx.y, bacc[e]);
         }
     }
 }
@@ -351,14 +354,18 @@ int saicv_dwconv2d_wgrad(int dtype, const void* dy, const void* x, float* dwt, f
     ranges = (npix + ppb - 1) / ppb;
     SAICV_REQUIRE(ranges <= 65535, "dwconv2d_wgrad: %zu pixel ranges", ranges);
     dim3 grid(groups, (unsigned)ranges);
+    saicv::DetParts det;
+    if (det.begin(st, (int)ranges, (size_t)K * K * C + (dbias ? C : 0), "dwconv2d_wgrad")) return -1;
 #define DW_WG(TT, KK) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_kernel<TT, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (KK + 1) * 8 * 4); \
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<TT, KK>), grid, dim3(256), 256 * (KK + 1) * n * sizeof(float), st, (const TT*)dy, (const TT*)x, dwt, dbias, N, H, W, OH, OW, C, stride, pad, dil, (int)ppb, cpb)
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<TT, KK>), grid, dim3(256), 256 * (KK + 1) * n * sizeof(float), st, (const TT*)dy, (const TT*)x, dwt, dbias, N, H, W, OH, OW, C, stride, pad, dil, (int)ppb, cpb, det.sink())
 #define DW_WGK(TT) switch (K) { case 1: { DW_WG(TT, 1); } break; case 2: { DW_WG(TT, 2); } break; case 3: { DW_WG(TT, 3); } break; case 4: { DW_WG(TT, 4); } break; \
                                  case 5: { DW_WG(TT, 5); } break; case 6: { DW_WG(TT, 6); } break; case 7: { DW_WG(TT, 7); } break; default: { DW_WG(TT, 8); } break; }
     if (dtype == SAICV_DTYPE_BF16) { DW_WGK(bf16_t) } else { DW_WGK(float) }
 #undef DW_WGK
 #undef DW_WG
-    return check_launch("dwconv2d_wgrad");
+    if (check_launch("dwconv2d_wgrad")) return -2;
+    if (det.fold(dwt, 0, (size_t)K * K * C)) return -1;
+    return dbias ? det.fold(dbias, (size_t)K * K * C, (size_t)C) : 0;
 }
 
 }  // extern "C"

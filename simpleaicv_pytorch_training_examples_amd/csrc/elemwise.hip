@@ -8,6 +8,7 @@
 // chunk column per lane group, reduce across the workgroup in LDS and leave one fp32 atomic per channel and workgroup.
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 namespace {
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(EW_THREADS) void scale_add_kernel(const T* __restri
 template <typename T, int MODE>
 __global__ __launch_bounds__(EW_THREADS) void colred_kernel(const T* __restrict__ p0, const T* __restrict__ p1, const float* __restrict__ s,
                                                             T* __restrict__ dy, float* __restrict__ r0, float* __restrict__ r1,
-                                                            size_t M, int C, int cw, size_t rows_per_block) {
+                                                            size_t M, int C, int cw, size_t rows_per_block, const saicv::DetSink det) {
     constexpr int N = Chunk<T>::N;
     __shared__ float red[EW_THREADS * N * (MODE == 0 ? 2 : 1)];
     const int cpr = C / N;
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(EW_THREADS) void colred_kernel(const T* __restrict_
                 t0 += red[(r * cw + threadIdx.x) * N + j];
                 if (MODE == 0) t1 += red[EW_THREADS * N + (r * cw + threadIdx.x) * N + j];
             }
-            atomicAdd(r0 + col * N + j, t0);
-            if (MODE == 0) atomicAdd(r1 + col * N + j, t1);
+            saicv::det_add(det, r0 + col * N + j, (size_t)col * N + j, blockIdx.y, t0);      // row range blockIdx.y = partial blockIdx.y
+            if (MODE == 0) saicv::det_add(det, r1 + col * N + j, (size_t)C + col * N + j, blockIdx.y, t1);
         }
     }
 }
@@ -363,13 +364,16 @@ int saicv_channel_scale_add_bwd(int dtype, const void* dout, const void* y, cons
     hipStream_t st = (hipStream_t)stream;
     const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     const ColGeom g = col_geom(M, C / e);
+    saicv::DetParts det;
+    if (det.begin(st, ds ? (int)g.grid.y : 0, (size_t)C, "channel_scale_add_bwd")) return -1;
     if (dtype == SAICV_DTYPE_BF16)
         hipLaunchKernelGGL((colred_kernel<bf16_t, 1>), g.grid, dim3(EW_THREADS), 0, st, (const bf16_t*)dout, (const bf16_t*)y, s, (bf16_t*)dy, ds,
-                           (float*)nullptr, M, C, g.cw, g.rpb);
+                           (float*)nullptr, M, C, g.cw, g.rpb, det.sink());
     else
         hipLaunchKernelGGL((colred_kernel<float, 1>), g.grid, dim3(EW_THREADS), 0, st, (const float*)dout, (const float*)y, s, (float*)dy, ds,
-                           (float*)nullptr, M, C, g.cw, g.rpb);
-    return saicv::check_launch("channel_scale_add_bwd");
+                           (float*)nullptr, M, C, g.cw, g.rpb, det.sink());
+    if (saicv::check_launch("channel_scale_add_bwd")) return -2;
+    return det.fold(ds, 0, (size_t)C);
 }
 
 // per-channel sum and sum of squares of x[M][C], ADDED into sum[C] / sq[C] (fp32, zeroed by the caller): the statistics of a
@@ -424,13 +428,17 @@ int saicv_bn_stats(int dtype, const void* x, size_t M, int C, float* sum, float*
     hipStream_t st = (hipStream_t)stream;
     const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     const ColGeom g = col_geom(M, C / e);
+    saicv::DetParts det;
+    if (det.begin(st, (int)g.grid.y, (size_t)2 * C, "bn_stats")) return -1;
     if (dtype == SAICV_DTYPE_BF16)
         hipLaunchKernelGGL((colred_kernel<bf16_t, 0>), g.grid, dim3(EW_THREADS), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr,
-                           (bf16_t*)nullptr, sum, sq, M, C, g.cw, g.rpb);
+                           (bf16_t*)nullptr, sum, sq, M, C, g.cw, g.rpb, det.sink());
     else
         hipLaunchKernelGGL((colred_kernel<float, 0>), g.grid, dim3(EW_THREADS), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr,
-                           (float*)nullptr, sum, sq, M, C, g.cw, g.rpb);
-    return saicv::check_launch("bn_stats");
+                           (float*)nullptr, sum, sq, M, C, g.cw, g.rpb, det.sink());
+    if (saicv::check_launch("bn_stats")) return -2;
+    if (det.fold(sum, 0, (size_t)C)) return -1;
+    return det.fold(sq, (size_t)C, (size_t)C);
 }
 
 }  // extern "C"

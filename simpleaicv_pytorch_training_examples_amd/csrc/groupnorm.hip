@@ -10,6 +10,7 @@
 //             gn_apply_bwd   dx
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 namespace {
 
@@ -19,7 +20,7 @@ constexpr int GN_THREADS = 256;
 template <typename T, int MODE>
 __global__ __launch_bounds__(GN_THREADS) void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ ab,
                                                                float* __restrict__ out0, float* __restrict__ out1, int HW, int C, int cw,
-                                                               int rows_per_block, int relu) {
+                                                               int rows_per_block, int relu, const saicv::DetSink det) {
     constexpr int N = Chunk<T>::N;
     __shared__ float red[GN_THREADS * N * 2];
     const int cpr = C / N;
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_reduce_kernel(const T* __restri
                 t0 += red[(r * cw + threadIdx.x) * N + j];
                 t1 += red[GN_THREADS * N + (r * cw + threadIdx.x) * N + j];
             }
-            atomicAdd(out0 + (size_t)n * C + col * N + j, t0);
-            atomicAdd(out1 + (size_t)n * C + col * N + j, t1);
+            // row range blockIdx.y = partial blockIdx.y of the [2][N][C] sums
+            saicv::det_add(det, out0 + (size_t)n * C + col * N + j, (size_t)n * C + col * N + j, blockIdx.y, t0);
+            saicv::det_add(det, out1 + (size_t)n * C + col * N + j, (size_t)gridDim.z * C + (size_t)n * C + col * N + j, blockIdx.y, t1);
         }
     }
 }
@@ -223,12 +225,15 @@ int saicv_groupnorm_fwd(int dtype, const void* x, const float* gamma, const floa
     float* sums = ws;                                   // [2][N][C]
     if (hipMemsetAsync(sums, 0, (size_t)2 * N * C * sizeof(float), st) != hipSuccess) { saicv::set_error("groupnorm_fwd: memset failed"); return -1; }
     const GnGeom g = gn_geom(N, HW, C / e);
+    saicv::DetParts det;
+    if (det.begin(st, (int)g.grid.y, (size_t)2 * N * C, "groupnorm_fwd")) return -1;
     if (dtype == SAICV_DTYPE_BF16)
         hipLaunchKernelGGL((gn_reduce_kernel<bf16_t, 0>), g.grid, dim3(GN_THREADS), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr,
-                           sums, sums + (size_t)N * C, HW, C, g.cw, g.rpb, 0);
+                           sums, sums + (size_t)N * C, HW, C, g.cw, g.rpb, 0, det.sink());
     else
         hipLaunchKernelGGL((gn_reduce_kernel<float, 0>), g.grid, dim3(GN_THREADS), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr,
-                           sums, sums + (size_t)N * C, HW, C, g.cw, g.rpb, 0);
+                           sums, sums + (size_t)N * C, HW, C, g.cw, g.rpb, 0, det.sink());
+    if (det.fold(sums, 0, (size_t)2 * N * C)) return -1;
     hipLaunchKernelGGL(gn_coeffs_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, sums, gamma, beta, mean_rstd, ab, N, C, C / G,
                        (float)((double)HW * (C / G)), (float)eps);
     const size_t chunks = (size_t)N * HW * (C / e);
@@ -252,12 +257,15 @@ int saicv_groupnorm_bwd(int dtype, const void* dy, const void* x, const float* g
     float* pqr = ws + (size_t)2 * N * C;                // [3][N][C]
     if (hipMemsetAsync(AB, 0, (size_t)2 * N * C * sizeof(float), st) != hipSuccess) { saicv::set_error("groupnorm_bwd: memset failed"); return -1; }
     const GnGeom g = gn_geom(N, HW, C / e);
+    saicv::DetParts det;
+    if (det.begin(st, (int)g.grid.y, (size_t)2 * N * C, "groupnorm_bwd")) return -1;
     if (dtype == SAICV_DTYPE_BF16)
         hipLaunchKernelGGL((gn_reduce_kernel<bf16_t, 1>), g.grid, dim3(GN_THREADS), 0, st, (const bf16_t*)x, (const bf16_t*)dy, ab, AB, AB + (size_t)N * C,
-                           HW, C, g.cw, g.rpb, relu);
+                           HW, C, g.cw, g.rpb, relu, det.sink());
     else
         hipLaunchKernelGGL((gn_reduce_kernel<float, 1>), g.grid, dim3(GN_THREADS), 0, st, (const float*)x, (const float*)dy, ab, AB, AB + (size_t)N * C,
-                           HW, C, g.cw, g.rpb, relu);
+                           HW, C, g.cw, g.rpb, relu, det.sink());
+    if (det.fold(AB, 0, (size_t)2 * N * C)) return -1;
     hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, st, AB, mean_rstd, gamma, pqr, dgamma, dbeta, N, C, C / G,
                        (float)((double)HW * (C / G)));
     const size_t chunks = (size_t)N * HW * (C / e);

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 namespace {
 
@@ -1740,6 +1741,7 @@ struct TNParams {
     int m_per_split;            // multiple of BR
     int d_img, d_oh, d_ow;      // mixed-radix digits of BR in (img, oh, ow)
     FastDiv fd_ohw, fd_ow;
+    saicv::DetSink det;         // deterministic mode: split s parks its tile in part[s][n * Kd + kk], its bias sums in part[s][Cout * Kd + n]
 };
 
 template <typename T, int BA, int BB, int NWA, int NWB>
@@ -1970,7 +1972,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_kernel(const TNParams
             for (int k = 0; k < EPC; ++k) {
                 float sgm = 0.f;
                 for (int t = 0; t < RPP_A; ++t) sgm += red[(t * CPR_A + ca) * EPC + k];
-                unsafeAtomicAdd(p.dbias + n_ld + k, sgm);
+                saicv::det_add(p.det, p.dbias + n_ld + k, (size_t)p.Cout * p.Kd + n_ld + k, split, sgm);
             }
         }
     }
@@ -1985,7 +1987,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_kernel(const TNParams
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (n0 + r < p.Cout)
-                        unsafeAtomicAdd(p.dw + (size_t)(n0 + r) * (size_t)p.Kd + kk, acc[ai][bi][r]);
+                        saicv::det_add(p.det, p.dw + (size_t)(n0 + r) * (size_t)p.Kd + kk, (size_t)(n0 + r) * (size_t)p.Kd + kk, split, acc[ai][bi][r]);
             }
         }
     }
@@ -2231,7 +2233,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
             const int n0 = tile_a * BA + wa * WA + (wb * ABT + t) * 16 + lg * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (n0 + r < p.Cout) unsafeAtomicAdd(p.dbias + n0 + r, bacc[t][r]);
+                if (n0 + r < p.Cout) saicv::det_add(p.det, p.dbias + n0 + r, (size_t)p.Cout * p.Kd + n0 + r, split, bacc[t][r]);
         }
     }
     // epilogue: D row -> n = .. + lg*4 + r ; D col -> kk = .. + l15
@@ -2245,7 +2247,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void igemm_tn_dma_kernel(const TNPa
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (n0 + r < p.Cout)
-                        unsafeAtomicAdd(p.dw + (size_t)(n0 + r) * (size_t)p.Kd + kk, acc[ai][bi][r]);
+                        saicv::det_add(p.det, p.dw + (size_t)(n0 + r) * (size_t)p.Kd + kk, (size_t)(n0 + r) * (size_t)p.Kd + kk, split, acc[ai][bi][r]);
             }
         }
     }
@@ -2656,6 +2658,8 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
 #undef NT_DISPATCH
 }
 
+static int igemm_tn_launch(int dtype, TNParams& p, int splits, bool big, int ba, int bb, int BR, hipStream_t st);
+
 int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W, int C, int OH,
              int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st, float* dbias) {
     const int epc = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
@@ -2706,6 +2710,19 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     int rt_per = (total_rt + splits - 1) / splits;
     splits = (total_rt + rt_per - 1) / rt_per;
     p.m_per_split = rt_per * BR;
+    // deterministic mode (det.h): the splits park their tiles (and bias sums) side by side, one launch folds them in split order
+    DetParts det;
+    if (det.begin(st, splits, (size_t)Cout * Kd + (dbias ? Cout : 0), "igemm_tn")) return -1;
+    p.det = det.sink();
+    const int rc = igemm_tn_launch(dtype, p, splits, big, ba, bb, BR, st);
+    if (rc) return rc;
+    if (det.fold(dw, 0, (size_t)Cout * Kd)) return -1;
+    if (dbias && det.fold(dbias, (size_t)Cout * Kd, (size_t)Cout)) return -1;
+    return 0;
+}
+
+static int igemm_tn_launch(int dtype, TNParams& p, int splits, bool big, int ba, int bb, int BR, hipStream_t st) {
+    const int OH = p.OH, OW = p.OW, R = p.R, S = p.S, stride = p.stride, pad = p.pad, H = p.H, W = p.W;
     const int ohw = OH * OW;
     p.d_img = BR / ohw;
     const int rem = BR - p.d_img * ohw;

@@ -12,6 +12,7 @@
 // HBM-bound: algorithmic bytes = logits + targets read once (forward), + d logits written (backward).
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 namespace {
 
@@ -40,7 +41,7 @@ template <typename T>
 __global__ __launch_bounds__(ML_THREADS) void mask_loss_stats_kernel(const T* __restrict__ logits,
                                                                       const float* __restrict__ targets,
                                                                       float* __restrict__ stats, int M, size_t HW,
-                                                                      float alpha, float gamma, float thr) {
+                                                                      float alpha, float gamma, float thr, const saicv::DetSink det) {
     constexpr int N = Chunk<T>::N;
     const int bm = blockIdx.y, b = bm / M;
     const T* lg = logits + (size_t)bm * HW;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(ML_THREADS) void mask_loss_stats_kernel(const T* __
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < ML_THREADS / 64; ++w) v += red[w][threadIdx.x];
-        atomicAdd(&stats[(size_t)bm * 6 + threadIdx.x], v);
+        saicv::det_add(det, &stats[(size_t)bm * 6 + threadIdx.x], (size_t)bm * 6 + threadIdx.x, blockIdx.x, v);      // pixel slab = partial
     }
 }
 
@@ -139,13 +140,16 @@ int mask_loss_stats(int dtype, const void* logits, const float* targets, float* 
     hipMemsetAsync(stats, 0, (size_t)B * M * 6 * sizeof(float), st);
     const size_t per_block = (size_t)ML_THREADS * ML_CHUNKS * n;
     dim3 grid((unsigned)((HW + per_block - 1) / per_block), B * M);
+    DetParts det;
+    if (det.begin(st, (int)grid.x, (size_t)B * M * 6, "mask_loss_stats")) return -1;
     if (dtype == SAICV_DTYPE_BF16)
         hipLaunchKernelGGL(mask_loss_stats_kernel<bf16_t>, grid, dim3(ML_THREADS), 0, st, (const bf16_t*)logits, targets,
-                           stats, M, HW, (float)alpha, (float)gamma, (float)thr);
+                           stats, M, HW, (float)alpha, (float)gamma, (float)thr, det.sink());
     else
         hipLaunchKernelGGL(mask_loss_stats_kernel<float>, grid, dim3(ML_THREADS), 0, st, (const float*)logits, targets,
-                           stats, M, HW, (float)alpha, (float)gamma, (float)thr);
-    return check_launch("mask_loss_stats");
+                           stats, M, HW, (float)alpha, (float)gamma, (float)thr, det.sink());
+    if (check_launch("mask_loss_stats")) return -2;
+    return det.fold(stats, 0, (size_t)B * M * 6);
 }
 
 int mask_loss_grad(int dtype, const void* logits, const float* targets, const float* coef, void* dlogits, int B, int M,

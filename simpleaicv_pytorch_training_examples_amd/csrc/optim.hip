@@ -7,6 +7,7 @@
 // tools/utils.py:292-679 (build_optimizer) and GradScaler (tools/utils.py:199-200).
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 // cache policy of the fused optimizer kernels (library variant for A/B runs: -DSAICV_OPT_NT = streaming loads and stores: every
 // value is read once and written once per step)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
 // found_inf[0] = 1 if any gradient is inf/nan;  sumsq[0] += sum(g^2)  (for clip_grad_norm_)
 __global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict__ g, size_t n,
                                                          float* __restrict__ found_inf,
-                                                         float* __restrict__ sumsq) {
+                                                         float* __restrict__ sumsq, const saicv::DetSink det) {
     const size_t gstride = (size_t)gridDim.x * blockDim.x * 4;
     float ss = 0.f;
     bool bad = false;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict
     ss = wave_sum(ss);
     const unsigned long long anybad = __ballot(bad);
     if ((threadIdx.x & 63) == 0) {
-        if (sumsq) unsafeAtomicAdd(sumsq, ss);
+        if (sumsq) saicv::det_add(det, sumsq, 0, blockIdx.x * 4 + (threadIdx.x >> 6), ss);      // one partial per wavefront
         if (anybad && found_inf) found_inf[0] = 1.f;
     }
 }
@@ -209,8 +210,11 @@ int grad_stats(const float* g, size_t n, float* found_inf, float* sumsq, hipStre
     size_t b = (n / 4 + 255) / 256;
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
-    hipLaunchKernelGGL(grad_stats_kernel, dim3((unsigned)b), dim3(256), 0, st, g, n, found_inf, sumsq);
-    return check_launch("grad_stats");
+    DetParts det;
+    if (det.begin(st, sumsq ? (int)b * 4 : 0, 1, "grad_stats")) return -1;
+    hipLaunchKernelGGL(grad_stats_kernel, dim3((unsigned)b), dim3(256), 0, st, g, n, found_inf, sumsq, det.sink());
+    if (check_launch("grad_stats")) return -2;
+    return det.fold(sumsq, 0, 1);
 }
 
 int grad_clip_scale(float* g, size_t n, const float* sumsq, const float* inv_scale, double max_norm,

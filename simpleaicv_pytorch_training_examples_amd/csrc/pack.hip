@@ -8,6 +8,7 @@
 //  - unpack_wgrad: fp32 dW[O][R][S][Ip] -> gradient tensor [O,I,R,S] with arbitrary strides.
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 #include "../../include/saicv_hip.h"
 
 namespace {
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_s2d_kernel(const float* __re
 constexpr int CS_THREADS = 1024;
 template <typename T>
 __global__ __launch_bounds__(CS_THREADS) void colsum_kernel(const T* __restrict__ x, int M, int N,
-                                                            int rows_per, float* __restrict__ out) {
+                                                            int rows_per, float* __restrict__ out, const saicv::DetSink det) {
     constexpr int E = Chunk<T>::N;
     const int cpr = N / E;
     const int cols = cpr < CS_THREADS ? cpr : CS_THREADS;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(CS_THREADS) void colsum_kernel(const T* __restrict_
             for (int k = 0; k < E; ++k) {
                 float sgm = 0.f;
                 for (int t = 0; t < rpp; ++t) sgm += red[(t * cols + tx) * E + k];
-                unsafeAtomicAdd(out + cb * E + k, sgm);
+                saicv::det_add(det, out + cb * E + k, (size_t)cb * E + k, blockIdx.x, sgm);      // slab blockIdx.x = partial blockIdx.x
             }
         }
         __syncthreads();
@@ -400,11 +401,14 @@ int colsum(int dtype, const void* x, int M, int N, float* out, hipStream_t st) {
     if (slabs < 1) slabs = 1;
     const int rows_per = (M + slabs - 1) / slabs;
     slabs = (M + rows_per - 1) / rows_per;
+    DetParts det;
+    if (det.begin(st, slabs, (size_t)N, "colsum")) return -1;
     if (dtype == SAICV_DTYPE_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(slabs), dim3(CS_THREADS), 0, st, (const bf16_t*)x, M, N, rows_per, out);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(slabs), dim3(CS_THREADS), 0, st, (const bf16_t*)x, M, N, rows_per, out, det.sink());
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(slabs), dim3(CS_THREADS), 0, st, (const float*)x, M, N, rows_per, out);
-    return check_launch("colsum");
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(slabs), dim3(CS_THREADS), 0, st, (const float*)x, M, N, rows_per, out, det.sink());
+    if (check_launch("colsum")) return -2;
+    return det.fold(out, 0, (size_t)N);
 }
 
 }  // namespace saicv

@@ -4,6 +4,7 @@
 // HBM-bound streaming kernels; one 16-byte chunk of channels per thread.
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 namespace {
 
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_kernel(const T
                                                                          const float* __restrict__ invstd, const float* __restrict__ scale,
                                                                          const float* __restrict__ shift, float* __restrict__ sums,
                                                                          int Nimg, int H, int W, int C, int OH, int OW, int K, int stride,
-                                                                         int pad) {
+                                                                         int pad, const saicv::DetSink det) {
     constexpr int N = Chunk<T>::N;
     const int cpr = C / N;
     const size_t total = (size_t)Nimg * OH * OW * cpr;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_kernel(const T
         float a = 0.f;
         for (int t = c0; t < 256; t += cpr) a += red[t * 2 * N + e];
         const int which = e / N, j = e - which * N;
-        unsafeAtomicAdd(sums + (size_t)which * C + c0 * N + j, a);
+        saicv::det_add(det, sums + (size_t)which * C + c0 * N + j, (size_t)which * C + c0 * N + j, blockIdx.x, a);      // workgroup = partial
     }
 }
 
@@ -450,11 +451,15 @@ int bn_relu_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, const v
     SAICV_REQUIRE(K <= 2 * stride + 1, "bn_relu_maxpool_bwd: K=%d, stride=%d: more than 2 x 2 windows cover a pixel", K, stride);
     if (hipMemsetAsync(ws, 0, 2 * (size_t)C * sizeof(float), st) != hipSuccess) { set_error("bn_relu_maxpool_bwd: memset failed"); return -1; }
     const size_t total = (size_t)Nimg * H * W * (C / n), ptotal = (size_t)Nimg * OH * OW * (C / n);
+    DetParts det;
+    if (det.begin(st, sgrid(ptotal), (size_t)2 * C, "bn_relu_maxpool_bwd")) return -1;
     if (dtype == SAICV_DTYPE_BF16) {
-        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<bf16_t>, dim3(sgrid(ptotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad);
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<bf16_t>, dim3(sgrid(ptotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
+        if (det.fold(ws, 0, (size_t)2 * C)) return -1;
         hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, gamma, mean, invstd, scale, shift, ws, (bf16_t*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
     } else {
-        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<float>, dim3(sgrid(ptotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad);
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<float>, dim3(sgrid(ptotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
+        if (det.fold(ws, 0, (size_t)2 * C)) return -1;
         hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, gamma, mean, invstd, scale, shift, ws, (float*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
     }
     return check_launch("bn_relu_maxpool_bwd");

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 namespace {
 
@@ -88,6 +89,7 @@ struct RelPosParams {
     float* dtab_h; float* dtab_w;         // table gradients: RP_COPIES privatised copies, `copy_stride` floats apart
     long copy_stride;
     int B, heads, Sh, Sw;
+    int copies;                           // RP_COPIES; deterministic mode: one copy per workgroup (its adds then have no second contributor)
 };
 
 // stage the table rows this block needs: H rows for query row qh are tab_h[qh - kh + Sh - 1], kh = 0..Sh-1
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(RP_THREADS) void relpos_bwd_tab_kernel(const RelPos
             for (int i = 0; i < NW; ++i) aw[i] += gwr[-16 * i] * qv;
         }
     }
-    const int copy = (blockIdx.y * gridDim.x + blockIdx.x) % RP_COPIES;
+    const int copy = (blockIdx.y * gridDim.x + blockIdx.x) % p.copies;
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
         const int kh = r0 + 16 * i;
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(RP_THREADS) void relpos_bwd_tab_mfma_kernel(const R
         }
     }
     // D tile: rows m = mt*16 + lg*4 + r (kh or j), column = channel wave*16 + l15
-    const int copy = (blockIdx.y * gridDim.x + blockIdx.x) % RP_COPIES;
+    const int copy = (blockIdx.y * gridDim.x + blockIdx.x) % p.copies;
     float* dh = p.dtab_h + (size_t)copy * p.copy_stride;
     float* dw = p.dtab_w + (size_t)copy * p.copy_stride;
     const int c = wave * 16 + l15;
@@ -676,7 +678,16 @@ int relpos_bwd(int dtype, const void* q, void* dq, long q_rs, long q_bs, const f
     p.dq = dq; p.rel_h = const_cast<float*>(d_rel_h); p.rel_w = const_cast<float*>(d_rel_w);
     p.copy_stride = n_h + n_w;
     p.dtab_h = ws; p.dtab_w = ws ? ws + n_h : nullptr;       // kernels write the privatised copies
-    if (dtab_h) hipMemsetAsync(ws, 0, relpos_bwd_ws_floats(Sh, Sw) * sizeof(float), st);
+    p.copies = RP_COPIES;
+    // deterministic mode (det.h): a copy per workgroup in the library's workspace, folded in workgroup order
+    DetParts det;
+    if (dtab_h && det.begin(st, Sh * B, (size_t)(n_h + n_w), "relpos_bwd")) return -1;
+    if (det.on()) {
+        p.dtab_h = det.sink().part; p.dtab_w = det.sink().part + n_h;
+        p.copies = Sh * B;
+    } else if (dtab_h) {
+        hipMemsetAsync(ws, 0, relpos_bwd_ws_floats(Sh, Sw) * sizeof(float), st);
+    }
     const size_t smem1 = (size_t)(Sh + 2 * Sw - 1) * RP_PITCH * sizeof(float);
     const int nh = (Sh + 15) / 16, nw = (2 * Sw - 1 + 15) / 16;
     const int NHc = nh <= 1 ? 1 : nh <= 4 ? 4 : 8, NWc = nw <= 2 ? 2 : 8;
@@ -715,6 +726,11 @@ int relpos_bwd(int dtype, const void* q, void* dq, long q_rs, long q_bs, const f
         if (dtab_h) RP_TAB(float);
     }
 #undef RP_TAB
+    if (det.on()) {
+        if (check_launch("relpos_bwd")) return -2;
+        if (det.fold(dtab_h, 0, (size_t)n_h)) return -1;
+        return det.fold(dtab_w, (size_t)n_h, (size_t)n_w);
+    }
     if (dtab_h)
         hipLaunchKernelGGL(relpos_tab_reduce_kernel, dim3((n_h + n_w + 255) / 256), dim3(256), 0, st, ws, p.copy_stride,
                            n_h + n_w, dtab_h, n_h, dtab_w);

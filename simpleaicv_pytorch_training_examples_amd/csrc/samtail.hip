@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "saicv_internal.h"
+#include "det.h"
 
 namespace {
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(ST_THREADS) void hyper_fwd_kernel(const T* __restri
 template <typename T, int C>
 __global__ __launch_bounds__(ST_THREADS) void hyper_bwd_kernel(const T* __restrict__ x, const T* __restrict__ hyper,
                                                                 const T* __restrict__ dout, T* __restrict__ dx,
-                                                                float* __restrict__ dhyper, int Tm, int P) {
+                                                                float* __restrict__ dhyper, int Tm, int P, const saicv::DetSink det) {
     __shared__ float hs[8 * C];
     __shared__ float xs[ST_THREADS][C + 1];
     __shared__ float ds[8][ST_THREADS];
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(ST_THREADS) void hyper_bwd_kernel(const T* __restri
         const int t = i / C, c = i - t * C;
         float a = 0.f;
         for (int q = 0; q < ST_THREADS; ++q) a = fmaf(ds[t][q], xs[q][c], a);
-        unsafeAtomicAdd(dhyper + (size_t)b * Tm * C + i, a);
+        saicv::det_add(det, dhyper + (size_t)b * Tm * C + i, (size_t)b * Tm * C + i, blockIdx.x, a);      // pixel block = partial
     }
 }
 
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(ST_THREADS) void up4_bwd_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(ST_THREADS) void stats_up4_kernel(const T* __restrict__ low, const float* __restrict__ targets,
                                                                 float* __restrict__ stats, int M, int h, int w,
-                                                                float alpha, float gamma, float thr) {
+                                                                float alpha, float gamma, float thr, const saicv::DetSink det) {
     const int bm = blockIdx.z, b = bm / M, q = blockIdx.y;
     const int j = blockIdx.x * ST_THREADS + threadIdx.x;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(ST_THREADS) void stats_up4_kernel(const T* __restri
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < ST_THREADS / 64; ++k) s += red[k][threadIdx.x];
-        atomicAdd(&stats[(size_t)bm * 6 + threadIdx.x], s);
+        // (column block, low-resolution row) = partial
+        saicv::det_add(det, &stats[(size_t)bm * 6 + threadIdx.x], (size_t)bm * 6 + threadIdx.x, blockIdx.y * gridDim.x + blockIdx.x, s);
     }
 }
 
@@ -349,11 +351,14 @@ int hyper_product_bwd(int dtype, const void* x, const void* hyper, const void* d
     SAICV_REQUIRE(B > 0 && P > 0 && Tm >= 1 && Tm <= 8, "hyper_product: bad sizes B=%d P=%d T=%d", B, P, Tm);
     hipMemsetAsync(dhyper, 0, (size_t)B * Tm * C * sizeof(float), st);
     dim3 grid((P + ST_THREADS - 1) / ST_THREADS, B);
+    DetParts det;
+    if (det.begin(st, (int)grid.x, (size_t)B * Tm * C, "hyper_product_bwd")) return -1;
     if (dtype == SAICV_DTYPE_BF16)
-        hipLaunchKernelGGL((hyper_bwd_kernel<bf16_t, 32>), grid, dim3(ST_THREADS), 0, st, (const bf16_t*)x, (const bf16_t*)hyper, (const bf16_t*)dout, (bf16_t*)dx, dhyper, Tm, P);
+        hipLaunchKernelGGL((hyper_bwd_kernel<bf16_t, 32>), grid, dim3(ST_THREADS), 0, st, (const bf16_t*)x, (const bf16_t*)hyper, (const bf16_t*)dout, (bf16_t*)dx, dhyper, Tm, P, det.sink());
     else
-        hipLaunchKernelGGL((hyper_bwd_kernel<float, 32>), grid, dim3(ST_THREADS), 0, st, (const float*)x, (const float*)hyper, (const float*)dout, (float*)dx, dhyper, Tm, P);
-    return check_launch("hyper_product_bwd");
+        hipLaunchKernelGGL((hyper_bwd_kernel<float, 32>), grid, dim3(ST_THREADS), 0, st, (const float*)x, (const float*)hyper, (const float*)dout, (float*)dx, dhyper, Tm, P, det.sink());
+    if (check_launch("hyper_product_bwd")) return -2;
+    return det.fold(dhyper, 0, (size_t)B * Tm * C);
 }
 
 #define UP4_CHECK(who)                                                                                                   \
@@ -381,11 +386,14 @@ int mask_loss_stats_up4(int dtype, const void* low, const float* targets, float*
     UP4_CHECK("mask_loss_stats_up4");
     hipMemsetAsync(stats, 0, (size_t)planes * 6 * sizeof(float), st);
     dim3 grid((w + ST_THREADS - 1) / ST_THREADS, h, planes);
+    DetParts det;
+    if (det.begin(st, (int)(grid.x * grid.y), (size_t)planes * 6, "mask_loss_stats_up4")) return -1;
     if (dtype == SAICV_DTYPE_BF16)
-        hipLaunchKernelGGL(stats_up4_kernel<bf16_t>, grid, dim3(ST_THREADS), 0, st, (const bf16_t*)low, targets, stats, M, h, w, (float)alpha, (float)gamma, (float)thr);
+        hipLaunchKernelGGL(stats_up4_kernel<bf16_t>, grid, dim3(ST_THREADS), 0, st, (const bf16_t*)low, targets, stats, M, h, w, (float)alpha, (float)gamma, (float)thr, det.sink());
     else
-        hipLaunchKernelGGL(stats_up4_kernel<float>, grid, dim3(ST_THREADS), 0, st, (const float*)low, targets, stats, M, h, w, (float)alpha, (float)gamma, (float)thr);
-    return check_launch("mask_loss_stats_up4");
+        hipLaunchKernelGGL(stats_up4_kernel<float>, grid, dim3(ST_THREADS), 0, st, (const float*)low, targets, stats, M, h, w, (float)alpha, (float)gamma, (float)thr, det.sink());
+    if (check_launch("mask_loss_stats_up4")) return -2;
+    return det.fold(stats, 0, (size_t)planes * 6);
 }
 
 int mask_loss_grad_up4(int dtype, const void* low, const float* targets, const float* coef, void* dlow, int B, int M, int h,

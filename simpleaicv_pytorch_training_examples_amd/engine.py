@@ -640,6 +640,12 @@ class NativeComm:
 
 
 class DistributedDataParallel(torch.nn.Module):
+    _slots_env_set = False
+
+    def __del__(self):
+        if self._slots_env_set:          # the CU-slot share this wrapper asked the weight-gradient kernel for ends with it
+            os.environ.pop('SAICV_TN_SLOTS_PCT', None)
+
     """Drop-in for nn.parallel.DistributedDataParallel on the flat gradient arena.
 
     Honours the surface the reference loop uses (tools/scripts.py:124,155,173,185,219;
@@ -663,7 +669,11 @@ class DistributedDataParallel(torch.nn.Module):
         if self.world > 1 and self.comm is None and self.arena.device.type == 'cuda':
             # torch.distributed's own RCCL kernels will share the GPU with backward: the library only knows about communicators
             # it created itself (g_saicv_comm_world), so tell the weight-gradient kernel to leave CU slots free (csrc/igemm.hip)
-            os.environ.setdefault('SAICV_TN_SLOTS_PCT', '85')
+            # (set for the life of THIS wrapper only -- ADVICE r05: it used to stay in os.environ and slowed every later single-GPU
+            # model of the process; __del__ / close() restore it)
+            if 'SAICV_TN_SLOTS_PCT' not in os.environ:
+                os.environ['SAICV_TN_SLOTS_PCT'] = '85'
+                self._slots_env_set = True
         self._sync = True
         self._works = []
         self._next_bucket = 0           # buckets are launched in list order on every rank

@@ -146,6 +146,34 @@ BN_FUSE = _os.environ.get('SAICV_BN_FUSE', '1') == '1'
 BN_INLINE = _os.environ.get('SAICV_BN_INLINE', '1') == '1'
 
 
+def set_deterministic(on=True):
+    """The engine's counterpart of `torch.backends.cudnn.deterministic = True` (reference tools/utils.py:106-107): with `on`, every
+    reduction of libsaicv_hip.so is ordered (csrc/det.h: partials parked side by side, folded in index order) and the BatchNorm
+    statistics of the convolution epilogues take the fixed-order partial rows -- an fp32 step is then bit-reproducible run to run.
+    Costs a fold launch per weight gradient; the fast default adds partials with fp32 atomics in completion order.
+    tools.utils.set_seed() turns it on (SAICV_DETERMINISTIC=0 in the environment keeps the fast path, as bench.py does);
+    SAICV_DETERMINISTIC=1 turns it on at import.  Returns the previous setting."""
+    global BN_INLINE
+    L = lib()
+    prev = bool(L.saicv_set_deterministic(1 if on else 0))
+    if on:
+        BN_INLINE = False
+        if torch.cuda.is_available():
+            check(L.saicv_deterministic_prepare(stream()), 'deterministic_prepare')
+    else:
+        BN_INLINE = _os.environ.get('SAICV_BN_INLINE', '1') == '1'
+    return prev
+
+
+def is_deterministic():
+    return bool(lib().saicv_get_deterministic())
+
+
+if _os.environ.get('SAICV_DETERMINISTIC') == '1' and _lib.available():
+    lib().saicv_set_deterministic(1)          # (the workspace is allocated by the first reduction: no device context at import)
+    BN_INLINE = False
+
+
 class _BnLink:
     """What the data gradient of the NEXT conv needs to produce the backward partial sums of a BatchNorm(+ReLU) node,
     and where that node finds them.  Travels forward as an attribute of the node's output tensor."""

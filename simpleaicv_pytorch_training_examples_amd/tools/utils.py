@@ -48,12 +48,17 @@ def set_seed(seed):
         torch.cuda.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
     # The reference asks for deterministic kernels here (cudnn.deterministic = True, tools/utils.py:106-107).  This engine's
-    # counterpart: BatchNorm statistics are summed in a FIXED order (one partial row per tile row + the finalize kernels)
-    # instead of being added with fp32 atomics into a few pooled rows (ops.BN_INLINE, the 0.35-0.4 ms faster default of the
-    # benchmark) -- unless SAICV_BN_INLINE=1 asks for the fast path explicitly.  What stays order-dependent: the fp32-atomic
-    # split reduction of the weight gradients ("Deviations").  There is no autotuning to pin.
+    # counterpart is ops.set_deterministic(): every reduction of the HIP library is ordered (weight / bias gradients, statistics,
+    # table gradients, loss sums, the gradient norm: csrc/det.h) and the convolution epilogues write their BatchNorm statistics as
+    # fixed-order partial rows -- an fp32 step is bit-reproducible run to run.  SAICV_DETERMINISTIC=0 keeps the fast atomically
+    # accumulated path (bench.py sets it unless --deterministic); SAICV_BN_INLINE=1 keeps the atomic BatchNorm statistics only.
+    # There is no autotuning to pin.
     from .. import ops
-    if os.environ.get('SAICV_BN_INLINE') is None:
+    if os.environ.get('SAICV_DETERMINISTIC', '1') != '0':
+        ops.set_deterministic(True)
+        if os.environ.get('SAICV_BN_INLINE') == '1':
+            ops.BN_INLINE = True
+    elif os.environ.get('SAICV_BN_INLINE') is None:
         ops.BN_INLINE = False
 
 

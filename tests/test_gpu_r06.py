@@ -1,0 +1,206 @@
+"""Round 6: the deterministic mode (ops.set_deterministic / csrc/det.h) -- the engine's counterpart of the reference's
+`torch.backends.cudnn.deterministic = True` (tools/utils.py:95-107).  Every reduction that adds workgroup partials with fp32 atomics
+in the fast path parks them side by side and folds them in index order instead.  Checked three ways: (1) repeated launches of each
+kernel family give BIT-IDENTICAL results; (2) the ordered result equals the atomically accumulated one up to fp32 summation order
+and the torch fp32 reference of the same op; (3) whole models (every kernel family on the hot path and next to it) repeat their
+forward + backward bit for bit from a fresh construction."""
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu]
+
+
+@pytest.fixture
+def deterministic():
+    from simpleaicv_pytorch_training_examples_amd import ops
+    prev = ops.set_deterministic(True)
+    yield
+    ops.set_deterministic(prev)
+
+
+CONV_GEOMS = [(8, 64, 56, 56, 64, 3, 1, 1), (8, 64, 56, 56, 128, 3, 2, 1), (4, 256, 28, 28, 512, 1, 2, 0), (2, 16, 37, 41, 24, 3, 1, 1),
+              (3, 8, 19, 23, 16, 7, 2, 3), (16, 512, 7, 7, 512, 3, 1, 1), (64, 64, 32, 32, 64, 3, 1, 1), (32, 256, 14, 14, 1024, 1, 1, 0)]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('geom', CONV_GEOMS)
+def test_conv_weight_gradient_is_bit_reproducible_in_deterministic_mode(geom, dtype):
+    """igemm_tn_kernel (fp32) / igemm_tn_dma_kernel (bf16): the split reduction over the pixels parks split s in part[s] and
+    det_fold adds the splits in order.  Three launches: identical bits.  Against the atomic path: within fp32 summation-order noise;
+    against torch's fp32 convolution weight gradient: within the dtype's resolution."""
+    from simpleaicv_pytorch_training_examples_amd import ops
+    n, ci, h, w, co, k, stride, pad = geom
+    g = torch.Generator().manual_seed(sum(geom))
+    x = torch.randn(n, h, w, ci, generator=g).permute(0, 3, 1, 2).cuda().to(dtype)
+    wt = torch.randn(co, ci, k, k, generator=g) * 0.1
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = torch.randn(n, oh, ow, co, generator=g).permute(0, 3, 1, 2).cuda().to(dtype)
+
+    def grad():
+        wp = wt.clone().cuda().requires_grad_(True)
+        ops.bump_weights_epoch()
+        y = ops.conv2d(x.clone().requires_grad_(True), wp, None, stride, pad)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return wp.grad.float().clone()
+
+    atomic = grad()
+    prev = ops.set_deterministic(True)
+    try:
+        runs = [grad() for _ in range(3)]
+    finally:
+        ops.set_deterministic(prev)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), geom
+    ref = torch.nn.grad.conv2d_weight(x.float().cpu(), wt.shape, dy.float().cpu(), stride=stride, padding=pad)
+    scale = float(ref.abs().max())
+    assert float((runs[0] - atomic).abs().max()) <= 2e-5 * scale, geom
+    assert float((runs[0].cpu() - ref).abs().max()) <= (2e-2 if dtype == torch.bfloat16 else 1e-4) * scale, geom
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('mkn', [(300, 96, 40), (4096, 768, 768), (513, 200, 1000), (50432, 768, 2304), (129, 32, 30), (12608, 3072, 768)])
+def test_linear_weight_and_bias_gradients_are_bit_reproducible(mkn, dtype, deterministic):
+    """The same kernels through the linear entry point, with the bias gradient riding in the weight-gradient launch (the dbias
+    partials sit behind the tile partials of a split: det.h)."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    m, k, n = mkn
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g).to(dtype).cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5)
+    b = torch.randn(n, generator=g)
+    dy = torch.randn(m, n, generator=g).to(dtype).cuda()
+
+    def grads():
+        wg, bg = w.clone().cuda().requires_grad_(True), b.clone().cuda().requires_grad_(True)
+        ops_tfm.linear_nd(x.clone().requires_grad_(True), wg, bg).backward(dy)
+        torch.cuda.synchronize()
+        return wg.grad.clone(), bg.grad.clone()
+
+    (w1, b1), (w2, b2), (w3, b3) = grads(), grads(), grads()
+    assert torch.equal(w1, w2) and torch.equal(w1, w3) and torch.equal(b1, b2) and torch.equal(b1, b3), mkn
+    ref_w = dy.float().cpu().t() @ x.float().cpu()
+    ref_b = dy.float().cpu().sum(0)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert float((w1.cpu() - ref_w).abs().max()) <= tol * float(ref_w.abs().max()), mkn
+    assert float((b1.cpu() - ref_b).abs().max()) <= tol * float(ref_b.abs().max()), mkn
+
+
+def test_gradient_norm_is_bit_reproducible(deterministic):
+    """grad_stats_kernel (clip_grad_norm_): one partial per wavefront, folded in order."""
+    from simpleaicv_pytorch_training_examples_amd import _lib
+    g = torch.randn(3 * 1024 * 1024 + 4096, device='cuda')
+    outs = []
+    for _ in range(4):
+        flag, ss = torch.zeros(1, device='cuda'), torch.zeros(1, device='cuda')
+        _lib.check(_lib.lib().saicv_grad_stats(_lib.ptr(g), g.numel(), _lib.ptr(flag), _lib.ptr(ss), _lib.stream()), 'grad_stats')
+        outs.append(float(ss))
+    assert len(set(outs)) == 1 and abs(outs[0] - float((g.double() ** 2).sum())) <= 1e-5 * outs[0], outs
+
+
+def _twice(build, forward, autocast=False):
+    """Two fresh constructions from the same seed, one forward + backward each: -> (outputs equal, list of parameters whose gradients
+    differ, number of parameters with a gradient)."""
+    res = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        model, inputs = build()
+        if autocast:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out = forward(model, inputs)
+        else:
+            out = forward(model, inputs)
+        out.float().backward() if out.dim() == 0 else out.float().pow(2).mean().backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().float().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                    {n: b.detach().clone() for n, b in model.named_buffers()}))
+    (o1, g1, b1), (o2, g2, b2) = res
+    assert set(g1) == set(g2) and len(g1) > 0
+    bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+    bad += ['buffer:' + n for n in b1 if not torch.equal(b1[n], b2[n])]
+    return torch.equal(o1, o2), bad, len(g1)
+
+
+MODEL_CASES = ['resnet18cifar', 'resnet50', 'vit_tiny', 'van_b0', 'convformer', 'darknet19', 'sam_encoder', 'retinanet', 'fcos', 'detr']
+
+
+@pytest.mark.parametrize('amp', [False, True], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('case', MODEL_CASES)
+def test_models_repeat_forward_and_backward_bit_for_bit(case, amp, deterministic):
+    """Every kernel family with a reduction, through the models that use it: implicit-GEMM convolutions with BatchNorm statistics in
+    the epilogue and the stem's fused pool backward (ResNets), LayerNorm / attention / linears (ViT), depthwise convolutions,
+    BatchNorm statistics of block inputs and layer-scale gradients (VAN, ConvFormer), LeakyReLU blocks (Darknet), windowed attention
+    with relative-position table gradients (SAM encoder), GroupNorm heads and the pyramid (RetinaNet, FCOS), the DETR transformer."""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification import backbones
+
+    def images(b, s, seed=1):
+        return torch.randn(b, s, s, 3, generator=torch.Generator().manual_seed(seed)).permute(0, 3, 1, 2).cuda()
+
+    if case == 'resnet18cifar':
+        build = lambda: (backbones.resnet18cifar(num_classes=100).cuda().train(), images(64, 32))
+        fwd = lambda m, x: m(x)
+    elif case == 'resnet50':
+        build = lambda: (backbones.resnet50(num_classes=100).cuda().train(), images(16, 128))
+        fwd = lambda m, x: m(x)
+    elif case == 'vit_tiny':
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.backbones import vit
+        build = lambda: (vit.ViT(patch_size=16, embedding_planes=192, block_nums=3, head_nums=3, feedforward_ratio=4, image_size=64,
+                                 dropout_prob=0., drop_path_prob=0., global_pool=False, num_classes=10).cuda().train(), images(8, 64))
+        fwd = lambda m, x: m(x)
+    elif case == 'van_b0':
+        build = lambda: (backbones.van_b0(num_classes=16).cuda().train(), images(8, 64))
+        fwd = lambda m, x: m(x)
+    elif case == 'convformer':
+        build = lambda: (backbones.convformer_s18(num_classes=16).cuda().train(), images(4, 64))
+        fwd = lambda m, x: m(x)
+    elif case == 'darknet19':
+        build = lambda: (backbones.darknet19(num_classes=16).cuda().train(), images(8, 64))
+        fwd = lambda m, x: m(x)
+    elif case == 'sam_encoder':
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.models.segment_anything.image_encoder import ViTImageEncoder
+        build = lambda: (ViTImageEncoder(image_size=256, patch_size=16, inplanes=3, embedding_planes=128, block_nums=2, head_nums=2, mlp_ratio=4,
+                                         out_planes=64, window_size=7, global_attn_indexes=[1]).cuda().train(), images(2, 256))
+        fwd = lambda m, x: m(x)
+    elif case in ('retinanet', 'fcos'):
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import fcos, retinanet
+        factory = retinanet.resnet18_retinanet if case == 'retinanet' else fcos.resnet18_fcos
+        build = lambda: (factory(num_classes=20).cuda().train(), images(2, 256))
+        fwd = lambda m, x: sum(o.float().pow(2).mean() for outs in m(x) for o in (outs if isinstance(outs, (list, tuple)) else [outs]))
+    else:
+        from oracle.make_golden_detr import detr_inputs, zero_dropout
+        from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.models import detr
+
+        def build():
+            m = detr.resnet18_detr(hidden_inplanes=256, query_nums=20, num_classes=20)
+            zero_dropout(m)
+            im, mask, _ = detr_inputs(2, 1000)
+            return m.cuda().train(), (im.cuda(), mask.cuda())
+        fwd = lambda m, xm: sum(o.float().pow(2).mean() for o in m(*xm))
+    same_out, bad, n = _twice(build, fwd, autocast=amp)
+    assert same_out, f'{case}: the outputs of two runs differ'
+    assert not bad, f'{case}: {len(bad)} of {n} gradients / buffers differ between two runs, e.g. {bad[:5]}'
+
+
+def test_losses_and_prompt_path_of_sam_repeat_bit_for_bit(deterministic):
+    """The SAM tail: prompt tokens, two-way transformer, hyper-network product, x4 upsampling, the six mask-loss sums per mask and
+    their gradient -- one forward + backward of the tiny SAM with SAMLoss, twice."""
+    from oracle.make_golden_sam import SAM_TINY, sam_inputs, sam_two_pass_loss
+    from oracle.torch_oracle import sam_randomize_zero_init
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation import losses
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.interactive_segmentation.models.segment_anything import sam
+    crit = losses.SAMLoss(alpha=0.25, gamma=2, focal_loss_weight=20, dice_loss_weight=1, iou_predict_loss_weight=1, supervise_all_iou=True,
+                          mask_threshold=0.0)
+    res = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        net = sam.SAM(**SAM_TINY)
+        sam_randomize_zero_init(net.named_parameters(), 100)
+        net = net.cuda().train()
+        images, masks, points, boxes = sam_inputs(SAM_TINY, 2, 2000)
+        ld, total, _, _ = sam_two_pass_loss(net, crit, images.cuda(), masks.cuda(), points.cuda(), boxes.cuda(), SAM_TINY['image_size'])
+        total.backward()
+        torch.cuda.synchronize()
+        res.append(({k: float(v) for k, v in ld.items()}, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    (l1, g1), (l2, g2) = res
+    assert l1 == l2, (l1, l2)
+    bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+    assert not bad, bad[:8]
