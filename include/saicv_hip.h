@@ -494,6 +494,13 @@ int saicv_channel_scale_add_bwd(int dtype, const void* dout, const void* y, cons
  * BatchNorm2d whose input is not a convolution output (van.py:176,178,260; convformer.py:34-35,143,149); feed them to
  * saicv_bn_finalize_fwd(rows = 1), then saicv_bn_act_fwd / saicv_bn_act_bwd as for the fused blocks. */
 int saicv_bn_stats(int dtype, const void* x, size_t M, int C, float* sum, float* sq, void* stream);
+/* The feature pyramid's top-down merge (reference SimpleAICV/detection/models/fpn.py:57-75): out[N,H,W,C] (fp32) =
+ * F.interpolate(top[N,h,w,C], size=(H,W), mode='bilinear', align_corners=False) + lateral[N,H,W,C] (NULL: the resize alone), ATen's
+ * fp32 tap arithmetic; and its gradient towards `top` as a fixed-order GATHER (ATen's backward scatters with atomics: not
+ * reproducible run to run).  dtype_top / dtype_lat: SAICV_BF16 | SAICV_F32; C % 4 == 0. */
+int saicv_resize_bilinear_add_fwd(int dtype_top, int dtype_lat, const void* top, const void* lateral, float* out, int N, int h, int w,
+                                  int H, int W, int C, void* stream);
+int saicv_resize_bilinear_bwd(int dtype_top, const float* dout, void* dtop, int N, int h, int w, int H, int W, int C, void* stream);
 
 /* ---- nn.GroupNorm (+ ReLU) on NHWC activations (csrc/groupnorm.hip; reference SimpleAICV/detection/models/head.py:101-124) ---- */
 size_t saicv_groupnorm_ws_floats(int N, int C);

@@ -29,6 +29,8 @@ class RetinaFPN(nn.Module):
 
     @staticmethod
     def _merge(top, lateral):
+        if top.is_cuda and top.shape[1] % 4 == 0:
+            return ops.resize_bilinear_add(top, lateral)      # one pass; its backward is a fixed-order gather (ATen's uses atomics)
         return F.interpolate(top, size=(lateral.shape[2], lateral.shape[3]), mode='bilinear') + lateral
 
     def forward(self, inputs):

@@ -173,6 +173,8 @@ SIGNATURES = {
     'saicv_channel_scale_add_fwd': (c_int, [c_int, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'saicv_channel_scale_add_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'saicv_bn_stats': (c_int, [c_int, _P, c_size_t, c_int, _P, _P, _P]),
+    'saicv_resize_bilinear_add_fwd': (c_int, [c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'saicv_resize_bilinear_bwd': (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_retina_assign': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'saicv_focal_loss_level': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_double, _P]),
     'saicv_smoothl1_level': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, _P]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsaicv_hip.so')
-SOURCES = ['igemm.hip', 'bn.hip', 'pool.hip', 'loss.hip', 'pack.hip', 'optim.hip', 'tfm.hip', 'attn_stream.hip', 'maskloss.hip', 'sam.hip', 'samtail.hip', 'input.hip', 'dwconv.hip', 'elemwise.hip', 'detloss.hip', 'groupnorm.hip', 'comm.hip', 'det.hip', 'capi.hip']
+SOURCES = ['igemm.hip', 'pwstream.hip', 'bn.hip', 'pool.hip', 'loss.hip', 'pack.hip', 'optim.hip', 'tfm.hip', 'attn_stream.hip', 'maskloss.hip', 'sam.hip', 'samtail.hip', 'input.hip', 'dwconv.hip', 'elemwise.hip', 'detloss.hip', 'groupnorm.hip', 'comm.hip', 'det.hip', 'capi.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
          '-Wno-unused-result', '-Wno-unused-value']
 # attn_stream.hip: the running-maximum chains of the softmax are v_max3_f32 only when the compiler need not quiet signalling

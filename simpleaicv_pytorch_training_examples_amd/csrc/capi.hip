@@ -139,7 +139,7 @@ int saicv_unpack_wgrad_s2d(const float* dw, int O, int I, int R, int Sx, int Cq,
 
 int saicv_conv2d_stat_rows(const saicv_conv_desc* d) {
     if (!d) return -1;
-    return conv_stat_rows(d->N * d->OH * d->OW, d->K, d->R * d->S * d->C, d->dtype);
+    return conv_stat_rows(d->N * d->OH * d->OW, d->K, d->R * d->S * d->C, d->dtype, d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1);
 }
 
 int saicv_conv2d_fwd(const saicv_conv_desc* d, const void* x, const void* wf, const float* bias,
@@ -229,7 +229,8 @@ int saicv_conv2d_dgrad_add(const saicv_conv_desc* d, const void* dy, const void*
 }
 int saicv_conv2d_dgrad_stat_rows(const saicv_conv_desc* d) {
     if (!d) return -1;
-    return conv_bwd_stat_rows(d->N * d->H * d->W, d->H, d->W, d->C, d->R * d->S * d->K, d->stride, d->dtype);
+    return conv_bwd_stat_rows(d->N * d->H * d->W, d->H, d->W, d->C, d->R * d->S * d->K, d->stride, d->dtype,
+                              d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1);
 }
 int saicv_conv2d_dgrad_fused(const saicv_conv_desc* d, const void* dy, const void* wd, const saicv_dgrad_fuse* f, void* dx,
                              void* stream) {

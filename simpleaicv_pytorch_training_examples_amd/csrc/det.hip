@@ -10,21 +10,58 @@ int g_deterministic = 0;
 
 namespace {
 
-// One workspace per stream that ever ran a deterministic reduction (the step's kernels run on one stream; the optional weight-gradient
-// side stream of ops._SideStream is a second).  A reduction's partials live from its kernel to its fold, both on the same stream, so
-// successive reductions of a stream reuse the same memory in stream order.
+// One workspace per stream that ever ran a deterministic reduction eagerly (the step's kernels run on one stream; the optional
+// weight-gradient side stream of ops._SideStream is a second -- ops.set_deterministic switches it off).  A reduction's partials live
+// from its kernel to its fold, both on the same stream, so successive reductions of a stream reuse the same memory in stream order.
+// A stream that is being CAPTURED into a hipGraph (torch captures on a stream of its own) cannot allocate: every capturing stream
+// takes the one capture workspace, which is kept as large as the largest eager workspace -- the eager warm-up steps that precede a
+// capture have sized it.  Graph nodes of one capture are ordered by the capture's dependencies like launches of one stream.
 struct StreamWs { hipStream_t st; float* p; size_t floats; };
-constexpr int MAX_STREAMS = 8;
-StreamWs g_ws[MAX_STREAMS] = {};
-int g_nws = 0;
-std::mutex g_mu;
-
 // The weight-gradient kernels need at most 512 resident tiles of 128 x 128 (or 256 of 256 x 256) fp32 partials = 32 / 64 MiB; every
 // other user stays far below.  Allocated up front so that no allocation falls inside a hipGraph capture.
 constexpr size_t kInitialFloats = (size_t)24 << 20;      // 96 MiB
+constexpr int MAX_STREAMS = 8;
+StreamWs g_ws[MAX_STREAMS] = {};
+int g_nws = 0;
+StreamWs g_capture = {nullptr, nullptr, 0};
+size_t g_max_floats = 0;
+std::mutex g_mu;
+
+bool is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cap != hipStreamCaptureStatusNone;
+}
+
+bool grow(StreamWs* w, size_t floats, size_t start, const char* who) {
+    if (w->floats >= floats) return true;
+    size_t want = w->floats ? w->floats : start;
+    while (want < floats) want *= 2;
+    float* fresh = nullptr;
+    const hipError_t e = hipMalloc(&fresh, want * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        saicv::set_error("%s: deterministic workspace of %zu MiB: %s", who, want * sizeof(float) >> 20, hipGetErrorString(e));
+        return false;
+    }
+    // the old block may still be read by a fold in flight: it is left to the process (growth is rare and doubles)
+    w->p = fresh;
+    w->floats = want;
+    if (want > g_max_floats) g_max_floats = want;
+    return true;
+}
 
 float* ws_for(hipStream_t st, size_t floats, const char* who) {
     std::lock_guard<std::mutex> lock(g_mu);
+    if (is_capturing(st)) {
+        if (g_capture.floats < floats) {
+            set_error("%s: the deterministic capture workspace holds %zu MiB, %zu MiB needed (a workspace cannot grow inside a hipGraph "
+                      "capture: call saicv_deterministic_prepare / run the step eagerly once before capturing it)", who,
+                      g_capture.floats * sizeof(float) >> 20, floats * sizeof(float) >> 20);
+            return nullptr;
+        }
+        return g_capture.p;
+    }
     StreamWs* w = nullptr;
     for (int i = 0; i < g_nws; ++i)
         if (g_ws[i].st == st) { w = &g_ws[i]; break; }
@@ -36,21 +73,8 @@ float* ws_for(hipStream_t st, size_t floats, const char* who) {
         w = &g_ws[g_nws++];
         *w = StreamWs{st, nullptr, 0};
     }
-    if (w->floats < floats) {
-        size_t want = w->floats ? w->floats : kInitialFloats;
-        while (want < floats) want *= 2;
-        float* fresh = nullptr;
-        const hipError_t e = hipMalloc(&fresh, want * sizeof(float));
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("%s: deterministic workspace of %zu MiB: %s (a workspace cannot grow inside a hipGraph capture: run the step "
-                      "eagerly once first)", who, want * sizeof(float) >> 20, hipGetErrorString(e));
-            return nullptr;
-        }
-        // the old block may still be read by a fold in flight on this stream: it is left to the process (growth is rare and doubles)
-        w->p = fresh;
-        w->floats = want;
-    }
+    if (!grow(w, floats, kInitialFloats, who)) return nullptr;
+    if (!grow(&g_capture, g_max_floats, kInitialFloats, who)) return nullptr;      // (outside any capture here)
     return w->p;
 }
 

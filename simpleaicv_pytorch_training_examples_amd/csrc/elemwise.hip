@@ -174,6 +174,91 @@ __global__ __launch_bounds__(EW_THREADS) void colred_kernel(const T* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- bilinear resize (feature pyramid)
+// F.interpolate(top, size=(H, W), mode='bilinear') (align_corners = False) + lateral of the pyramid's top-down path (reference
+// SimpleAICV/detection/models/fpn.py:57-75), NHWC.  ATen's arithmetic in fp32: scale = in / out, src = max(scale * (dst + 0.5) - 0.5, 0),
+// i0 = int(src), i1 = i0 + (i0 < in - 1), weights (1 - frac, frac).  The output is fp32 whatever the inputs are (torch.autocast
+// runs interpolate in fp32 and the add promotes).  ATen's backward scatters with atomics (not reproducible run to run); here the
+// gradient is a GATHER: a source pixel walks the few destination rows / columns whose taps touch it, in a fixed order.
+struct ResizeTap { int i0, i1; float w0, w1; };
+DEVINL ResizeTap resize_tap(int d, float scale, int n_in) {
+    const float src = fmaxf(scale * ((float)d + 0.5f) - 0.5f, 0.f);
+    ResizeTap t;
+    t.i0 = (int)src;
+    t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
+    t.w1 = src - (float)t.i0;
+    t.w0 = 1.f - t.w1;
+    return t;
+}
+template <typename T> DEVINL f32x4 ld4(const T* p);
+template <> DEVINL f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> DEVINL f32x4 ld4<bf16_t>(const bf16_t* p) {
+    const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+}
+template <typename T> DEVINL void st4(T* p, f32x4 v);
+template <> DEVINL void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> DEVINL void st4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+template <typename TT, typename TL>
+__global__ __launch_bounds__(EW_THREADS) void resize_add_fwd_kernel(const TT* __restrict__ top, const TL* __restrict__ lat, float* __restrict__ out,
+                                                                    int Nn, int h, int w, int H, int W, int C, float sh, float sw) {
+    const int c4 = C / 4;
+    const size_t items = (size_t)Nn * H * W * c4;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < items; i += (size_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % c4);
+        size_t t = i / c4;
+        const int ox = (int)(t % W); t /= W;
+        const int oy = (int)(t % H);
+        const int n = (int)(t / H);
+        const ResizeTap ty = resize_tap(oy, sh, h), tx = resize_tap(ox, sw, w);
+        const TT* b = top + (size_t)n * h * w * C + (size_t)c * 4;
+        const f32x4 v00 = ld4(b + ((size_t)ty.i0 * w + tx.i0) * C), v01 = ld4(b + ((size_t)ty.i0 * w + tx.i1) * C);
+        const f32x4 v10 = ld4(b + ((size_t)ty.i1 * w + tx.i0) * C), v11 = ld4(b + ((size_t)ty.i1 * w + tx.i1) * C);
+        f32x4 o = ty.w0 * (tx.w0 * v00 + tx.w1 * v01) + ty.w1 * (tx.w0 * v10 + tx.w1 * v11);
+        if (lat) o += ld4(lat + i * 4);
+        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    }
+}
+
+// dtop[n, y, x, :] = sum over destination pixels (oy, ox) of wy(oy -> y) * wx(ox -> x) * dout[n, oy, ox, :]
+template <typename TT>
+__global__ __launch_bounds__(EW_THREADS) void resize_bwd_kernel(const float* __restrict__ dout, TT* __restrict__ dtop, int Nn, int h, int w, int H,
+                                                                int W, int C, float sh, float sw) {
+    const int c4 = C / 4;
+    const size_t items = (size_t)Nn * h * w * c4;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < items; i += (size_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % c4);
+        size_t t = i / c4;
+        const int x = (int)(t % w); t /= w;
+        const int y = (int)(t % h);
+        const int n = (int)(t / h);
+        // destination rows whose source position lies in (y - 1, y + 1): a generous integer window, the taps decide
+        const int oy0 = max((int)(((float)y - 1.f + 0.5f) / sh - 0.5f) - 1, 0), oy1 = min((int)(((float)y + 1.f + 0.5f) / sh - 0.5f) + 2, H - 1);
+        const int ox0 = max((int)(((float)x - 1.f + 0.5f) / sw - 0.5f) - 1, 0), ox1 = min((int)(((float)x + 1.f + 0.5f) / sw - 0.5f) + 2, W - 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* g = dout + (size_t)n * H * W * C + (size_t)c * 4;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const ResizeTap ty = resize_tap(oy, sh, h);
+            const float wy = (ty.i0 == y ? ty.w0 : 0.f) + (ty.i1 == y ? ty.w1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const ResizeTap tx = resize_tap(ox, sw, w);
+                const float wx = (tx.i0 == x ? tx.w0 : 0.f) + (tx.i1 == x ? tx.w1 : 0.f);
+                if (wx == 0.f) continue;
+                acc += (wy * wx) * *reinterpret_cast<const f32x4*>(g + ((size_t)oy * W + ox) * C);
+            }
+        }
+        st4(dtop + i * 4, acc);
+    }
+}
+
 struct ColGeom { int cw; dim3 grid; size_t rpb; };
 inline ColGeom col_geom(size_t M, int cpr) {
     ColGeom g;
@@ -439,6 +524,33 @@ int saicv_bn_stats(int dtype, const void* x, size_t M, int C, float* sum, float*
     if (saicv::check_launch("bn_stats")) return -2;
     if (det.fold(sum, 0, (size_t)C)) return -1;
     return det.fold(sq, (size_t)C, (size_t)C);
+}
+
+// out[N, H, W, C] (fp32) = bilinear_resize(top[N, h, w, C]) + lateral[N, H, W, C] (NULL: none); dtype_top / dtype_lat: SAICV_BF16 | SAICV_F32
+int saicv_resize_bilinear_add_fwd(int dtype_top, int dtype_lat, const void* top, const void* lateral, float* out, int N, int h, int w, int H,
+                                  int W, int C, void* stream) {
+    SAICV_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "resize_bilinear_add_fwd: N=%d %dx%d -> %dx%d C=%d (C %% 4)", N, h, w, H, W, C);
+    hipStream_t st = (hipStream_t)stream;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const size_t items = (size_t)N * H * W * (C / 4);
+    const bool tb = dtype_top == SAICV_DTYPE_BF16, lb = dtype_lat == SAICV_DTYPE_BF16;
+#define RS_FWD(TT, TL) hipLaunchKernelGGL((resize_add_fwd_kernel<TT, TL>), dim3(ew_grid(items)), dim3(EW_THREADS), 0, st, (const TT*)top, (const TL*)lateral, out, N, h, w, H, W, C, sh, sw)
+    if (tb && lb) RS_FWD(bf16_t, bf16_t); else if (tb) RS_FWD(bf16_t, float); else if (lb) RS_FWD(float, bf16_t); else RS_FWD(float, float);
+#undef RS_FWD
+    return saicv::check_launch("resize_bilinear_add_fwd");
+}
+
+// dtop[N, h, w, C] (dtype_top) = the transposed map applied to dout[N, H, W, C] (fp32): a gather in a fixed order
+int saicv_resize_bilinear_bwd(int dtype_top, const float* dout, void* dtop, int N, int h, int w, int H, int W, int C, void* stream) {
+    SAICV_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "resize_bilinear_bwd: N=%d %dx%d -> %dx%d C=%d (C %% 4)", N, h, w, H, W, C);
+    hipStream_t st = (hipStream_t)stream;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const size_t items = (size_t)N * h * w * (C / 4);
+    if (dtype_top == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL((resize_bwd_kernel<bf16_t>), dim3(ew_grid(items)), dim3(EW_THREADS), 0, st, dout, (bf16_t*)dtop, N, h, w, H, W, C, sh, sw);
+    else
+        hipLaunchKernelGGL((resize_bwd_kernel<float>), dim3(ew_grid(items)), dim3(EW_THREADS), 0, st, dout, (float*)dtop, N, h, w, H, W, C, sh, sw);
+    return saicv::check_launch("resize_bilinear_bwd");
 }
 
 }  // extern "C"

@@ -2476,7 +2476,11 @@ namespace saicv {
 
 // rows of BN partial statistics written by the forward kernel: one per row of workgroups (per row of wavefronts when the
 // launch is persistent)
-int conv_stat_rows(int M, int Nn, int Kd, int dtype) {
+int conv_stat_rows(int M, int Nn, int Kd, int dtype, bool dense_rows) {
+    if (dense_rows) {                                      // pointwise, stride 1, no padding: the streaming kernel's row per workgroup
+        const int pw = pw_stream_blocks(dtype, M, Nn, Kd);
+        if (pw > 0) return pw;
+    }
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
     const NTPlan pl = nt_plan(dtype, 0, 1, M, Nn, (Kd + bk - 1) / bk, dtype == SAICV_DTYPE_F32);
     const NTTile& g = kTiles[pl.tile];
@@ -2484,7 +2488,11 @@ int conv_stat_rows(int M, int Nn, int Kd, int dtype) {
 }
 
 // partial rows the data gradient writes with EpiExtra::bs_*: (rows of tiles of the largest parity class) x classes
-int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype) {
+int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype, bool dense_rows) {
+    if (dense_rows && stride == 1) {
+        const int pw = pw_stream_blocks(dtype, M, Nn, Kd);
+        if (pw > 0) return pw;
+    }
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
     int M_tile = M;
     if (stride > 1) M_tile = (M / (OH * OW)) * ((OH + stride - 1) / stride) * ((OW + stride - 1) / stride);
@@ -2550,6 +2558,15 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
         const int osz = (out_f32 || dtype == SAICV_DTYPE_F32) ? 4 : 2;
         SAICV_REQUIRE((ldo * osz) % 16 == 0, "igemm_nt: fused residual needs a 16-byte aligned leading dimension");
         SAICV_REQUIRE(p.rows_per_scale >= 1, "igemm_nt: rows_per_scale must be >= 1");
+    }
+    // Small-K x small-N pointwise products over many rows (ResNet stage 1-2 1 x 1 convolutions and their data gradients): the
+    // weight-resident streaming kernel of pwstream.hip -- no tiles, no workgroup barriers, one partial row per workgroup.
+    if (dtype == SAICV_DTYPE_BF16 && !out_f32 && R == 1 && S == 1 && pad == 0 && stride == 1 && ldo == Nn && !bias && !p.act_mode &&
+        !p.row_scale && !p.out2 && !(stat_sum && (p.addend || p.bs_y))) {
+        static const long min_mb = getenv("SAICV_NT_STREAM_MIN_MB") ? atol(getenv("SAICV_NT_STREAM_MIN_MB")) : 0;
+        const int so = (size_t)M * Nn * 2 >= (size_t)min_mb * 1024 * 1024 ? 1 : 0;
+        const int rc = pw_stream(M, Nn, Kd, src, wgt, out, stat_sum, stat_sq, p.stat_atomic_rows, ex, so, st);
+        if (rc != 0) return rc < 0 ? rc : 0;
     }
     p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = M; p.Nn = Nn; p.Kd = Kd; p.ldo = ldo;

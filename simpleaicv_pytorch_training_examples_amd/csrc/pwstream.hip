@@ -1,0 +1,317 @@
+// Streaming pointwise convolution for the small-K x small-N layers of a residual stage (r06).
+//
+// ResNet-50's first stage at batch 256 runs 1 x 1 convolutions over M = 802 816 pixels with K, N in {64, 256}
+// (reference SimpleAICV/classification/backbones/resnet.py:100-155, nn.Conv2d(inplanes, planes, 1) inside ConvBnActBlock :33-43)
+// and their data gradients.  Per 16 pixels that is 2-8 KiB in, 2-8 KiB out and 0.13-0.5 MFLOP: HBM-bound by a factor of three to
+// ten.  The tiled kernel (igemm.hip, igemm_nt1_kernel) spends 6.5-8 us of fixed cost per 128- or 256-row tile around a K loop of
+// 1 us (profiles/r05_nt_timeline.md) and reaches 0.25-0.55 of the HBM bound on these shapes.
+//
+// Here there is no tile seam at all:
+//   * the grid is ONE resident round of workgroups; every wavefront is an independent stream over 16-pixel row groups
+//     (group g, g + G, g + 2G, ...), it never meets a workgroup barrier before the last statistics row;
+//   * the WEIGHTS LIVE IN REGISTERS for the whole launch: a wavefront owns 64 output channels, i.e. 4 MFMA row tiles x K / 32
+//     k-steps of 16-byte fragments = 32 (K = 64) to 128 (K = 256) VGPRs, loaded once; wider layers split the channels over the
+//     NSPLIT wavefronts of a group, which then read the same (small) input rows -- L1 / L2 hits;
+//   * the activations need no LDS either: with the weights as the FIRST MFMA operand, lane (pixel = lane & 15, k-group = lane >> 4)
+//     of the second operand is 16 contiguous bytes of that pixel's row -- one global load per k-step, DEPTH row groups in flight
+//     in registers ahead of the one being multiplied;
+//   * the accumulators (channel rows x pixel columns) are staged through a WAVE-PRIVATE 2 KiB strip of LDS and read back as
+//     16-byte row chunks, so that HBM sees whole 128-byte lines per pixel and every fused operand (shortcut gradient, its ReLU
+//     gate, the pre-BatchNorm activation and its mask) is addressed exactly like the output; LDS operations of one wavefront
+//     execute in order, so the strip needs no barrier;
+//   * BatchNorm statistics (forward) and BatchNorm-backward sums (data gradient) accumulate in 16 registers per lane over the
+//     wavefront's WHOLE stream and are combined once, at the end: one row of partials per workgroup (or atomics into the few
+//     pooled rows of SAICV_BN_INLINE).
+// Same arithmetic as the tiled kernel: bf16 operands, fp32 accumulation, statistics of the values as stored (rounded to bf16).
+#include <stdlib.h>
+
+#include "common.h"
+#include "saicv_internal.h"
+
+namespace {
+
+struct PWParams {
+    const bf16_t* src;          // [M][KD]
+    const bf16_t* wgt;          // [ND][KD]
+    bf16_t* out;                // [M][ND]
+    float* stat_sum;            // forward BatchNorm statistics [rows][ND] (nullptr: none)
+    float* stat_sq;
+    int stat_atomic_rows;       // > 0: both kinds of sums are ADDED into this many zeroed rows; 0: row = workgroup
+    const bf16_t* addend;       // out += addend (where its gate bit is set)
+    const uint8_t* addend_gate; // one byte per 16-byte chunk of out
+    const bf16_t* bs_y;         // BatchNorm-backward sums of the stored output: g = out * [mask], bs_g = sum g,
+    const uint8_t* bs_mask;     //   bs_gx = sum g * (y - mean) * invstd
+    const float* bs_mean;
+    const float* bs_invstd;
+    float* bs_g;
+    float* bs_gx;
+    uint32_t src_bytes;
+    int M, mtiles, units;       // rows, 16-row groups, wavefront groups of the launch
+    int stream_out;
+};
+
+DEVINL void st_stream(void* q, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+}
+
+// KD input channels, ND output channels; NSPLIT wavefronts share a row group, 64 channels each (ND = 64 * NSPLIT)
+template <int KD, int ND, int NSPLIT, bool STATS, bool EXTRAS>
+__global__ __launch_bounds__(64 * (NSPLIT > 4 ? NSPLIT : 4)) void pw_stream_kernel(const PWParams p) {
+    constexpr int NWAVES = NSPLIT > 4 ? NSPLIT : 4;
+    constexpr int GPB = NWAVES / NSPLIT;          // row-group streams per workgroup
+    constexpr int NT = 4, KS = KD / 32;           // MFMA row tiles (channels) and k-steps per wavefront
+    constexpr int CPR = 8, RPP = 8, NPASS = 2;    // staged strip: 16 rows x 128 bytes, copied out 8 rows per pass
+    constexpr int PITCH = 128 + 16;
+    constexpr int DEPTH = KD <= 64 ? 4 : 2;       // row groups in flight in registers
+    constexpr uint32_t OOB = 0xfffffff0u;
+    static_assert(ND == 64 * NSPLIT && KD % 32 == 0, "64 channels per wavefront");
+    __shared__ __attribute__((aligned(16))) char strip[NWAVES][16 * PITCH];
+    __shared__ float red[(STATS || EXTRAS) ? NWAVES * 2 * 64 : 1];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int slice = wave % NSPLIT;              // which 64 channels
+    const int nc0 = slice * 64;
+    const int unit = blockIdx.x * GPB + wave / NSPLIT;
+    const int U = p.units;
+
+    // ---- weights: fragment (nt, ks) = rows nc0 + nt*16 + l15, k = ks*32 + lg*8 .. +7
+    u32x4 wf[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wf[nt][ks] = ld_chunk(p.wgt + (size_t)(nc0 + nt * 16 + l15) * KD + ks * 32 + lg * 8);
+
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.src), 0, p.src_bytes, 0x00020000);
+    u32x4 bfr[DEPTH][KS];
+    const uint32_t lane_off = (uint32_t)l15 * (KD * 2) + (uint32_t)lg * 16;
+    auto load_tile = [&](u32x4 (&dst)[KS], int tile) __attribute__((always_inline)) {
+        const uint32_t base = tile < p.mtiles ? (uint32_t)tile * (16 * KD * 2) + lane_off : OOB;       // rows past M read zeros (buffer bounds)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            dst[ks] = __builtin_amdgcn_raw_buffer_load_b128(src_rs, (int)(tile < p.mtiles ? base + ks * 64 : OOB), 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_tile(bfr[d], unit + d * U);
+
+    float ssum[8], ssq[8];        // STATS: sum / sum of squares; EXTRAS: sum g / sum g * y   of this lane's 8 channels
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    const bool addp = EXTRAS && p.addend != nullptr, gatep = EXTRAS && p.addend_gate != nullptr;
+    const bool bsp = EXTRAS && p.bs_y != nullptr, maskp = EXTRAS && p.bs_mask != nullptr;
+    const bool stream_out = p.stream_out != 0;
+    char* const my = strip[wave];
+    const int crow = lane / CPR, cchunk = lane % CPR;             // copy-out coordinates: row of the pass, 16-byte chunk of the 128-byte row
+
+    for (int t0 = unit; t0 < p.mtiles; t0 += DEPTH * U) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int tile = t0 + d * U;
+            if (tile >= p.mtiles) break;                          // wave-uniform
+            // fused operands of the two passes: requested before the products, consumed behind the staging round trip
+            u32x4 av[NPASS], yv[NPASS];
+            unsigned gb[NPASS], mb[NPASS];
+            size_t ooff[NPASS];
+            bool rok[NPASS];
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = tile * 16 + ps * RPP + crow;
+                rok[ps] = row < p.M;
+                ooff[ps] = (size_t)row * ND + nc0 + cchunk * 8;
+                av[ps] = u32x4{0u, 0u, 0u, 0u};
+                yv[ps] = u32x4{0u, 0u, 0u, 0u};
+                gb[ps] = 0xffu;
+                mb[ps] = 0xffu;
+                if (EXTRAS && rok[ps]) {
+                    if (addp) av[ps] = ld_chunk(p.addend + ooff[ps]);
+                    if (bsp) yv[ps] = ld_chunk(p.bs_y + ooff[ps]);
+                    if (gatep) gb[ps] = p.addend_gate[ooff[ps] >> 3];
+                    if (maskp) mb[ps] = p.bs_mask[ooff[ps] >> 3];
+                }
+            }
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) Mma<bf16_t>::run(acc[nt], wf[nt][ks], bfr[d][ks]);
+            load_tile(bfr[d], tile + DEPTH * U);                  // the slot is free again: DEPTH groups ahead
+            // accumulators -> strip: D row lg*4 + r of tile nt = channel nt*16 + lg*4 + r, D column = pixel l15
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)acc[nt][r];
+                *reinterpret_cast<bf16x4*>(my + l15 * PITCH + (nt * 16 + lg * 4) * 2) = pk;
+            }
+            __builtin_amdgcn_wave_barrier();                      // (compiler ordering only: one wavefront's LDS operations execute in order)
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                u32x4 v = ld_chunk(my + (ps * RPP + crow) * PITCH + cchunk * 16);
+                float f[8];
+                if (EXTRAS && (addp || bsp)) {
+                    Chunk<bf16_t>::unpack(v, f);
+                    if (addp) {
+                        float a[8];
+                        Chunk<bf16_t>::unpack(av[ps], a);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += ((gb[ps] >> e) & 1u) ? a[e] : 0.f;
+                        v = Chunk<bf16_t>::pack(f);
+                        if (bsp) Chunk<bf16_t>::unpack(v, f);     // the sums are over what is stored
+                    }
+                    if (bsp) {
+                        float yy[8];
+                        Chunk<bf16_t>::unpack(yv[ps], yy);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float ge = ((mb[ps] >> e) & 1u) ? f[e] : 0.f;
+                            ssum[e] += ge;
+                            ssq[e] = fmaf(ge, yy[e], ssq[e]);
+                        }
+                    }
+                }
+                if (STATS) {
+                    Chunk<bf16_t>::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] = fmaf(f[e], f[e], ssq[e]); }
+                }
+                if (rok[ps]) {
+                    if (stream_out) st_stream(p.out + ooff[ps], v);
+                    else st_chunk(p.out + ooff[ps], v);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    if constexpr (STATS || EXTRAS) {
+        const bool want = STATS ? p.stat_sum != nullptr : bsp;     // uniform
+        if (want) {
+            if (EXTRAS) {
+                // sum g * (y - mean) * invstd = invstd * (sum g y - mean * sum g): the mean leaves while the sums are this lane's few
+                // dozen rows -- not after the whole column (cancellation)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = nc0 + cchunk * 8 + e;
+                    ssq[e] = p.bs_invstd[c] * fmaf(-p.bs_mean[c], ssum[e], ssq[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                          // the 8 row lanes of a chunk column: lanes cchunk + 8 j
+                ssum[e] += __shfl_xor(ssum[e], 8, 64);  ssq[e] += __shfl_xor(ssq[e], 8, 64);
+                ssum[e] += __shfl_xor(ssum[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64);
+                ssum[e] += __shfl_xor(ssum[e], 32, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
+            }
+            if (lane < CPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[(wave * 2 + 0) * 64 + lane * 8 + e] = ssum[e];
+                    red[(wave * 2 + 1) * 64 + lane * 8 + e] = ssq[e];
+                }
+            }
+        }
+        __syncthreads();
+        if (want) {
+            float* const d0 = STATS ? p.stat_sum : p.bs_g;
+            float* const d1 = STATS ? p.stat_sq : p.bs_gx;
+            const size_t row = p.stat_atomic_rows ? (size_t)(blockIdx.x % p.stat_atomic_rows) : (size_t)blockIdx.x;
+            for (int c = threadIdx.x; c < 2 * ND; c += 64 * NWAVES) {
+                const int which = c / ND, col = c - which * ND;
+                const int sl = col / 64, cc = col - sl * 64;
+                float a = 0.f;
+#pragma unroll
+                for (int g = 0; g < GPB; ++g) a += red[((g * NSPLIT + sl) * 2 + which) * 64 + cc];       // fixed order over the streams
+                float* dst = (which ? d1 : d0) + row * ND + col;
+                if (p.stat_atomic_rows) unsafeAtomicAdd(dst, a); else *dst = a;
+            }
+        }
+    }
+}
+
+struct PWShape { int kd, nd, nsplit; };
+constexpr PWShape kShapes[] = {{64, 64, 1}, {64, 256, 4}, {256, 64, 1}, {128, 128, 2}, {256, 128, 2}, {128, 512, 8}};
+
+int blocks_per_cu() {
+    static const int v = getenv("SAICV_PW_BPC") ? atoi(getenv("SAICV_PW_BPC")) : 2;
+    return v < 1 ? 1 : v > 8 ? 8 : v;
+}
+
+template <int KD, int ND, int NSPLIT>
+int launch(const PWParams& p, int blocks, bool stats, bool extras, hipStream_t st) {
+    constexpr int NWAVES = NSPLIT > 4 ? NSPLIT : 4;
+    dim3 grid(blocks), block(64 * NWAVES);
+    if (stats) hipLaunchKernelGGL((pw_stream_kernel<KD, ND, NSPLIT, true, false>), grid, block, 0, st, p);
+    else if (extras) hipLaunchKernelGGL((pw_stream_kernel<KD, ND, NSPLIT, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((pw_stream_kernel<KD, ND, NSPLIT, false, false>), grid, block, 0, st, p);
+    return saicv::check_launch("pw_stream");
+}
+
+}  // namespace
+
+namespace saicv {
+
+// Workgroups (= rows of partial statistics) of the streaming launch for a pointwise bf16 product [M][Kd] x [Nn][Kd]^T, 0 if this
+// product stays on the tiled kernel.  A pure function of the shape and of SAICV_PW_STREAM / SAICV_PW_MIN_ROWS / SAICV_PW_BPC.
+int pw_stream_blocks(int dtype, int M, int Nn, int Kd) {
+    const char* es = getenv("SAICV_PW_STREAM");           // (read per call: tests and tuning sweeps flip them in-process)
+    const char* er = getenv("SAICV_PW_MIN_ROWS");
+    const int on = es ? atoi(es) : 1;
+    const int min_rows = er ? atoi(er) : 65536;
+    if (!on || dtype != SAICV_DTYPE_BF16 || M < min_rows) return 0;
+    for (const PWShape& s : kShapes) {
+        if (s.kd != Kd || s.nd != Nn) continue;
+        if (on < 2 && Kd * Nn > 64 * 256) return 0;            // the wider shapes (stage 2) only on request until measured
+        const int nwaves = s.nsplit > 4 ? s.nsplit : 4;
+        const int gpb = nwaves / s.nsplit;
+        const int mtiles = (M + 15) / 16;
+        const int want = (mtiles + gpb - 1) / gpb;
+        const int cap = 256 * blocks_per_cu() * 4 / nwaves;
+        return want < cap ? want : cap;
+    }
+    return 0;
+}
+
+// -> 1 launched, 0 not eligible (the caller takes the tiled kernel), < 0 error
+int pw_stream(int M, int Nn, int Kd, const void* src, const void* wgt, void* out, float* stat_sum, float* stat_sq,
+              int stat_atomic_rows, const EpiExtra* ex, int stream_out, hipStream_t st) {
+    const int blocks = pw_stream_blocks(SAICV_DTYPE_BF16, M, Nn, Kd);
+    if (blocks == 0) return 0;
+    const bool extras = ex && (ex->addend || ex->bs_y);
+    if (stat_sum && extras) return 0;
+    PWParams p = {};
+    p.src = (const bf16_t*)src; p.wgt = (const bf16_t*)wgt; p.out = (bf16_t*)out;
+    p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.stat_atomic_rows = stat_atomic_rows;
+    if (ex) {
+        p.addend = (const bf16_t*)ex->addend; p.addend_gate = ex->addend_gate;
+        p.bs_y = (const bf16_t*)ex->bs_y; p.bs_mask = ex->bs_mask; p.bs_mean = ex->bs_mean; p.bs_invstd = ex->bs_invstd;
+        p.bs_g = ex->bs_g; p.bs_gx = ex->bs_gx;
+    }
+    const size_t src_bytes = (size_t)M * Kd * 2;
+    if (src_bytes >= 0xfffffff0ull) return 0;
+    p.src_bytes = (uint32_t)src_bytes;
+    p.M = M;
+    p.mtiles = (M + 15) / 16;
+    p.stream_out = stream_out;
+    const bool stats = stat_sum != nullptr;
+#define PW_CASE(KD, ND, NS)                                                        \
+    if (Kd == KD && Nn == ND) {                                                    \
+        constexpr int NW = NS > 4 ? NS : 4;                                        \
+        p.units = blocks * (NW / NS);                                              \
+        const int rc = launch<KD, ND, NS>(p, blocks, stats, extras, st);           \
+        return rc ? rc : 1;                                                        \
+    }
+    PW_CASE(64, 64, 1)
+    PW_CASE(64, 256, 4)
+    PW_CASE(256, 64, 1)
+    PW_CASE(128, 128, 2)
+    PW_CASE(256, 128, 2)
+    PW_CASE(128, 512, 8)
+#undef PW_CASE
+    return 0;
+}
+
+}  // namespace saicv

@@ -8,7 +8,8 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // igemm.hip
-int conv_stat_rows(int M, int Nn, int Kd, int dtype);
+// dense_rows: the product reads whole consecutive rows of its source (pointwise, stride 1, no padding)
+int conv_stat_rows(int M, int Nn, int Kd, int dtype, bool dense_rows = false);
 // optional epilogue extras: out = addend + row_scale[m / rows_per_scale] * (acc + bias)
 struct EpiExtra {
     const void* addend = nullptr;      // same dtype / layout as out
@@ -27,7 +28,7 @@ struct EpiExtra {
     int stat_atomic_rows = 0;              // > 0: statistics added atomically into this many rows of a zeroed buffer
 };
 // partial rows the data gradient (mode 1; M rows on the OH x OW pixel grid) writes with bs_*
-int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype);
+int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype, bool dense_rows = false);
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
              int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st,
@@ -35,6 +36,11 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
 int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W, int C, int OH,
              int OW, int R, int S, int stride, int pad, int M, int Cout, int Kd, hipStream_t st,
              float* dbias = nullptr);
+
+// pwstream.hip: weight-resident streaming kernel for small pointwise products; blocks = rows of partial statistics (0: not eligible)
+int pw_stream_blocks(int dtype, int M, int Nn, int Kd);
+int pw_stream(int M, int Nn, int Kd, const void* src, const void* wgt, void* out, float* stat_sum, float* stat_sq,
+              int stat_atomic_rows, const EpiExtra* ex, int stream_out, hipStream_t st);
 
 // sam.hip
 int window_partition(int dtype, const void* x, void* out, int B, int H, int W, int C, int ws, hipStream_t st);

@@ -157,7 +157,9 @@ def set_deterministic(on=True):
     L = lib()
     prev = bool(L.saicv_set_deterministic(1 if on else 0))
     if on:
+        global WGRAD_SIDE_STREAM
         BN_INLINE = False
+        WGRAD_SIDE_STREAM = False           # (one partials workspace per stream; a forked branch of a capture would share it)
         if torch.cuda.is_available():
             check(L.saicv_deterministic_prepare(stream()), 'deterministic_prepare')
     else:
@@ -285,6 +287,39 @@ def _nhwc(x):
 
 def _empty_nhwc(n, c, h, w, dtype, device):
     return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+class ResizeBilinearAddFn(torch.autograd.Function):
+    """F.interpolate(top, size=lateral.shape[2:], mode='bilinear') + lateral, the top-down merge of a feature pyramid (reference
+    SimpleAICV/detection/models/fpn.py:57-75), as one pass over NHWC tensors; fp32 output as under torch.autocast (which runs the
+    resize in fp32).  The gradient towards `top` is a gather in a fixed order -- ATen's upsample backward scatters with atomics, the
+    one place where a RetinaNet / FCOS step was not reproducible in deterministic mode."""
+
+    @staticmethod
+    def forward(ctx, top, lateral):
+        require_gpu(top, lateral)
+        top, lateral = _nhwc(top), _nhwc(lateral)
+        n, c, h, w = top.shape
+        _, _, H, W = lateral.shape
+        out = _empty_nhwc(n, c, H, W, torch.float32, top.device)
+        check(lib().saicv_resize_bilinear_add_fwd(dtype_code(top.dtype), dtype_code(lateral.dtype), ptr(top), ptr(lateral), ptr(out),
+                                                  n, h, w, H, W, c, stream()), 'resize_bilinear_add_fwd')
+        ctx.geom = (n, c, h, w, H, W, top.dtype, lateral.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, c, h, w, H, W, tdt, ldt = ctx.geom
+        dout = _nhwc(dout.float())
+        dtop = None
+        if ctx.needs_input_grad[0]:
+            dtop = _empty_nhwc(n, c, h, w, tdt, dout.device)
+            check(lib().saicv_resize_bilinear_bwd(dtype_code(tdt), ptr(dout), ptr(dtop), n, h, w, H, W, c, stream()), 'resize_bilinear_bwd')
+        return dtop, (dout.to(ldt) if ctx.needs_input_grad[1] else None)
+
+
+def resize_bilinear_add(top, lateral):
+    return ResizeBilinearAddFn.apply(top, lateral)
 
 
 _desc_cache = {}

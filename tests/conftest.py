@@ -33,3 +33,13 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture
+def deterministic():
+    """The engine's deterministic mode (ops.set_deterministic, what tools.utils.set_seed() turns on -- reference tools/utils.py:95-107)
+    for the duration of one test: ordered reductions instead of fp32 atomics, bit-reproducible run to run."""
+    from simpleaicv_pytorch_training_examples_amd import ops
+    prev = ops.set_deterministic(True)
+    yield
+    ops.set_deterministic(prev)

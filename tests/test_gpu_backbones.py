@@ -45,7 +45,7 @@ def _build(name):
 
 
 @pytest.mark.parametrize('name', NAMES)
-def test_backbone_fp32_matches_reference(name):
+def test_backbone_fp32_matches_reference(name, deterministic):
     fx, model, x = _build(name)
     logits = model(x)
     assert logits.dtype == torch.float32 and tuple(logits.shape) == tuple(fx['logits'].shape)
@@ -129,11 +129,14 @@ BF16_SAMPLE_X, BF16_SAMPLE_FLOOR = 4.0, 1.5e-1
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
 @pytest.mark.parametrize('case', ['van', 'convformer', 'dinov3convnext'])
-def test_detection_van_convformer_backbones_match_reference(case, dtype):
+def test_detection_van_convformer_backbones_match_reference(case, dtype, deterministic):
     """VANBackbone / MetaFormerBackbone / Dinov3ConvNeXtBackbone (reference detection/models/backbones/van.py:32-130,
     convformer.py:29-117, dinov3convnext.py:120-199): the four stage outputs, every parameter gradient and the BatchNorm buffers
     after a training-mode step against what the reference produced on 4 x 3 x 256 x 256 (>= 256 samples per BatchNorm channel in
-    every stage).  fp32: 1e-4 on outputs, 3e-3 on gradient norms (VAN: 2e-4 ... 1e-3 from run to run -- BatchNorm statistics are summed with atomics -- the others 1e-6), 1e-2 on gradient samples.  bf16: each quantity within a small
+    every stage).  Run in the deterministic mode
+    (conftest.deterministic; scripts/probes/van_noise_probe.py: with atomically summed BatchNorm statistics VAN's gradient norms move
+    2e-4 ... 1e-3 from run to run, with ordered sums not at all and sit within 2e-6 of the reference's).  fp32: 1e-4 on outputs,
+    1e-4 on gradient norms (north_star: 1e-3), 1e-2 on gradient samples.  bf16: each quantity within a small
     multiple of what the reference itself moves by under CPU autocast (constants above)."""
     fx, m, x, g = _det_backbone(case)
     assert m.out_channels == fx['kwargs']['embedding_planes']
@@ -175,7 +178,7 @@ def test_detection_van_convformer_backbones_match_reference(case, dtype):
             assert gn <= (1e-6 if f32 else 3e-3) * top, (n, gn, top)
             continue
         e_norm = abs(gn - ref_n) / ref_n
-        g_norm = 3e-3 if f32 else max(BF16_NORM_X * drift['grad_norm'][n], BF16_NORM_FLOOR)
+        g_norm = 1e-4 if f32 else max(BF16_NORM_X * drift['grad_norm'][n], BF16_NORM_FLOOR)
         assert e_norm <= g_norm, (n, 'norm', e_norm, g_norm)
         ref = fx['grad_sample'][n]
         got = p.grad.flatten()[:64].float().cpu()

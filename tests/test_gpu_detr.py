@@ -29,7 +29,7 @@ def _build(fx):
 
 
 @pytest.mark.parametrize('name', ['detr_r18_tiny', 'detr_r50_small'])
-def test_detr_fp32_matches_reference(name):
+def test_detr_fp32_matches_reference(name, deterministic):
     """detr_r50_small: resnet50_detr as the reference config builds it (real ResNet-50 backbone, 100 queries, 80 classes)
     on a 256 x 256 canvas -- fixture produced by the reference's DETR + DETRLoss (oracle/make_golden_detr.py)."""
     fx = load_golden(name)

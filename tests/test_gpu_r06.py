@@ -204,3 +204,92 @@ def test_losses_and_prompt_path_of_sam_repeat_bit_for_bit(deterministic):
     assert l1 == l2, (l1, l2)
     bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('geom', [(2, 64, 8, 8, 16, 16), (1, 256, 7, 10, 13, 19), (2, 128, 5, 5, 10, 9), (1, 8, 3, 4, 12, 16), (2, 32, 13, 17, 25, 34)])
+def test_pyramid_merge_equals_interpolate_plus_lateral(geom, dtype):
+    """saicv_resize_bilinear_add_fwd / _bwd (the top-down merge of reference SimpleAICV/detection/models/fpn.py:57-75) against
+    F.interpolate(mode='bilinear') + lateral and its autograd gradient in fp32 (1e-6 relative: the same tap arithmetic, the gradient
+    gathered in a fixed order instead of scattered with atomics); two launches give identical bits."""
+    import torch.nn.functional as F
+    from simpleaicv_pytorch_training_examples_amd import ops
+    n, c, h, w, H, W = geom
+    g = torch.Generator().manual_seed(sum(geom))
+    top = torch.randn(n, h, w, c, generator=g).permute(0, 3, 1, 2).cuda().to(dtype)
+    lat = torch.randn(n, H, W, c, generator=g).permute(0, 3, 1, 2).cuda().to(dtype)
+    dout = torch.randn(n, H, W, c, generator=g).permute(0, 3, 1, 2).cuda()
+    runs = []
+    for _ in range(2):
+        t, l = top.clone().requires_grad_(True), lat.clone().requires_grad_(True)
+        out = ops.resize_bilinear_add(t, l)
+        out.backward(dout)
+        torch.cuda.synchronize()
+        runs.append((out.detach().clone(), t.grad.clone(), l.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
+    t, l = top.float().clone().requires_grad_(True), lat.float().clone().requires_grad_(True)
+    ref = F.interpolate(t, size=(H, W), mode='bilinear') + l
+    ref.backward(dout)
+    out, dt, dl = runs[0]
+    assert out.dtype == torch.float32 and dt.dtype == dtype and dl.dtype == dtype
+    assert float((out - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-6
+    assert float((dt.float() - t.grad).abs().max()) <= tol * float(t.grad.abs().max())
+    assert float((dl.float() - l.grad).abs().max()) <= tol * float(l.grad.abs().max())
+
+
+def _stage(chain):
+    """A chain of Bottleneck blocks [(inplanes, planes), ...] as in ResNet-50's layer1 / layer2 (stride 1)."""
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.backbones.resnet import Bottleneck, _init_like_reference
+    net = torch.nn.Sequential(*[Bottleneck(i, p, 1) for i, p in chain])
+    _init_like_reference(net)
+    return net
+
+
+@pytest.mark.parametrize('chain,hw', [([(64, 64), (256, 64)], (61, 47)), ([(256, 128), (512, 128)], (37, 41)), ([(128, 32), (128, 128)], (29, 31))],
+                         ids=['stage1', 'stage2', 'k128'])
+def test_streaming_pointwise_convolutions_equal_the_tiled_kernel_and_torch(chain, hw, monkeypatch):
+    """pw_stream_kernel (csrc/pwstream.hip: ResNet-50 stage-1 / stage-2 1 x 1 convolutions, reference
+    SimpleAICV/classification/backbones/resnet.py:33-43,100-155): two Bottleneck blocks forward + backward under bf16 autocast with
+    every eligible shape on the streaming kernel (BatchNorm statistics in the forward; gated shortcut gradient and
+    BatchNorm-backward sums in the data gradient; a row count that is no multiple of 16) against (1) the same blocks on the tiled
+    kernel -- same bf16 operands and fp32 accumulation, only the summation order differs -- and (2) the fp32 torch modules on the CPU."""
+    h, w = hw
+    n = 24
+    x0 = torch.randn(n, h, w, chain[0][0], generator=torch.Generator().manual_seed(5)).permute(0, 3, 1, 2)
+    torch.manual_seed(3)
+    ref_net = _stage(chain).train()
+    state = {k: v.clone() for k, v in ref_net.state_dict().items()}
+    dout = torch.randn(n, h, w, chain[-1][1] * 4, generator=torch.Generator().manual_seed(6)).permute(0, 3, 1, 2)
+
+    def run(stream):
+        from simpleaicv_pytorch_training_examples_amd import ops
+        monkeypatch.setenv('SAICV_PW_STREAM', '2' if stream else '0')
+        monkeypatch.setenv('SAICV_PW_MIN_ROWS', '1024')
+        net = _stage(chain)
+        net.load_state_dict(state)
+        net = net.cuda().train()
+        ops.bump_weights_epoch()
+        x = x0.cuda().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = net(x)
+        y.float().backward(dout.cuda())
+        torch.cuda.synchronize()
+        return y.detach().float().cpu(), x.grad.float().cpu(), {k: p.grad.float().cpu() for k, p in net.named_parameters()}, \
+            {k: b.detach().float().cpu() for k, b in net.named_buffers() if 'running' in k}
+
+    ys, dxs, gs, bs = run(True)
+    yt, dxt, gt, bt = run(False)
+    xr = x0.clone().requires_grad_(True)
+    yr = ref_net(xr)
+    yr.backward(dout)
+    gr = {k: p.grad for k, p in ref_net.named_parameters()}
+    rel = lambda a, b: float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20)
+    assert rel(ys, yt) <= 1e-2 and rel(dxs, dxt) <= 1e-2, (rel(ys, yt), rel(dxs, dxt))           # a few 1-ulp bf16 flips
+    assert float((ys - yt).abs().mean()) <= 2e-4 * float(yt.abs().mean())
+    assert rel(ys, yr.detach()) <= 3e-2 and rel(dxs, xr.grad) <= 4e-2, (rel(ys, yr.detach()), rel(dxs, xr.grad))
+    for k in gs:
+        assert rel(gs[k], gt[k]) <= 2e-2, (k, rel(gs[k], gt[k]))
+        assert rel(gs[k], gr[k]) <= 6e-2, (k, rel(gs[k], gr[k]))
+    for k in bs:
+        assert rel(bs[k], bt[k]) <= 1e-4, (k, rel(bs[k], bt[k]))

@@ -165,7 +165,7 @@ def _sam_inputs(fx):
 
 
 @pytest.mark.parametrize('name', ['sam_encoder_tiny', 'sam_b_encoder_256'])
-def test_sam_encoder_fp32_matches_reference(name):
+def test_sam_encoder_fp32_matches_reference(name, deterministic):
     """sam_b_encoder_256: the encoder at sam_b's real dimensions (768 planes, 12 heads x 64, window 14, global blocks
     2/5/8/11) on a 256 x 256 image -- fixture produced by the reference's ViTImageEncoder (oracle/make_golden_sam.py)."""
     fx = load_golden(name)
