@@ -1180,7 +1180,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_, (BM_T == 256 && BN_T == 128 && !OUT
     // 16x16x4 MFMAs take 32 cycles each, an LDS round trip hides behind any group of them.
     constexpr bool ASM_FRAGS = sizeof(T) == 2;
     constexpr int RPH = KSUB * (MT_ + NT_);      // reads per 64-byte half
-    static_assert(RPH <= 15, "lgkmcnt counts 15 operations");
+    // (16 reads: the counter holds 15, the sixteenth issues once the first -- they return in order -- has landed, which is what lgkmcnt(15) then asks for)
+    static_assert(RPH <= 16, "lgkmcnt counts 15 operations");
     const uint32_t lds0 = lds_addr32(smem);
     auto frag_reads = [&](int stage, auto KS, u32x4 (&af)[KSUB][MT_], u32x4 (&wf)[KSUB][NT_]) __attribute__((always_inline)) {
         constexpr int ks = decltype(KS)::value;
@@ -2660,9 +2661,14 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
             }
         }
     }
+// -DSAICV_NT_T0_WN=2: the 256 x 256 tile on FOUR wavefronts of 128 x 128 (with -DSAICV_NT_MFMA32: the probe's cheapest form per flop)
+#ifndef SAICV_NT_T0_WN
+#define SAICV_NT_T0_WN 4
+#endif
+#define NT_T0_WN SAICV_NT_T0_WN
 #define NT_DISPATCH(TT, MODE_)                                                              \
     switch (t) {                                                                            \
-        case 0: return launch_nt1<TT, 256, 256, 2, 4, MODE_>(p, f32o, st);                  \
+        case 0: return launch_nt1<TT, 256, 256, 2, NT_T0_WN, MODE_>(p, f32o, st);           \
         case 1: return launch_nt1<TT, 256, 128, 4, 2, MODE_>(p, f32o, st);                  \
         case 2: return launch_nt1<TT, 128, 128, 2, 2, MODE_>(p, f32o, st);                  \
         default: return launch_nt1<TT, 128, 64, 2, 2, MODE_>(p, f32o, st);                  \

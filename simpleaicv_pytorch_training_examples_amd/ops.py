@@ -949,6 +949,9 @@ ConvBnActFn._backward_pooled = staticmethod(_conv_bn_act_backward_pooled)
 def conv_bn_act(x, weight, bn, stride, pad, relu, residual=None, want_skip=False, pool=None, defer=False):
     """defer=True: ONLY for a tensor whose single consumer is the `residual` argument of another conv_bn_act call (what comes
     back is the raw convolution output; its values are not the block's output until that consumer applies the coefficients)."""
+    # as conv2d below: under autocast the block's convolution computes in the autocast dtype whatever its input's dtype
+    if torch.is_autocast_enabled('cuda') and x.is_floating_point() and x.dtype != compute_dtype() and getattr(x, '_saicv_s2d', None) is None:
+        x = x.to(compute_dtype())
     if pool is not None:
         return ConvBnActFn.apply(x, weight, bn.weight, bn.bias, None, bn, stride, pad, relu, False, pool)
     if defer:

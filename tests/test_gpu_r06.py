@@ -253,18 +253,18 @@ def test_streaming_pointwise_convolutions_equal_the_tiled_kernel_and_torch(chain
     SimpleAICV/classification/backbones/resnet.py:33-43,100-155): two Bottleneck blocks forward + backward under bf16 autocast with
     every eligible shape on the streaming kernel (BatchNorm statistics in the forward; gated shortcut gradient and
     BatchNorm-backward sums in the data gradient; a row count that is no multiple of 16) against (1) the same blocks on the tiled
-    kernel -- same bf16 operands and fp32 accumulation, only the summation order differs -- and (2) the fp32 torch modules on the CPU."""
+    kernel -- same bf16 operands and fp32 accumulation, only the summation order differs -- and (2) the oracle's fp32 blocks on the CPU."""
     h, w = hw
     n = 24
-    x0 = torch.randn(n, h, w, chain[0][0], generator=torch.Generator().manual_seed(5)).permute(0, 3, 1, 2)
+    # (the blocks compute in their input's dtype; in the models the stem hands them bf16)
+    x0 = torch.randn(n, h, w, chain[0][0], generator=torch.Generator().manual_seed(5)).permute(0, 3, 1, 2).bfloat16()
     torch.manual_seed(3)
-    ref_net = _stage(chain).train()
-    state = {k: v.clone() for k, v in ref_net.state_dict().items()}
+    state = {k: v.clone() for k, v in _stage(chain).state_dict().items()}
     dout = torch.randn(n, h, w, chain[-1][1] * 4, generator=torch.Generator().manual_seed(6)).permute(0, 3, 1, 2)
 
     def run(stream):
         from simpleaicv_pytorch_training_examples_amd import ops
-        monkeypatch.setenv('SAICV_PW_STREAM', '2' if stream else '0')
+        monkeypatch.setenv('SAICV_PW_STREAM', '1' if stream else '0')
         monkeypatch.setenv('SAICV_PW_MIN_ROWS', '1024')
         net = _stage(chain)
         net.load_state_dict(state)
@@ -273,23 +273,39 @@ def test_streaming_pointwise_convolutions_equal_the_tiled_kernel_and_torch(chain
         x = x0.cuda().requires_grad_(True)
         with torch.autocast('cuda', dtype=torch.bfloat16):
             y = net(x)
-        y.float().backward(dout.cuda())
+        assert y.dtype == torch.bfloat16
+        y.backward(dout.cuda().bfloat16())
         torch.cuda.synchronize()
         return y.detach().float().cpu(), x.grad.float().cpu(), {k: p.grad.float().cpu() for k, p in net.named_parameters()}, \
             {k: b.detach().float().cpu() for k, b in net.named_buffers() if 'running' in k}
 
     ys, dxs, gs, bs = run(True)
     yt, dxt, gt, bt = run(False)
-    xr = x0.clone().requires_grad_(True)
-    yr = ref_net(xr)
-    yr.backward(dout)
-    gr = {k: p.grad for k, p in ref_net.named_parameters()}
+    # the oracle's fp32 restatement of Bottleneck.forward (oracle/torch_oracle.py, reference resnet.py:141-155) on the CPU
+    from oracle.torch_oracle import bottleneck
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and 'running' not in k) for k, v in state.items()}
+    xr = x0.float().requires_grad_(True)
+    yr = xr
+    for i, (inp, pl) in enumerate(chain):
+        yr = bottleneck(yr, sd, str(i), 1, inp != pl * 4, True)
+    yr.backward(dout.bfloat16().float())
+    gr = {k: sd[k].grad for k in gs}
     rel = lambda a, b: float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20)
-    assert rel(ys, yt) <= 1e-2 and rel(dxs, dxt) <= 1e-2, (rel(ys, yt), rel(dxs, dxt))           # a few 1-ulp bf16 flips
-    assert float((ys - yt).abs().mean()) <= 2e-4 * float(yt.abs().mean())
-    assert rel(ys, yr.detach()) <= 3e-2 and rel(dxs, xr.grad) <= 4e-2, (rel(ys, yr.detach()), rel(dxs, xr.grad))
+    l2 = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
+    yr, dxr = yr.detach(), xr.grad
+    print(f'[{chain}] streaming vs tiled: y max {rel(ys, yt):.2e} l2 {l2(ys, yt):.2e}; dx max {rel(dxs, dxt):.2e} l2 {l2(dxs, dxt):.2e} | vs fp32 oracle: '
+          f'y {l2(ys, yr):.2e} (tiled {l2(yt, yr):.2e}), dx {l2(dxs, dxr):.2e} (tiled {l2(dxt, dxr):.2e})')
+    # the two kernels differ by rounding only (another fp32 summation order in front of each bf16 rounding): their distance from each
+    # other is a fraction of their common distance from the fp32 oracle (bf16 operands, ReLU gates and BatchNorm-backward cancellation:
+    # 0.8 % on the outputs, 12.5 % on the input gradient for either kernel), and neither is further from the oracle than the other
+    assert l2(ys, yt) <= 0.5 * l2(yt, yr) and l2(dxs, dxt) <= 0.3 * l2(dxt, dxr), (l2(ys, yt), l2(dxs, dxt))
+    assert l2(ys, yr) <= 1.05 * l2(yt, yr) + 1e-4 and l2(dxs, dxr) <= 1.05 * l2(dxt, dxr) + 1e-3
+    assert l2(ys, yr) <= 2e-2 and l2(dxs, dxr) <= 0.2, (l2(ys, yr), l2(dxs, dxr))
+    worst = 0.0
     for k in gs:
-        assert rel(gs[k], gt[k]) <= 2e-2, (k, rel(gs[k], gt[k]))
-        assert rel(gs[k], gr[k]) <= 6e-2, (k, rel(gs[k], gr[k]))
+        worst = max(worst, l2(gs[k], gr[k]))
+        assert l2(gs[k], gr[k]) <= 1.1 * l2(gt[k], gr[k]) + 5e-3, (k, l2(gs[k], gr[k]), l2(gt[k], gr[k]))
+        assert l2(gs[k], gt[k]) <= 0.5 * l2(gt[k], gr[k]) + 2e-3, (k, l2(gs[k], gt[k]), l2(gt[k], gr[k]))
+    print(f'    parameter gradients: worst distance from the fp32 oracle {worst:.2e}')
     for k in bs:
         assert rel(bs[k], bt[k]) <= 1e-4, (k, rel(bs[k], bt[k]))
