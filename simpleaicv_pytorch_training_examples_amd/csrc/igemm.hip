@@ -2479,7 +2479,7 @@ namespace saicv {
 // launch is persistent)
 int conv_stat_rows(int M, int Nn, int Kd, int dtype, bool dense_rows) {
     if (dense_rows) {                                      // pointwise, stride 1, no padding: the streaming kernel's row per workgroup
-        const int pw = pw_stream_blocks(dtype, M, Nn, Kd);
+        const int pw = pw_stream_blocks(dtype, M, Nn, Kd, false);
         if (pw > 0) return pw;
     }
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
@@ -2491,7 +2491,7 @@ int conv_stat_rows(int M, int Nn, int Kd, int dtype, bool dense_rows) {
 // partial rows the data gradient writes with EpiExtra::bs_*: (rows of tiles of the largest parity class) x classes
 int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype, bool dense_rows) {
     if (dense_rows && stride == 1) {
-        const int pw = pw_stream_blocks(dtype, M, Nn, Kd);
+        const int pw = pw_stream_blocks(dtype, M, Nn, Kd, true);
         if (pw > 0) return pw;
     }
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;

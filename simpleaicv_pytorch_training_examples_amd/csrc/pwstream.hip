@@ -10,11 +10,11 @@
 //   * the grid is ONE resident round of workgroups; every wavefront is an independent stream over 16-pixel row groups
 //     (group g, g + G, g + 2G, ...), it never meets a workgroup barrier before the last statistics row;
 //   * the WEIGHTS LIVE IN REGISTERS for the whole launch: a wavefront owns 64 output channels, i.e. 4 MFMA row tiles x K / 32
-//     k-steps of 16-byte fragments = 32 (K = 64) to 64 (K = 128) VGPRs, loaded once; wider layers split the channels over the
-//     NSPLIT wavefronts of a group, which then read the same (small) input rows -- L1 / L2 hits.  K = 256 (128 VGPRs of weights
-//     leave room for two row groups in flight only: 3.7 TB/s measured against 5.4 for K = 64) keeps the weights in LDS instead
-//     (WLDS: ND rows of K * 2 + 16 bytes, one ds_read_b128 per MFMA = a quarter of the LDS bandwidth at the HBM rate) and
-//     doubles the row groups in flight;
+//     k-steps of 16-byte fragments = 32 (K = 64) to 128 (K = 256) VGPRs, loaded once; wider layers split the channels over the
+//     NSPLIT wavefronts of a group, which then read the same (small) input rows -- L1 / L2 hits.  (r06, measured and removed:
+//     the K = 256 weights in LDS with four row groups in flight instead of two -- forward 137 -> 129 us, data gradient 143 ->
+//     157 us, profiles/r06_nt_experiments.md; read-heavy K = 256 products without fused operands stay on the tiled kernel,
+//     whose LDS-DMA loads reach 4.9 TB/s on them against 4.0 here);
 //   * the activations need no LDS either: with the weights as the FIRST MFMA operand, lane (pixel = lane & 15, k-group = lane >> 4)
 //     of the second operand is 16 contiguous bytes of that pixel's row -- one global load per k-step, DEPTH row groups in flight
 //     in registers ahead of the one being multiplied;
@@ -58,16 +58,14 @@ DEVINL void st_stream(void* q, u32x4 v) {
 }
 
 // KD input channels, ND output channels; NSPLIT wavefronts share a row group, 64 channels each (ND = 64 * NSPLIT)
-template <int KD, int ND, int NSPLIT, bool STATS, bool EXTRAS, bool WLDS>
+template <int KD, int ND, int NSPLIT, bool STATS, bool EXTRAS>
 __global__ __launch_bounds__(64 * (NSPLIT > 4 ? NSPLIT : 4)) void pw_stream_kernel(const PWParams p) {
     constexpr int NWAVES = NSPLIT > 4 ? NSPLIT : 4;
     constexpr int GPB = NWAVES / NSPLIT;          // row-group streams per workgroup
     constexpr int NT = 4, KS = KD / 32;           // MFMA row tiles (channels) and k-steps per wavefront
     constexpr int CPR = 8, RPP = 8, NPASS = 2;    // staged strip: 16 rows x 128 bytes, copied out 8 rows per pass
     constexpr int PITCH = 128 + 16;
-    constexpr int DEPTH = (KD <= 64 || WLDS) ? 4 : 2;       // row groups in flight in registers
-    constexpr int WPITCH = KD * 2 + 16;           // WLDS: bytes per weight row (a 4-dword skew per row: conflict-free 16-byte fragment reads)
-    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    constexpr int DEPTH = KD <= 64 ? 4 : 2;       // row groups in flight in registers
     constexpr uint32_t OOB = 0xfffffff0u;
     static_assert(ND == 64 * NSPLIT && KD % 32 == 0, "64 channels per wavefront");
     __shared__ __attribute__((aligned(16))) char strip[NWAVES][16 * PITCH];
@@ -82,22 +80,12 @@ __global__ __launch_bounds__(64 * (NSPLIT > 4 ? NSPLIT : 4)) void pw_stream_kern
     const int U = p.units;
 
     // ---- weights: fragment (nt, ks) = rows nc0 + nt*16 + l15, k = ks*32 + lg*8 .. +7
-    u32x4 wf[WLDS ? 1 : NT][WLDS ? 1 : KS];
-    if constexpr (WLDS) {
-        constexpr int CPROW = KD / 8;             // 16-byte chunks per weight row
-        for (int c = threadIdx.x; c < ND * CPROW; c += 64 * NWAVES) {
-            const int row = c / CPROW, ch = c - row * CPROW;
-            *reinterpret_cast<u32x4*>(wlds + row * WPITCH + ch * 16) = ld_chunk(p.wgt + (size_t)row * KD + ch * 8);
-        }
-        __syncthreads();
-    } else {
+    u32x4 wf[NT][KS];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                wf[nt][ks] = ld_chunk(p.wgt + (size_t)(nc0 + nt * 16 + l15) * KD + ks * 32 + lg * 8);
-    }
-    const char* const wrow = wlds + (nc0 + l15) * WPITCH + lg * 16;      // WLDS: this lane's fragment of (nt, ks) at + nt * 16 rows + ks * 64
+        for (int ks = 0; ks < KS; ++ks)
+            wf[nt][ks] = ld_chunk(p.wgt + (size_t)(nc0 + nt * 16 + l15) * KD + ks * 32 + lg * 8);
 
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.src), 0, p.src_bytes, 0x00020000);
     u32x4 bfr[DEPTH][KS];
@@ -152,10 +140,7 @@ __global__ __launch_bounds__(64 * (NSPLIT > 4 ? NSPLIT : 4)) void pw_stream_kern
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if constexpr (WLDS) Mma<bf16_t>::run(acc[nt], ld_chunk(wrow + nt * 16 * WPITCH + ks * 64), bfr[d][ks]);
-                    else Mma<bf16_t>::run(acc[nt], wf[nt][ks], bfr[d][ks]);
-                }
+                for (int nt = 0; nt < NT; ++nt) Mma<bf16_t>::run(acc[nt], wf[nt][ks], bfr[d][ks]);
             load_tile(bfr[d], tile + DEPTH * U);                  // the slot is free again: DEPTH groups ahead
             // accumulators -> strip: D row lg*4 + r of tile nt = channel nt*16 + lg*4 + r, D column = pixel l15
 #pragma unroll
@@ -250,8 +235,7 @@ __global__ __launch_bounds__(64 * (NSPLIT > 4 ? NSPLIT : 4)) void pw_stream_kern
 }
 
 struct PWShape { int kd, nd, nsplit; };
-constexpr PWShape kShapes[] = {{64, 64, 1}, {64, 256, 4}, {256, 64, 1}, {128, 128, 2}, {256, 128, 2}, {128, 512, 8}, {128, 256, 4}};
-constexpr bool weights_in_lds(int kd) { return kd >= 256; }
+constexpr PWShape kShapes[] = {{64, 64, 1}, {64, 256, 4}, {256, 64, 1}, {128, 128, 2}, {128, 512, 8}, {128, 256, 4}};
 
 int blocks_per_cu() {
     static const int v = getenv("SAICV_PW_BPC") ? atoi(getenv("SAICV_PW_BPC")) : 2;
@@ -261,22 +245,10 @@ int blocks_per_cu() {
 template <int KD, int ND, int NSPLIT>
 int launch(const PWParams& p, int blocks, bool stats, bool extras, hipStream_t st) {
     constexpr int NWAVES = NSPLIT > 4 ? NSPLIT : 4;
-    constexpr bool WL = weights_in_lds(KD);
-    constexpr size_t smem = WL ? (size_t)ND * (KD * 2 + 16) : 0;
     dim3 grid(blocks), block(64 * NWAVES);
-#define PW_LAUNCH(ST, EX)                                                                                   \
-    {                                                                                                       \
-        auto k = pw_stream_kernel<KD, ND, NSPLIT, ST, EX, WL>;                                              \
-        if (smem > 48 * 1024) {                                                                             \
-            static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem), true); \
-            (void)once;                                                                                     \
-        }                                                                                                   \
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);                                                    \
-    }
-    if (stats) PW_LAUNCH(true, false)
-    else if (extras) PW_LAUNCH(false, true)
-    else PW_LAUNCH(false, false)
-#undef PW_LAUNCH
+    if (stats) hipLaunchKernelGGL((pw_stream_kernel<KD, ND, NSPLIT, true, false>), grid, block, 0, st, p);
+    else if (extras) hipLaunchKernelGGL((pw_stream_kernel<KD, ND, NSPLIT, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((pw_stream_kernel<KD, ND, NSPLIT, false, false>), grid, block, 0, st, p);
     return saicv::check_launch("pw_stream");
 }
 
@@ -285,8 +257,8 @@ int launch(const PWParams& p, int blocks, bool stats, bool extras, hipStream_t s
 namespace saicv {
 
 // Workgroups (= rows of partial statistics) of the streaming launch for a pointwise bf16 product [M][Kd] x [Nn][Kd]^T, 0 if this
-// product stays on the tiled kernel.  A pure function of the shape and of SAICV_PW_STREAM / SAICV_PW_MIN_ROWS / SAICV_PW_BPC.
-int pw_stream_blocks(int dtype, int M, int Nn, int Kd) {
+// product stays on the tiled kernel (fused_dgrad: a data gradient with a shortcut addend or BatchNorm-backward sums).  A pure function of its arguments and of SAICV_PW_STREAM / SAICV_PW_MIN_ROWS / SAICV_PW_BPC.
+int pw_stream_blocks(int dtype, int M, int Nn, int Kd, bool fused_dgrad) {
     const char* es = getenv("SAICV_PW_STREAM");           // (read per call: tests and tuning sweeps flip them in-process)
     const char* er = getenv("SAICV_PW_MIN_ROWS");
     const int on = es ? atoi(es) : 1;
@@ -294,6 +266,9 @@ int pw_stream_blocks(int dtype, int M, int Nn, int Kd) {
     if (!on || dtype != SAICV_DTYPE_BF16 || M < min_rows) return 0;
     for (const PWShape& s : kShapes) {
         if (s.kd != Kd || s.nd != Nn) continue;
+        // K = 256: only the data gradient with fused operands (143 us against 159 tiled); forward + statistics and the plain data
+        // gradient measured 129-141 us here against 104 us on the tiled kernel (profiles/r06_nt_experiments.md)
+        if (Kd >= 256 && !fused_dgrad) return 0;
         const int nwaves = s.nsplit > 4 ? s.nsplit : 4;
         const int gpb = nwaves / s.nsplit;
         const int mtiles = (M + 15) / 16;
@@ -307,9 +282,9 @@ int pw_stream_blocks(int dtype, int M, int Nn, int Kd) {
 // -> 1 launched, 0 not eligible (the caller takes the tiled kernel), < 0 error
 int pw_stream(int M, int Nn, int Kd, const void* src, const void* wgt, void* out, float* stat_sum, float* stat_sq,
               int stat_atomic_rows, const EpiExtra* ex, int stream_out, hipStream_t st) {
-    const int blocks = pw_stream_blocks(SAICV_DTYPE_BF16, M, Nn, Kd);
-    if (blocks == 0) return 0;
     const bool extras = ex && (ex->addend || ex->bs_y);
+    const int blocks = pw_stream_blocks(SAICV_DTYPE_BF16, M, Nn, Kd, extras && !stat_sum);
+    if (blocks == 0) return 0;
     if (stat_sum && extras) return 0;
     PWParams p = {};
     p.src = (const bf16_t*)src; p.wgt = (const bf16_t*)wgt; p.out = (bf16_t*)out;
@@ -338,7 +313,6 @@ int pw_stream(int M, int Nn, int Kd, const void* src, const void* wgt, void* out
     PW_CASE(64, 256, 4)
     PW_CASE(256, 64, 1)
     PW_CASE(128, 128, 2)
-    PW_CASE(256, 128, 2)
     PW_CASE(128, 512, 8)
     PW_CASE(128, 256, 4)
 #undef PW_CASE

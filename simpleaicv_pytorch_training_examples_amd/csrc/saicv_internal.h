@@ -38,7 +38,7 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
              float* dbias = nullptr);
 
 // pwstream.hip: weight-resident streaming kernel for small pointwise products; blocks = rows of partial statistics (0: not eligible)
-int pw_stream_blocks(int dtype, int M, int Nn, int Kd);
+int pw_stream_blocks(int dtype, int M, int Nn, int Kd, bool fused_dgrad);
 int pw_stream(int M, int Nn, int Kd, const void* src, const void* wgt, void* out, float* stat_sum, float* stat_sq,
               int stat_atomic_rows, const EpiExtra* ex, int stream_out, hipStream_t st);
 

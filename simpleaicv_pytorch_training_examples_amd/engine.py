@@ -533,10 +533,20 @@ class StepGraph:
         dump = os.environ.get('SAICV_GRAPH_DUMP')       # path: write the captured graph as DOT (hipGraphDebugDotPrint) -- which
         if dump:                                        # kernels sit on which branch, e.g. the bucket all-reduces (tests/test_gpu_ddp.py)
             graph.enable_debug_mode()
-        with torch.cuda.graph(graph):
-            ops._ZeroPool.zero_all()    # the statistics scratch starts a replay all-zero, whatever ran eagerly in between
-            out = self.fn(*args)
-            ops.join_side_stream()      # every forked stream rejoins before the capture ends
+        failed = None
+        try:
+            with torch.cuda.graph(graph):
+                ops._ZeroPool.zero_all()    # the statistics scratch starts a replay all-zero, whatever ran eagerly in between
+                try:
+                    out = self.fn(*args)
+                except BaseException as e:      # the capture still has to END with every forked stream rejoined: a stream left
+                    failed = e                  # capturing refuses every later allocation and copy of the process
+                ops.join_side_stream()      # every forked stream rejoins before the capture ends
+        except BaseException as e:
+            failed = failed or e
+        if failed is not None:
+            torch.cuda.synchronize()
+            raise failed
         if dump:
             graph.debug_dump(dump)
         self.graph, self.static_out = graph, out

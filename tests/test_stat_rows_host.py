@@ -27,7 +27,7 @@ def test_stat_rows_is_one_row_per_wavefront_row(ci, co, k, s, h, batch, dt):
     # 256 x 256 (2 wavefront rows), 256 x 128 on four wavefronts (2), 128 x 128 (2), 128 x 64 (2)
     # r06: pointwise stride-1 products of the shapes of csrc/pwstream.hip over >= 65 536 rows run as ONE resident round of the streaming kernel
     # (csrc/pwstream.hip): one row per workgroup, 2 workgroups per CU
-    streamed = dt == torch.bfloat16 and k == 1 and s == 1 and m >= 65536 and (ci, co) in {(64, 64), (64, 256), (256, 64), (256, 128)}
+    streamed = dt == torch.bfloat16 and k == 1 and s == 1 and m >= 65536 and (ci, co) in {(64, 64), (64, 256)}
     if streamed:
         assert rows == 512, (rows, m)
     else:
