@@ -137,9 +137,16 @@ int saicv_unpack_wgrad_s2d(const float* dw, int O, int I, int R, int Sx, int Cq,
     return unpack_wgrad_s2d(dw, O, I, R, Sx, Cq, grad, sO, sI, sR, sS, accumulate, S(stream));
 }
 
+// which streaming form (csrc/pwstream.hip) a convolution's geometry allows: 1 pointwise / stride 1 / no padding, 2 3 x 3 / stride 1 / padding 1
+static int stream_form(const saicv_conv_desc* d) {
+    if (d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1) return 1;
+    if (d->R == 3 && d->S == 3 && d->pad == 1 && d->stride == 1) return 2;
+    return 0;
+}
+
 int saicv_conv2d_stat_rows(const saicv_conv_desc* d) {
     if (!d) return -1;
-    return conv_stat_rows(d->N * d->OH * d->OW, d->K, d->R * d->S * d->C, d->dtype, d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1);
+    return conv_stat_rows(d->N * d->OH * d->OW, d->K, d->R * d->S * d->C, d->dtype, stream_form(d));
 }
 
 int saicv_conv2d_fwd(const saicv_conv_desc* d, const void* x, const void* wf, const float* bias,
@@ -229,8 +236,7 @@ int saicv_conv2d_dgrad_add(const saicv_conv_desc* d, const void* dy, const void*
 }
 int saicv_conv2d_dgrad_stat_rows(const saicv_conv_desc* d) {
     if (!d) return -1;
-    return conv_bwd_stat_rows(d->N * d->H * d->W, d->H, d->W, d->C, d->R * d->S * d->K, d->stride, d->dtype,
-                              d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1);
+    return conv_bwd_stat_rows(d->N * d->H * d->W, d->H, d->W, d->C, d->R * d->S * d->K, d->stride, d->dtype, stream_form(d));
 }
 int saicv_conv2d_dgrad_fused(const saicv_conv_desc* d, const void* dy, const void* wd, const saicv_dgrad_fuse* f, void* dx,
                              void* stream) {

@@ -2477,9 +2477,9 @@ namespace saicv {
 
 // rows of BN partial statistics written by the forward kernel: one per row of workgroups (per row of wavefronts when the
 // launch is persistent)
-int conv_stat_rows(int M, int Nn, int Kd, int dtype, bool dense_rows) {
-    if (dense_rows) {                                      // pointwise, stride 1, no padding: the streaming kernel's row per workgroup
-        const int pw = pw_stream_blocks(dtype, M, Nn, Kd, false);
+int conv_stat_rows(int M, int Nn, int Kd, int dtype, int form) {
+    if (form) {                                            // the streaming kernels' row per workgroup (csrc/pwstream.hip)
+        const int pw = form == 1 ? pw_stream_blocks(dtype, M, Nn, Kd, false) : pw3_stream_blocks(dtype, M, Nn, Kd);
         if (pw > 0) return pw;
     }
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
@@ -2489,9 +2489,9 @@ int conv_stat_rows(int M, int Nn, int Kd, int dtype, bool dense_rows) {
 }
 
 // partial rows the data gradient writes with EpiExtra::bs_*: (rows of tiles of the largest parity class) x classes
-int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype, bool dense_rows) {
-    if (dense_rows && stride == 1) {
-        const int pw = pw_stream_blocks(dtype, M, Nn, Kd, true);
+int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype, int form) {
+    if (form && stride == 1) {
+        const int pw = form == 1 ? pw_stream_blocks(dtype, M, Nn, Kd, true) : pw3_stream_blocks(dtype, M, Nn, Kd);
         if (pw > 0) return pw;
     }
     const int bk = dtype == SAICV_DTYPE_BF16 ? 32 : 16;
@@ -2567,6 +2567,14 @@ int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, c
         static const long min_mb = getenv("SAICV_NT_STREAM_MIN_MB") ? atol(getenv("SAICV_NT_STREAM_MIN_MB")) : 0;
         const int so = (size_t)M * Nn * 2 >= (size_t)min_mb * 1024 * 1024 ? 1 : 0;
         const int rc = pw_stream(M, Nn, Kd, src, wgt, out, stat_sum, stat_sq, p.stat_atomic_rows, ex, so, st);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
+    // ... and the 3 x 3 / stride 1 / padding 1 convolution 64 -> 64 of the same stage and its data gradient, as the same stream over nine taps
+    if (dtype == SAICV_DTYPE_BF16 && !out_f32 && R == 3 && S == 3 && pad == 1 && stride == 1 && C == 64 && Nn == 64 && Kd == 576 && ldo == Nn &&
+        H == OH && W == OW && !bias && !p.act_mode && !p.row_scale && !p.out2 && !(stat_sum && (p.addend || p.bs_y))) {
+        static const long min_mb3 = getenv("SAICV_NT_STREAM_MIN_MB") ? atol(getenv("SAICV_NT_STREAM_MIN_MB")) : 0;
+        const int so = (size_t)M * Nn * 2 >= (size_t)min_mb3 * 1024 * 1024 ? 1 : 0;
+        const int rc = pw3_stream(mode, M, H, W, src, wgt, out, stat_sum, stat_sq, p.stat_atomic_rows, ex, so, st);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
     p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.R = R; p.S = S; p.stride = stride; p.pad = pad;

@@ -8,8 +8,8 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // igemm.hip
-// dense_rows: the product reads whole consecutive rows of its source (pointwise, stride 1, no padding)
-int conv_stat_rows(int M, int Nn, int Kd, int dtype, bool dense_rows = false);
+// form: 1 = the product reads whole consecutive rows of its source (pointwise, stride 1, no padding), 2 = 3 x 3 / stride 1 / padding 1
+int conv_stat_rows(int M, int Nn, int Kd, int dtype, int form = 0);
 // optional epilogue extras: out = addend + row_scale[m / rows_per_scale] * (acc + bias)
 struct EpiExtra {
     const void* addend = nullptr;      // same dtype / layout as out
@@ -28,7 +28,7 @@ struct EpiExtra {
     int stat_atomic_rows = 0;              // > 0: statistics added atomically into this many rows of a zeroed buffer
 };
 // partial rows the data gradient (mode 1; M rows on the OH x OW pixel grid) writes with bs_*
-int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype, bool dense_rows = false);
+int conv_bwd_stat_rows(int M, int OH, int OW, int Nn, int Kd, int stride, int dtype, int form = 0);
 int igemm_nt(int dtype, int mode, const void* src, const void* wgt, void* out, const float* bias,
              float* stat_sum, float* stat_sq, int H, int W, int C, int OH, int OW, int R, int S,
              int stride, int pad, int M, int Nn, int Kd, int ldo, int out_f32, hipStream_t st,
@@ -41,6 +41,9 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
 int pw_stream_blocks(int dtype, int M, int Nn, int Kd, bool fused_dgrad);
 int pw_stream(int M, int Nn, int Kd, const void* src, const void* wgt, void* out, float* stat_sum, float* stat_sq,
               int stat_atomic_rows, const EpiExtra* ex, int stream_out, hipStream_t st);
+int pw3_stream_blocks(int dtype, int M, int Nn, int Kd);
+int pw3_stream(int mode, int M, int H, int W, const void* src, const void* wgt, void* out, float* stat_sum, float* stat_sq,
+               int stat_atomic_rows, const EpiExtra* ex, int stream_out, hipStream_t st);
 
 // sam.hip
 int window_partition(int dtype, const void* x, void* out, int B, int H, int W, int C, int ws, hipStream_t st);

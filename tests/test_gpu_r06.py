@@ -251,7 +251,7 @@ def _stage(chain):
 def test_streaming_pointwise_convolutions_equal_the_tiled_kernel_and_torch(chain, hw, monkeypatch):
     """pw_stream_kernel (csrc/pwstream.hip: ResNet-50 stage-1 / stage-2 1 x 1 convolutions, reference
     SimpleAICV/classification/backbones/resnet.py:33-43,100-155): two Bottleneck blocks forward + backward under bf16 autocast with
-    every eligible shape on the streaming kernel (BatchNorm statistics in the forward; gated shortcut gradient and
+    every eligible shape on the streaming kernel -- the 1 x 1 products and, in stage 1, the 3 x 3 / 64 -> 64 convolution as nine taps (BatchNorm statistics in the forward; gated shortcut gradient and
     BatchNorm-backward sums in the data gradient; a row count that is no multiple of 16) against (1) the same blocks on the tiled
     kernel -- same bf16 operands and fp32 accumulation, only the summation order differs -- and (2) the oracle's fp32 blocks on the CPU."""
     h, w = hw
@@ -265,6 +265,7 @@ def test_streaming_pointwise_convolutions_equal_the_tiled_kernel_and_torch(chain
     def run(stream):
         from simpleaicv_pytorch_training_examples_amd import ops
         monkeypatch.setenv('SAICV_PW_STREAM', '1' if stream else '0')
+        monkeypatch.setenv('SAICV_PW_STREAM3', '1' if stream else '0')
         monkeypatch.setenv('SAICV_PW_MIN_ROWS', '1024')
         net = _stage(chain)
         net.load_state_dict(state)
