@@ -57,8 +57,8 @@ LOOP_MODELS = {'resnet50_detr_config': ('tools.scripts.train_detection', 8, 1024
                # full SAM step: one encoder pass (972.1 GFLOP fwd) + 1 + decoder_iters light decoder passes
                'sam_b': ('tools.interactive_segmentation_scripts.train_sam_segmentation', 8, 1024, 3 * 972.1)}
 # HBM bytes per launch per kernel family, from separate rocprofv3 --pmc passes of the same command (scripts/gpu_r05.sh pmc:<model>)
-PMC_FILES = {'resnet50': ['profiles/r05_pmc_hbm_traffic.json', 'profiles/r04_pmc_hbm_traffic.json', 'profiles/r03_pmc_hbm_traffic.json', 'profiles/r02_pmc_hbm_traffic.json'],
-             'vit_base_patch16': ['profiles/r05_pmc_hbm_traffic_vit_base_patch16.json', 'profiles/r04_pmc_hbm_traffic_vit_base_patch16.json']}
+PMC_FILES = {'resnet50': ['profiles/r06_pmc_hbm_traffic.json', 'profiles/r05_pmc_hbm_traffic.json', 'profiles/r04_pmc_hbm_traffic.json', 'profiles/r03_pmc_hbm_traffic.json', 'profiles/r02_pmc_hbm_traffic.json'],
+             'vit_base_patch16': ['profiles/r06_pmc_hbm_traffic_vit_base_patch16.json', 'profiles/r05_pmc_hbm_traffic_vit_base_patch16.json', 'profiles/r04_pmc_hbm_traffic_vit_base_patch16.json']}
 # what each bracketed family is in the rocprofv3 kernel lists
 FAMILY_KERNELS = {'igemm_nt': 'igemm_nt1_kernel (implicit-GEMM conv / linear: forward + data gradient)',
                   'igemm_tn': 'igemm_tn_dma_kernel (weight gradient)',
@@ -417,6 +417,11 @@ def measure(name, args, world, rank, device, use_graph, primary):
                                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                                'traffic_source': (f'{traffic_file} (separate rocprofv3 --pmc passes of this command, not this run)'
                                                   if traffic is not None else None),
+                               # the same traffic read from the L2's fabric REQUEST counters (TCC_EA0_RDREQ / WRREQ x 64 B, 32-byte reads at
+                               # 32 B; scripts/make_tcc_traffic.py): FETCH_SIZE's x 2 rule for gfx950 assumes 128-byte reads and over-counts
+                               # the 64-byte K-slice requests of the LDS-DMA loads, this reading under-counts true 128-byte requests --
+                               # the two bracket the real figure
+                               'traffic_fabric_requests': tcc_traffic(name, 'igemm_nt', kk['bytes'] / max(kk['calls'], 1)),
                                'launches': kk['calls'], 'avg_launch_us': round(kk['ms'] * 1e3 / kk['calls'], 2),
                                # what the SHAPES allow: sum over the launches of max(flops / MFMA peak, algorithmic bytes /
                                # HBM peak) -- many ResNet-50 launches (K <= 256, and the data gradients that also carry a
@@ -611,6 +616,17 @@ def pmc_traffic(model, kernel):
         except (OSError, KeyError, ValueError):
             continue
     return None, None
+
+
+def tcc_traffic(model, kernel, algorithmic_bytes_per_launch):
+    """{'bytes_per_launch', 'ratio_to_algorithmic', 'source'} from the committed TCC request-counter summary of this command, or None."""
+    f = 'profiles/r06_tcc_traffic' + ('' if model == 'resnet50' else '_' + model) + '.json'
+    try:
+        b = json.load(open(os.path.join(ROOT, f)))['kernels'][kernel]['bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+    return {'bytes_per_launch': b, 'ratio_to_algorithmic': round(b / algorithmic_bytes_per_launch, 3) if algorithmic_bytes_per_launch else None,
+            'source': f'{f} (a rocprofv3 --pmc pass of its own over this command, not this run)'}
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -810,7 +826,7 @@ def worker(args):
         gc.collect()
         torch.cuda.empty_cache()
         a3 = _ap.Namespace(**vars(args))
-        a3.batch, a3.steps, a3.warmup, a3.max_windows, a3.min_gpu_seconds, a3.no_kernel_timer = 8, 5, 5, 1, 0.0, True
+        a3.batch, a3.steps, a3.warmup, a3.max_windows, a3.min_gpu_seconds, a3.no_kernel_timer = 8, 5, 5, 1, 0.0, False      # (r06: priced like the others)
         try:
             detr = measure('resnet50_detr_config', a3, world, rank, device, want_step_graph(args.eager, args.graph, world, os.environ.get('SAICV_STEP_GRAPH')), False)
             detr['steps'], detr['warmup'] = a3.steps, a3.warmup

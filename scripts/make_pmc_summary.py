@@ -14,6 +14,8 @@ FAMILIES = ['igemm_nt', 'igemm_tn', 'bn_bwd_apply', 'bn_bwd_reduce', 'bn_act_fwd
 
 
 def family(name):
+    if 'pw_stream' in name:          # the streaming forms of the same products (csrc/pwstream.hip) are priced with the tiled kernel's family
+        return 'igemm_nt'
     for f in FAMILIES:
         if f in name:
             return f

@@ -1,0 +1,39 @@
+"""Fabric traffic per kernel family from the TCC request counters of `scripts/gpu_r06.sh tcc:<model>` (scripts/pmc_fold.py output):
+reads = TCC_EA0_RDREQ x 64 B (32-byte requests counted at 32 B), writes = TCC_EA0_WRREQ x 64 B -- the reading VERDICT r05 asks the
+bench line to carry for ViT-B instead of the FETCH_SIZE x 2 rule, which over-counts the 64-byte K-slice requests of the LDS-DMA loads.
+
+    python scripts/make_tcc_traffic.py <tcc json> <steps profiled> <out json> [model]"""
+import json
+import sys
+
+from make_pmc_summary import family
+
+
+def main():
+    src, steps, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    model = sys.argv[4] if len(sys.argv) > 4 else 'resnet50'
+    fam = {}
+    for name, e in json.load(open(src)).items():
+        f = family(name.replace(' ', ''))
+        if f is None or 'TCC_EA0_RDREQ_sum' not in e:
+            continue
+        n = e['launches']
+        rd32 = e.get('TCC_EA0_RDREQ_32B_sum', 0.0)
+        rd = ((e['TCC_EA0_RDREQ_sum'] - rd32) * 64 + rd32 * 32) * n          # (pmc_fold stores per-launch averages)
+        wr = e.get('TCC_EA0_WRREQ_sum', 0.0) * 64 * n
+        a = fam.setdefault(f, {'launches': 0, 'read': 0.0, 'write': 0.0})
+        a['launches'] += n
+        a['read'] += rd
+        a['write'] += wr
+    out = {'_doc': f'fabric bytes from TCC_EA0_RDREQ / TCC_EA0_WRREQ (x 64 B; 32-byte reads at 32 B) over the eager step of `bench.py --model {model}` '
+                   '(b256 bf16), rocprofv3 --pmc in a pass of its own', 'steps_profiled': steps, 'kernels': {}}
+    for f, a in sorted(fam.items()):
+        n = max(a['launches'], 1)
+        out['kernels'][f] = {'launches_per_step': round(n / steps, 1), 'read_GB_per_step': round(a['read'] / steps / 1e9, 2),
+                             'write_GB_per_step': round(a['write'] / steps / 1e9, 2), 'bytes_per_launch': int((a['read'] + a['write']) / n)}
+    json.dump(out, open(out_path, 'w'), indent=1)
+    print(json.dumps(out['kernels'], indent=1))
+
+
+if __name__ == '__main__':
+    main()

@@ -30,10 +30,13 @@
 // TAPS = 9 (r06): the 3 x 3 / stride 1 / padding 1 convolution 64 -> 64 of the same stage (resnet.py:112, 84 % of stage 1's
 // flops) and its data gradient as the SAME stream: the reduction is 9 taps x 64 channels, tap (r, s) of pixel (y, x) is the 128-byte
 // row of pixel (y + r - 1, x + s - 1) -- one more address per tap, a buffer offset beyond the tensor (hardware zeros) where the tap
-// leaves the image.  The 72 KiB of weights do not fit registers: they sit in LDS (64 rows of 9 * 128 + 16 bytes, conflict-free
-// 16-byte fragment reads), one workgroup of 8 streams per CU shares them.  A stream walks CONSECUTIVE row groups, so the eight
-// neighbours of a pixel row are re-read from L1 / the XCD's L2, not from HBM: HBM sees each input row once, where the tiled
-// kernel's gather (9 K-slices per tile through LDS-DMA) runs at 0.25 of the launch's HBM bound (profiles/r06_nt_experiments.md).
+// leaves the image.  The 72 KiB of weights do not fit registers: they sit in LDS (64 rows of 9 * 128 + 32 bytes, conflict-free
+// 16-byte fragment reads), one workgroup of 8 streams per CU shares them.  The activations go through a WAVE-PRIVATE LDS window:
+// the three image rows around a row group, 18 pixels each, are fetched once per row group (9 loads of 16 bytes per lane, prefetched
+// one row group ahead) and the nine taps read their fragments from there -- the first version fetched every tap from L1 / L2
+// (18 loads per row group, 0.9 GB through the L2s per launch: 110 us, bound by exactly that, profiles/r06_nt_experiments.md).  One
+// wavefront's LDS operations execute in order, so window writes, fragment reads and the staged output strip (which reuses the
+// window) need no barrier.  A stream walks CONSECUTIVE row groups: the rows a neighbouring group needs again come from the XCD's L2.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -74,8 +77,8 @@ DEVINL uint32_t lds_addr32(const char* q) { return (uint32_t)reinterpret_cast<ui
 template <int IMM> DEVINL void lds_rd128(u32x4& d, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM) : "memory");
 }
-template <int N> DEVINL void lgkm_release(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+template <int N> DEVINL void lgkm_release(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N) : "memory");
 }
 template <int B, int E, typename F> DEVINL void static_for(F&& f) {
     if constexpr (B < E) {
@@ -109,13 +112,20 @@ __global__ __launch_bounds__(64 * pw_nwaves(NSPLIT, TAPS)) void pw_stream_kernel
     constexpr int NT = 4, KS = KD / 32;           // MFMA row tiles (channels) and k-steps per wavefront
     constexpr int CPR = 8, RPP = 8, NPASS = 2;    // staged strip: 16 rows x 128 bytes, copied out 8 rows per pass
     constexpr int PITCH = 128 + 16;
-    constexpr int DEPTH = TAPS > 1 ? 2 : KD <= 64 ? 4 : 2;       // row groups in flight in registers
+    constexpr int DEPTH = TAPS > 1 ? 1 : KD <= 64 ? 4 : 2;       // row groups in flight in registers
     constexpr bool WLDS = TAPS > 1;               // the weights live in LDS
-    constexpr int WPITCH = KD * 2 + 16;           //   bytes per weight row (4 dwords of skew per row: conflict-free 16-byte fragment reads)
+    // LDS pitches of the nine-tap form, conflict-free for ds_read_b128's lane groups ({0-3, 12-15, 20-27}, ... -- MI355X_MICROARCH.md, LDS):
+    // 16 rows (pixels) at this pitch with the 16-byte k-group offsets of a fragment read meet 64 distinct banks in every group
+    constexpr int WPITCH = KD * 2 + 32;           //   bytes per weight row
+    constexpr int PW = CK * 2 + 32;               //   bytes per pixel of the wavefront's input window
+    constexpr int WIN_PX = 18;                    //   pixels per window row: the 16 of the row group + one on each side
+    constexpr int WIN_BYTES = 3 * WIN_PX * PW;    //   three image rows; + 128 zero bytes a tap outside the image reads instead
+    constexpr int WAVE_LDS = WIN_BYTES + 128;
     constexpr uint32_t OOB = 0xfffffff0u;
     static_assert(ND == 64 * NSPLIT && KD % 32 == 0 && (TAPS == 1 || (TAPS == 9 && CK == 64)), "64 channels per wavefront");
     extern __shared__ __attribute__((aligned(16))) char wlds[];
-    __shared__ __attribute__((aligned(16))) char strip[NWAVES][16 * PITCH];
+    __shared__ __attribute__((aligned(16))) char strip[TAPS > 1 ? 1 : NWAVES][16 * PITCH];     // (nine taps: the strip reuses the window)
+    static_assert(16 * PITCH <= WIN_BYTES, "the staged strip fits the window");
     __shared__ float red[(STATS || EXTRAS) ? NWAVES * 2 * 64 : 1];
 
     const int lane = threadIdx.x & 63;
@@ -145,45 +155,45 @@ __global__ __launch_bounds__(64 * pw_nwaves(NSPLIT, TAPS)) void pw_stream_kernel
     const uint32_t waddr = lds_addr32(wlds + (nc0 + l15) * WPITCH + lg * 16);      // WLDS: this lane's fragment (nt, ks) at + nt * 16 rows + ks * 64 bytes
 
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.src), 0, p.src_bytes, 0x00020000);
-    u32x4 bfr[DEPTH][KS];
+    u32x4 bfr[DEPTH][TAPS > 1 ? 1 : KS];
     // the stream's i-th row group: strided over the launch (pointwise: the chip reads one advancing window) or consecutive (TAPS = 9)
     const int count = TAPS == 1 ? (unit < p.mtiles ? (p.mtiles - unit + U - 1) / U : 0)
                                 : max(0, min(p.tiles_per_unit, p.mtiles - unit * p.tiles_per_unit));
     auto tile_of = [&](int i) { return i >= count ? p.mtiles : TAPS == 1 ? unit + i * U : unit * p.tiles_per_unit + i; };   // p.mtiles: no row group
     const uint32_t lane_off = (uint32_t)l15 * (CK * 2) + (uint32_t)lg * 16;
-    auto load_tile = [&](u32x4 (&dst)[KS], int tile) __attribute__((always_inline)) {
+    auto load_tile = [&](u32x4 (&dst)[TAPS > 1 ? 1 : KS], int tile) __attribute__((always_inline)) {
         if constexpr (TAPS == 1) {
             const uint32_t base = tile < p.mtiles ? (uint32_t)tile * (16 * KD * 2) + lane_off : OOB;       // rows past M read zeros (buffer bounds)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 dst[ks] = __builtin_amdgcn_raw_buffer_load_b128(src_rs, (int)(tile < p.mtiles ? base + ks * 64 : OOB), 0, 0);
-        } else {
-            // this lane's pixel and, per tap, the byte offset of the pixel the tap reads (outside the image / past M: zeros)
-            // (the coordinates are computed for every lane and pinned: left free, the compiler moves the divisions under a divergent
-            // branch on `live` and the loads with them -- two copies of every load, joined by moves behind vmcnt(0))
-            const int pix = tile * 16 + l15;
-            const bool live = tile < p.mtiles && pix < p.M;
-            const int row = pix / p.W;
-            int x = pix - row * p.W;
-            int y = row % p.H;
-            asm volatile("" : "+v"(x), "+v"(y));
-            const uint32_t base = (uint32_t)pix * (CK * 2) + (uint32_t)lg * 16;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int dy = p.tap_sign * (r - 1), dx = p.tap_sign * (t - 1);
-                    const bool ok = live && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
-                    uint32_t off = ok ? base + (uint32_t)((dy * p.W + dx) * (CK * 2)) : OOB - 256;      // (+ 64 stays beyond the tensor and below 2^32)
-                    asm volatile("" : "+v"(off));
-#pragma unroll
-                    for (int h = 0; h < CK / 32; ++h)
-                        dst[(r * 3 + t) * (CK / 32) + h] = __builtin_amdgcn_raw_buffer_load_b128(src_rs, (int)(off + h * 64), 0, 0);
-                }
         }
     };
+    // TAPS = 9: the three image rows around a row group, 18 pixels each (pixel index q0 + px, q0 = first pixel + (row - 1) * W - 1), as
+    // 16-byte chunks: lane -> (pixel (lane >> 3) + 8 j, chunk lane & 7), j = 0 .. 2.  Pixels before the tensor / past M read zeros; a
+    // pixel of the neighbouring image row or image is loaded as it is -- the taps that would use it are redirected to zeros below.
+    char* const win = WLDS ? wlds + ND * WPITCH + wave * WAVE_LDS : nullptr;
+    u32x4 pf[WLDS ? 9 : 1];
+    auto load_rows = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_tile(bfr[d], tile_of(d));
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int px = (lane >> 3) + 8 * j;
+                const int q = tile * 16 + (rr - 1) * p.W - 1 + px;
+                const bool ok = tile < p.mtiles && px < WIN_PX && (unsigned)q < (unsigned)p.M;
+                uint32_t off = ok ? (uint32_t)q * (CK * 2) + (uint32_t)(lane & 7) * 16 : OOB;
+                asm volatile("" : "+v"(off));
+                pf[rr * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(src_rs, (int)off, 0, 0);
+            }
+    };
+    if constexpr (WLDS) {
+        if (lane < 8) *reinterpret_cast<u32x4*>(win + WIN_BYTES + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        load_rows(tile_of(0));
+    } else {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load_tile(bfr[d], tile_of(d));
+    }
 
     float ssum[8], ssq[8];        // STATS: sum / sum of squares; EXTRAS: sum g / sum g * y   of this lane's 8 channels
 #pragma unroll
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(64 * pw_nwaves(NSPLIT, TAPS)) void pw_stream_kernel
     const bool addp = EXTRAS && p.addend != nullptr, gatep = EXTRAS && p.addend_gate != nullptr;
     const bool bsp = EXTRAS && p.bs_y != nullptr, maskp = EXTRAS && p.bs_mask != nullptr;
     const bool stream_out = p.stream_out != 0;
-    char* const my = strip[wave];
+    char* const my = WLDS ? win : strip[WLDS ? 0 : wave];
     const int crow = lane / CPR, cchunk = lane % CPR;             // copy-out coordinates: row of the pass, 16-byte chunk of the 128-byte row
 
     // One row group of slot D (a compile-time index: the slots are registers).  The loop below has NO path that skips a slot: with a
@@ -227,18 +237,47 @@ __global__ __launch_bounds__(64 * pw_nwaves(NSPLIT, TAPS)) void pw_stream_kernel
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (WLDS) {
             static_assert(NT == 4, "four fragments per k-step");
-            u32x4 wa[2][NT];
+            // the prefetched rows of THIS row group -> window (chunks of one pixel are 128 contiguous bytes: conflict-free stores)
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int px = (lane >> 3) + 8 * j;
+                    if (px < WIN_PX) *reinterpret_cast<u32x4*>(win + (rr * WIN_PX + px) * PW + (lane & 7) * 16) = pf[rr * 3 + j];
+                }
+            // this lane's pixel and, per tap, where its 16-byte k-group sits in the window (outside the image / past M: the zero chunk).
+            // (the coordinates are computed for every lane and pinned: left free, the compiler moves the divisions under a divergent branch)
+            const int pix = tile * 16 + l15;
+            const bool live = pix < p.M;
+            const int row = pix / p.W;
+            int x = pix - row * p.W;
+            int y = row % p.H;
+            asm volatile("" : "+v"(x), "+v"(y));
+            const uint32_t win32 = lds_addr32(win);
+            uint32_t baddr[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int dy = p.tap_sign * (r - 1), dx = p.tap_sign * (t - 1);
+                    const bool ok = live && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+                    baddr[r * 3 + t] = win32 + (ok ? (uint32_t)(((dy + 1) * WIN_PX + l15 + dx + 1) * PW) : (uint32_t)WIN_BYTES) + (uint32_t)lg * 16;
+                }
+            load_rows(tile_of(i + 1));                            // the next row group's rows travel during the products
+            // fragment reads of k-step k + 1 (four of the weights, one of the window) in flight during the MFMAs of k-step k
+            u32x4 wa[2][NT], wb[2];
             auto issue = [&](auto KSI) __attribute__((always_inline)) {
                 constexpr int k = decltype(KSI)::value;
                 static_for<0, NT>([&](auto NI) { lds_rd128<decltype(NI)::value * 16 * WPITCH + k * 64>(wa[k & 1][decltype(NI)::value], waddr); });
+                lds_rd128<(k % (CK / 32)) * 64>(wb[k & 1], baddr[k / (CK / 32)]);
             };
             issue(std::integral_constant<int, 0>{});
             static_for<0, KS>([&](auto KSI) {
                 constexpr int k = decltype(KSI)::value;
                 if constexpr (k + 1 < KS) issue(std::integral_constant<int, k + 1>{});
-                lgkm_release<(k + 1 < KS) ? NT : 0>(wa[k & 1][0], wa[k & 1][1], wa[k & 1][2], wa[k & 1][3]);
+                lgkm_release<(k + 1 < KS) ? NT + 1 : 0>(wa[k & 1][0], wa[k & 1][1], wa[k & 1][2], wa[k & 1][3], wb[k & 1]);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) Mma<bf16_t>::run(acc[nt], wa[k & 1][nt], bfr[d][k]);
+                for (int nt = 0; nt < NT; ++nt) Mma<bf16_t>::run(acc[nt], wa[k & 1][nt], wb[k & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             });
         } else {
@@ -246,8 +285,8 @@ __global__ __launch_bounds__(64 * pw_nwaves(NSPLIT, TAPS)) void pw_stream_kernel
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) Mma<bf16_t>::run(acc[nt], wf[nt][ks], bfr[d][ks]);
+            load_tile(bfr[d], tile_of(i + DEPTH));           // the slot is free again: DEPTH groups ahead
         }
-        load_tile(bfr[d], tile_of(i + DEPTH));           // the slot is free again: DEPTH groups ahead
         // accumulators -> strip: D row lg*4 + r of tile nt = channel nt*16 + lg*4 + r, D column = pixel l15
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -362,9 +401,9 @@ int launch(const PWParams& p, int blocks, bool stats, bool extras, hipStream_t s
     return saicv::check_launch("pw_stream");
 }
 
-// the 3 x 3 form: 64 -> 64 channels, one workgroup of 8 streams per CU, weights in 73 KiB of dynamic LDS
+// the 3 x 3 form: 64 -> 64 channels, one workgroup of 8 streams per CU; dynamic LDS = weights (64 rows of 1 184 bytes) + 8 windows
 int launch_taps9(const PWParams& p, int blocks, bool stats, bool extras, hipStream_t st) {
-    constexpr size_t smem = (size_t)64 * (576 * 2 + 16);
+    constexpr size_t smem = (size_t)64 * (576 * 2 + 32) + 8 * (size_t)(3 * 18 * (64 * 2 + 32) + 128);      // (kernel: ND * WPITCH + NWAVES * WAVE_LDS)
     dim3 grid(blocks), block(64 * pw_nwaves(1, 9));
 #define PW3_LAUNCH(ST, EX)                                                                                                        \
     {                                                                                                                             \
