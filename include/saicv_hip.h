@@ -306,6 +306,12 @@ size_t saicv_layernorm_bwd_ws_floats(int M, int C);
 int saicv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                         const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
                         int M, int C, int accumulate, void* stream);
+/* The same with a second output dx_scaled[row] = out_scale[row / rows_per_scale] * dx[row] (the factor applied to the stored, rounded
+ * gradient): the drop-path branch that produced this LayerNorm's input consumes exactly that (vit.py:160-161, x + drop_path(branch(x)):
+ * d branch = factor * d out), so the separate saicv_row_scale pass over the residual-stream gradient disappears. */
+int saicv_layernorm_bwd_scaled(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                               const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
+                               int M, int C, int accumulate, const float* out_scale, int rows_per_scale, void* dx_scaled, void* stream);
 /* nn.GELU() (exact erf form), vit.py:87-99 */
 int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream);
 int saicv_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, void* stream);

@@ -74,7 +74,7 @@ int scaler_update(float*, const float*, double, double, int, hipStream_t);
 int layernorm_fwd(int, const void*, const float*, const float*, void*, float*, float*, int, int, double, hipStream_t);
 size_t layernorm_bwd_ws_floats(int, int);
 int layernorm_bwd(int, const void*, const void*, const float*, const float*, const float*, const void*, void*,
-                  float*, float*, float*, int, int, int, hipStream_t);
+                  float*, float*, float*, int, int, int, hipStream_t, const float* = nullptr, int = 1, void* = nullptr);
 int gelu_fwd(int, const void*, void*, size_t, hipStream_t);
 int gelu_bwd(int, const void*, const void*, void*, size_t, hipStream_t);
 int attention_fwd(int, const void*, void*, float*, int, int, int, int, double, hipStream_t);
@@ -412,6 +412,12 @@ int saicv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* g
                         const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
                         int M, int C, int accumulate, void* stream) {
     return layernorm_bwd(dtype, dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, S(stream));
+}
+int saicv_layernorm_bwd_scaled(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                               const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
+                               int M, int C, int accumulate, const float* out_scale, int rows_per_scale, void* dx_scaled, void* stream) {
+    return layernorm_bwd(dtype, dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, S(stream), out_scale,
+                         rows_per_scale, dx_scaled);
 }
 int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream) {
     return gelu_fwd(dtype, x, y, n, S(stream));

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* 
                                                             const float* __restrict__ rstd,
                                                             const T* __restrict__ addend, T* __restrict__ dx,
                                                             float* __restrict__ part_g, float* __restrict__ part_b,
-                                                            int M, int C, int rows_per) {
+                                                            int M, int C, int rows_per, const float* __restrict__ out_scale,
+                                                            int rows_per_scale, T* __restrict__ dxs) {
     constexpr int N = Chunk<T>::N;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cpr = C / N;
@@ -160,7 +161,16 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* 
 #pragma unroll
                     for (int k = 0; k < N; ++k) o[k] += a[k];
                 }
-                st_chunk(dx + (size_t)row * C + c * N, Chunk<T>::pack(o));
+                const auto packed = Chunk<T>::pack(o);
+                st_chunk(dx + (size_t)row * C + c * N, packed);
+                if (dxs != nullptr) {           // the drop-path twin: row factor x the STORED (rounded) gradient, as a separate row_scale pass would give
+                    float r[N];
+                    Chunk<T>::unpack(packed, r);
+                    const float sc = out_scale[row / rows_per_scale];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) r[k] *= sc;
+                    st_chunk(dxs + (size_t)row * C + c * N, Chunk<T>::pack(r));
+                }
             }
         }
     }
@@ -245,7 +255,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_half_kernel(cons
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const T* __restrict__ addend,
                                                                  T* __restrict__ dx, float* __restrict__ part_g,
-                                                                 float* __restrict__ part_b, int M, int C, int rows_per) {
+                                                                 float* __restrict__ part_b, int M, int C, int rows_per,
+                                                                 const float* __restrict__ out_scale, int rows_per_scale, T* __restrict__ dxs) {
     // rows_per counts ROW PAIRS per wavefront here: a block covers rows_per * LNB_WAVES * 2 rows
     constexpr int N = Chunk<T>::N;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sl = lane & 31, sub = lane >> 5;
@@ -327,7 +338,16 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_half_kernel(cons
 #pragma unroll
                     for (int k = 0; k < N; ++k) o[k] += a[k];
                 }
-                st_chunk(dx + (size_t)row * C + c * N, Chunk<T>::pack(o));
+                const auto packed = Chunk<T>::pack(o);
+                st_chunk(dx + (size_t)row * C + c * N, packed);
+                if (dxs != nullptr) {           // the drop-path twin: row factor x the STORED (rounded) gradient, as a separate row_scale pass would give
+                    float r[N];
+                    Chunk<T>::unpack(packed, r);
+                    const float sc = out_scale[row / rows_per_scale];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) r[k] *= sc;
+                    st_chunk(dxs + (size_t)row * C + c * N, Chunk<T>::pack(r));
+                }
             }
         }
     }
@@ -1055,7 +1075,7 @@ size_t layernorm_bwd_ws_floats(int M, int C) {
 template <typename T>
 static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, const float* mean,
                            const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
-                           int M, int C, int accumulate, hipStream_t st) {
+                           int M, int C, int accumulate, hipStream_t st, const float* out_scale, int rows_per_scale, void* dxs) {
     constexpr int N = Chunk<T>::N;
     const int nch = (C / N + 63) / 64;
     int rp;
@@ -1063,12 +1083,12 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
     float* pg = ws;
     float* pb = ws + (size_t)nb * C;
     dim3 grid(nb), block(64 * LNB_WAVES);
-#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)addend, (T*)dx, pg, pb, M, C, rp)
+#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)addend, (T*)dx, pg, pb, M, C, rp, out_scale, rows_per_scale, (T*)dxs)
     if (ln_half_rows(C / N)) {
         // the same nb blocks (the workspace is sized for them), each covering 2 * rp2 * LNB_WAVES rows with rp2 row PAIRS per wavefront
         const int rp2 = (rp + 1) / 2;
         hipLaunchKernelGGL((layernorm_bwd_half_kernel<T, 3>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
-                           (const T*)addend, (T*)dx, pg, pb, M, C, rp2);
+                           (const T*)addend, (T*)dx, pg, pb, M, C, rp2, out_scale, rows_per_scale, (T*)dxs);
     } else
     if (nch <= 1) LN_LAUNCH(1);
     else if (nch <= 2) LN_LAUNCH(2);
@@ -1079,14 +1099,17 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
     return check_launch("layernorm_bwd");
 }
 
+// out_scale / rows_per_scale / dxs (optional): also write dxs[row] = out_scale[row / rows_per_scale] * dx[row] -- the gradient the
+// drop-path branch below this LayerNorm's input consumes (reference vit.py:160-161: x + drop_path(branch(x))), saving its own pass
 int layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                   const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws, int M,
-                  int C, int accumulate, hipStream_t st) {
+                  int C, int accumulate, hipStream_t st, const float* out_scale, int rows_per_scale, void* dxs) {
     const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
     SAICV_REQUIRE(C % n == 0 && M > 0, "layernorm_bwd: C=%d must be a multiple of %d", C, n);
+    SAICV_REQUIRE(dxs == nullptr || (out_scale != nullptr && rows_per_scale >= 1), "layernorm_bwd: a scaled output needs its row factors");
     if (dtype == SAICV_DTYPE_BF16)
-        return layernorm_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, st);
-    return layernorm_bwd_t<float>(dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, st);
+        return layernorm_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, st, out_scale, rows_per_scale, dxs);
+    return layernorm_bwd_t<float>(dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, st, out_scale, rows_per_scale, dxs);
 }
 
 int gelu_fwd(int dtype, const void* x, void* y, size_t n, hipStream_t st) {

@@ -166,8 +166,10 @@ def ln_fwd(x2, weight, bias, eps):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x2, weight, bias, mean, rstd, addend=None):
-    """-> (dx, dgamma or None, dbeta or None)  (None: accumulated into the arena gradient)"""
+def ln_bwd(dy, x2, weight, bias, mean, rstd, addend=None, scaled_for=None):
+    """-> (dx, dgamma or None, dbeta or None)  (None: accumulated into the arena gradient).
+    scaled_for = (row factors [M / rows_per_scale] fp32, rows_per_scale): the drop-path factors of the branch that PRODUCED x2; the same
+    pass also writes factor * dx and hangs it on dx as `_saicv_scaled` = (tensor, factors) for that branch's backward to pick up."""
     m, c = x2.shape
     L = lib()
     dx = torch.empty_like(x2)
@@ -180,10 +182,18 @@ def ln_bwd(dy, x2, weight, bias, mean, rstd, addend=None):
     if dy.dtype != x2.dtype:
         dy = dy.to(x2.dtype)
     t0 = KernelTimer.begin('layernorm_bwd')
-    check(L.saicv_layernorm_bwd(dtype_code(x2.dtype), ptr(dy), ptr(x2), ptr(weight), ptr(mean), ptr(rstd), ptr(addend),
-                                ptr(dx), ptr(dg), ptr(db), ptr(ws), m, c, int(direct), stream()), 'layernorm_bwd')
-    # dy, x (and the residual-stream addend) read, dx written; the partial dgamma / dbeta rows are noise next to them
-    KernelTimer.end(t0, 'layernorm_bwd', 0, (3.0 + (1.0 if addend is not None else 0.0)) * m * c * x2.element_size() + 8.0 * m)
+    if scaled_for is not None:
+        factors, rows_per = scaled_for
+        dxs = torch.empty_like(x2)
+        check(L.saicv_layernorm_bwd_scaled(dtype_code(x2.dtype), ptr(dy), ptr(x2), ptr(weight), ptr(mean), ptr(rstd), ptr(addend),
+                                           ptr(dx), ptr(dg), ptr(db), ptr(ws), m, c, int(direct), ptr(factors), int(rows_per), ptr(dxs),
+                                           stream()), 'layernorm_bwd_scaled')
+        dx._saicv_scaled = (dxs, factors)
+    else:
+        check(L.saicv_layernorm_bwd(dtype_code(x2.dtype), ptr(dy), ptr(x2), ptr(weight), ptr(mean), ptr(rstd), ptr(addend),
+                                    ptr(dx), ptr(dg), ptr(db), ptr(ws), m, c, int(direct), stream()), 'layernorm_bwd')
+    # dy, x (and the residual-stream addend) read, dx (and its drop-path twin) written; the partial dgamma / dbeta rows are noise next to them
+    KernelTimer.end(t0, 'layernorm_bwd', 0, (3.0 + (1.0 if addend is not None else 0.0) + (1.0 if scaled_for is not None else 0.0)) * m * c * x2.element_size() + 8.0 * m)
     if direct:
         return dx, None, None
     return dx, dg, db
@@ -481,12 +491,47 @@ def stream_attention(q, k, v, heads, scale, key_bias=None, dropout_p=0.0):
 
 
 # ------------------------------------------------------------------------------ fused ViT sub-layers
+# r06 -- the drop-path factor of a branch reaches its gradient without a pass of its own.  `out = x + s * branch(x)`: d branch = s * d out,
+# and d out is what the LayerNorm backward of the NEXT sub-layer writes (LayerNorm gradient + residual-stream gradient).  That kernel
+# writes s * d out beside it (saicv_layernorm_bwd_scaled): one more store instead of a load + store (24 passes over [B * N, C] per ViT-B
+# step).  The plumbing rides on tensor attributes, like the BatchNorm links of ops.py: a sub-layer's output carries its factors
+# (`_saicv_drop`), the sub-layer that consumes it hands them to its LayerNorm backward, whose result carries the scaled twin
+# (`_saicv_scaled`, with the version counter of the gradient it belongs to: autograd accumulating another gradient into the same tensor,
+# or any other route by which a different tensor arrives, falls back to the separate pass).  SAICV_LN_SCALED=0 switches it off.
+LN_SCALED = _os.environ.get('SAICV_LN_SCALED', '1') != '0'
+
+
+def _producer_factors(x):
+    """(factors, rows per factor) of the drop-path branch that produced x, or None"""
+    return getattr(x, '_saicv_drop', None) if LN_SCALED else None
+
+
+def _scaled_gradient(dout, drop_scale, dtype):
+    """factor * dout if the kernel that produced dout already wrote it (see above), else None"""
+    tw = getattr(dout, '_saicv_scaled', None)
+    if tw is None or drop_scale is None:
+        return None
+    twin, factors, version = tw
+    if factors.data_ptr() != drop_scale.data_ptr() or version != dout._version or twin.dtype != dtype:
+        return None
+    return twin
+
+
+def _with_twin(dx, shape):
+    out = dx.view(shape)
+    tw = getattr(dx, '_saicv_scaled', None)
+    if tw is not None:
+        out._saicv_scaled = (tw[0], tw[1], out._version)
+    return out
+
+
 class AttnSubLayerFn(torch.autograd.Function):
     """out = x + s * proj(attention(qkv(LN(x))))   -- one node (reference vit.py:160)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, drop_scale, heads, eps):
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, drop_scale, heads, eps, producer=None):
         require_gpu(x, qkv_w)
+        ctx.producer = producer
         b, n, c = x.shape
         x2 = _as2d(x)
         h, mean, rstd = ln_fwd(x2, ln_w, ln_b, eps)
@@ -505,12 +550,13 @@ class AttnSubLayerFn(torch.autograd.Function):
         dy = _as2d(dout)
         if dy.dtype != x2.dtype:
             dy = dy.to(x2.dtype)
-        dys = row_scale(dy, drop_scale, n) if drop_scale is not None else dy
+        dys = _scaled_gradient(dout, drop_scale, x2.dtype)
+        dys = _as2d(dys) if dys is not None else row_scale(dy, drop_scale, n) if drop_scale is not None else dy
         da, dpw, dpb = lin_bwd(a, proj_w, proj_b, dys)
         dqkv = attn_bwd(qkv, a, da, lse, b, n, heads, scale)
         dh, dqw, dqb = lin_bwd(h, qkv_w, qkv_b, dqkv)
-        dx, dlw, dlb = ln_bwd(dh, x2, ln_w, ln_b, mean, rstd, addend=dy)     # + residual-stream gradient
-        return dx.view(b, n, c), dlw, dlb, dqw, dqb, dpw, dpb, None, None, None
+        dx, dlw, dlb = ln_bwd(dh, x2, ln_w, ln_b, mean, rstd, addend=dy, scaled_for=ctx.producer)     # + residual-stream gradient
+        return _with_twin(dx, (b, n, c)), dlw, dlb, dqw, dqb, dpw, dpb, None, None, None, None
 
 
 class MlpSubLayerFn(torch.autograd.Function):
@@ -519,8 +565,9 @@ class MlpSubLayerFn(torch.autograd.Function):
     (reference detection/models/backbones/dinov3convnext.py:103-117)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, drop_scale, eps, residual=True):
+    def forward(ctx, x, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, drop_scale, eps, residual=True, producer=None):
         require_gpu(x, fc1_w)
+        ctx.producer = producer
         b, n, c = x.shape
         x2 = _as2d(x)
         h, mean, rstd = ln_fwd(x2, ln_w, ln_b, eps)
@@ -539,21 +586,29 @@ class MlpSubLayerFn(torch.autograd.Function):
         dy = _as2d(dout)
         if dy.dtype != x2.dtype:
             dy = dy.to(x2.dtype)
-        dys = row_scale(dy, drop_scale, n) if drop_scale is not None else dy
+        dys = _scaled_gradient(dout, drop_scale, x2.dtype)
+        dys = _as2d(dys) if dys is not None else row_scale(dy, drop_scale, n) if drop_scale is not None else dy
         df1, d2w, d2b = lin_bwd(g, fc2_w, fc2_b, dys, **({'gelu_dact': f1} if ctx.f1_is_dact else {'gelu_pre': f1}))      # dgrad epilogue applies gelu'
         dh, d1w, d1b = lin_bwd(h, fc1_w, fc1_b, df1)
-        dx, dlw, dlb = ln_bwd(dh, x2, ln_w, ln_b, mean, rstd, addend=dy if ctx.residual else None)
-        return dx.view(b, n, c), dlw, dlb, d1w, d1b, d2w, d2b, None, None, None
+        dx, dlw, dlb = ln_bwd(dh, x2, ln_w, ln_b, mean, rstd, addend=dy if ctx.residual else None,
+                              scaled_for=ctx.producer if ctx.residual else None)
+        return _with_twin(dx, (b, n, c)), dlw, dlb, d1w, d1b, d2w, d2b, None, None, None, None
+
+
+def _tag_drop(out, drop_scale):
+    if drop_scale is not None and LN_SCALED:
+        out._saicv_drop = (drop_scale, out.shape[1])
+    return out
 
 
 def attn_sublayer(x, norm, attn, drop_scale):
-    return AttnSubLayerFn.apply(x, norm.weight, norm.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight,
-                                attn.proj.bias, drop_scale, attn.head_nums, norm.eps)
+    return _tag_drop(AttnSubLayerFn.apply(x, norm.weight, norm.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight,
+                                          attn.proj.bias, drop_scale, attn.head_nums, norm.eps, _producer_factors(x)), drop_scale)
 
 
 def mlp_sublayer(x, norm, mlp, drop_scale):
-    return MlpSubLayerFn.apply(x, norm.weight, norm.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias,
-                               drop_scale, norm.eps)
+    return _tag_drop(MlpSubLayerFn.apply(x, norm.weight, norm.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias,
+                                         drop_scale, norm.eps, True, _producer_factors(x)), drop_scale)
 
 
 def norm_mlp_branch(x, norm, fc1, fc2):

@@ -310,3 +310,42 @@ def test_streaming_pointwise_convolutions_equal_the_tiled_kernel_and_torch(chain
     print(f'    parameter gradients: worst distance from the fp32 oracle {worst:.2e}')
     for k in bs:
         assert rel(bs[k], bt[k]) <= 1e-4, (k, rel(bs[k], bt[k]))
+
+
+@pytest.mark.parametrize('amp', [False, True], ids=['fp32', 'bf16'])
+def test_drop_path_gradient_from_the_layernorm_backward_equals_the_separate_pass(amp, monkeypatch, deterministic):
+    """saicv_layernorm_bwd_scaled: the LayerNorm backward of a sub-layer also writes factor * (its output), the gradient the drop-path
+    branch in front of it consumes (reference vit.py:160-161, x + drop_path(branch(x))).  A ViT with drop-path 0.4 forward + backward
+    with the twin (default) and with the separate saicv_row_scale pass (ops_tfm.LN_SCALED = False): the twin scales the STORED gradient,
+    so every parameter gradient is bit-identical; and the twin path really ran (no row_scale launch where a twin existed)."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.classification.backbones import vit
+    x = torch.randn(8, 64, 64, 3, generator=torch.Generator().manual_seed(2)).permute(0, 3, 1, 2).cuda()
+    calls = []
+    real = ops_tfm.row_scale
+    monkeypatch.setattr(ops_tfm, 'row_scale', lambda *a: (calls.append(1), real(*a))[1])
+
+    def run(twin):
+        monkeypatch.setattr(ops_tfm, 'LN_SCALED', twin)
+        torch.manual_seed(0)
+        m = vit.ViT(patch_size=16, embedding_planes=192, block_nums=4, head_nums=3, feedforward_ratio=4, image_size=64, dropout_prob=0.,
+                    drop_path_prob=0.4, global_pool=False, num_classes=10).cuda().train()
+        del calls[:]
+        torch.manual_seed(5)                      # the drop-path draws
+        if amp:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out = m(x)
+        else:
+            out = m(x)
+        out.float().pow(2).mean().backward()
+        torch.cuda.synchronize()
+        return out.detach().float().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}, len(calls)
+
+    o1, g1, n_twin = run(True)
+    o0, g0, n_sep = run(False)
+    assert torch.equal(o0, o1)
+    bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    assert not bad, bad[:5]
+    # 4 blocks x 2 branches, the first block's rate is 0 (the rates rise linearly): 6 separate passes; with the twin only the last branch
+    # (its gradient comes from the final norm, not from a sub-layer) keeps one
+    assert n_sep == 6 and n_twin <= 1, (n_sep, n_twin)
