@@ -52,6 +52,9 @@ class config:
     batch_size = int(os.environ.get('SAICV_SAM_BATCH', 160))
     num_workers = int(os.environ.get('SAICV_SAM_WORKERS', 32))
     accumulation_steps = 1
+    # 1 = the whole iteration as one replayed hipGraph per drawn prompt combination (tools/interactive_segmentation_scripts.py, r06);
+    # off by default: every replay has to be followed by a stream drain, so one GPU gains nothing over eager launches
+    use_step_graph = os.environ.get('SAICV_SAM_GRAPH', '0') == '1'
 
     optimizer = ('AdamW', {'lr': 1e-5, 'global_weight_decay': False, 'weight_decay': 0,
                            'no_weight_decay_layer_name_list': []})

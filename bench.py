@@ -185,7 +185,8 @@ def classification_workload(name, args, world, rank, device, use_graph):
         state['loss'] = scripts.train_classification(DeviceLoader([data] * k, config.batch_size, iters_per_epoch), model,
                                                      config.train_criterion, optimizer, scheduler, 1, logger, config)
         graphs = getattr(config, '_saicv_step_graphs', None)
-        state['step_graph'] = next(iter(graphs.values())) if graphs else None
+        state['step_graph'] = max(graphs.values(), key=lambda g: g.replays) if graphs else None
+        state['step_graphs'] = {'captured': sum(g.graph is not None for g in graphs.values()), 'replays': sum(g.replays for g in graphs.values())} if graphs else None
 
     info = {'config_file': cfg_path, 'loop': 'tools.scripts.train_classification', 'optimizer': config.optimizer[0],
             'param_groups': len(optimizer.param_groups)}
@@ -194,7 +195,9 @@ def classification_workload(name, args, world, rank, device, use_graph):
 
 def loop_workload(name, args, world, rank, device, use_graph=False):
     """DETR / full SAM through the reference's own config and loop.  DETR (r05) runs as ONE captured step when `use_graph`: its
-    Hungarian assignment is a device kernel (saicv_detr_assign).  The SAM loop stays eager (host-side prompt-type draw)."""
+    Hungarian assignment is a device kernel (saicv_detr_assign).  The SAM loop (r06) is captured too: one graph per drawn prompt
+    combination (the reference config draws point-only or box-only prompts: two graphs, each captured after three eager steps) when
+    its config asks for it (SAICV_SAM_GRAPH=1; off by default, see tools/interactive_segmentation_scripts.py)."""
     import numpy as np
     import torch
     from simpleaicv_pytorch_training_examples_amd.tools import interactive_segmentation_scripts, scripts, utils
@@ -214,8 +217,10 @@ def loop_workload(name, args, world, rank, device, use_graph=False):
     is_det = LOOP_MODELS[name][0].endswith('train_detection')
     is_detr = 'detr' in getattr(config, 'network', '')
     # r05: DETR captured whole -- its Hungarian assignment runs on the device (DETRLoss.assign_device, saicv_detr_assign)
-    graphed = bool(use_graph and is_det and ((not is_detr and getattr(config.train_criterion, 'capturable', False)) or
-                                             (is_detr and getattr(config.train_criterion, 'static_form', False))))
+    # (the SAM loop's captured step is opt-in, SAICV_SAM_GRAPH=1 in its config: it needs a stream drain after every replay and gains nothing on one GPU)
+    graphed = bool(use_graph and ((not is_det and getattr(config, 'use_step_graph', False)) or
+                                  (is_det and not is_detr and getattr(config.train_criterion, 'capturable', False)) or
+                                  (is_detr and getattr(config.train_criterion, 'static_form', False))))
     config.use_step_graph = graphed
     model = config.model.to(device)
     optimizer, _ = utils.build_optimizer(config, model)
@@ -234,7 +239,8 @@ def loop_workload(name, args, world, rank, device, use_graph=False):
         state['loss'] = fn(DeviceLoader([data] * k, config.batch_size, iters_per_epoch), model, config.train_criterion,
                            optimizer, scheduler, 1, logger, config)
         graphs = getattr(config, '_saicv_step_graphs', None)
-        state['step_graph'] = next(iter(graphs.values())) if graphs else None
+        state['step_graph'] = max(graphs.values(), key=lambda g: g.replays) if graphs else None
+        state['step_graphs'] = {'captured': sum(g.graph is not None for g in graphs.values()), 'replays': sum(g.replays for g in graphs.values())} if graphs else None
 
     info = {'config_file': cfg_path, 'loop': loop_name, 'optimizer': config.optimizer[0], 'param_groups': len(optimizer.param_groups)}
     state['graphed'] = graphed
@@ -370,7 +376,7 @@ def measure(name, args, world, rank, device, use_graph, primary):
         'config': {'workload': f'{name} 3x{size}x{size} synthetic training step (fwd+loss+bwd+all-reduce+optimizer), per-GPU batch {batch}',
                    'model': name, 'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}',
                    'final_loss': round(float(state['loss']), 4), 'loss_scale': scaler.get_scale() if scaler is not None else None,
-                   'step_graph': bool(use_graph),
+                   'step_graph': bool(use_graph), 'step_graphs': state.get('step_graphs') if isinstance(state, dict) else None,
                    'bn_statistics': 'fp32 atomics into pooled rows (SAICV_BN_INLINE=1)' if ops.BN_INLINE else 'fixed-order partial rows',
                    'host_ms_per_step': round(statistics.median(host) / args.steps * 1e3, 3),
                    # host time spent ISSUING a step when it is a graph replay (input copies, hyper-parameter refresh,
@@ -833,6 +839,29 @@ def worker(args):
         except Exception as e:      # noqa: BLE001
             detr = {'error': f'{type(e).__name__}: {e}'}
 
+    sam_full = None
+    if args.model == 'resnet50' and not args.no_secondary and not args.no_sam and world == 1:
+        # BASELINE.json configs[4] as the reference trains it (r06): the FULL SAM step -- image encoder + 1 + decoder_iters prompt /
+        # decoder passes + SAMLoss + AdamW -- through tools.interactive_segmentation_scripts.train_sam_segmentation and the reference's
+        # config, per-GPU batch 8 (eager launches unless SAICV_SAM_GRAPH=1: then one graph per drawn prompt combination, the 12 warm-up
+        # steps capture both of the config's)
+        import argparse as _ap
+        import gc
+        for cfg in _CONFIGS.values():
+            for attr in ('_saicv_step_graphs', 'model', 'ema_model'):
+                if hasattr(cfg, attr):
+                    setattr(cfg, attr, None)
+        _CONFIGS.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+        a4 = _ap.Namespace(**vars(args))
+        a4.batch, a4.steps, a4.warmup, a4.max_windows, a4.min_gpu_seconds, a4.no_kernel_timer = 8, 5, 12, 1, 0.0, False
+        try:
+            sam_full = measure('sam_b', a4, world, rank, device, want_step_graph(args.eager, args.graph, world, os.environ.get('SAICV_STEP_GRAPH')), False)
+            sam_full['steps'], sam_full['warmup'] = a4.steps, a4.warmup
+        except Exception as e:      # noqa: BLE001
+            sam_full = {'error': f'{type(e).__name__}: {e}'}
+
     if rank == 0:
         out = {'metric': 'training images/sec/node', 'value': primary['value'], 'unit': 'images/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': primary['ms_per_step'], 'higher_is_better': True,
@@ -849,6 +878,8 @@ def worker(args):
             out['sam_b_encoder'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **sam}
         if detr is not None:
             out['resnet50_detr_config'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **detr}
+        if sam_full is not None:
+            out['sam_b'] = {'metric': 'training images/sec/node', 'unit': 'images/s', **sam_full}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model)
         line = json.dumps(out)

@@ -436,6 +436,11 @@ int saicv_random_erase(float* x, const saicv_erase_box* boxes, int nboxes, int B
 int saicv_sam_sample_point(int pred_dtype, const float* gt, const void* pred, long pred_plane_stride, const long long* pred_index,
                            int pred_channels, float gt_threshold, float pred_threshold, unsigned int seed,
                            unsigned long long* keys_ws, float* points, int B, int H, int W, void* stream);
+/* The same with the seed completed on the device: seed + *seed_device (NULL: seed alone).  A training step captured into a hipGraph
+ * (tools/interactive_segmentation_scripts.py, config.use_step_graph) bakes `seed` in; the host bumps *seed_device between replays. */
+int saicv_sam_sample_point_dseed(int pred_dtype, const float* gt, const void* pred, long pred_plane_stride, const long long* pred_index,
+                                 int pred_channels, float gt_threshold, float pred_threshold, unsigned int seed, const unsigned int* seed_device,
+                                 unsigned long long* keys_ws, float* points, int B, int H, int W, void* stream);
 
 /* SAM sparse prompt tokens in one launch (reference segment_anything/prompt_encoder.py:150-190 embed_points / embed_boxes over
  * :28-49 PositionEmbeddingRandom): points fp32 [B][Np][3] = (x, y, label) or NULL, `pad` = 1 appends the reference's padding

@@ -57,6 +57,9 @@ def _conv_transpose_2x2(x_nhwc, deconv):
     return y.view(b, h, w, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(b, 2 * h, 2 * w, co)
 
 
+_INDEX_CACHE = {}
+
+
 class MaskDecoder(nn.Module):
 
     def __init__(self, inplanes=256, num_multimask_outputs=3, iou_prediction_head_block_nums=3,
@@ -105,6 +108,15 @@ class MaskDecoder(nn.Module):
         # HIP kernel each way (csrc/samtail.hip) instead of a skinny batched GEMM plus a permute copy
         mask_preds = ops_tfm.hyper_product(x.view(b, h4 * w4, c8), hyper_in).view(b, -1, h4, w4)
         iou_preds = self.iou_prediction_head(iou_token_out)
-        mask_preds = mask_preds[:, mask_out_idxs, :, :]
-        iou_preds = iou_preds[:, mask_out_idxs]
-        return mask_preds, iou_preds
+        # (reference mask_decoder.py: mask_preds[:, mask_out_idxs]; a python list as an index is a host -> device copy per call, which a
+        # captured step cannot contain: every output = no selection, a contiguous run = a slice, anything else = a cached index tensor)
+        idxs = [int(i) for i in mask_out_idxs]
+        if idxs == list(range(mask_preds.shape[1])):
+            return mask_preds, iou_preds
+        if idxs == list(range(idxs[0], idxs[0] + len(idxs))):
+            return mask_preds[:, idxs[0]:idxs[0] + len(idxs)], iou_preds[:, idxs[0]:idxs[0] + len(idxs)]
+        key = (tuple(idxs), mask_preds.device)
+        sel = _INDEX_CACHE.get(key)
+        if sel is None:
+            sel = _INDEX_CACHE[key] = torch.tensor(idxs, dtype=torch.long, device=mask_preds.device)
+        return mask_preds.index_select(1, sel), iou_preds.index_select(1, sel)

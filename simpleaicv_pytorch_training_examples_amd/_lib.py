@@ -186,6 +186,8 @@ SIGNATURES = {
     'saicv_groupnorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'saicv_sam_sample_point': (c_int, [c_int, _P, _P, c_long, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _P, _P,
                                        c_int, c_int, c_int, _P]),
+    'saicv_sam_sample_point_dseed': (c_int, [c_int, _P, _P, c_long, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _P, _P, _P,
+                                             c_int, c_int, c_int, _P]),
     'saicv_comm_available': (c_int, []),
     'saicv_comm_unique_id': (c_int, [_P]),
     'saicv_comm_reduce_scatter': (c_int, [_P, _P, _P, c_size_t, c_int, _P]),

@@ -98,8 +98,10 @@ DEVINL unsigned long long wave_max_u64(unsigned long long v) {
 template <typename TP>
 __global__ __launch_bounds__(256) void sample_point_scan_kernel(const float* __restrict__ gt, const TP* __restrict__ pred, long pred_stride,
                                                                 const int64_t* __restrict__ pred_index, int pred_channels,
-                                                                float gt_threshold, float pred_threshold, uint32_t seed,
+                                                                float gt_threshold, float pred_threshold, uint32_t seed0,
+                                                                const uint32_t* __restrict__ seed_dev,
                                                                 unsigned long long* __restrict__ keys, int B, int HW) {
+    const uint32_t seed = seed_dev ? seed0 + *seed_dev : seed0;       // a captured step draws its seed from device memory (the host bumps it between replays)
     const int b = blockIdx.y;
     const float* g = gt + (size_t)b * HW;
     const TP* p = nullptr;
@@ -329,6 +331,13 @@ int saicv_soft_labels(const long long* labels, const saicv_mix_plan* plan, float
 int saicv_sam_sample_point(int pred_dtype, const float* gt, const void* pred, long pred_plane_stride, const long long* pred_index,
                            int pred_channels, float gt_threshold, float pred_threshold, unsigned int seed,
                            unsigned long long* keys_ws, float* points, int B, int H, int W, void* stream) {
+    return saicv_sam_sample_point_dseed(pred_dtype, gt, pred, pred_plane_stride, pred_index, pred_channels, gt_threshold, pred_threshold, seed,
+                                        nullptr, keys_ws, points, B, H, W, stream);
+}
+
+int saicv_sam_sample_point_dseed(int pred_dtype, const float* gt, const void* pred, long pred_plane_stride, const long long* pred_index,
+                                 int pred_channels, float gt_threshold, float pred_threshold, unsigned int seed, const unsigned int* seed_device,
+                                 unsigned long long* keys_ws, float* points, int B, int H, int W, void* stream) {
     SAICV_REQUIRE(gt && keys_ws && points && B > 0 && H > 0 && W > 0, "saicv_sam_sample_point: bad arguments");
     SAICV_REQUIRE((size_t)H * W < (1ull << 31), "saicv_sam_sample_point: mask too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -343,10 +352,10 @@ int saicv_sam_sample_point(int pred_dtype, const float* gt, const void* pred, lo
     dim3 grid(gx, B);
     if (pred_dtype == SAICV_DTYPE_BF16)
         hipLaunchKernelGGL(sample_point_scan_kernel<bf16_t>, grid, dim3(256), 0, st, gt, (const bf16_t*)pred, pred_plane_stride,
-                           (const int64_t*)pred_index, pred_channels, gt_threshold, pred_threshold, seed, keys_ws, B, HW);
+                           (const int64_t*)pred_index, pred_channels, gt_threshold, pred_threshold, seed, seed_device, keys_ws, B, HW);
     else
         hipLaunchKernelGGL(sample_point_scan_kernel<float>, grid, dim3(256), 0, st, gt, (const float*)pred, pred_plane_stride,
-                           (const int64_t*)pred_index, pred_channels, gt_threshold, pred_threshold, seed, keys_ws, B, HW);
+                           (const int64_t*)pred_index, pred_channels, gt_threshold, pred_threshold, seed, seed_device, keys_ws, B, HW);
     hipLaunchKernelGGL(sample_point_pick_kernel, dim3((B + 63) / 64), dim3(64), 0, st, keys_ws, points, B, W);
     return saicv::check_launch("sam_sample_point");
 }

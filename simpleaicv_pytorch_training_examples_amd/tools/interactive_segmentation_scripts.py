@@ -28,6 +28,7 @@ from .scripts import _device_of, _dist_on, all_reduce_sum_packed
 
 
 _click_serial = [0]
+_click_seed_dev = [None]      # int32[1] on the device while a step that may be captured runs: the kernel adds it to the baked-in seed
 
 
 def sample_error_click(gt_masks, mask_logits=None, channel=None, gt_threshold=0.5, pred_threshold=0.0, seed=None):
@@ -54,9 +55,10 @@ def sample_error_click(gt_masks, mask_logits=None, channel=None, gt_threshold=0.
     keys = torch.empty(b * 4, dtype=torch.int64, device=gt.device)
     points = torch.empty((b, 1, 3), dtype=torch.float32, device=gt.device)
     m = mask_logits.shape[1] if mask_logits is not None else 1
-    check(lib().saicv_sam_sample_point(dtype_code(mask_logits.dtype) if mask_logits is not None else 1, ptr(gt), ptr(mask_logits),
-                                       h * w, ptr(channel), m, float(gt_threshold), float(pred_threshold), int(seed), ptr(keys),
-                                       ptr(points), b, h, w, stream()), 'sam_sample_point')
+    # inside a step that is (or will be) captured, `seed` is frozen with the graph: the varying part comes from device memory
+    check(lib().saicv_sam_sample_point_dseed(dtype_code(mask_logits.dtype) if mask_logits is not None else 1, ptr(gt), ptr(mask_logits),
+                                             h * w, ptr(channel), m, float(gt_threshold), float(pred_threshold), int(seed),
+                                             ptr(_click_seed_dev[0]), ptr(keys), ptr(points), b, h, w, stream()), 'sam_sample_point')
     return points
 
 
@@ -161,12 +163,8 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
     def amp():
         return autocast(device_type=device.type, dtype=amp_type, enabled=bool(config.use_amp))
 
-    micro = 0      # accumulation phase by issued micro-batch (see tools/scripts.py train_classification)
-    for data in train_loader:
-        micro += 1
-        images, masks = data['image'].to(device, non_blocking=True), data['mask'].to(device, non_blocking=True)
-        prompts, decoder_iters = _choose_prompts(config, data['prompt_point'], data['prompt_box'], data['prompt_mask'],
-                                                 device)
+    def forward_backward(images, masks, prompts, decoder_iters, boundary):
+        """image encoder, 1 + decoder_iters prompt / decoder passes, SAMLoss, (scaled) backward -> packed [skip, loss / acc_steps, terms]"""
         bad = any_nonfinite(images)
         with amp():
             batch_image_embeddings = net.forward_image_encoder(images)
@@ -186,38 +184,101 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
         terms = torch.stack([loss_value[k].detach().float() for k in keys]) / acc_steps
         bad = bad | (loss == 0.) | ~torch.isfinite(loss) | ~torch.isfinite(terms).all()
         loss = loss / acc_steps
-        boundary = micro % acc_steps == 0
         scaled = scaler.scale(loss) if scaler is not None else loss
         if boundary:
             scaled.backward()
         else:
             with model.no_sync():
                 scaled.backward()
-
         packed = torch.cat([torch.stack([bad.float(), loss.detach().float()]), terms])
         all_reduce_sum_packed(packed, model, config.group)
+        return packed
+
+    def update(packed):
+        model.finish_gradient_sync()
+        skip_flag = packed[0:1]
+        if getattr(config, 'skip_inf_nan_grad', False) or scaler is not None:
+            optimizer.check_finite()
+            skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
+        inv_scale = scaler.state[2:3] if scaler is not None else None
+        if clip_value > 0:
+            optimizer.clip_grad_value_(clip_value, inv_scale)
+            inv_scale = None
+        if clip_norm > 0:
+            optimizer.clip_grad_norm_(clip_norm, inv_scale)
+            inv_scale = None
+        optimizer.step(inv_scale, skip_flag)
+        if scaler is not None:
+            scaler._found_inf = optimizer.found_inf
+            scaler.update()
+        optimizer.zero_grad()
+
+    # config.use_step_graph (r06): the whole iteration as ONE hipGraph, as in tools/scripts.py -- the step has no host read (the skip
+    # decision, the clicks and the best-mask selection are device work).  The prompt-type draw stays on the host, once per iteration
+    # BEFORE the step (reference :314-353): it decides which prompt tensors exist and how many decoder passes run, i.e. the SHAPE of
+    # the step, so there is one captured graph per drawn combination (at most five), each captured after its own eager warm-up.
+    # The click sampler's seed is frozen with a graph; its varying part lives in device memory and is bumped before every step.
+    # Every replay is followed by a stream drain (engine.StepGraph, drain_after_replay -- an ordering escape of this step's graph
+    # that is not understood yet), which costs the overlap of the next batch's upload with the step: on ONE GPU the captured step
+    # is no faster than eager launches (65.2 vs 65.6 ms at b8) and the reference config leaves it OFF; what it is for is the
+    # bucketed all-reduce on the communication stream under backward, which only a captured step gets (engine.py).
+    use_graph = bool(getattr(config, 'use_step_graph', False)) and acc_steps == 1 and device.type == 'cuda'
+    if use_graph:
+        # ... and only where the draw has ONE outcome (every probability 0 or 1).  With two combinations in play -- replays of one graph
+        # between eager iterations or replays of the other -- the losses of the replayed combination turn to garbage after a few
+        # iterations (scripts/probes/sam_b_graph_probe.py at the reference config's 0.5 / 0.5 draw; one combination alone trains
+        # exactly like the eager loop).  What the two share is not found yet: such a config runs eagerly, and says so.
+        probs = [config.prompt_probs[k] for k in ('prompt_point', 'prompt_box', 'prompt_mask')]
+        if any(0. < q < 1. for q in probs):
+            use_graph = False
+            if main:
+                logger.info('use_step_graph: the prompt draw has more than one outcome, the SAM step runs eagerly')
+    graphs = None
+    if use_graph:
+        from .. import engine
+        graphs = getattr(config, '_saicv_step_graphs', None)
+        if graphs is None:
+            graphs = {}
+            config._saicv_step_graphs = graphs
+        if _click_seed_dev[0] is None or _click_seed_dev[0].device != device:
+            _click_seed_dev[0] = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def graph_for(prompts, decoder_iters):
+        names = tuple(k for k in ('prompt_point', 'prompt_box', 'prompt_mask') if prompts[k] is not None)
+        key = (id(model), id(optimizer), names, decoder_iters)
+        g = graphs.get(key)
+        if g is None:
+            def whole_step(images, masks, *tensors):
+                pr = {'prompt_point': None, 'prompt_box': None, 'prompt_mask': None}
+                pr.update(zip(names, tensors))
+                packed = forward_backward(images, masks, pr, decoder_iters, True)
+                update(packed)
+                return packed
+            g = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,),
+                                 drain_after_replay=True)
+            graphs[key] = g
+        return g, [prompts[k] for k in names]
+
+    micro = 0      # accumulation phase by issued micro-batch (see tools/scripts.py train_classification)
+    for data in train_loader:
+        micro += 1
+        images, masks = data['image'].to(device, non_blocking=True), data['mask'].to(device, non_blocking=True)
+        prompts, decoder_iters = _choose_prompts(config, data['prompt_point'], data['prompt_box'], data['prompt_mask'],
+                                                 device)
+        boundary = micro % acc_steps == 0
+        if use_graph:
+            _click_seed_dev[0].add_(7919)          # outside the graph: every replay samples its clicks with another seed
+            g, tensors = graph_for(prompts, decoder_iters)
+            packed = g(images, masks, *tensors).clone()
+        else:
+            packed = forward_backward(images, masks, prompts, decoder_iters, boundary)
         if carried_bad is not None:
             packed = torch.cat([torch.maximum(packed[0:1], carried_bad), packed[1:]])
         carried_bad = None if boundary else packed[0:1]
 
         if boundary:
-            model.finish_gradient_sync()
-            skip_flag = packed[0:1]
-            if getattr(config, 'skip_inf_nan_grad', False) or scaler is not None:
-                optimizer.check_finite()
-                skip_flag = torch.maximum(skip_flag, optimizer.found_inf)
-            inv_scale = scaler.state[2:3] if scaler is not None else None
-            if clip_value > 0:
-                optimizer.clip_grad_value_(clip_value, inv_scale)
-                inv_scale = None
-            if clip_norm > 0:
-                optimizer.clip_grad_norm_(clip_norm, inv_scale)
-                inv_scale = None
-            optimizer.step(inv_scale, skip_flag)
-            if scaler is not None:
-                scaler._found_inf = optimizer.found_inf
-                scaler.update()
-            optimizer.zero_grad()
+            if not use_graph:
+                update(packed)
             scheduler.step(optimizer, iter_index / iters + (epoch - 1))
             log_fmt = None
             if iter_index % int(config.print_interval * acc_steps) == 0:

@@ -11,6 +11,7 @@ These are the amplification-sensitive tests of the suite; the file sorts last so
 :900-1092 (detection), :1774-1934 (MAE), tools/interactive_segmentation_scripts.py:274-564 (SAM), tools/utils.py:95-107 (set_seed asks
 for deterministic kernels)."""
 import logging
+import os
 
 import numpy as np
 import pytest
@@ -579,7 +580,23 @@ def test_detection_step_graph_replays_the_same_training_as_eager_launches():
 
 
 # ------------------------------------------------------------------------------------------ SAM (BASELINE configs[4])
-def _run_sam_tiny(regime, monkeypatch):
+def _first_error_click_device(gt_masks, pred_masks):
+    """oracle.make_golden_traj_det_sam.first_error_click without host reads (a captured step cannot branch on device values): the first
+    pixel in row-major order of the error region (label 1 on a missed foreground pixel, 0 on a falsely predicted one), else the first
+    background pixel (label 0), else pixel 0."""
+    gt = gt_masks.bool()
+    pred = torch.zeros_like(gt) if pred_masks is None else pred_masks.bool()
+    b, _, h, w = gt.shape
+    g, p = gt.reshape(b, -1), pred.reshape(b, -1)
+    err, bg = g != p, ~g
+    k_err, k_bg = err.int().argmax(dim=1), bg.int().argmax(dim=1)          # argmax returns the FIRST maximum
+    any_err, any_bg = err.any(dim=1), bg.any(dim=1)
+    k = torch.where(any_err, k_err, torch.where(any_bg, k_bg, torch.zeros_like(k_bg)))
+    lab = torch.where(any_err, g.gather(1, k[:, None])[:, 0].float(), torch.zeros(b, device=gt.device))
+    return torch.stack([(k % w).float(), (k // w).float(), lab], dim=1).view(b, 1, 3)
+
+
+def _run_sam_tiny(regime, monkeypatch, step_graph=False, device_click=False):
     from conftest import load_golden
     from oracle.make_golden_sam import SAM_TINY, sam_inputs
     from oracle.make_golden_traj_det_sam import first_error_click, sam_config
@@ -596,6 +613,8 @@ def _run_sam_tiny(regime, monkeypatch):
     for k, v in vars(ref_cfg).items():
         setattr(config, k, v)
     config.network, config.sync_bn, config.find_unused_parameters, config.host_sync_lag = 'sam_tiny', False, True, 2
+    if os.environ.get('SAM_PROBE_AMP'):                     # (scripts/probes/sam_graph_debug.py)
+        config.use_amp = True
     torch.manual_seed(0)
     np.random.seed(0)
     net = sam.SAM(**SAM_TINY)
@@ -610,9 +629,11 @@ def _run_sam_tiny(regime, monkeypatch):
         if mask_logits is not None:
             idx = channel if channel is not None else torch.zeros(mask_logits.shape[0], dtype=torch.long, device=mask_logits.device)
             pred = (mask_logits[torch.arange(mask_logits.shape[0], device=mask_logits.device), idx].unsqueeze(1).float() > pred_threshold)
-        return first_error_click(gt_masks > gt_threshold, pred)
+        return (_first_error_click_device if device_click else first_error_click)(gt_masks > gt_threshold, pred)
 
-    monkeypatch.setattr(iss, 'sample_error_click', click)
+    if not os.environ.get('SAM_PROBE_REAL_CLICK'):          # (scripts/probes/sam_graph_debug.py: the product's sampler)
+        monkeypatch.setattr(iss, 'sample_error_click', click)
+    config.use_step_graph = step_graph
     batches = []
     q = SAM_TINY['image_size'] // 4
     for s in range(steps):
@@ -631,6 +652,10 @@ def _run_sam_tiny(regime, monkeypatch):
     finally:
         restore()
     torch.cuda.synchronize()
+    if step_graph:
+        graphs = getattr(config, '_saicv_step_graphs', {})
+        assert len(graphs) == 1 and all(g.graph is not None and g.replays >= steps - 3 for g in graphs.values()), \
+            [(k[2:], g.replays) for k, g in graphs.items()]
     return fx, got, avg, model.arena.flat_param.detach().clone()
 
 
@@ -649,6 +674,54 @@ def test_sam_loop_follows_the_reference_loop(regime, monkeypatch):
     _, got2, avg2, params2 = _run_sam_tiny(regime, monkeypatch)
     assert got2 == got and avg2 == avg, [(i, a, b) for i, (a, b) in enumerate(zip(got, got2)) if a != b]
     assert torch.equal(params, params2), float((params - params2).abs().max())
+
+
+@pytest.mark.parametrize('regime', ['all', 'iters'])
+def test_sam_step_graph_replays_the_same_training_as_eager_launches(regime, monkeypatch):
+    """config.use_step_graph for the SAM loop (r06; BASELINE configs[4], reference tools/interactive_segmentation_scripts.py:274-564): the
+    whole iteration -- image encoder, 1 + decoder_iters prompt / decoder passes with the clicks and best masks chosen on the device,
+    SAMLoss, backward, clipping, AdamW -- captured after three eager iterations and replayed.  In deterministic mode the losses of all
+    six iterations and the parameters afterwards equal the eager loop's bit for bit, and both follow the reference trajectory.  The
+    click rule is the fixture's deterministic one, written without host reads (checked against the oracle's below)."""
+    from oracle.make_golden_traj_det_sam import first_error_click
+    g = torch.Generator().manual_seed(3)
+    for case in range(4):
+        gt = (torch.rand(3, 1, 16, 16, generator=g) > (0.5 if case < 3 else -1.0))
+        pr = None if case == 0 else gt.clone() if case == 1 else (torch.rand(3, 1, 16, 16, generator=g) > 0.5)
+        assert torch.equal(_first_error_click_device(gt.cuda(), None if pr is None else pr.cuda()).cpu(), first_error_click(gt, pr)), case
+    fx, eager, avg_e, p_eager = _run_sam_tiny(regime, monkeypatch, False, True)
+    _, graph, avg_g, p_graph = _run_sam_tiny(regime, monkeypatch, True, True)
+    worst = _gate_trajectory(eager, fx, 1e-3, 2e-3)
+    print(f'[sam step graph {regime}] eager worst relative loss error {worst:.2e}; graph == eager: {graph == eager}, parameters '
+          f'{float((p_eager - p_graph).norm() / p_eager.norm()):.2e}')
+    assert graph == eager, [(i, a, b) for i, (a, b) in enumerate(zip(eager, graph)) if a != b]
+    assert torch.equal(p_eager, p_graph)
+
+
+def test_click_sampler_takes_the_varying_part_of_its_seed_from_device_memory():
+    """saicv_sam_sample_point_dseed: inside a captured step the host-side seed is frozen; the loop bumps an int32 in device memory
+    before every replay.  Same device seed -> the same clicks, another one -> other clicks, each still inside the error region."""
+    from simpleaicv_pytorch_training_examples_amd.tools import interactive_segmentation_scripts as iss
+    g = torch.Generator().manual_seed(4)
+    gt = (torch.rand(6, 1, 64, 64, generator=g) > 0.5).float().cuda()
+    logits = torch.randn(6, 1, 64, 64, generator=g).cuda()
+    dev = torch.zeros(1, dtype=torch.int32, device='cuda')
+    old = iss._click_seed_dev[0]
+    iss._click_seed_dev[0] = dev
+    try:
+        a = iss.sample_error_click(gt, logits, None, 0.5, 0.0, seed=123).clone()
+        b = iss.sample_error_click(gt, logits, None, 0.5, 0.0, seed=123).clone()
+        dev.add_(7919)
+        c = iss.sample_error_click(gt, logits, None, 0.5, 0.0, seed=123).clone()
+    finally:
+        iss._click_seed_dev[0] = old
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    for pts in (a, c):
+        x, y, lab = pts[:, 0, 0].long(), pts[:, 0, 1].long(), pts[:, 0, 2]
+        i = torch.arange(6, device='cuda')
+        gm, pm = gt[i, 0, y, x] > 0.5, logits[i, 0, y, x] > 0.0
+        assert bool((gm != pm).all()) and bool((lab == gm.float()).all())
 
 
 # ------------------------------------------------------------------------------------------ MAE
