@@ -496,9 +496,11 @@ class StepGraph:
     optimizer.refresh_hyper for the scheduler's learning rates).  Returned tensors are static buffers overwritten
     by the next replay: clone what must outlive a step."""
 
-    def __init__(self, fn, warmup=3, before_replay=(), drain_after_replay=False):
+    def __init__(self, fn, warmup=3, before_replay=(), drain_after_replay=False, side_stream_warmup=False):
         self.fn, self.warmup, self.before_replay = fn, warmup, tuple(before_replay)
         self.drain_after_replay = drain_after_replay
+        self.side_stream_warmup = side_stream_warmup
+        self._side_stream = None
         self.calls = 0
         self.graph = None
         self.static_in = self.static_out = None
@@ -509,7 +511,21 @@ class StepGraph:
         if self.graph is None:
             if self.calls < self.warmup:
                 self.calls += 1
-                return self.fn(*inputs)
+                if not self.side_stream_warmup:
+                    return self.fn(*inputs)
+                # the warm-up iterations on the stream the capture will use (torch's CUDA-graph recipe): autograd runs a leaf's
+                # gradient accumulation on the stream its accumulator node was created on, and nodes kept alive by the arena's
+                # post-accumulate hooks since an eager step on the DEFAULT stream would pull that stream into the capture as a branch
+                side = self._side()
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    out = self.fn(*inputs)
+                cur.wait_stream(side)
+                for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)
+                return out
             self._capture(inputs)
         t0 = time.perf_counter()
         for s, x in zip(self.static_in, inputs):
@@ -534,6 +550,11 @@ class StepGraph:
         self.replay_host_s += time.perf_counter() - t0
         return self.static_out
 
+    def _side(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
+
     def _capture(self, inputs):
         self.static_in = [x.clone() if torch.is_tensor(x) else None for x in inputs]    # clone keeps NHWC strides
         args = [s if s is not None else x for s, x in zip(self.static_in, inputs)]
@@ -546,7 +567,7 @@ class StepGraph:
             graph.enable_debug_mode()
         failed = None
         try:
-            with torch.cuda.graph(graph):
+            with (torch.cuda.graph(graph, stream=self._side()) if self.side_stream_warmup else torch.cuda.graph(graph)):
                 ops._ZeroPool.zero_all()    # the statistics scratch starts a replay all-zero, whatever ran eagerly in between
                 try:
                     out = self.fn(*args)

@@ -15,6 +15,7 @@ overlapped with backward; skip decisions stay on the device and reach the host `
 iterations later; no per-iteration barrier.
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -229,7 +230,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
         # iterations (scripts/probes/sam_b_graph_probe.py at the reference config's 0.5 / 0.5 draw; one combination alone trains
         # exactly like the eager loop).  What the two share is not found yet: such a config runs eagerly, and says so.
         probs = [config.prompt_probs[k] for k in ('prompt_point', 'prompt_box', 'prompt_mask')]
-        if any(0. < q < 1. for q in probs):
+        if any(0. < q < 1. for q in probs) and os.environ.get('SAICV_SAM_GRAPH_MIXED') != '1':
             use_graph = False
             if main:
                 logger.info('use_step_graph: the prompt draw has more than one outcome, the SAM step runs eagerly')
@@ -255,7 +256,8 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
                 update(packed)
                 return packed
             g = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,),
-                                 drain_after_replay=True)
+                                 drain_after_replay=os.environ.get('SAICV_SAM_GRAPH_DRAIN', '1') == '1',
+                                 side_stream_warmup=os.environ.get('SAICV_SAM_GRAPH_SIDE', '0') == '1')
             graphs[key] = g
         return g, [prompts[k] for k in names]
 
