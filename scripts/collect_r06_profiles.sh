@@ -26,7 +26,7 @@ for m in resnet50 vit_base_patch16; do
   if [ -f $O/tcc_$m.json ]; then
     cp $O/tcc_$m.json $P/r06_tcc_counters_$m.json
     s=""; [ $m != resnet50 ] && s="_$m"
-    (cd scripts && python make_tcc_traffic.py ../$O/tcc_$m.json 3 ../$P/r06_tcc_traffic$s.json $m > /dev/null)
+    (cd scripts && python make_tcc_traffic.py ../$O/tcc_$m.json ../$P/r06_pmc_hbm_traffic$s.json ../$P/r06_tcc_traffic$s.json $m > /dev/null)
   fi
 done
 [ -f $O/smoke.log ] && cp $O/smoke.log $P/r06_smoke.log

@@ -97,15 +97,15 @@ for step in "$@"; do
         n=$((n+1))
         (cd /tmp && env $e timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $O/${name}_${model}_$n -o p -- python $GRAFT_REPO_ROOT/bench.py --model $model --steps 2 --warmup 1 --eager --no-cpu-baseline --no-secondary --no-sam --no-kernel-timer --max-windows 1 > $O/${name}_${model}_$n.log 2>&1)
       done
-      python scripts/pmc_fold.py $O/${name}_${model}_1 $O/${name}_${model}_2 > $O/${name}_${model}.json 2> $O/${name}_${model}.err; head -c 3000 $O/${name}_${model}.json; tail -2 $O/${name}_${model}.err ;;
+      python scripts/pmc_fold.py $O/${name}_${model}_1 $O/${name}_${model}_2 > $O/${name}_${model}.json 2> $O/${name}_${model}.err; head -c 600 $O/${name}_${model}.json; tail -2 $O/${name}_${model}.err; rm -rf $O/${name}_${model}_1 $O/${name}_${model}_2 ;;
     bench)  timeout 900 python bench.py ${arg:-} > $O/bench_$(echo "${arg:-default}" | tr -c 'a-zA-Z0-9\n' '_').log 2>&1; tail -1 $O/bench_$(echo "${arg:-default}" | tr -c 'a-zA-Z0-9\n' '_').log | cut -c1-900 ;;
-    prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$arg -o $arg -- python $GRAFT_REPO_ROOT/bench.py --model $arg --no-secondary --no-cpu-baseline --no-sam --max-windows 2 --steps 5 --warmup 5 > $O/prof_$arg.log 2>&1); f=$(find $O/prof_$arg -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${arg}_rocprofv3_kernel_stats.csv && head -12 $f | cut -c1-200; t=$(find $O/prof_$arg -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python scripts/trace_compact.py $t > $O/${arg}_kernel_trace_compact.csv ;;
+    prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$arg -o $arg -- python $GRAFT_REPO_ROOT/bench.py --model $arg --no-secondary --no-cpu-baseline --no-sam --max-windows 2 --steps 5 --warmup 5 > $O/prof_$arg.log 2>&1); f=$(find $O/prof_$arg -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${arg}_rocprofv3_kernel_stats.csv && head -12 $f | cut -c1-200; t=$(find $O/prof_$arg -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python scripts/trace_compact.py $t > $O/${arg}_kernel_trace_compact.csv; rm -rf $O/prof_$arg ;;      # (raw traces: tens of MiB each, the merge-back limit is 64 MiB)
     pmc)    # HBM traffic: separate FETCH_SIZE / WRITE_SIZE passes of the eager step, folded per kernel family (MI355X_MICROARCH.md corrections)
       for c in FETCH_SIZE WRITE_SIZE; do
         (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$arg -o $c -- python $GRAFT_REPO_ROOT/bench.py --model $arg --steps 2 --warmup 1 --eager --no-cpu-baseline --no-secondary --no-sam --no-power --no-kernel-timer --max-windows 1 > $O/pmc_${arg}_$c.log 2>&1); echo "pmc $arg $c rc=$?"
       done
       suffix=""; [ "$arg" != "resnet50" ] && suffix="_$arg"
-      python scripts/make_pmc_summary.py $O/pmc_$arg 3 $O/r06_pmc_hbm_traffic$suffix.json $arg | head -30 ;;
+      python scripts/make_pmc_summary.py $O/pmc_$arg 3 $O/r06_pmc_hbm_traffic$suffix.json $arg | head -30; rm -rf $O/pmc_$arg ;;
     *) echo "unknown step $step" ;;
   esac
 done

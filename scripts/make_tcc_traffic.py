@@ -2,7 +2,9 @@
 reads = TCC_EA0_RDREQ x 64 B (32-byte requests counted at 32 B), writes = TCC_EA0_WRREQ x 64 B -- the reading VERDICT r05 asks the
 bench line to carry for ViT-B instead of the FETCH_SIZE x 2 rule, which over-counts the 64-byte K-slice requests of the LDS-DMA loads.
 
-    python scripts/make_tcc_traffic.py <tcc json> <steps profiled> <out json> [model]"""
+    python scripts/make_tcc_traffic.py <tcc json> <pmc summary json (launches per step)> <out json> [model]
+(the counter CSVs hold several rows per dispatch, so the fold's row count is not a launch count: launches per step come from the
+FETCH_SIZE / WRITE_SIZE summary of the same command, scripts/make_pmc_summary.py)"""
 import json
 import sys
 
@@ -10,7 +12,8 @@ from make_pmc_summary import family
 
 
 def main():
-    src, steps, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    src, pmc_path, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+    per_step = {k: v['launches_per_step'] for k, v in json.load(open(pmc_path))['kernels'].items()}
     model = sys.argv[4] if len(sys.argv) > 4 else 'resnet50'
     fam = {}
     for name, e in json.load(open(src)).items():
@@ -26,11 +29,13 @@ def main():
         a['read'] += rd
         a['write'] += wr
     out = {'_doc': f'fabric bytes from TCC_EA0_RDREQ / TCC_EA0_WRREQ (x 64 B; 32-byte reads at 32 B) over the eager step of `bench.py --model {model}` '
-                   '(b256 bf16), rocprofv3 --pmc in a pass of its own', 'steps_profiled': steps, 'kernels': {}}
+                   '(b256 bf16), rocprofv3 --pmc in a pass of its own; launches per step from ' + pmc_path, 'kernels': {}}
     for f, a in sorted(fam.items()):
         n = max(a['launches'], 1)
-        out['kernels'][f] = {'launches_per_step': round(n / steps, 1), 'read_GB_per_step': round(a['read'] / steps / 1e9, 2),
-                             'write_GB_per_step': round(a['write'] / steps / 1e9, 2), 'bytes_per_launch': int((a['read'] + a['write']) / n)}
+        lps = per_step.get(f)
+        out['kernels'][f] = {'launches_per_step': lps, 'read_GB_per_step': round(a['read'] / n * lps / 1e9, 2) if lps else None,
+                             'write_GB_per_step': round(a['write'] / n * lps / 1e9, 2) if lps else None,
+                             'bytes_per_launch': int((a['read'] + a['write']) / n)}
     json.dump(out, open(out_path, 'w'), indent=1)
     print(json.dumps(out['kernels'], indent=1))
 
