@@ -418,11 +418,15 @@ class _PackRegistry:
     pinned_tables = []
 
     @classmethod
-    def get(cls, weight, dtype, cin_padded, cout_padded, need_wd):
+    def get(cls, weight, dtype, cin_padded, cout_padded, need_wd, rows=None):
+        """rows = (parameter, r0, r1): `weight` is the row block parameter[r0:r1] of a packed parameter (nn.MultiheadAttention's
+        in_proj_weight through ops_tfm.linear_rows) -- an entry of its own, refreshed by the same batched launch from the
+        parameter's storage (r06: DETR spent 83 single-matrix pack launches per step on them)."""
         import weakref
-        k = (id(weight), dtype, cin_padded, cout_padded)
+        base = weight if rows is None else rows[0]
+        k = (id(base), None if rows is None else (rows[1], rows[2]), dtype, cin_padded, cout_padded)
         e = cls.entries.get(k)
-        if e is not None and e['ref']() is not weight:
+        if e is not None and e['ref']() is not base:
             e = None                                            # id() reused by another tensor
         if e is None:
             w = weight.detach()
@@ -431,7 +435,7 @@ class _PackRegistry:
             else:
                 o, i, r, s = w.shape
             alloc = torch.empty if cout_padded == o else torch.zeros
-            e = {'ref': weakref.ref(weight), 'dtype': dtype, 'ip': cin_padded, 'op': cout_padded, 'dims': (o, i, r, s),
+            e = {'ref': weakref.ref(base), 'rows': None if rows is None else (rows[1], rows[2]), 'dtype': dtype, 'ip': cin_padded, 'op': cout_padded, 'dims': (o, i, r, s),
                  'wf': alloc((cout_padded, r, s, cin_padded), dtype=dtype, device=w.device), 'wd': None, 'key': None, 'used': 0}
             cls.entries[k] = e
             cls.table = None
@@ -454,12 +458,14 @@ class _PackRegistry:
                 cls.table = None
         # weights nobody asked for since the epoch before last (another model of the process) wait until they are wanted
         live = [(k, e, w) for k, e, w in live if w is not None and w.is_cuda and e['used'] >= _weights_epoch[0] - 1]
+        # (an entry of a row block packs the view parameter[r0:r1]; its key is stamped with the parameter's version)
+        views = {id(e): (w.detach()[e['rows'][0]:e['rows'][1]] if e.get('rows') else w.detach()) for _, e, w in live}
         if not live:
             return
         by_dtype = {}
         for k, e, w in live:
             by_dtype.setdefault(e['dtype'], []).append((e, w))
-        sig = tuple((id(e), w.data_ptr(), w.stride(), ptr(e['wf']), ptr(e['wd'])) for _, e, w in live)
+        sig = tuple((id(e), views[id(e)].data_ptr(), views[id(e)].stride(), ptr(e['wf']), ptr(e['wd'])) for _, e, w in live)
         if cls.table is None or cls.table[0] != sig:
             tables = []
             for dt, items in by_dtype.items():
@@ -467,7 +473,7 @@ class _PackRegistry:
                 t0 = 0
                 for j, (e, w) in enumerate(items):
                     o, i, r, s = e['dims']
-                    wv = w.detach()
+                    wv = views[id(e)]
                     if wv.dim() == 2:
                         so, si = wv.stride()
                         sr = ss = 0
@@ -492,7 +498,7 @@ class _PackRegistry:
         for dt, dev, n, tiles in cls.table[1]:
             check(lib().saicv_pack_weight_batched(dtype_code(dt), ptr(dev), n, tiles, stream()), 'pack_weight_batched')
         for _, e, w in live:
-            e['key'] = (w._version, _weights_epoch[0], w.data_ptr())
+            e['key'] = (w._version, _weights_epoch[0], views[id(e)].data_ptr())
 
     @classmethod
     def used_now(cls):
@@ -513,9 +519,10 @@ def packed_weight(weight, dtype, cin_padded, need_wd, cout_padded=None):
 
     Returns (wf [Op][R][S][Ip], wd [I][R][S][Op] or None); rows/cols beyond O are zero."""
     cout_padded = cout_padded or weight.shape[0]
-    if _PackRegistry.BATCH and isinstance(weight, torch.nn.Parameter) and weight.is_cuda:
-        e = _PackRegistry.get(weight, dtype, cin_padded, cout_padded, need_wd)
-        if e['key'] != (weight._version, _weights_epoch[0], weight.data_ptr()):
+    rows = getattr(weight, '_saicv_rows_of', None)          # (parameter, r0, r1): ops_tfm.LinearRowsFn
+    if _PackRegistry.BATCH and weight.is_cuda and (isinstance(weight, torch.nn.Parameter) or rows is not None):
+        e = _PackRegistry.get(weight, dtype, cin_padded, cout_padded, need_wd, rows)
+        if e['key'] != ((weight if rows is None else rows[0])._version, _weights_epoch[0], weight.data_ptr()):
             _PackRegistry.refresh()
         return e['wf'], (e['wd'] if need_wd else None)
     key = (weight._version, _weights_epoch[0], dtype, cin_padded, cout_padded, weight.data_ptr())

@@ -394,6 +394,8 @@ class LinearRowsFn(torch.autograd.Function):
         require_gpu(x, weight)
         x2 = _as2d(x)
         w = weight.detach()[r0:r1]
+        if isinstance(weight, torch.nn.Parameter):
+            w._saicv_rows_of = (weight, r0, r1)            # packed with every other weight by the step's one batched launch (ops._PackRegistry)
         b = bias.detach()[r0:r1] if bias is not None else None
         y = lin_fwd(x2, w, b, False, need_wd=ctx.needs_input_grad[0])
         ctx.save_for_backward(x2, weight, bias)
@@ -405,6 +407,8 @@ class LinearRowsFn(torch.autograd.Function):
         x2, weight, bias = ctx.saved_tensors
         shape, r0, r1 = ctx.cfg
         w = weight.detach()[r0:r1]
+        if isinstance(weight, torch.nn.Parameter):
+            w._saicv_rows_of = (weight, r0, r1)
         b = bias.detach()[r0:r1] if bias is not None else None
         gw_full = ops._arena_grad(weight) if weight.is_contiguous() else None
         gb_full = ops._arena_grad(bias) if bias is not None else None
