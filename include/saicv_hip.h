@@ -312,6 +312,17 @@ int saicv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* g
 int saicv_layernorm_bwd_scaled(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                                const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
                                int M, int C, int accumulate, const float* out_scale, int rows_per_scale, void* dx_scaled, void* stream);
+/* DETR's post-norm residual norm(x + dropout(branch)) (reference detection/models/detr.py:89,92,114,118,122) as ONE pass each way.
+ * Forward: sum_out = x + mask / (1 - p) * branch (stored, rounded), y = LayerNorm(sum_out), mean / rstd of its rows.  The mask is a
+ * counter-based function of (seed + *seed_device, row, column) -- keep iff hash >= p * 2^32 -- regenerated by the backward, which
+ * returns dsum (the gradient of x) and dbranch = mask / (1 - p) * dsum; dgamma / dbeta as saicv_layernorm_bwd.  seed_device: NULL or
+ * a word in device memory (see saicv_attn_desc.seed_device). */
+int saicv_dropout_add_layernorm_fwd(int dtype, const void* x, const void* branch, double p, unsigned int seed, const unsigned int* seed_device,
+                                    const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd, int M, int C,
+                                    double eps, void* stream);
+int saicv_dropout_add_layernorm_bwd(int dtype, const void* dy, const void* sum, const float* gamma, const float* mean, const float* rstd,
+                                    double p, unsigned int seed, const unsigned int* seed_device, void* dsum, void* dbranch,
+                                    float* dgamma, float* dbeta, float* ws, int M, int C, int accumulate, void* stream);
 /* nn.GELU() (exact erf form), vit.py:87-99 */
 int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream);
 int saicv_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, void* stream);
@@ -392,6 +403,8 @@ typedef struct saicv_attn_desc {
     float scale;
     float dropout_p;                /* attention-probability dropout (0 = off); same seed in fwd and bwd */
     unsigned int seed;
+    const unsigned int* seed_device; /* NULL, or a word in device memory ADDED to `seed` (a step captured into a hipGraph freezes `seed`;
+                                      * the host bumps this word before every replay so that replays draw different masks) */
 } saicv_attn_desc;
 int saicv_attention_stream_fwd(int dtype, int D, const saicv_attn_desc* desc, void* stream);
 /* backward = dQ pass (also writes dsum and d_rel_*) followed by the dK/dV pass */

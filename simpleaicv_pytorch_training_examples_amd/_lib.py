@@ -35,7 +35,7 @@ class AttnDesc(Structure):
                 ('lse', _P), ('dsum', _P), ('key_bias', _P), ('rel_h', _P), ('rel_w', _P),
                 ('d_rel_h', _P), ('d_rel_w', _P),
                 ('Sh', c_int), ('Sw', c_int), ('B', c_int), ('H', c_int), ('Nq', c_int), ('Nk', c_int),
-                ('scale', c_float), ('dropout_p', c_float), ('seed', ctypes.c_uint32)]
+                ('scale', c_float), ('dropout_p', c_float), ('seed', ctypes.c_uint32), ('seed_device', _P)]
 
 
 _PA = POINTER(AttnDesc)
@@ -129,6 +129,8 @@ SIGNATURES = {
     # transformer kernels (tfm.hip)
     'saicv_layernorm_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
     'saicv_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_dropout_add_layernorm_fwd': (c_int, [c_int, _P, _P, c_double, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
+    'saicv_dropout_add_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_double, ctypes.c_uint, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_layernorm_bwd_scaled': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
     'saicv_layernorm_bwd_ws_floats': (c_size_t, [c_int, c_int]),
     'saicv_gelu_fwd': (c_int, [c_int, _P, _P, c_size_t, _P]),

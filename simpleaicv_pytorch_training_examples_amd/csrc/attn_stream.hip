@@ -405,6 +405,8 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
     const float c2 = p.scale * LOG2E;
     constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
+    // (r06) a captured step freezes p.seed; the varying part lives in device memory and is bumped by the host before every replay
+    const unsigned dseed = (DROP && p.seed_device != nullptr) ? p.seed + *p.seed_device : p.seed;
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     const float inv_sw = TAB ? 1.f / (float)p.Sw : 0.f;
     const sa_rsrc_t k_rsrc = S::rsrc(kg, p.k_rs, p.Nk), v_rsrc = S::rsrc(vg, p.v_rs, p.Nk);
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_fwd_kernel(const SAParams p)
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        st[qt][kt][r] = sa_keep(p.seed, bh, q0 + qt * 16 + l15, k0 + kt * 16 + lg * 4 + r, p.Nk, dthresh)
+                        st[qt][kt][r] = sa_keep(dseed, bh, q0 + qt * 16 + l15, k0 + kt * 16 + lg * 4 + r, p.Nk, dthresh)
                                             ? st[qt][kt][r] * inv_keep : 0.f;
         }
         {
@@ -919,6 +921,8 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
     const f32x4 c2v = {c2, c2, c2, c2};
     constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
+    // (r06) a captured step freezes p.seed; the varying part lives in device memory and is bumped by the host before every replay
+    const unsigned dseed = (DROP && p.seed_device != nullptr) ? p.seed + *p.seed_device : p.seed;
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     // C operand of the dO.V^T tiles: -D (without dropout, which masks dP before D is subtracted)
     f32x4 dinit[2];
@@ -1028,7 +1032,7 @@ __global__ __launch_bounds__(SA_THREADS, (REL == 0 && !DROP && !KB && sizeof(T) 
                 if constexpr (drop) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool keep = sa_keep(p.seed, bh, q0 + qt * 16 + l15, k0 + kt * 16 + lg * 4 + r, p.Nk, dthresh);
+                        const bool keep = sa_keep(dseed, bh, q0 + qt * 16 + l15, k0 + kt * 16 + lg * 4 + r, p.Nk, dthresh);
                         gv[r] = pr[r] * ((keep ? dp[qt][r] * inv_keep : 0.f) - dsum[qt]);
                     }
                 } else {
@@ -1226,6 +1230,8 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
     const f32x4 c2v = {c2, c2, c2, c2};
     constexpr bool drop = DROP;      // compiled out of the relative-position instantiations (register budget)
     const unsigned dthresh = sa_thresh(p.dropout_p);
+    // (r06) a captured step freezes p.seed; the varying part lives in device memory and is bumped by the host before every replay
+    const unsigned dseed = (DROP && p.seed_device != nullptr) ? p.seed + *p.seed_device : p.seed;
     const float inv_keep = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
     const sa_rsrc_t q_rsrc = S::rsrc(qg, p.q_rs, p.Nq), o_rsrc = S::rsrc(dog, p.o_rs, p.Nq);
     float pf_d = 0.f, pf_l = 0.f, pf_rh = 0.f;             // D (tid < 64), lse * log2(e) and the rel_h column tid >> 6 (tid < 128)
@@ -1374,7 +1380,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_bwd_dkv_kernel(const SAParam
                     if constexpr (drop) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float keepf = sa_keep(p.seed, bh, q0 + ql0 + r, key0 + t * 16 + l15, p.Nk, dthresh) ? inv_keep : 0.f;
+                            const float keepf = sa_keep(dseed, bh, q0 + ql0 + r, key0 + t * 16 + l15, p.Nk, dthresh) ? inv_keep : 0.f;
                             pt[t][qq][r] = pr[r] * keepf;
                             dst[t][qq][r] = pr[r] * (dp[r] * keepf + nd[r]);
                         }

@@ -73,6 +73,10 @@ int grad_clip_value(float*, size_t, const float*, double, hipStream_t);
 int scaler_update(float*, const float*, double, double, int, hipStream_t);
 int layernorm_fwd(int, const void*, const float*, const float*, void*, float*, float*, int, int, double, hipStream_t);
 size_t layernorm_bwd_ws_floats(int, int);
+int dropout_add_layernorm_fwd(int, const void*, const void*, double, unsigned, const unsigned*, const float*, const float*, void*, void*,
+                              float*, float*, int, int, double, hipStream_t);
+int dropout_add_layernorm_bwd(int, const void*, const void*, const float*, const float*, const float*, double, unsigned, const unsigned*,
+                              void*, void*, float*, float*, float*, int, int, int, hipStream_t);
 int layernorm_bwd(int, const void*, const void*, const float*, const float*, const float*, const void*, void*,
                   float*, float*, float*, int, int, int, hipStream_t, const float* = nullptr, int = 1, void* = nullptr);
 int gelu_fwd(int, const void*, void*, size_t, hipStream_t);
@@ -412,6 +416,17 @@ int saicv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* g
                         const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
                         int M, int C, int accumulate, void* stream) {
     return layernorm_bwd(dtype, dy, x, gamma, mean, rstd, addend, dx, dgamma, dbeta, ws, M, C, accumulate, S(stream));
+}
+int saicv_dropout_add_layernorm_fwd(int dtype, const void* x, const void* branch, double p, unsigned int seed, const unsigned int* seed_device,
+                                    const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd, int M, int C,
+                                    double eps, void* stream) {
+    return dropout_add_layernorm_fwd(dtype, x, branch, p, seed, seed_device, gamma, beta, sum_out, y, mean, rstd, M, C, eps, S(stream));
+}
+int saicv_dropout_add_layernorm_bwd(int dtype, const void* dy, const void* sum, const float* gamma, const float* mean, const float* rstd,
+                                    double p, unsigned int seed, const unsigned int* seed_device, void* dsum, void* dbranch,
+                                    float* dgamma, float* dbeta, float* ws, int M, int C, int accumulate, void* stream) {
+    return dropout_add_layernorm_bwd(dtype, dy, sum, gamma, mean, rstd, p, seed, seed_device, dsum, dbranch, dgamma, dbeta, ws, M, C,
+                                     accumulate, S(stream));
 }
 int saicv_layernorm_bwd_scaled(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                                const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,

@@ -26,17 +26,34 @@ namespace {
 
 // ======================================================================== LayerNorm
 // one wavefront per row; a lane holds NCH chunks (columns lane, lane+64, ...) in registers
+// The keep decision of the fused residual dropout (reference detection/models/detr.py:89,92,114,118,122: norm(x + dropout(branch))): a
+// counter-based hash of (seed, row, column), the same in the forward and the backward kernel.  keep iff hash >= p * 2^32.
+DEVINL bool ln_keep(unsigned seed, unsigned row, unsigned col, unsigned thresh) {
+    unsigned h = seed ^ (row * 0x9E3779B1u) ^ (col * 0x85EBCA77u);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h >= thresh;
+}
+struct LnDrop {                 // branch == nullptr: a plain LayerNorm
+    const void* branch;         // [M][C], added to x behind the dropout
+    void* sum_out;              // x + dropout(branch): what the LayerNorm normalises, kept for the backward
+    unsigned seed;
+    const unsigned* seed_device;
+    unsigned thresh;
+    float inv_keep;
+};
+
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             T* __restrict__ y, float* __restrict__ mean,
-                                                            float* __restrict__ rstd, int M, int C, float eps) {
+                                                            float* __restrict__ rstd, int M, int C, float eps, const LnDrop dr) {
     constexpr int N = Chunk<T>::N;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     const int cpr = C / N;
+    const unsigned dseed = dr.branch != nullptr && dr.seed_device != nullptr ? dr.seed + *dr.seed_device : dr.seed;
     float v[NCH][N];
     float s = 0.f;
 #pragma unroll
@@ -44,6 +61,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         const int c = lane + 64 * j;
         if (c < cpr) {
             Chunk<T>::unpack(LN_LD(x + (size_t)row * C + c * N), v[j]);
+            if (dr.branch != nullptr) {         // s = x + dropout(branch), rounded to T as a separate add kernel would store it
+                float b[N];
+                Chunk<T>::unpack(LN_LD(reinterpret_cast<const T*>(dr.branch) + (size_t)row * C + c * N), b);
+#pragma unroll
+                for (int k = 0; k < N; ++k) v[j][k] += ln_keep(dseed, (unsigned)row, (unsigned)(c * N + k), dr.thresh) ? b[k] * dr.inv_keep : 0.f;
+                const auto packed = Chunk<T>::pack(v[j]);
+                st_chunk(reinterpret_cast<T*>(dr.sum_out) + (size_t)row * C + c * N, packed);
+                Chunk<T>::unpack(packed, v[j]);
+            }
 #pragma unroll
             for (int k = 0; k < N; ++k) s += v[j][k];
         } else {
@@ -85,10 +111,11 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* 
                                                             const T* __restrict__ addend, T* __restrict__ dx,
                                                             float* __restrict__ part_g, float* __restrict__ part_b,
                                                             int M, int C, int rows_per, const float* __restrict__ out_scale,
-                                                            int rows_per_scale, T* __restrict__ dxs) {
+                                                            int rows_per_scale, T* __restrict__ dxs, const LnDrop dr) {
     constexpr int N = Chunk<T>::N;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cpr = C / N;
+    const unsigned dseed = dr.branch != nullptr && dr.seed_device != nullptr ? dr.seed + *dr.seed_device : dr.seed;
     float gam[NCH][N], ag[NCH][N], ab[NCH][N];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -166,9 +193,14 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const T* 
                 if (dxs != nullptr) {           // the drop-path twin: row factor x the STORED (rounded) gradient, as a separate row_scale pass would give
                     float r[N];
                     Chunk<T>::unpack(packed, r);
-                    const float sc = out_scale[row / rows_per_scale];
+                    if (dr.branch != nullptr) {  // ... or the gradient of the branch behind the fused residual dropout: mask / keep, element by element
 #pragma unroll
-                    for (int k = 0; k < N; ++k) r[k] *= sc;
+                        for (int k = 0; k < N; ++k) r[k] = ln_keep(dseed, (unsigned)row, (unsigned)(c * N + k), dr.thresh) ? r[k] * dr.inv_keep : 0.f;
+                    } else {
+                        const float sc = out_scale[row / rows_per_scale];
+#pragma unroll
+                        for (int k = 0; k < N; ++k) r[k] *= sc;
+                    }
                     st_chunk(dxs + (size_t)row * C + c * N, Chunk<T>::pack(r));
                 }
             }
@@ -256,7 +288,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_half_kernel(cons
                                                                  const float* __restrict__ rstd, const T* __restrict__ addend,
                                                                  T* __restrict__ dx, float* __restrict__ part_g,
                                                                  float* __restrict__ part_b, int M, int C, int rows_per,
-                                                                 const float* __restrict__ out_scale, int rows_per_scale, T* __restrict__ dxs) {
+                                                                 const float* __restrict__ out_scale, int rows_per_scale, T* __restrict__ dxs,
+                                                                 const LnDrop dr) {
+    const unsigned dseed = dr.branch != nullptr && dr.seed_device != nullptr ? dr.seed + *dr.seed_device : dr.seed;
     // rows_per counts ROW PAIRS per wavefront here: a block covers rows_per * LNB_WAVES * 2 rows
     constexpr int N = Chunk<T>::N;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sl = lane & 31, sub = lane >> 5;
@@ -343,9 +377,14 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_half_kernel(cons
                 if (dxs != nullptr) {           // the drop-path twin: row factor x the STORED (rounded) gradient, as a separate row_scale pass would give
                     float r[N];
                     Chunk<T>::unpack(packed, r);
-                    const float sc = out_scale[row / rows_per_scale];
+                    if (dr.branch != nullptr) {  // ... or the gradient of the branch behind the fused residual dropout: mask / keep, element by element
 #pragma unroll
-                    for (int k = 0; k < N; ++k) r[k] *= sc;
+                        for (int k = 0; k < N; ++k) r[k] = ln_keep(dseed, (unsigned)row, (unsigned)(c * N + k), dr.thresh) ? r[k] * dr.inv_keep : 0.f;
+                    } else {
+                        const float sc = out_scale[row / rows_per_scale];
+#pragma unroll
+                        for (int k = 0; k < N; ++k) r[k] *= sc;
+                    }
                     st_chunk(dxs + (size_t)row * C + c * N, Chunk<T>::pack(r));
                 }
             }
@@ -1030,16 +1069,16 @@ static bool ln_half_rows(int cpr) {
 
 template <typename T>
 static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                           float* rstd, int M, int C, double eps, hipStream_t st) {
+                           float* rstd, int M, int C, double eps, hipStream_t st, const LnDrop dr = LnDrop{}) {
     constexpr int N = Chunk<T>::N;
     const int nch = (C / N + 63) / 64;
-    if (ln_half_rows(C / N)) {              // 32 lanes per row, no idle chunk slots at 96 chunks
+    if (dr.branch == nullptr && ln_half_rows(C / N)) {              // 32 lanes per row, no idle chunk slots at 96 chunks
         hipLaunchKernelGGL((layernorm_fwd_half_kernel<T, 3>), dim3((M + 7) / 8), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
                            rstd, M, C, (float)eps);
         return check_launch("layernorm_fwd");
     }
     dim3 grid((M + 3) / 4), block(256);
-#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), grid, block, 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, M, C, (float)eps)
+#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), grid, block, 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, M, C, (float)eps, dr)
     if (nch <= 1) LN_LAUNCH(1);
     else if (nch <= 2) LN_LAUNCH(2);
     else if (nch <= 4) LN_LAUNCH(4);
@@ -1055,6 +1094,25 @@ int layernorm_fwd(int dtype, const void* x, const float* gamma, const float* bet
     SAICV_REQUIRE(C % n == 0 && M > 0, "layernorm_fwd: C=%d must be a multiple of %d", C, n);
     if (dtype == SAICV_DTYPE_BF16) return layernorm_fwd_t<bf16_t>(x, gamma, beta, y, mean, rstd, M, C, eps, st);
     return layernorm_fwd_t<float>(x, gamma, beta, y, mean, rstd, M, C, eps, st);
+}
+
+static LnDrop ln_drop(const void* branch, void* sum_out, double p, unsigned seed, const unsigned* seed_device) {
+    LnDrop d;
+    d.branch = branch; d.sum_out = sum_out; d.seed = seed; d.seed_device = seed_device;
+    d.thresh = (unsigned)fmin(p * 4294967296.0, 4294967040.0);
+    d.inv_keep = (float)(1.0 / (1.0 - p));
+    return d;
+}
+
+// out = LayerNorm(sum), sum = x + dropout_p(branch)   (DETR's post-norm residual, reference detection/models/detr.py:89,92,114,118,122)
+int dropout_add_layernorm_fwd(int dtype, const void* x, const void* branch, double p, unsigned seed, const unsigned* seed_device,
+                              const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd, int M, int C,
+                              double eps, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && M > 0 && branch && sum_out && p >= 0.0 && p < 1.0, "dropout_add_layernorm_fwd: C=%d (multiple of %d), p=%g in [0, 1)", C, n, p);
+    const LnDrop dr = ln_drop(branch, sum_out, p, seed, seed_device);
+    if (dtype == SAICV_DTYPE_BF16) return layernorm_fwd_t<bf16_t>(x, gamma, beta, y, mean, rstd, M, C, eps, st, dr);
+    return layernorm_fwd_t<float>(x, gamma, beta, y, mean, rstd, M, C, eps, st, dr);
 }
 
 static int ln_bwd_blocks(int M, int* rows_per) {
@@ -1075,7 +1133,8 @@ size_t layernorm_bwd_ws_floats(int M, int C) {
 template <typename T>
 static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, const float* mean,
                            const float* rstd, const void* addend, void* dx, float* dgamma, float* dbeta, float* ws,
-                           int M, int C, int accumulate, hipStream_t st, const float* out_scale, int rows_per_scale, void* dxs) {
+                           int M, int C, int accumulate, hipStream_t st, const float* out_scale, int rows_per_scale, void* dxs,
+                           const LnDrop dr = LnDrop{}) {
     constexpr int N = Chunk<T>::N;
     const int nch = (C / N + 63) / 64;
     int rp;
@@ -1083,12 +1142,12 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
     float* pg = ws;
     float* pb = ws + (size_t)nb * C;
     dim3 grid(nb), block(64 * LNB_WAVES);
-#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)addend, (T*)dx, pg, pb, M, C, rp, out_scale, rows_per_scale, (T*)dxs)
+#define LN_LAUNCH(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)addend, (T*)dx, pg, pb, M, C, rp, out_scale, rows_per_scale, (T*)dxs, dr)
     if (ln_half_rows(C / N)) {
         // the same nb blocks (the workspace is sized for them), each covering 2 * rp2 * LNB_WAVES rows with rp2 row PAIRS per wavefront
         const int rp2 = (rp + 1) / 2;
         hipLaunchKernelGGL((layernorm_bwd_half_kernel<T, 3>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
-                           (const T*)addend, (T*)dx, pg, pb, M, C, rp2, out_scale, rows_per_scale, (T*)dxs);
+                           (const T*)addend, (T*)dx, pg, pb, M, C, rp2, out_scale, rows_per_scale, (T*)dxs, dr);
     } else
     if (nch <= 1) LN_LAUNCH(1);
     else if (nch <= 2) LN_LAUNCH(2);
@@ -1097,6 +1156,18 @@ static int layernorm_bwd_t(const void* dy, const void* x, const float* gamma, co
 #undef LN_LAUNCH
     hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64, 2), dim3(1024), 0, st, pg, pb, nb, C, dgamma, dbeta, accumulate);
     return check_launch("layernorm_bwd");
+}
+
+// The backward of dropout_add_layernorm_fwd: dsum (= the gradient of x) and dbranch = mask / (1 - p) * dsum in one pass
+int dropout_add_layernorm_bwd(int dtype, const void* dy, const void* sum, const float* gamma, const float* mean, const float* rstd,
+                              double p, unsigned seed, const unsigned* seed_device, void* dsum, void* dbranch, float* dgamma,
+                              float* dbeta, float* ws, int M, int C, int accumulate, hipStream_t st) {
+    const int n = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    SAICV_REQUIRE(C % n == 0 && M > 0 && dbranch && p >= 0.0 && p < 1.0, "dropout_add_layernorm_bwd: C=%d (multiple of %d), p=%g in [0, 1)", C, n, p);
+    const LnDrop dr = ln_drop(sum, nullptr, p, seed, seed_device);        // (branch != nullptr marks the dropout form of the second output)
+    if (dtype == SAICV_DTYPE_BF16)
+        return layernorm_bwd_t<bf16_t>(dy, sum, gamma, mean, rstd, nullptr, dsum, dgamma, dbeta, ws, M, C, accumulate, st, nullptr, 1, dbranch, dr);
+    return layernorm_bwd_t<float>(dy, sum, gamma, mean, rstd, nullptr, dsum, dgamma, dbeta, ws, M, C, accumulate, st, nullptr, 1, dbranch, dr);
 }
 
 // out_scale / rows_per_scale / dxs (optional): also write dxs[row] = out_scale[row / rows_per_scale] * dx[row] -- the gradient the

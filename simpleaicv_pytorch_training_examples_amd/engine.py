@@ -32,7 +32,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from . import _lib, ops
+from . import _lib, ops, ops_tfm
 from ._lib import check, lib, ptr
 
 ALIGN = 1024          # elements; one optimizer workgroup never straddles two parameters
@@ -533,6 +533,7 @@ class StepGraph:
                 s.copy_(x, non_blocking=True)
         for cb in self.before_replay:
             cb()
+        ops_tfm.advance_dropout_step()      # the captured dropout seeds are frozen: their device-side part moves on (ops_tfm.py)
         self.graph.replay()
         if self.drain_after_replay:
             # r06, the SAM step: work enqueued on the SAME stream after this replay was seen to START before the replay had finished --

@@ -244,6 +244,25 @@ def attn_bwd(qkv, out, dout, lse, b, n, heads, scale):
     return dqkv
 
 
+# r06 -- dropout inside a captured step.  The masks of this library's dropouts (attention probabilities, the fused residual dropout
+# below) are pure functions of a seed drawn on the HOST generator at trace time; a step captured into a hipGraph freezes that seed,
+# i.e. every replay would drop the same elements.  The kernels therefore add one word of device memory to the seed, and
+# engine.StepGraph advances that word before every replay (an eager step draws fresh host seeds anyway).
+_DROPOUT_STEP = {}
+
+
+def dropout_step_word(device):
+    t = _DROPOUT_STEP.get(device)
+    if t is None:
+        t = _DROPOUT_STEP[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def advance_dropout_step():
+    for t in _DROPOUT_STEP.values():
+        t.add_(40503)
+
+
 def _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w, dropout_p=0.0, seed=0):
     """q [B, Nq, H*D], k / v [B, Nk, H*D]: any batch / row strides, unit stride on the last axis."""
     b, nq, c = q.shape
@@ -259,6 +278,7 @@ def _attn_desc(q, k, v, heads, scale, key_bias, rel_h, rel_w, dropout_p=0.0, see
     d.B, d.H, d.Nq, d.Nk = b, heads, nq, nk
     d.scale = float(scale)
     d.dropout_p, d.seed = float(dropout_p), int(seed) & 0xffffffff
+    d.seed_device = ptr(dropout_step_word(q.device)) if dropout_p > 0 else None
     if key_bias is not None:
         if key_bias.dtype != torch.float32 or tuple(key_bias.shape) != (b, nk) or not key_bias.is_contiguous():
             raise ValueError('key_bias must be a contiguous fp32 [B, Nk] tensor')
@@ -340,6 +360,67 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, weight, bias, eps):
     return LayerNormFn.apply(x, weight, bias, eps)
+
+
+class DropoutAddLayerNormFn(torch.autograd.Function):
+    """LayerNorm(x + dropout_p(branch)) -- the post-norm residual of DETR's transformer layers (reference detection/models/detr.py:
+    89,92,114,118,122: `norm(src + self.dropout(src2))`) as one kernel each way instead of dropout + add + LayerNorm (and, backwards,
+    LayerNorm backward + masked scale + a gradient accumulation).  The mask is a counter-based function of (seed, row, column) drawn
+    like the attention dropout's: a host seed at trace time plus the device-side step word (dropout_step_word), so replays of a
+    captured step drop different elements.  Same distribution as nn.Dropout (keep with probability 1 - p, survivors / (1 - p)),
+    another random stream."""
+
+    @staticmethod
+    def forward(ctx, x, branch, weight, bias, p, eps):
+        require_gpu(x, branch, weight)
+        x2 = _as2d(x)
+        b2 = _as2d(branch)
+        if b2.dtype != x2.dtype:
+            b2 = b2.to(x2.dtype)
+        m, c = x2.shape
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())          # host generator: no device synchronisation
+        word = dropout_step_word(x2.device)
+        s = torch.empty_like(x2)
+        y = torch.empty_like(x2)
+        mean = torch.empty(m, dtype=torch.float32, device=x2.device)
+        rstd = torch.empty(m, dtype=torch.float32, device=x2.device)
+        t0 = KernelTimer.begin('layernorm_fwd')
+        check(lib().saicv_dropout_add_layernorm_fwd(dtype_code(x2.dtype), ptr(x2), ptr(b2), float(p), seed, ptr(word), ptr(weight), ptr(bias),
+                                                    ptr(s), ptr(y), ptr(mean), ptr(rstd), m, c, float(eps), stream()), 'dropout_add_layernorm_fwd')
+        KernelTimer.end(t0, 'layernorm_fwd', 0, 4.0 * m * c * x2.element_size() + 8.0 * m)
+        ctx.save_for_backward(s, weight, bias, mean, rstd)
+        ctx.cfg = (float(p), seed, branch.dtype)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, weight, bias, mean, rstd = ctx.saved_tensors
+        p, seed, branch_dtype = ctx.cfg
+        m, c = s.shape
+        L = lib()
+        dy2 = _as2d(dy).contiguous()
+        if dy2.dtype != s.dtype:
+            dy2 = dy2.to(s.dtype)
+        dsum = torch.empty_like(s)
+        dbranch = torch.empty_like(s)
+        gg, gb = _arena_grad(weight), _arena_grad(bias)
+        direct = gg is not None and gb is not None
+        dg = gg if direct else torch.empty(c, dtype=torch.float32, device=s.device)
+        db = gb if direct else torch.empty(c, dtype=torch.float32, device=s.device)
+        ws = torch.empty(L.saicv_layernorm_bwd_ws_floats(m, c), dtype=torch.float32, device=s.device)
+        t0 = KernelTimer.begin('layernorm_bwd')
+        check(L.saicv_dropout_add_layernorm_bwd(dtype_code(s.dtype), ptr(dy2), ptr(s), ptr(weight), ptr(mean), ptr(rstd), p, seed,
+                                                ptr(dropout_step_word(s.device)), ptr(dsum), ptr(dbranch), ptr(dg), ptr(db), ptr(ws), m, c,
+                                                int(direct), stream()), 'dropout_add_layernorm_bwd')
+        KernelTimer.end(t0, 'layernorm_bwd', 0, 4.0 * m * c * s.element_size() + 8.0 * m)
+        dbr = dbranch.view(dy.shape)
+        if dbr.dtype != branch_dtype:
+            dbr = dbr.to(branch_dtype)
+        return dsum.view(dy.shape), dbr, (None if direct else dg), (None if direct else db), None, None
+
+
+def dropout_add_layer_norm(x, branch, weight, bias, p, eps):
+    return DropoutAddLayerNormFn.apply(x, branch, weight, bias, p, eps)
 
 
 class GeluFn(torch.autograd.Function):

@@ -349,3 +349,82 @@ def test_drop_path_gradient_from_the_layernorm_backward_equals_the_separate_pass
     # 4 blocks x 2 branches, the first block's rate is 0 (the rates rise linearly): 6 separate passes; with the twin only the last branch
     # (its gradient comes from the final norm, not from a sub-layer) keeps one
     assert n_sep == 6 and n_twin <= 1, (n_sep, n_twin)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('mc', [(300, 256), (1000, 96), (257, 768), (64, 1024)])
+def test_fused_residual_dropout_layernorm(mc, dtype):
+    """saicv_dropout_add_layernorm_fwd / _bwd (DETR's norm(x + dropout(branch)), reference detection/models/detr.py:89,92,114,118,122).
+    p = 0: the autograd function equals LayerNorm(x + branch) and its gradients (torch fp32).  p = 0.3: the stored sum is x + mask / 0.7 *
+    branch with a mask whose keep rate is 0.7 within 4 sigma, the output is the LayerNorm of that sum, and the backward's branch gradient is
+    the SAME mask / 0.7 times its sum gradient (the mask is regenerated, not stored).  The device-side seed word changes the mask."""
+    import torch.nn.functional as F
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    m, c = mc
+    g = torch.Generator().manual_seed(m + c)
+    x = torch.randn(m, c, generator=g).to(dtype).cuda()
+    b = (torch.rand(m, c, generator=g) + 1.0).to(dtype).cuda()            # (in [1, 2): the mask is read off sum - x)
+    w = (torch.rand(c, generator=g) + 0.5).cuda()
+    bias = torch.randn(c, generator=g).cuda()
+    dy = torch.randn(m, c, generator=g).to(dtype).cuda()
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    # p = 0 against torch
+    xg, bg, wg, biasg = x.clone().requires_grad_(True), b.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    y = ops_tfm.dropout_add_layer_norm(xg, bg, wg, biasg, 0.0, 1e-5)
+    y.backward(dy)
+    xr, br, wr, biasr = (t.detach().float().requires_grad_(True) for t in (x, b, w, bias))
+    yr = F.layer_norm((xr + br).to(dtype).float(), (c,), wr, biasr, 1e-5)
+    yr.backward(dy.float())
+    rel = lambda a, r: float((a.float() - r).abs().max() / (r.abs().max() + 1e-12))
+    assert rel(y, yr) <= tol and rel(xg.grad, xr.grad) <= tol and rel(bg.grad, br.grad) <= tol
+    assert rel(wg.grad, wr.grad) <= max(tol, 1e-4) and rel(biasg.grad, biasr.grad) <= max(tol, 1e-4)
+    assert torch.equal(xg.grad, bg.grad)
+    # p = 0.3 through the C-ABI (the sum is an internal of the autograd function)
+    from simpleaicv_pytorch_training_examples_amd._lib import check, dtype_code, lib, ptr, stream
+    L = lib()
+    word = torch.zeros(1, dtype=torch.int32, device='cuda')
+
+    def forward(seed):
+        s, out = torch.empty_like(x), torch.empty_like(x)
+        mean, rstd = torch.empty(m, device='cuda'), torch.empty(m, device='cuda')
+        check(L.saicv_dropout_add_layernorm_fwd(dtype_code(dtype), ptr(x), ptr(b), 0.3, seed, ptr(word), ptr(w), ptr(bias), ptr(s), ptr(out),
+                                                ptr(mean), ptr(rstd), m, c, 1e-5, stream()), 'fwd')
+        return s, out, mean, rstd
+    s, out, mean, rstd = forward(1234)
+    mask = (s.float() - x.float()).abs() > 0.5
+    keep = float(mask.float().mean())
+    assert abs(keep - 0.7) <= 4 * (0.21 / (m * c)) ** 0.5 + 1e-3, keep
+    assert rel(s, x.float() + mask.float() * b.float() / 0.7) <= tol
+    assert rel(out, F.layer_norm(s.float(), (c,), w, bias, 1e-5)) <= tol
+    s2, _, _, _ = forward(1234)
+    assert torch.equal(s, s2)
+    word.add_(40503)
+    s3, _, _, _ = forward(1234)
+    assert not torch.equal(s, s3)
+    word.zero_()
+    dsum, dbranch = torch.empty_like(x), torch.empty_like(x)
+    dg, db = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    ws = torch.empty(L.saicv_layernorm_bwd_ws_floats(m, c), device='cuda')
+    check(L.saicv_dropout_add_layernorm_bwd(dtype_code(dtype), ptr(dy), ptr(s), ptr(w), ptr(mean), ptr(rstd), 0.3, 1234, ptr(word), ptr(dsum),
+                                            ptr(dbranch), ptr(dg), ptr(db), ptr(ws), m, c, 0, stream()), 'bwd')
+    torch.cuda.synchronize()
+    sr = s.detach().float().requires_grad_(True)
+    F.layer_norm(sr, (c,), w, bias, 1e-5).backward(dy.float())
+    assert rel(dsum, sr.grad) <= tol
+    assert rel(dbranch, mask.float() * dsum.float() / 0.7) <= (8e-3 if dtype == torch.bfloat16 else 1e-6)
+    assert bool((dbranch[~mask] == 0).all())
+
+
+def test_attention_dropout_mask_follows_the_device_seed_word():
+    """saicv_attn_desc.seed_device: a captured step freezes the host-side seed of the attention-probability dropout (DETR,
+    nn.MultiheadAttention(dropout=0.1)); engine.StepGraph advances the word in device memory before every replay.  Same word -> the same
+    output, advanced -> another mask."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    g = torch.Generator().manual_seed(9)
+    q, k, v = (torch.randn(2, 70, 256, generator=g).bfloat16().cuda() for _ in range(3))
+    a, _ = ops_tfm.sattn_fwd(q, k, v, 8, 32 ** -0.5, dropout_p=0.3, seed=77)
+    b, _ = ops_tfm.sattn_fwd(q, k, v, 8, 32 ** -0.5, dropout_p=0.3, seed=77)
+    ops_tfm.advance_dropout_step()
+    c, _ = ops_tfm.sattn_fwd(q, k, v, 8, 32 ** -0.5, dropout_p=0.3, seed=77)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and not torch.equal(a, c)
