@@ -482,6 +482,15 @@ def any_nonfinite(*tensors):
     return bad if other is None else (bad | other)
 
 
+def _kernel_copy(src, dst=None):
+    """src -> dst (or a new tensor) by an elementwise KERNEL, not hipMemcpyAsync (see StepGraph.kernel_copies)"""
+    if src.dtype.is_floating_point or src.dtype.is_complex:
+        return torch.mul(src, 1, out=dst) if dst is not None else torch.mul(src, 1)
+    if src.dtype == torch.bool:
+        return torch.logical_or(src, src, out=dst) if dst is not None else torch.logical_or(src, src)
+    return torch.bitwise_or(src, src, out=dst) if dst is not None else torch.bitwise_or(src, src)
+
+
 class StepGraph:
     """One training step as a hipGraph: `fn(*tensors) -> tensor | tuple of tensors` runs eagerly `warmup` times,
     is then captured once (torch.cuda.CUDAGraph on a side stream; every saicv kernel is launched on torch's current
@@ -496,9 +505,13 @@ class StepGraph:
     optimizer.refresh_hyper for the scheduler's learning rates).  Returned tensors are static buffers overwritten
     by the next replay: clone what must outlive a step."""
 
-    def __init__(self, fn, warmup=3, before_replay=(), drain_after_replay=False, side_stream_warmup=False):
+    def __init__(self, fn, warmup=3, before_replay=(), drain_after_replay=False, side_stream_warmup=False, kernel_copies=False):
         self.fn, self.warmup, self.before_replay = fn, warmup, tuple(before_replay)
         self.drain_after_replay = drain_after_replay
+        # kernel_copies (experiment switch of DESIGN.md section 3k): the input copies and a copy of the outputs as elementwise kernels
+        # instead of hipMemcpyAsync.  With it the tiny 'iters' SAM run is clean without a drain, the 'all' run and the two-combination
+        # run are not: device-to-device memcpys racing the replay are PART of that step's ordering problem, not all of it.
+        self.kernel_copies = kernel_copies or os.environ.get('SAICV_GRAPH_COPY') == 'kernel'
         self.side_stream_warmup = side_stream_warmup
         self._side_stream = None
         self.calls = 0
@@ -528,9 +541,13 @@ class StepGraph:
                 return out
             self._capture(inputs)
         t0 = time.perf_counter()
+        kcopy = self.kernel_copies
         for s, x in zip(self.static_in, inputs):
             if s is not None and s.data_ptr() != x.data_ptr():
-                s.copy_(x, non_blocking=True)
+                if kcopy:
+                    _kernel_copy(x, s)
+                else:
+                    s.copy_(x, non_blocking=True)
         for cb in self.before_replay:
             cb()
         ops_tfm.advance_dropout_step()      # the captured dropout seeds are frozen: their device-side part moves on (ops_tfm.py)
@@ -549,6 +566,9 @@ class StepGraph:
         ops._PackRegistry.touch(self._pack_entries)     # ... and the replayed step used its compute-dtype copies
         self.replays += 1
         self.replay_host_s += time.perf_counter() - t0
+        if kcopy:       # what the caller clones / reads must not be the graph's own buffer (see kernel_copies)
+            out = self.static_out
+            return _kernel_copy(out) if torch.is_tensor(out) else type(out)(_kernel_copy(t) if torch.is_tensor(t) else t for t in out)
         return self.static_out
 
     def _side(self):

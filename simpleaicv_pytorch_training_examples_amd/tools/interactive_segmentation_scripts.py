@@ -257,7 +257,8 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
                 return packed
             g = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,),
                                  drain_after_replay=os.environ.get('SAICV_SAM_GRAPH_DRAIN', '1') == '1',
-                                 side_stream_warmup=os.environ.get('SAICV_SAM_GRAPH_SIDE', '0') == '1')
+                                 side_stream_warmup=os.environ.get('SAICV_SAM_GRAPH_SIDE', '0') == '1',
+                                 kernel_copies=os.environ.get('SAICV_SAM_GRAPH_KCOPY', '0') == '1')
             graphs[key] = g
         return g, [prompts[k] for k in names]
 
