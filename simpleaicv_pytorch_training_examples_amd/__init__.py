@@ -9,3 +9,15 @@ its import root:
 Kernels live in csrc/ (hand-written HIP for gfx950) behind the C-ABI in include/saicv_hip.h.
 """
 __version__ = '0.1.0'
+
+import os as _os
+
+# r06 -- ROCm's "graph packet capture" (hipGraph replays as pre-recorded AQL packets, DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default in
+# ROCm 7.2) breaks the SAM training step as a captured graph: work enqueued on the launch stream after a replay starts before the replay
+# has finished, and replays of one graph between other work turn its outputs to garbage (DESIGN.md section 3k; with the switch at 0
+# the captured loop equals the eager loop bit for bit and two prompt combinations alternate cleanly).  The HIP runtime reads the switch
+# once, before the process's first HIP call -- so what matters is the environment at that moment.  GRAPH_PACKET_CAPTURE_OFF records
+# what this package saw when it was imported; tools.interactive_segmentation_scripts allows the full captured SAM step only then.
+# The other captured steps (ResNet / ViT / DETR / RetinaNet / MAE) are bit-exact against their eager loops either way and keep the
+# runtime's default (packet capture saves 0.6 ms / 4.3 ms of host enqueue per ResNet-50 / DETR step, 0.04 / 0.19 ms of step time).
+GRAPH_PACKET_CAPTURE_OFF = _os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'

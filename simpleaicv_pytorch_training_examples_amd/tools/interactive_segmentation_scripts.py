@@ -219,21 +219,23 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
     # BEFORE the step (reference :314-353): it decides which prompt tensors exist and how many decoder passes run, i.e. the SHAPE of
     # the step, so there is one captured graph per drawn combination (at most five), each captured after its own eager warm-up.
     # The click sampler's seed is frozen with a graph; its varying part lives in device memory and is bumped before every step.
-    # Every replay is followed by a stream drain (engine.StepGraph, drain_after_replay -- an ordering escape of this step's graph
-    # that is not understood yet), which costs the overlap of the next batch's upload with the step: on ONE GPU the captured step
-    # is no faster than eager launches (65.2 vs 65.6 ms at b8) and the reference config leaves it OFF; what it is for is the
-    # bucketed all-reduce on the communication stream under backward, which only a captured step gets (engine.py).
+    # On ONE GPU the captured step is no faster than eager launches (65.2 vs 65.6 ms at b8: the step is GPU-bound) and the reference
+    # config leaves it OFF; what it is for is the bucketed all-reduce on the communication stream under backward, which only a
+    # captured step gets (engine.py).
     use_graph = bool(getattr(config, 'use_step_graph', False)) and acc_steps == 1 and device.type == 'cuda'
-    if use_graph:
-        # ... and only where the draw has ONE outcome (every probability 0 or 1).  With two combinations in play -- replays of one graph
-        # between eager iterations or replays of the other -- the losses of the replayed combination turn to garbage after a few
-        # iterations (scripts/probes/sam_b_graph_probe.py at the reference config's 0.5 / 0.5 draw; one combination alone trains
-        # exactly like the eager loop).  What the two share is not found yet: such a config runs eagerly, and says so.
+    # ROCm's graph packet capture breaks THIS step's graph (package __init__.py).  With it off
+    # (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the first HIP call: the entry script sets it) every drawn prompt
+    # combination gets its graph and replays need no drain.  With it on, the restricted form that was pinned before the cause was
+    # found stays: only configs whose draw has ONE outcome are captured, and every replay is followed by a stream drain.
+    from .. import GRAPH_PACKET_CAPTURE_OFF
+    full_capture = GRAPH_PACKET_CAPTURE_OFF or os.environ.get('SAICV_SAM_GRAPH_MIXED') == '1'
+    if use_graph and not full_capture:
         probs = [config.prompt_probs[k] for k in ('prompt_point', 'prompt_box', 'prompt_mask')]
-        if any(0. < q < 1. for q in probs) and os.environ.get('SAICV_SAM_GRAPH_MIXED') != '1':
+        if any(0. < q < 1. for q in probs):
             use_graph = False
             if main:
-                logger.info('use_step_graph: the prompt draw has more than one outcome, the SAM step runs eagerly')
+                logger.info('use_step_graph: graph packet capture is on (DEBUG_CLR_GRAPH_PACKET_CAPTURE != 0) and the prompt draw has more '
+                            'than one outcome: the SAM step runs eagerly')
     graphs = None
     if use_graph:
         from .. import engine
@@ -256,7 +258,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
                 update(packed)
                 return packed
             g = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,),
-                                 drain_after_replay=os.environ.get('SAICV_SAM_GRAPH_DRAIN', '1') == '1',
+                                 drain_after_replay=os.environ.get('SAICV_SAM_GRAPH_DRAIN', '0' if GRAPH_PACKET_CAPTURE_OFF else '1') == '1',
                                  side_stream_warmup=os.environ.get('SAICV_SAM_GRAPH_SIDE', '0') == '1',
                                  kernel_copies=os.environ.get('SAICV_SAM_GRAPH_KCOPY', '0') == '1')
             graphs[key] = g
