@@ -37,6 +37,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# r06: ROCm's graph packet capture (hipGraph replays as pre-recorded AQL packets) turned replays of the captured SAM step to garbage
+# (DESIGN.md section 3k); the single-GPU captured steps measured here are bit-exact against their eager loops with it and keep it.  An
+# N-rank captured step adds RCCL kernel nodes on a second stream and has never run on hardware: it takes the conventional replay path
+# (0.04 ms of a ResNet-50 step), one unknown fewer.  The runtime reads the switch before its first call -- torch is imported below.
+if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('SAICV_SAM_GRAPH') == '1':
+    os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 # SURVEY.md section 8(d); DETR: 189.1 GFLOP fwd at 800x1344, scaled to the 800x1333 content of the padded canvas

@@ -20,4 +20,20 @@ import os as _os
 # what this package saw when it was imported; tools.interactive_segmentation_scripts allows the full captured SAM step only then.
 # The other captured steps (ResNet / ViT / DETR / RetinaNet / MAE) are bit-exact against their eager loops either way and keep the
 # runtime's default (packet capture saves 0.6 ms / 4.3 ms of host enqueue per ResNet-50 / DETR step, 0.04 / 0.19 ms of step time).
+# A captured step of an N-rank job carries RCCL kernel nodes on a second stream and has never run on hardware here: it takes the
+# conventional replay path too (one unknown fewer for 0.04 ms of a ResNet-50 step).  Only if HIP is not initialised yet -- later the
+# runtime would not see the change.
+import sys as _sys
+
+
+def _hip_initialised():
+    t = _sys.modules.get('torch')
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:       # noqa: BLE001
+        return False
+
+
+if (int(_os.environ.get('WORLD_SIZE', '1') or 1) > 1 or _os.environ.get('SAICV_SAM_GRAPH') == '1') and not _hip_initialised():
+    _os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 GRAPH_PACKET_CAPTURE_OFF = _os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'
