@@ -1,4 +1,5 @@
-"""Debug aid (r06): the full SAM-B step of the reference config through bench.loop_workload, per-iteration log lines printed.
+"""Debug aid (r06; the SAICV_SAM_GRAPH_* / SAICV_GRAPH_COPY experiment switches it was run with are gone from the product again -- what remains
+useful is DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 / 1 in the environment): the full SAM-B step of the reference config through bench.loop_workload, per-iteration log lines printed.
     python scripts/probes/sam_b_graph_probe.py <graph 0|1> <p_point> <steps> [batch]"""
 import argparse
 import logging

@@ -1,4 +1,5 @@
-"""Debug aid (r06): the tiny SAM loop of tests/test_zz_gpu_trajectories.py with the step graph on, parameter / gradient norms printed
+"""Debug aid (r06; the SAICV_SAM_GRAPH_* / SAICV_GRAPH_COPY experiment switches it was run with are gone from the product again -- what remains
+useful is DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 / 1 in the environment): the tiny SAM loop of tests/test_zz_gpu_trajectories.py with the step graph on, parameter / gradient norms printed
 around every StepGraph call."""
 import os
 import sys

@@ -482,15 +482,6 @@ def any_nonfinite(*tensors):
     return bad if other is None else (bad | other)
 
 
-def _kernel_copy(src, dst=None):
-    """src -> dst (or a new tensor) by an elementwise KERNEL, not hipMemcpyAsync (see StepGraph.kernel_copies)"""
-    if src.dtype.is_floating_point or src.dtype.is_complex:
-        return torch.mul(src, 1, out=dst) if dst is not None else torch.mul(src, 1)
-    if src.dtype == torch.bool:
-        return torch.logical_or(src, src, out=dst) if dst is not None else torch.logical_or(src, src)
-    return torch.bitwise_or(src, src, out=dst) if dst is not None else torch.bitwise_or(src, src)
-
-
 class StepGraph:
     """One training step as a hipGraph: `fn(*tensors) -> tensor | tuple of tensors` runs eagerly `warmup` times,
     is then captured once (torch.cuda.CUDAGraph on a side stream; every saicv kernel is launched on torch's current
@@ -505,15 +496,11 @@ class StepGraph:
     optimizer.refresh_hyper for the scheduler's learning rates).  Returned tensors are static buffers overwritten
     by the next replay: clone what must outlive a step."""
 
-    def __init__(self, fn, warmup=3, before_replay=(), drain_after_replay=False, side_stream_warmup=False, kernel_copies=False):
+    def __init__(self, fn, warmup=3, before_replay=(), drain_after_replay=False):
         self.fn, self.warmup, self.before_replay = fn, warmup, tuple(before_replay)
+        # drain_after_replay: a host-side stream synchronisation after every replay.  Only the SAM loop asks for it, and only while ROCm's
+        # graph packet capture is on (tools/interactive_segmentation_scripts.py, DESIGN.md section 3k)
         self.drain_after_replay = drain_after_replay
-        # kernel_copies (experiment switch of DESIGN.md section 3k): the input copies and a copy of the outputs as elementwise kernels
-        # instead of hipMemcpyAsync.  With it the tiny 'iters' SAM run is clean without a drain, the 'all' run and the two-combination
-        # run are not: device-to-device memcpys racing the replay are PART of that step's ordering problem, not all of it.
-        self.kernel_copies = kernel_copies or os.environ.get('SAICV_GRAPH_COPY') == 'kernel'
-        self.side_stream_warmup = side_stream_warmup
-        self._side_stream = None
         self.calls = 0
         self.graph = None
         self.static_in = self.static_out = None
@@ -524,57 +511,23 @@ class StepGraph:
         if self.graph is None:
             if self.calls < self.warmup:
                 self.calls += 1
-                if not self.side_stream_warmup:
-                    return self.fn(*inputs)
-                # the warm-up iterations on the stream the capture will use (torch's CUDA-graph recipe): autograd runs a leaf's
-                # gradient accumulation on the stream its accumulator node was created on, and nodes kept alive by the arena's
-                # post-accumulate hooks since an eager step on the DEFAULT stream would pull that stream into the capture as a branch
-                side = self._side()
-                cur = torch.cuda.current_stream()
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    out = self.fn(*inputs)
-                cur.wait_stream(side)
-                for t in (out if isinstance(out, (tuple, list)) else (out,)):
-                    if torch.is_tensor(t):
-                        t.record_stream(cur)
-                return out
+                return self.fn(*inputs)
             self._capture(inputs)
         t0 = time.perf_counter()
-        kcopy = self.kernel_copies
         for s, x in zip(self.static_in, inputs):
             if s is not None and s.data_ptr() != x.data_ptr():
-                if kcopy:
-                    _kernel_copy(x, s)
-                else:
-                    s.copy_(x, non_blocking=True)
+                s.copy_(x, non_blocking=True)
         for cb in self.before_replay:
             cb()
         ops_tfm.advance_dropout_step()      # the captured dropout seeds are frozen: their device-side part moves on (ops_tfm.py)
         self.graph.replay()
         if self.drain_after_replay:
-            # r06, the SAM step: work enqueued on the SAME stream after this replay was seen to START before the replay had finished --
-            # the next iteration's input copies overwrote the masks / images its backward still read, an eager iteration of another
-            # prompt combination re-packed weights under its optimizer step (wrong gradients, garbage losses a step or two later).
-            # Measured with a host synchronisation at four places around the replay (scripts/probes/sam_graph_debug.py,
-            # scripts/probes/sam_b_graph_probe.py): before the next inputs are touched or right after the replay --
-            # correct, bit-equal to the eager loop; anywhere between the input copies and the replay -- wrong.  The ResNet / DETR /
-            # MAE steps do not show it (their replay-equals-eager tests are bit-exact without).  Until the node kind that escapes the
-            # launch stream's ordering is identified, such a step drains the stream after every replay.
             torch.cuda.current_stream().synchronize()
         ops.bump_weights_epoch()        # the replayed optimizer kernels rewrote the parameters
         ops._PackRegistry.touch(self._pack_entries)     # ... and the replayed step used its compute-dtype copies
         self.replays += 1
         self.replay_host_s += time.perf_counter() - t0
-        if kcopy:       # what the caller clones / reads must not be the graph's own buffer (see kernel_copies)
-            out = self.static_out
-            return _kernel_copy(out) if torch.is_tensor(out) else type(out)(_kernel_copy(t) if torch.is_tensor(t) else t for t in out)
         return self.static_out
-
-    def _side(self):
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
-        return self._side_stream
 
     def _capture(self, inputs):
         self.static_in = [x.clone() if torch.is_tensor(x) else None for x in inputs]    # clone keeps NHWC strides
@@ -588,7 +541,7 @@ class StepGraph:
             graph.enable_debug_mode()
         failed = None
         try:
-            with (torch.cuda.graph(graph, stream=self._side()) if self.side_stream_warmup else torch.cuda.graph(graph)):
+            with torch.cuda.graph(graph):
                 ops._ZeroPool.zero_all()    # the statistics scratch starts a replay all-zero, whatever ran eagerly in between
                 try:
                     out = self.fn(*args)

@@ -228,7 +228,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
     # combination gets its graph and replays need no drain.  With it on, the restricted form that was pinned before the cause was
     # found stays: only configs whose draw has ONE outcome are captured, and every replay is followed by a stream drain.
     from .. import GRAPH_PACKET_CAPTURE_OFF
-    full_capture = GRAPH_PACKET_CAPTURE_OFF or os.environ.get('SAICV_SAM_GRAPH_MIXED') == '1'
+    full_capture = GRAPH_PACKET_CAPTURE_OFF
     if use_graph and not full_capture:
         probs = [config.prompt_probs[k] for k in ('prompt_point', 'prompt_box', 'prompt_mask')]
         if any(0. < q < 1. for q in probs):
@@ -258,9 +258,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
                 update(packed)
                 return packed
             g = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,),
-                                 drain_after_replay=os.environ.get('SAICV_SAM_GRAPH_DRAIN', '0' if GRAPH_PACKET_CAPTURE_OFF else '1') == '1',
-                                 side_stream_warmup=os.environ.get('SAICV_SAM_GRAPH_SIDE', '0') == '1',
-                                 kernel_copies=os.environ.get('SAICV_SAM_GRAPH_KCOPY', '0') == '1')
+                                 drain_after_replay=not GRAPH_PACKET_CAPTURE_OFF)
             graphs[key] = g
         return g, [prompts[k] for k in names]
 

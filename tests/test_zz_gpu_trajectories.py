@@ -711,7 +711,6 @@ def test_sam_step_graphs_of_two_prompt_combinations_alternate_with_graph_packet_
     import sys
     from conftest import ROOT
     env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE='0')
-    env.pop('SAICV_SAM_GRAPH_DRAIN', None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'sam_mixed_graph_worker.py')], env=env, capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
