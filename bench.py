@@ -37,12 +37,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# r06: ROCm's graph packet capture (hipGraph replays as pre-recorded AQL packets) turned replays of the captured SAM step to garbage
-# (DESIGN.md section 3k); the single-GPU captured steps measured here are bit-exact against their eager loops with it and keep it.  An
-# N-rank captured step adds RCCL kernel nodes on a second stream and has never run on hardware: it takes the conventional replay path
-# (0.04 ms of a ResNet-50 step), one unknown fewer.  The runtime reads the switch before its first call -- torch is imported below.
-if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('SAICV_SAM_GRAPH') == '1':
-    os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+# r06: ROCm's graph packet capture (hipGraph replays as pre-recorded AQL packets) gave wrong results in two captured steps (the SAM
+# step; a deterministic ResNet-50 step -- DESIGN.md section 3k) and buys nothing measurable (ResNet-50 20.42 / 20.41 ms, ViT-B 39.02 /
+# 39.02 ms on / off): every captured step takes the conventional replay path.  The package sets the same default when it is imported;
+# here too because the runtime reads the switch before its first call and torch is imported below.
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 # SURVEY.md section 8(d); DETR: 189.1 GFLOP fwd at 800x1344, scaled to the 800x1333 content of the padded canvas
@@ -144,6 +143,10 @@ def load_config(model_name):
     path = os.path.join(ROOT, CONFIG_DIR[model_name], 'train_config.py')
     spec = importlib.util.spec_from_file_location(f'bench_train_config_{model_name}', path)
     mod = importlib.util.module_from_spec(spec)
+    # the config builds its model while it is imported -- BEFORE the entry script's set_seed(), in the reference too (its weights
+    # are a fresh draw per process).  Seeded here so that two bench processes start from the same weights and `final_loss` compares.
+    import torch
+    torch.manual_seed(0)
     spec.loader.exec_module(mod)
     return mod.config, os.path.relpath(path, ROOT)
 

@@ -13,16 +13,17 @@ __version__ = '0.1.0'
 import os as _os
 
 # r06 -- ROCm's "graph packet capture" (hipGraph replays as pre-recorded AQL packets, DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default in
-# ROCm 7.2) breaks the SAM training step as a captured graph: work enqueued on the launch stream after a replay starts before the replay
-# has finished, and replays of one graph between other work turn its outputs to garbage (with the switch at 0
-# the captured loop equals the eager loop bit for bit and two prompt combinations alternate cleanly).  The HIP runtime reads the switch
-# once, before the process's first HIP call -- so what matters is the environment at that moment.  GRAPH_PACKET_CAPTURE_OFF records
-# what this package saw when it was imported; tools.interactive_segmentation_scripts allows the full captured SAM step only then.
-# The other captured steps (ResNet / ViT / DETR / RetinaNet / MAE) are bit-exact against their eager loops either way and keep the
-# runtime's default (packet capture saves 0.6 ms / 4.3 ms of host enqueue per ResNet-50 / DETR step, 0.04 / 0.19 ms of step time).
-# A captured step of an N-rank job carries RCCL kernel nodes on a second stream and has never run on hardware here: it takes the
-# conventional replay path too (one unknown fewer for 0.04 ms of a ResNet-50 step).  Only if HIP is not initialised yet -- later the
-# runtime would not see the change.
+# ROCm 7.2) gave wrong results in two independent captured steps here:
+#   * the SAM training step: work enqueued on the launch stream after a replay starts before the replay has finished, and replays of
+#     one graph between other work turn its outputs to garbage;
+#   * a deterministic-mode ResNet-50 b256 step once the weight-gradient partials workspace (reused by all 54 layers of a step) is no
+#     longer cleared in front of every use (csrc/det.hip): from the SECOND replay on the weights differ from the eager loop's, in 5 of 5
+#     processes (scripts/probes/bench_repro_probe.py) -- with the switch at 0 the same graph equals the eager loop bit for bit, 5 of 5.
+# Same-box A/B (profiles/r06_nt_experiments.md section 6): ResNet-50 20.42 / 20.41 ms, ViT-B 39.02 / 39.02 ms with it on / off, DETR
+# +0.19 ms -- nothing to keep it for.  So EVERY captured step takes the conventional replay path: the switch is set to 0 here unless
+# the environment already sets it.  The HIP runtime reads it once, before the process's first HIP call, so this only works if HIP is not
+# initialised yet; GRAPH_PACKET_CAPTURE_OFF records what the runtime will have seen.  With it on (a process that initialised HIP before
+# importing this package) engine.StepGraph warns once and runs every step eagerly.
 import sys as _sys
 
 
@@ -34,6 +35,7 @@ def _hip_initialised():
         return False
 
 
-if (int(_os.environ.get('WORLD_SIZE', '1') or 1) > 1 or _os.environ.get('SAICV_SAM_GRAPH') == '1') and not _hip_initialised():
+_HIP_WAS_UP = _hip_initialised()
+if not _HIP_WAS_UP:
     _os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 GRAPH_PACKET_CAPTURE_OFF = _os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'

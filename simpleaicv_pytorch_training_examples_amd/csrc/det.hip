@@ -98,17 +98,91 @@ __global__ __launch_bounds__(256) void det_fold4_kernel(const float* __restrict_
     f32x4* d = reinterpret_cast<f32x4*>(dst + i * 4);
     *d = *d + acc;
 }
+// The chain above with the LOADS spread over the workgroup (r06): the statistics folds (BatchNorm sums and their backward sums: 2 C
+// elements, up to 512 parts) are one workgroup's worth of elements and `nparts` dependent L2 round trips per thread -- 20 ... 45 us
+// each, 1 ms of a deterministic ResNet-50 step.  Eight loader lanes per element quad bring 32 parts at a time into LDS (double
+// buffered), lane 0 adds them in ascending part order: bit for bit the chain's result (scripts/probes/det_fold_probe.py compares).
+constexpr int COOP_J = 8, COOP_E = 256 / COOP_J, COOP_CH = 32;
+__global__ __launch_bounds__(256) void det_fold4_coop_kernel(const float* __restrict__ part, size_t n, int nparts, size_t off, size_t count4,
+                                                             float* __restrict__ dst) {
+    __shared__ f32x4 buf[2][COOP_CH][COOP_E];
+    const int e = threadIdx.x % COOP_E, j = threadIdx.x / COOP_E;
+    const size_t i = (size_t)blockIdx.x * COOP_E + e;
+    const bool live = i < count4;
+    const float* p = part + off + (live ? i : 0) * 4;
+    const int chunks = (nparts + COOP_CH - 1) / COOP_CH;
+    auto load = [&](int c) {
+        f32x4 v[COOP_CH / COOP_J];
+#pragma unroll
+        for (int t = 0; t < COOP_CH / COOP_J; ++t) {
+            const int k = c * COOP_CH + t * COOP_J + j;
+            v[t] = (live && k < nparts) ? *reinterpret_cast<const f32x4*>(p + (size_t)k * n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < COOP_CH / COOP_J; ++t) buf[c & 1][t * COOP_J + j][e] = v[t];
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    load(0);
+    __syncthreads();
+    for (int c = 0; c < chunks; ++c) {
+        if (c + 1 < chunks) load(c + 1);                    // the other buffer: its last readers passed the barrier below
+        if (j == 0) {
+            const int cnt = min(COOP_CH, nparts - c * COOP_CH);
+            int kk = 0;
+            if (c == 0) { acc = buf[0][0][e]; kk = 1; }     // the chain starts FROM part 0 (not 0 + part 0: the sign of a zero)
+            for (; kk < cnt; ++kk) acc += buf[c & 1][kk][e];
+        }
+        __syncthreads();
+    }
+    if (j == 0 && live) {
+        f32x4* d = reinterpret_cast<f32x4*>(dst + i * 4);
+        *d = *d + acc;
+    }
+}
+// The same for MANY parts (a weight gradient's pixel splits: 32 ... 512 of them over a few thousand elements).  One thread per
+// element walking every part is a chain of `nparts` dependent additions on 36 workgroups: 44 us per fold, 2.5 ms of a ResNet-50 step
+// in deterministic mode (r06 profile).  Here J = 8 threads share an element quad: thread j adds parts j, j + 8, j + 16, ... in that
+// order (four loads in flight), the eight sub-sums are added in the order j = 0 .. 7 through LDS.  A fixed function of (nparts, J):
+// as reproducible as the single chain, another (equally valid) association of the same sum.
+constexpr int FOLD_J = 8, FOLD_E = 256 / FOLD_J;
+__global__ __launch_bounds__(256) void det_fold4_wide_kernel(const float* __restrict__ part, size_t n, int nparts, size_t off, size_t count4,
+                                                             float* __restrict__ dst) {
+    __shared__ f32x4 red[FOLD_J][FOLD_E];
+    const int e = threadIdx.x % FOLD_E, j = threadIdx.x / FOLD_E;
+    const size_t i = (size_t)blockIdx.x * FOLD_E + e;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (i < count4) {
+        const float* p = part + off + i * 4;
+#pragma unroll 4
+        for (int k = j; k < nparts; k += FOLD_J) acc += *reinterpret_cast<const f32x4*>(p + (size_t)k * n);
+    }
+    red[j][e] = acc;
+    __syncthreads();
+    if (j == 0 && i < count4) {
+        f32x4 a = red[0][e];
+#pragma unroll
+        for (int jj = 1; jj < FOLD_J; ++jj) a += red[jj][e];
+        f32x4* d = reinterpret_cast<f32x4*>(dst + i * 4);
+        *d = *d + a;
+    }
+}
 
 }  // namespace
 
-int DetParts::begin(hipStream_t stream, int parts, size_t n, const char* who) {
+int DetParts::begin(hipStream_t stream, int parts, size_t n, const char* who, bool zero) {
     s = DetSink{nullptr, n};
     nparts = parts;
     st = stream;
     if (!g_deterministic || parts <= 1 || n == 0) return 0;      // one contributor per element: its atomics are already ordered
     float* p = ws_for(stream, (size_t)parts * n, who);
     if (!p) return -1;
-    if (hipMemsetAsync(p, 0, (size_t)parts * n * sizeof(float), stream) != hipSuccess) {
+    // A kernel that writes every element of every part (`zero == false`) needs no clearing pass.  (r06: under ROCm's graph packet capture
+    // a captured step without it replayed wrongly -- the fold read stale partials -- and the pass in front only hid that when the eager
+    // warm-up steps had it too; captured steps now run with packet capture off, package __init__.py.  SAICV_ORDERED_ZERO=1 brings the pass
+    // back for the A/B, scripts/probes/bench_repro_probe.py.)
+    static const bool force = getenv("SAICV_ORDERED_ZERO") && atoi(getenv("SAICV_ORDERED_ZERO")) != 0;
+    const bool clear = zero || force;
+    if (clear && hipMemsetAsync(p, 0, (size_t)parts * n * sizeof(float), stream) != hipSuccess) {
         set_error("%s: clearing the deterministic workspace failed: %s", who, hipGetErrorString(hipGetLastError()));
         return -1;
     }
@@ -116,10 +190,17 @@ int DetParts::begin(hipStream_t stream, int parts, size_t n, const char* who) {
     return 0;
 }
 
-int DetParts::fold(float* dst, size_t offset, size_t count) const {
+int DetParts::fold(float* dst, size_t offset, size_t count, bool wide_ok) const {
     if (!s.part || count == 0) return 0;
     const bool vec = (s.n % 4 == 0) && (offset % 4 == 0) && (count % 4 == 0) && ((uintptr_t)dst % 16 == 0);
-    if (vec)
+    // SAICV_ORDERED_FOLD=chain: every fold through the one-thread chain (the r06 A/B switch: "wide" changes the association of the weight-
+    // gradient sums, "coop" must not change a bit)
+    static const bool plain = getenv("SAICV_ORDERED_FOLD") && getenv("SAICV_ORDERED_FOLD")[0] == 'c';
+    if (vec && !plain && wide_ok && nparts >= 4 * FOLD_J)
+        hipLaunchKernelGGL(det_fold4_wide_kernel, dim3((unsigned)((count / 4 + FOLD_E - 1) / FOLD_E)), dim3(256), 0, st, s.part, s.n, nparts, offset, count / 4, dst);
+    else if (vec && !plain && nparts >= COOP_CH)
+        hipLaunchKernelGGL(det_fold4_coop_kernel, dim3((unsigned)((count / 4 + COOP_E - 1) / COOP_E)), dim3(256), 0, st, s.part, s.n, nparts, offset, count / 4, dst);
+    else if (vec)
         hipLaunchKernelGGL(det_fold4_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, st, s.part, s.n, nparts, offset, count / 4, dst);
     else
         hipLaunchKernelGGL(det_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, s.part, s.n, nparts, offset, count, dst);

@@ -2742,12 +2742,13 @@ int igemm_tn(int dtype, const void* dy, const void* src, float* dw, int H, int W
     splits = (total_rt + rt_per - 1) / rt_per;
     p.m_per_split = rt_per * BR;
     // deterministic mode (det.h): the splits park their tiles (and bias sums) side by side, one launch folds them in split order
+    // (not zeroed: every split owns at least one row tile -- (splits - 1) * rt_per < total_rt above -- and writes its whole tile and bias sums)
     DetParts det;
-    if (det.begin(st, splits, (size_t)Cout * Kd + (dbias ? Cout : 0), "igemm_tn")) return -1;
+    if (det.begin(st, splits, (size_t)Cout * Kd + (dbias ? Cout : 0), "igemm_tn", /*zero=*/false)) return -1;
     p.det = det.sink();
     const int rc = igemm_tn_launch(dtype, p, splits, big, ba, bb, BR, st);
     if (rc) return rc;
-    if (det.fold(dw, 0, (size_t)Cout * Kd)) return -1;
+    if (det.fold(dw, 0, (size_t)Cout * Kd, /*wide=*/true)) return -1;
     if (dbias && det.fold(dbias, (size_t)Cout * Kd, (size_t)Cout)) return -1;
     return 0;
 }

@@ -496,11 +496,21 @@ class StepGraph:
     optimizer.refresh_hyper for the scheduler's learning rates).  Returned tensors are static buffers overwritten
     by the next replay: clone what must outlive a step."""
 
-    def __init__(self, fn, warmup=3, before_replay=(), drain_after_replay=False):
+    _warned_packets = False
+
+    def __init__(self, fn, warmup=3, before_replay=()):
         self.fn, self.warmup, self.before_replay = fn, warmup, tuple(before_replay)
-        # drain_after_replay: a host-side stream synchronisation after every replay.  Only the SAM loop asks for it, and only while ROCm's
-        # graph packet capture is on (tools/interactive_segmentation_scripts.py, DESIGN.md section 3k)
-        self.drain_after_replay = drain_after_replay
+        # Two captured steps replayed WRONGLY under ROCm's graph packet capture (the SAM step; a deterministic ResNet-50 step whose
+        # weight-gradient partials workspace is reused layer after layer -- DESIGN.md section 3k).  The package switches it off when
+        # it is imported before the process's first HIP call; in a process where that came too late the step is never captured.
+        from . import GRAPH_PACKET_CAPTURE_OFF
+        self.eager_only = not GRAPH_PACKET_CAPTURE_OFF and os.environ.get('SAICV_STEP_GRAPH_WITH_PACKETS') != '1'     # (=1: the failing A/B leg)
+        if self.eager_only and not StepGraph._warned_packets:
+            StepGraph._warned_packets = True
+            import warnings
+            warnings.warn('StepGraph: ROCm graph packet capture is on (DEBUG_CLR_GRAPH_PACKET_CAPTURE != 0 when HIP started): captured '
+                          'steps can replay wrongly with it, so the step runs eagerly.  Import simpleaicv_pytorch_training_examples_amd '
+                          'before the first HIP call, or export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0', RuntimeWarning, stacklevel=2)
         self.calls = 0
         self.graph = None
         self.static_in = self.static_out = None
@@ -509,7 +519,7 @@ class StepGraph:
 
     def __call__(self, *inputs):
         if self.graph is None:
-            if self.calls < self.warmup:
+            if self.calls < self.warmup or self.eager_only:
                 self.calls += 1
                 return self.fn(*inputs)
             self._capture(inputs)
@@ -521,8 +531,6 @@ class StepGraph:
             cb()
         ops_tfm.advance_dropout_step()      # the captured dropout seeds are frozen: their device-side part moves on (ops_tfm.py)
         self.graph.replay()
-        if self.drain_after_replay:
-            torch.cuda.current_stream().synchronize()
         ops.bump_weights_epoch()        # the replayed optimizer kernels rewrote the parameters
         ops._PackRegistry.touch(self._pack_entries)     # ... and the replayed step used its compute-dtype copies
         self.replays += 1

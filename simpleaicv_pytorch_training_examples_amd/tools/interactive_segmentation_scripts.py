@@ -223,19 +223,8 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
     # config leaves it OFF; what it is for is the bucketed all-reduce on the communication stream under backward, which only a
     # captured step gets (engine.py).
     use_graph = bool(getattr(config, 'use_step_graph', False)) and acc_steps == 1 and device.type == 'cuda'
-    # ROCm's graph packet capture breaks THIS step's graph (package __init__.py).  With it off
-    # (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the first HIP call: the entry script sets it) every drawn prompt
-    # combination gets its graph and replays need no drain.  With it on, the restricted form that was pinned before the cause was
-    # found stays: only configs whose draw has ONE outcome are captured, and every replay is followed by a stream drain.
-    from .. import GRAPH_PACKET_CAPTURE_OFF
-    full_capture = GRAPH_PACKET_CAPTURE_OFF
-    if use_graph and not full_capture:
-        probs = [config.prompt_probs[k] for k in ('prompt_point', 'prompt_box', 'prompt_mask')]
-        if any(0. < q < 1. for q in probs):
-            use_graph = False
-            if main:
-                logger.info('use_step_graph: graph packet capture is on (DEBUG_CLR_GRAPH_PACKET_CAPTURE != 0) and the prompt draw has more '
-                            'than one outcome: the SAM step runs eagerly')
+    # (ROCm's graph packet capture breaks THIS step's graph -- package __init__.py, DESIGN.md section 3k: the package switches it off at
+    # import, and engine.StepGraph runs the step eagerly in a process where that came too late)
     graphs = None
     if use_graph:
         from .. import engine
@@ -257,8 +246,7 @@ def train_sam_segmentation(train_loader, model, criterion, optimizer, scheduler,
                 packed = forward_backward(images, masks, pr, decoder_iters, True)
                 update(packed)
                 return packed
-            g = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,),
-                                 drain_after_replay=not GRAPH_PACKET_CAPTURE_OFF)
+            g = engine.StepGraph(whole_step, warmup=getattr(config, 'step_graph_warmup', 3), before_replay=(optimizer.refresh_hyper,))
             graphs[key] = g
         return g, [prompts[k] for k in names]
 

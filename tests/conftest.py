@@ -1,8 +1,12 @@
 import os
 import sys
 
-import pytest
-import torch
+# ROCm's graph packet capture off for every captured step (package __init__.py): the HIP runtime reads the switch at
+# its first call, so it is set before torch is imported (the package sets the same default when a test module imports it)
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
+import pytest  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

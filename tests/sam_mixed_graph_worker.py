@@ -22,17 +22,18 @@ class MP:
 
 
 ops.set_deterministic(True)
-drains = []
+made = []
 orig_init = engine.StepGraph.__init__
 
 
 def spy_init(self, *a, **k):
     orig_init(self, *a, **k)
-    drains.append(self.drain_after_replay)
+    made.append(self)
 
 
 engine.StepGraph.__init__ = spy_init
 _, eager, _, p_eager = T._run_sam_tiny('iters', MP(), False, True, steps_override=18, mixed=True)
 _, graph, _, p_graph = T._run_sam_tiny('iters', MP(), True, True, steps_override=18, mixed=True)
-print(json.dumps({'packet_capture_off': pkg.GRAPH_PACKET_CAPTURE_OFF, 'drain': any(drains), 'graphs': len(drains), 'eager': eager, 'graph': graph,
+print(json.dumps({'packet_capture_off': pkg.GRAPH_PACKET_CAPTURE_OFF, 'graphs': len(made), 'captured': sum(g.graph is not None for g in made),
+                  'eager': eager, 'graph': graph,
                   'params_equal': bool(torch.equal(p_eager, p_graph))}))
