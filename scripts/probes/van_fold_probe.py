@@ -1,6 +1,8 @@
 """r06: how far do the detection VAN / ConvFormer fp32 gradient norms sit from the reference's under different (all fixed, all
-bit-reproducible) associations of the deterministic fold?  SAICV_ORDERED_FOLD = chain (one thread walks the parts in ascending order),
-wide (weight gradients only through the eight-lane form), all (every fold with >= 32 parts through it), rev (the chain descending)."""
+bit-reproducible) associations of the deterministic fold?  SAICV_ORDERED_FOLD = chain (one thread walks the parts in ascending order)
+against the default (cooperative chain, weight gradients through the eight-lane form).  profiles/r06_van_fold_probe.txt also holds two
+legs of an experiment build that is not kept: "all" (every fold with >= 32 parts through the eight lanes) and "rev" (the chain walked
+from the last part) -- the legs that showed VAN's BatchNorm backward amplifying a re-association to 2e-4 / 1e-3."""
 import os
 import subprocess
 import sys
@@ -34,5 +36,5 @@ if __name__ == '__main__':
         child(sys.argv[2])
         sys.exit(0)
     for case in ('van', 'convformer', 'dinov3convnext'):
-        for fold in ('chain', 'wide', 'all', 'rev'):
+        for fold in ('chain', 'default'):
             subprocess.run([sys.executable, os.path.abspath(__file__), 'child', case], env=dict(os.environ, SAICV_ORDERED_FOLD=fold))
