@@ -15,11 +15,8 @@ import os
 import sys
 import time
 
-# a captured SAM step (config.use_step_graph, SAICV_SAM_GRAPH=1) needs ROCm's graph packet capture OFF, and the HIP runtime reads that
-# switch before its first call: set here, before torch initialises HIP (package __init__.py)
-if os.environ.get('SAICV_SAM_GRAPH') == '1':
-    os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
-
+# (a captured step needs ROCm's graph packet capture OFF, and the HIP runtime reads that switch before its first call: running this
+# module with `-m` imports the package -- whose __init__ sets it -- before torch is imported below)
 import torch
 from torch.utils.data import DataLoader
 
