@@ -242,6 +242,25 @@ def train_classification(train_loader, model, criterion, optimizer, scheduler, e
     return losses.avg * acc_steps
 
 
+def all_ranks_agree(mine, config):
+    """True iff `mine` is true on EVERY rank of config.group -- a host-side decision made the same way everywhere.  The DETR loop
+    leaves the captured step for a batch whose images carry more boxes than config.max_annots (graph_inputs -> None); under DDP one
+    rank running the eager step (host-side assignment, eagerly issued bucket all-reduces) while the others replay the graph (captured
+    collectives) is two different collective sequences: a hang.  The flag travels over a gloo group (created once per
+    config, by every rank at the same iteration): no device synchronisation, ~0.1 ms of host time against a 23 ms step."""
+    world = int(getattr(config, 'gpus_num', 1) or 1)
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return bool(mine)
+    group = getattr(config, '_saicv_host_group', None)
+    if group is None:
+        own = getattr(config, 'group', None)
+        group = own if dist.get_backend(own) == 'gloo' else dist.new_group(backend='gloo')
+        config._saicv_host_group = group
+    flag = torch.tensor([1 if mine else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group if group is not None else dist.group.WORLD)
+    return bool(int(flag[0]))
+
+
 def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, total_name, iter_width,
                 graph_inputs=None, log_terms=True):
     """Shared iteration engine of the dict-loss loops (detection here; the SAM loop in
@@ -366,6 +385,8 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
         micro += 1
         boundary = micro % acc_steps == 0
         tensors = graph_inputs(data) if step_graph is not None else None     # None: this batch does not fit the captured shapes
+        if step_graph is not None and getattr(graph_inputs, 'may_decline', False) and not all_ranks_agree(tensors is not None, config):
+            tensors = None                                                   # ... on SOME rank: every rank takes the eager step
         if tensors is not None:
             packed = step_graph(*tensors).clone()
             n = tensors[0].size(0)
@@ -459,6 +480,7 @@ def train_detection(train_loader, model, criterion, optimizer, scheduler, epoch,
             else:
                 mask = data['mask'].to(device, non_blocking=True)
             return (data['image'].to(device, non_blocking=True), mask, ann)
+        graph_inputs.may_decline = True
     return _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config, step_fn, 'total_loss', 5, graph_inputs)
 
 

@@ -317,3 +317,43 @@ def test_rccl_unique_id_travels_through_the_process_group_store():
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] == bytes(range(128))
     assert res[0][2] == res[1][2] == bytes((255 - i) % 256 for i in range(128))
+
+
+# ------------------------------------------------------------------ leaving the captured DETR step is a collective decision
+def _worker_agree(rank, world, port, q):
+    import types
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    config = types.SimpleNamespace(gpus_num=world, group=None)
+    # iteration 1: every rank's batch fits the captured shapes; 2: rank 1's does not (an image with more boxes than max_annots); 3: rank 0's
+    fits = [(True, True), (True, False), (False, True), (True, True)]
+    out = [scripts.all_ranks_agree(f[rank], config) for f in fits]
+    q.put((rank, out, config._saicv_host_group is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_every_rank_leaves_the_captured_step_when_one_rank_must():
+    """tools/scripts.py train_detection -- a DETR batch beyond config.max_annots takes the eager step; under DDP the ranks
+    must take it TOGETHER (the eager and the captured step issue different collective sequences).  all_ranks_agree: a MIN over a gloo
+    group, here the default group itself (world of two)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_agree, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == [True, False, False, True], res
+
+
+def test_one_rank_decides_alone():
+    import types
+    from simpleaicv_pytorch_training_examples_amd.tools import scripts
+    assert scripts.all_ranks_agree(True, types.SimpleNamespace(gpus_num=1)) is True
+    assert scripts.all_ranks_agree(False, types.SimpleNamespace(gpus_num=1)) is False

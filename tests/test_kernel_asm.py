@@ -43,3 +43,45 @@ def test_streaming_kernels_of_the_late_additions_keep_their_registers(source, tm
         vgprs = int(re.search(r'\.amdhsa_next_free_vgpr\s+(\d+)', body).group(1))
         assert scratch == 0, (name, scratch)
         assert vgprs <= 128, (name, vgprs)
+
+
+@pytest.mark.timeout(1200)
+def test_asm_fragment_reads_are_not_touched_before_their_counted_wait():
+    """the `ds_read_b128` fragment reads of csrc/igemm.hip and csrc/pwstream.hip are inline asm with `=v` outputs the
+    compiler treats as valid at once, released by hand-counted `s_waitcnt lgkmcnt(N)` asm statements.  scripts/check_fragment_regs.py
+    replays the LGKM counter over the generated assembly of every kernel: no instruction reads or writes a fragment register while
+    its read is outstanding (a copy or spill the register allocator slipped in, or a compiler-generated LDS / scalar-memory
+    operation that made a count wrong, would show), and those kernels use no scratch.  The checker itself is checked by mutation:
+    a wait count raised by two, and a move inserted behind a read, must both be reported."""
+    import re
+    import check_fragment_regs as F
+    import check_ticket_regs as C
+    pw = F.assembly('pwstream.hip')
+    reports = F.check(pw) + F.check(C.assembly())
+    assert len([r for r in reports if 'pw_stream_kernel' in r[0]]) == 3           # the nine-tap forms: plain, + statistics, + data-gradient extras
+    assert len(reports) >= 60, len(reports)
+    for name, n_reads, n_waits, scratch, bad in reports:
+        assert n_reads >= 1 and n_waits >= 1 and scratch == 0 and not bad, (name, n_reads, n_waits, scratch, bad[:3])
+    # mutation 1: the first three counted waits release two reads too few
+    lines, in_asm, changed = pw.split('\n'), False, 0
+    for i, l in enumerate(lines):
+        if 'ASMSTART' in l:
+            in_asm = True
+        elif 'ASMEND' in l:
+            in_asm = False
+        elif in_asm and 's_waitcnt lgkmcnt(' in l and changed < 3:
+            n = int(re.search(r'lgkmcnt\((\d+)\)', l).group(1))
+            lines[i] = l.replace(f'lgkmcnt({n})', f'lgkmcnt({n + 2})')
+            changed += 1
+    assert changed == 3 and sum(len(r[4]) for r in F.check('\n'.join(lines))) > 0
+    # mutation 2: a copy of a fragment register right behind its read
+    lines, in_asm = pw.split('\n'), False
+    for i, l in enumerate(lines):
+        if 'ASMSTART' in l:
+            in_asm = True
+        elif 'ASMEND' in l:
+            in_asm = False
+        elif in_asm and 'ds_read_b128' in l:
+            lines.insert(i + 2, '\tv_mov_b32_e32 v200, v' + re.search(r'v\[(\d+):', l).group(1))
+            break
+    assert sum(len(r[4]) for r in F.check('\n'.join(lines))) == 1
