@@ -226,7 +226,7 @@ def loop_workload(name, args, world, rank, device, use_graph=False):
     is_det = LOOP_MODELS[name][0].endswith('train_detection')
     is_detr = 'detr' in getattr(config, 'network', '')
     # r05: DETR captured whole -- its Hungarian assignment runs on the device (DETRLoss.assign_device, saicv_detr_assign)
-    # (the SAM loop's captured step is opt-in, SAICV_SAM_GRAPH=1 in its config: it needs a stream drain after every replay and gains nothing on one GPU)
+    # (the SAM loop's captured step is opt-in, SAICV_SAM_GRAPH=1 in its config: it gains nothing on one GPU -- DESIGN.md section 3k)
     graphed = bool(use_graph and ((not is_det and getattr(config, 'use_step_graph', False)) or
                                   (is_det and not is_detr and getattr(config.train_criterion, 'capturable', False)) or
                                   (is_detr and getattr(config.train_criterion, 'static_form', False))))
