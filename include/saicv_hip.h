@@ -323,6 +323,12 @@ int saicv_dropout_add_layernorm_fwd(int dtype, const void* x, const void* branch
 int saicv_dropout_add_layernorm_bwd(int dtype, const void* dy, const void* sum, const float* gamma, const float* mean, const float* rstd,
                                     double p, unsigned int seed, const unsigned int* seed_device, void* dsum, void* dbranch,
                                     float* dgamma, float* dbeta, float* ws, int M, int C, int accumulate, void* stream);
+/* dropout(relu(x)) of DETR's feed-forward (reference detection/models/detr.py:90-91, 120-121: linear2(dropout(activation(linear1(x))))) as one
+ * pass each way: y = keep ? relu(x) / (1 - p) : 0, keep a counter-based function of (seed + *seed_device, element) as in
+ * saicv_dropout_add_layernorm_fwd; the backward reads y instead of a mask (y > 0 exactly where the gradient passes): dx = dy / (1 - p)
+ * there, 0 elsewhere.  n: elements, a multiple of 8 (bf16) / 4 (fp32). */
+int saicv_relu_dropout_fwd(int dtype, const void* x, void* y, size_t n, double p, unsigned int seed, const unsigned int* seed_device, void* stream);
+int saicv_relu_dropout_bwd(int dtype, const void* dy, const void* y, void* dx, size_t n, double p, void* stream);
 /* nn.GELU() (exact erf form), vit.py:87-99 */
 int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream);
 int saicv_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, void* stream);

@@ -53,15 +53,18 @@ def _mha(mha, q_in, k_in, v_in, key_bias, same_qk):
     # the packed parameters enter whole (row ranges): their gradients land in the arena rows directly
     # head dimension 64: the streaming attention kernels stage K and V with ONE row stride (csrc/attn_stream.hip), so K must not
     # be a column slice of the packed [q | k] projection (row stride 2c against V's c) -- project it on its own
+    p = mha.dropout if mha.training else 0.0
+    scale = (c // mha.num_heads) ** -0.5
+    v = ops_tfm.linear_rows(v_in, w, b, 2 * c, 3 * c)
     if same_qk and c // mha.num_heads != 64:
+        # one projection for [q | k]; the halves are taken inside the attention Function (r06: slicing here cost five autograd launches per
+        # call on the way back)
         qk = ops_tfm.linear_rows(q_in, w, b, 0, 2 * c)
-        q, k = qk[..., :c], qk[..., c:]
+        out = ops_tfm.stream_attention_packed_qk(qk, v, mha.num_heads, scale, key_bias, p)
     else:
         q = ops_tfm.linear_rows(q_in, w, b, 0, c)
         k = ops_tfm.linear_rows(k_in, w, b, c, 2 * c)
-    v = ops_tfm.linear_rows(v_in, w, b, 2 * c, 3 * c)
-    p = mha.dropout if mha.training else 0.0
-    out = ops_tfm.stream_attention(q, k, v, mha.num_heads, (c // mha.num_heads) ** -0.5, key_bias, p)
+        out = ops_tfm.stream_attention(q, k, v, mha.num_heads, scale, key_bias, p)
     return ops_tfm.linear_nd(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
@@ -75,6 +78,14 @@ def _res_ln(norm, x, branch, dropout):
     if dropout.training and dropout.p > 0. and x.is_cuda:
         return ops_tfm.dropout_add_layer_norm(x, branch, norm.weight, norm.bias, dropout.p, norm.eps)
     return _ln(norm, x + dropout(branch))
+
+
+def _ffn_hidden(act, dropout, h):
+    """dropout(activation(h)) of the feed-forward (reference detr.py:90-91, 120-121): one kernel each way for ReLU while the dropout is
+    active on the GPU (r06), the plain ops otherwise"""
+    if act.act_type == 'relu' and dropout.training and dropout.p > 0. and h.is_cuda and h.numel() % 8 == 0:
+        return ops_tfm.relu_dropout(h, dropout.p)
+    return dropout(act(h))
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -95,7 +106,7 @@ class TransformerEncoderLayer(nn.Module):
         qk = src + pos if pos is not None else src
         src2 = _mha(self.attention, qk, qk, src, src_key_padding_mask, True)
         src = _res_ln(self.norm1, src, src2, self.dropout)
-        src2 = ops_tfm.linear_nd(self.dropout(self.act(ops_tfm.linear_nd(src, self.linear1.weight, self.linear1.bias))),
+        src2 = ops_tfm.linear_nd(_ffn_hidden(self.act, self.dropout, ops_tfm.linear_nd(src, self.linear1.weight, self.linear1.bias)),
                                  self.linear2.weight, self.linear2.bias)
         return _res_ln(self.norm2, src, src2, self.dropout)
 
@@ -115,17 +126,19 @@ class TransformerDecoderLayer(nn.Module):
         self.dropout = nn.Dropout(dropout_prob)
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
-                memory_key_padding_mask=None, pos=None, query_pos=None):
+                memory_key_padding_mask=None, pos=None, query_pos=None, memory_pos=None):
+        """memory_pos: `memory + pos` computed once by the caller (the six decoder layers add the same two tensors: reference
+        detr.py:112 does it in every layer)"""
         assert tgt_mask is None and memory_mask is None
         qk = tgt + query_pos if query_pos is not None else tgt
         tgt2 = _mha(self.attention, qk, qk, tgt, tgt_key_padding_mask, True)
         tgt = _res_ln(self.norm1, tgt, tgt2, self.dropout)
         q = tgt + query_pos if query_pos is not None else tgt
-        k = memory + pos if pos is not None else memory
+        k = memory_pos if memory_pos is not None else (memory + pos if pos is not None else memory)
         tgt2 = _mha(self.multihead_attention, q, k, memory, memory_key_padding_mask, False)
         tgt = _res_ln(self.norm2, tgt, tgt2, self.dropout)
         tgt2 = ops_tfm.linear_nd(
-            self.dropout(self.activation(ops_tfm.linear_nd(tgt, self.linear1.weight, self.linear1.bias))),
+            _ffn_hidden(self.activation, self.dropout, ops_tfm.linear_nd(tgt, self.linear1.weight, self.linear1.bias)),
             self.linear2.weight, self.linear2.bias)
         return _res_ln(self.norm3, tgt, tgt2, self.dropout)
 
@@ -171,8 +184,9 @@ class DETRTransformer(nn.Module):
         for layer in self.encoder_blocks:
             memory = layer(memory, src_key_padding_mask=key_bias, pos=pos_embed)
         intermediate = []
+        memory_pos = memory + pos_embed                                # the cross-attention key input of all six layers (r06: once, not six times)
         for layer in self.decoder_blocks:
-            tgt = layer(tgt, memory, memory_key_padding_mask=key_bias, pos=pos_embed, query_pos=query_pos)
+            tgt = layer(tgt, memory, memory_key_padding_mask=key_bias, pos=pos_embed, query_pos=query_pos, memory_pos=memory_pos)
             intermediate.append(_ln(self.decoder_norm, tgt))
         hs = torch.stack(intermediate)                                 # [layers, B, Q, C]
         memory = memory.permute(0, 2, 1).reshape(b, c, h, w)

@@ -129,6 +129,8 @@ SIGNATURES = {
     # transformer kernels (tfm.hip)
     'saicv_layernorm_fwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
     'saicv_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'saicv_relu_dropout_fwd': (c_int, [c_int, _P, _P, c_size_t, c_double, ctypes.c_uint, _P, _P]),
+    'saicv_relu_dropout_bwd': (c_int, [c_int, _P, _P, _P, c_size_t, c_double, _P]),
     'saicv_dropout_add_layernorm_fwd': (c_int, [c_int, _P, _P, c_double, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
     'saicv_dropout_add_layernorm_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_double, ctypes.c_uint, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'saicv_layernorm_bwd_scaled': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),

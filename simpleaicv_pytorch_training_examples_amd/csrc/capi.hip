@@ -81,6 +81,8 @@ int layernorm_bwd(int, const void*, const void*, const float*, const float*, con
                   float*, float*, float*, int, int, int, hipStream_t, const float* = nullptr, int = 1, void* = nullptr);
 int gelu_fwd(int, const void*, void*, size_t, hipStream_t);
 int gelu_bwd(int, const void*, const void*, void*, size_t, hipStream_t);
+int relu_dropout_fwd(int, const void*, void*, size_t, double, unsigned, const unsigned*, hipStream_t);
+int relu_dropout_bwd(int, const void*, const void*, void*, size_t, double, hipStream_t);
 int attention_fwd(int, const void*, void*, float*, int, int, int, int, double, hipStream_t);
 int attention_bwd(int, const void*, const void*, const void*, const float*, void*, int, int, int, int, double,
                   hipStream_t);
@@ -439,6 +441,12 @@ int saicv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream) {
 }
 int saicv_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, void* stream) {
     return gelu_bwd(dtype, dy, x, dx, n, S(stream));
+}
+int saicv_relu_dropout_fwd(int dtype, const void* x, void* y, size_t n, double p, unsigned int seed, const unsigned int* seed_device, void* stream) {
+    return relu_dropout_fwd(dtype, x, y, n, p, seed, seed_device, S(stream));
+}
+int saicv_relu_dropout_bwd(int dtype, const void* dy, const void* y, void* dx, size_t n, double p, void* stream) {
+    return relu_dropout_bwd(dtype, dy, y, dx, n, p, S(stream));
 }
 int saicv_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int N, int H, int D,
                         double scale, void* stream) {

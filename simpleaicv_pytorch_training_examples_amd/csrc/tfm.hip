@@ -466,6 +466,41 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy,
     }
 }
 
+// ======================================================================== dropout(relu(x)) in one pass
+// DETR's feed-forward `linear2(dropout(activation(linear1(x))))` (reference detection/models/detr.py:90-91, 120-121) spent a clamp, a dropout,
+// a threshold-backward and a masked-scale launch per layer on the [B * L, 4 C] hidden tensor.  y = keep ? relu(x) / (1 - p) : 0 with the
+// counter-based keep decision of the fused residual dropout (chunk index, lane in chunk); the backward needs no mask: y > 0 exactly where
+// the gradient passes (relu open AND kept), dx = dy / (1 - p) there.
+template <typename T>
+__global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t nchunks, unsigned seed,
+                                                               const unsigned* __restrict__ seed_device, unsigned thresh, float inv_keep) {
+    constexpr int N = Chunk<T>::N;
+    const unsigned dseed = seed_device ? seed + *seed_device : seed;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        float v[N];
+        Chunk<T>::unpack(ld_chunk(x + i * N), v);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = (v[k] > 0.f && ln_keep(dseed, (unsigned)i, (unsigned)k, thresh)) ? v[k] * inv_keep : 0.f;
+        st_chunk(y + i * N, Chunk<T>::pack(v));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                               size_t nchunks, float inv_keep) {
+    constexpr int N = Chunk<T>::N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        float v[N], g[N];
+        Chunk<T>::unpack(ld_chunk(y + i * N), v);
+        Chunk<T>::unpack(ld_chunk(dy + i * N), g);
+#pragma unroll
+        for (int k = 0; k < N; ++k) g[k] = v[k] > 0.f ? g[k] * inv_keep : 0.f;
+        st_chunk(dx + i * N, Chunk<T>::pack(g));
+    }
+}
+
 // ======================================================================== attention
 // LDS image of a [rows][64] operand: 16-byte chunks, chunk c of row r at slot c ^ swz(r), which
 // keeps both the row-fragment reads (ds_read_b128, 16 rows x one chunk) and the transposing
@@ -1201,6 +1236,39 @@ int gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, hipSt
     else
         hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(sgrid(n / e)), dim3(256), 0, st, (const float*)dy, (const float*)x, (float*)dx, n / e);
     return check_launch("gelu_bwd");
+}
+
+static int relu_dropout_check(const char* who, int dtype, size_t n, double p) {
+    SAICV_REQUIRE(dtype == SAICV_DTYPE_BF16 || dtype == SAICV_DTYPE_F32, "%s: dtype %d", who, dtype);
+    SAICV_REQUIRE(n % (dtype == SAICV_DTYPE_BF16 ? 8 : 4) == 0, "%s: length must be a multiple of %d", who, dtype == SAICV_DTYPE_BF16 ? 8 : 4);
+    SAICV_REQUIRE(n / (dtype == SAICV_DTYPE_BF16 ? 8 : 4) <= 0xffffffffull, "%s: more than 2^32 chunks", who);
+    SAICV_REQUIRE(p >= 0.0 && p < 1.0, "%s: dropout probability %g outside [0, 1)", who, p);
+    return 0;
+}
+
+int relu_dropout_fwd(int dtype, const void* x, void* y, size_t n, double p, unsigned seed, const unsigned* seed_device, hipStream_t st) {
+    if (relu_dropout_check("relu_dropout_fwd", dtype, n, p)) return -1;
+    if (n == 0) return 0;
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    const unsigned thresh = (unsigned)(p * 4294967296.0);
+    const float inv_keep = (float)(1.0 / (1.0 - p));
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(relu_dropout_fwd_kernel<bf16_t>, dim3(sgrid(n / e)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n / e, seed, seed_device, thresh, inv_keep);
+    else
+        hipLaunchKernelGGL(relu_dropout_fwd_kernel<float>, dim3(sgrid(n / e)), dim3(256), 0, st, (const float*)x, (float*)y, n / e, seed, seed_device, thresh, inv_keep);
+    return check_launch("relu_dropout_fwd");
+}
+
+int relu_dropout_bwd(int dtype, const void* dy, const void* y, void* dx, size_t n, double p, hipStream_t st) {
+    if (relu_dropout_check("relu_dropout_bwd", dtype, n, p)) return -1;
+    if (n == 0) return 0;
+    const int e = dtype == SAICV_DTYPE_BF16 ? 8 : 4;
+    const float inv_keep = (float)(1.0 / (1.0 - p));
+    if (dtype == SAICV_DTYPE_BF16)
+        hipLaunchKernelGGL(relu_dropout_bwd_kernel<bf16_t>, dim3(sgrid(n / e)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / e, inv_keep);
+    else
+        hipLaunchKernelGGL(relu_dropout_bwd_kernel<float>, dim3(sgrid(n / e)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / e, inv_keep);
+    return check_launch("relu_dropout_bwd");
 }
 
 static int attn_check(const char* who, int B, int N, int H, int D) {

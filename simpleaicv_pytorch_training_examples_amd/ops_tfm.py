@@ -423,6 +423,40 @@ def dropout_add_layer_norm(x, branch, weight, bias, p, eps):
     return DropoutAddLayerNormFn.apply(x, branch, weight, bias, p, eps)
 
 
+class ReluDropoutFn(torch.autograd.Function):
+    """dropout_p(relu(x)) -- the hidden activation of DETR's feed-forward (reference detection/models/detr.py:90-91, 120-121) -- as one
+    kernel each way instead of clamp + dropout and threshold-backward + masked scale.  The keep decision is the counter-based one of
+    DropoutAddLayerNormFn (host seed at trace time + the device-side step word, so replays of a captured step drop different elements);
+    the backward reads the OUTPUT, which is positive exactly where the gradient passes."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        require_gpu(x)
+        x = x.contiguous()
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())          # host generator: no device synchronisation
+        y = torch.empty_like(x)
+        check(lib().saicv_relu_dropout_fwd(dtype_code(x.dtype), ptr(x), ptr(y), x.numel(), float(p), seed, ptr(dropout_step_word(x.device)),
+                                           stream()), 'relu_dropout_fwd')
+        ctx.save_for_backward(y)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != y.dtype:
+            dy = dy.to(y.dtype)
+        dx = torch.empty_like(y)
+        check(lib().saicv_relu_dropout_bwd(dtype_code(y.dtype), ptr(dy), ptr(y), ptr(dx), y.numel(), ctx.p, stream()), 'relu_dropout_bwd')
+        return dx, None
+
+
+def relu_dropout(x, p):
+    """dropout(relu(x), p) in training mode; x: bf16 / fp32 on the GPU with a multiple of 8 / 4 elements"""
+    return ReluDropoutFn.apply(x, float(p))
+
+
 class GeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -573,6 +607,42 @@ class StreamAttentionFn(torch.autograd.Function):
 
 def stream_attention(q, k, v, heads, scale, key_bias=None, dropout_p=0.0):
     return StreamAttentionFn.apply(q, k, v, heads, scale, key_bias, float(dropout_p))
+
+
+class PackedQKStreamAttentionFn(torch.autograd.Function):
+    """stream_attention for q and k that are the two column halves of ONE projection output qk [B, N, 2 C] (self-attention with
+    q = k = x + pos, reference detection/models/detr.py:86-88, 110-113).  Slicing qk outside costs autograd two zero fills, two
+    copies and an add per call on the way back (SliceBackward of either half); here the halves are views taken inside, and the
+    backward kernels write dq and dk straight into the halves of one dqk buffer (they take the operands' strides)."""
+
+    @staticmethod
+    def forward(ctx, qk, v, heads, scale, key_bias, dropout_p):
+        require_gpu(qk, v)
+        qk = qk.contiguous()
+        c = qk.shape[-1] // 2
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if dropout_p > 0 else 0
+        out, lse = sattn_fwd(qk[..., :c], qk[..., c:], v, heads, scale, key_bias, dropout_p=dropout_p, seed=seed)
+        ctx.save_for_backward(qk, v, out, lse, key_bias)
+        ctx.cfg = (heads, scale, dropout_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qk, v, out, lse, key_bias = ctx.saved_tensors
+        heads, scale, dropout_p, seed = ctx.cfg
+        c = qk.shape[-1] // 2
+        dout = dout.contiguous()
+        if dout.dtype != qk.dtype:
+            dout = dout.to(qk.dtype)
+        dqk = torch.empty_like(qk)
+        dv = torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
+        sattn_bwd(qk[..., :c], qk[..., c:], v, out, dout, lse, heads, scale, dqk[..., :c], dqk[..., c:], dv, key_bias,
+                  dropout_p=dropout_p, seed=seed)
+        return dqk, dv, None, None, None, None
+
+
+def stream_attention_packed_qk(qk, v, heads, scale, key_bias=None, dropout_p=0.0):
+    return PackedQKStreamAttentionFn.apply(qk, v, heads, scale, key_bias, float(dropout_p))
 
 
 # ------------------------------------------------------------------------------ fused ViT sub-layers

@@ -428,3 +428,76 @@ def test_attention_dropout_mask_follows_the_device_seed_word():
     c, _ = ops_tfm.sattn_fwd(q, k, v, 8, 32 ** -0.5, dropout_p=0.3, seed=77)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+# ------------------------------------------------------------------------------------------ DETR launch diet (late r06)
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(8, 100, 2048), (3, 77, 256), (1, 8)])
+def test_relu_dropout_is_dropout_of_relu(shape, dtype):
+    """saicv_relu_dropout_fwd / _bwd (the hidden activation of DETR's feed-forward, reference detection/models/detr.py:90-91, 120-121):
+    y is 0 or relu(x) / (1 - p), zero wherever x <= 0, kept with probability 1 - p within 4 sigma where x > 0; the same (seed, word)
+    gives the same mask, another device word another; the backward passes dy / (1 - p) exactly where y > 0 -- torch's
+    F.dropout(relu(x)) backward for the same mask."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    from simpleaicv_pytorch_training_examples_amd._lib import check, dtype_code, lib, ptr, stream
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(dtype).cuda()
+    dy = torch.randn(*shape, generator=g).to(dtype).cuda()
+    p = 0.25
+    word = torch.zeros(1, dtype=torch.int32, device='cuda')
+    L = lib()
+
+    def fwd(seed):
+        y = torch.empty_like(x)
+        check(L.saicv_relu_dropout_fwd(dtype_code(dtype), ptr(x), ptr(y), x.numel(), p, seed, ptr(word), stream()), 'fwd')
+        return y
+    y = fwd(77)
+    pos = x > 0
+    assert bool((y[~pos] == 0).all())
+    kept = y > 0
+    expect = (x.float() / (1 - p)).to(dtype)
+    assert torch.equal(y[kept], expect[kept]) and bool((kept <= pos).all())
+    n_pos = int(pos.sum())
+    if n_pos > 1000:
+        rate = float(kept.sum()) / n_pos
+        assert abs(rate - (1 - p)) <= 4 * (p * (1 - p) / n_pos) ** 0.5 + 1e-3, rate
+    assert torch.equal(y, fwd(77)) and (x.numel() < 64 or not torch.equal(y, fwd(78)))
+    word.add_(40503)
+    assert x.numel() < 64 or not torch.equal(y, fwd(77))
+    dx = torch.empty_like(x)
+    check(L.saicv_relu_dropout_bwd(dtype_code(dtype), ptr(dy), ptr(y), ptr(dx), x.numel(), p, stream()), 'bwd')
+    ref = torch.where(kept, (dy.float() / (1 - p)), torch.zeros((), device='cuda')).to(dtype)
+    assert torch.equal(dx, ref)
+    # the autograd function: some mask with the right structure, gradient consistent with ITS output
+    xg = x.clone().requires_grad_(True)
+    out = ops_tfm.relu_dropout(xg, p)
+    out.backward(dy)
+    k2 = out > 0
+    assert bool((k2 <= pos).all()) and torch.equal(out[k2], expect[k2])
+    assert torch.equal(xg.grad, torch.where(k2, dy.float() / (1 - p), torch.zeros((), device='cuda')).to(dtype))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('bnc', [(2, 100, 256, 8), (3, 333, 256, 8), (1, 17, 64, 2)])
+def test_attention_over_a_packed_qk_projection_equals_attention_over_its_halves(bnc, dtype):
+    """ops_tfm.stream_attention_packed_qk(qk, v): the [q | k] projection enters whole and the backward writes dq / dk into the halves of
+    one buffer (DETR self-attention, head dim 32).  Bit-equal to stream_attention on the two slices, forward and all three gradients
+    (the slices' autograd route: two zero fills, two copies and an add per call)."""
+    from simpleaicv_pytorch_training_examples_amd import ops_tfm
+    b, n, c, heads = bnc
+    g = torch.Generator().manual_seed(b * n + c)
+    qk = torch.randn(b, n, 2 * c, generator=g).to(dtype).cuda()
+    v = torch.randn(b, n, c, generator=g).to(dtype).cuda()
+    bias = (torch.rand(b, n, generator=g) > 0.8).float().cuda() * -1e4
+    dout = torch.randn(b, n, c, generator=g).to(dtype).cuda()
+    scale = (c // heads) ** -0.5
+    a_qk, a_v = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    out_a = ops_tfm.stream_attention_packed_qk(a_qk, a_v, heads, scale, bias, 0.0)
+    out_a.backward(dout)
+    b_qk, b_v = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    out_b = ops_tfm.stream_attention(b_qk[..., :c], b_qk[..., c:], b_v, heads, scale, bias, 0.0)
+    out_b.backward(dout)
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(a_qk.grad, b_qk.grad) and torch.equal(a_v.grad, b_v.grad)
