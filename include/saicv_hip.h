@@ -475,6 +475,17 @@ int saicv_sam_grid_pe(const float* gauss, int F, int S, float* out, void* stream
  * padding) -> out fp32 [B][2F][H][W]; H * W <= 8192. */
 int saicv_detr_sine_pe(const unsigned char* mask, float* out, int B, int H, int W, int F, float temperature, float eps, void* stream);
 
+/* DETR box losses over the static-shape pair buffers (late r06; compute_batch_l1_iou_loss, reference SimpleAICV/detection/losses.py:938-954,
+ * as DETRLoss.forward_static states it): reg fp32 [L][B][Q][4] raw predictions (cx cy w h; clamped to [lo, hi] inside), gt fp32 [B][T][5]
+ * (rows with class < 0 are padding), src / tgt int64 [B][T] and w fp32 [B][T] from saicv_detr_assign.  out fp32 [2 L + 1]:
+ * out[l] = sum over pairs of w * |p - t|_1 / n, out[L + l] = sum of w * (1 - GIoU(p, t)) / n, out[2 L] = n = number of ground-truth rows
+ * (n = 0 gives nan, as the reference's 0 / 0).  Backward: dreg fp32 [L][B][Q][4] (every row written: zeros for unmatched queries) from
+ * d_l1 / d_iou fp32 [L] (either may be NULL = zeros) and the forward's out (for n). */
+int saicv_detr_box_loss_fwd(const float* reg, const float* gt, const long long* src, const long long* tgt, const float* w, int L, int B, int Q,
+                            int T, double lo, double hi, float* out, void* stream);
+int saicv_detr_box_loss_bwd(const float* reg, const float* gt, const long long* src, const long long* tgt, const float* w, const float* d_l1,
+                            const float* d_iou, const float* out, int L, int B, int Q, int T, double lo, double hi, float* dreg, void* stream);
+
 /* DETR Hungarian assignment on the device (r05; replaces the host-side scipy.optimize.linear_sum_assignment call of reference
  * SimpleAICV/detection/losses.py:1009-1090, which put a device -> host copy and a synchronisation between forward and loss of every
  * step): cost fp32 [B][Q][T] = matching cost of every query against every row of the padded ground truth, valid u8 [B][T] = rows that

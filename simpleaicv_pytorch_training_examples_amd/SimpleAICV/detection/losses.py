@@ -41,6 +41,41 @@ def _giou(b1, b2):
     return inter / union - (enclose - union) / enclose
 
 
+class _DetrBoxLossFn(torch.autograd.Function):
+    """(l1 [L], iou [L]) of DETRLoss.forward_static from the raw regression outputs and the static pair buffers in one kernel each way
+    (saicv_detr_box_loss_fwd / _bwd, csrc/detloss.hip): the torch formulation below it in forward_static -- gather, where, the
+    cxcywh -> xyxy conversions, _giou, the weighted sums -- was ~55 launches forward and ~130 backward on 4 800 pairs."""
+
+    @staticmethod
+    def forward(ctx, reg_preds, gt, src, tgt, w, lo, hi):
+        from ... import _lib
+        reg = reg_preds.float().contiguous()
+        gt = gt.float().contiguous()
+        l, b, q = reg.shape[0], reg.shape[1], reg.shape[2]
+        t = src.shape[1]
+        out = torch.empty(2 * l + 1, dtype=torch.float32, device=reg.device)
+        _lib.check(_lib.lib().saicv_detr_box_loss_fwd(_lib.ptr(reg), _lib.ptr(gt), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(w), l, b, q, t,
+                                                      float(lo), float(hi), _lib.ptr(out), _lib.stream()), 'detr_box_loss_fwd')
+        ctx.save_for_backward(reg, gt, src, tgt, w, out)
+        ctx.cfg = (l, b, q, t, float(lo), float(hi), reg_preds.dtype)
+        ctx.in_shape = reg_preds.shape
+        return out[:l], out[l:2 * l]
+
+    @staticmethod
+    def backward(ctx, d_l1, d_iou):
+        from ... import _lib
+        reg, gt, src, tgt, w, out = ctx.saved_tensors
+        l, b, q, t, lo, hi, dtype = ctx.cfg
+        d_l1 = None if d_l1 is None else d_l1.float().contiguous()
+        d_iou = None if d_iou is None else d_iou.float().contiguous()
+        dreg = torch.empty_like(reg)
+        _lib.check(_lib.lib().saicv_detr_box_loss_bwd(_lib.ptr(reg), _lib.ptr(gt), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(w),
+                                                      _lib.ptr(d_l1) if d_l1 is not None else None, _lib.ptr(d_iou) if d_iou is not None else None,
+                                                      _lib.ptr(out), l, b, q, t, lo, hi, _lib.ptr(dreg), _lib.stream()), 'detr_box_loss_bwd')
+        dreg = dreg.view(ctx.in_shape)
+        return (dreg if dtype == torch.float32 else dreg.to(dtype)), None, None, None, None, None, None
+
+
 class DETRLoss(nn.Module):
 
     def __init__(self, cls_match_cost=1.0, box_match_cost=5.0, giou_match_cost=2.0, cls_loss_weight=1.0,
@@ -58,6 +93,7 @@ class DETRLoss(nn.Module):
 
     def forward(self, preds, annotations):
         cls_preds, reg_preds = preds
+        raw_reg_preds = reg_preds
         reg_preds = torch.clamp(reg_preds, min=1e-4, max=1. - 1e-4).float()
         cls_preds = cls_preds.float()
         gt, counts = self._valid_targets(annotations)
@@ -72,7 +108,16 @@ class DETRLoss(nn.Module):
         # all decoder layers at once ([L, B, Q, *] tensors): the per-layer arithmetic of the reference's loop
         # (losses.py:905-935) in one pass -- six times fewer tiny launches on a path that is host-bound
         cls_l = self._cls_loss_layers(cls_preds, batch_idx, src_idx, matched[:, 4])
-        l1_l, iou_l = self._box_losses_layers(reg_preds[:, batch_idx, src_idx], matched[:, 0:4], target_num)
+        if raw_reg_preds.is_cuda and target_num > 0:
+            # the kernel of the static form (saicv_detr_box_loss_*), fed the flat pair list as ONE image of B * Q queries: the eager and the
+            # captured loop then share the per-pair arithmetic bit for bit (they differ in the order of the loss sums only)
+            l, b, q = cls_preds.shape[0], cls_preds.shape[1], cls_preds.shape[2]
+            n = matched.shape[0]
+            l1_l, iou_l = _DetrBoxLossFn.apply(raw_reg_preds.reshape(l, 1, b * q, 4), matched.view(1, n, 5), (batch_idx * q + src_idx).view(1, n),
+                                               torch.arange(n, device=matched.device).view(1, n),
+                                               torch.ones(1, n, dtype=torch.float32, device=matched.device), 1e-4, 1. - 1e-4)
+        else:
+            l1_l, iou_l = self._box_losses_layers(reg_preds[:, batch_idx, src_idx], matched[:, 0:4], target_num)
         loss_dict = {}
         for idx in range(cls_preds.shape[0]):
             loss_dict[f'layer_{idx}_cls_loss'] = self.cls_loss_weight * cls_l[idx]
@@ -193,7 +238,8 @@ class DETRLoss(nn.Module):
         """The loss of forward() from static-shape inputs: pairs (src[i, k], tgt[i, k]) of image i count where w[i, k] = 1.  Same
         per-pair arithmetic; padding pairs are computed on a harmless dummy box and multiplied by 0 (their gradient is exactly 0)."""
         cls_preds, reg_preds = preds
-        reg_preds = torch.clamp(reg_preds, min=1e-4, max=1. - 1e-4).float()
+        raw_reg_preds = reg_preds
+        reg_preds = torch.clamp(reg_preds, min=1e-4, max=1. - 1e-4).float() if not reg_preds.is_cuda else None
         cls_preds = cls_preds.float()
         gt = gt_pad.float()
         l, b, q = cls_preds.shape[0], cls_preds.shape[1], cls_preds.shape[2]
@@ -201,7 +247,6 @@ class DETRLoss(nn.Module):
         bidx = torch.arange(b, device=gt.device)[:, None].expand(b, t)
         on = w > 0
         m_cls = gt[bidx, tgt, 4]
-        m_box = gt[bidx, tgt, 0:4]
         # class map [B, Q]: the no-object class everywhere, the matched class at (i, src); padding pairs write column Q of a wider map
         gmap = torch.full((b, q + 1), self.num_classes, dtype=torch.long, device=gt.device)
         gmap[bidx, torch.where(on, src, torch.full_like(src, q))] = torch.where(on, m_cls.long(), torch.full_like(src, self.num_classes))
@@ -213,13 +258,18 @@ class DETRLoss(nn.Module):
         # the number of ground-truth boxes of the batch, as forward() and the reference (losses.py:938-954) divide by it -- NOT the
         # number of matched pairs (fewer when an image carries more boxes than queries) and not clamped: a batch without any box
         # gives 0 / 0 = nan here as it does there, and the loop skips the step
-        target_num = (gt[:, :, 4] >= 0).sum().float()
-        dummy = self._pairs['dummy_box']
-        pm = torch.where(on[None, :, :, None], reg_preds[:, bidx, src], dummy)                 # [L, B, T, 4]
-        tb = torch.where(on[:, :, None], m_box, dummy)                                          # [B, T, 4]
-        l1_l = ((pm - tb).abs().sum(dim=-1) * w).sum(dim=(1, 2)) / target_num
-        giou = _giou(_cxcywh_to_xyxy(pm), _cxcywh_to_xyxy(tb))
-        iou_l = ((1 - giou) * w).sum(dim=(1, 2)) / target_num
+        if raw_reg_preds.is_cuda:
+            # one kernel each way (late r06); the clamp, the pair gather and the count of ground-truth rows happen inside
+            l1_l, iou_l = _DetrBoxLossFn.apply(raw_reg_preds, gt, src, tgt, w, 1e-4, 1. - 1e-4)
+        else:
+            target_num = (gt[:, :, 4] >= 0).sum().float()
+            dummy = self._pairs['dummy_box']
+            m_box = gt[bidx, tgt, 0:4]
+            pm = torch.where(on[None, :, :, None], reg_preds[:, bidx, src], dummy)                 # [L, B, T, 4]
+            tb = torch.where(on[:, :, None], m_box, dummy)                                          # [B, T, 4]
+            l1_l = ((pm - tb).abs().sum(dim=-1) * w).sum(dim=(1, 2)) / target_num
+            giou = _giou(_cxcywh_to_xyxy(pm), _cxcywh_to_xyxy(tb))
+            iou_l = ((1 - giou) * w).sum(dim=(1, 2)) / target_num
         loss_dict = {}
         for idx in range(l):
             loss_dict[f'layer_{idx}_cls_loss'] = self.cls_loss_weight * cls_l[idx]

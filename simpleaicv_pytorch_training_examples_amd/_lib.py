@@ -164,6 +164,8 @@ SIGNATURES = {
     'saicv_mixup_cutmix': (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'saicv_soft_labels': (c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, c_int, c_int, _P]),
     'saicv_detr_sine_pe': (c_int, [_P, _P, c_int, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, _P]),
+    'saicv_detr_box_loss_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P, _P]),
+    'saicv_detr_box_loss_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P, _P]),
     'saicv_detr_assign': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     'saicv_sam_prompt_tokens': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, ctypes.c_float, _P, _P, c_int, _P]),
     'saicv_sam_prompt_tokens_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P]),
