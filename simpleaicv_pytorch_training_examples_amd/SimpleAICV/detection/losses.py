@@ -118,11 +118,18 @@ class DETRLoss(nn.Module):
                                                torch.ones(1, n, dtype=torch.float32, device=matched.device), 1e-4, 1. - 1e-4)
         else:
             l1_l, iou_l = self._box_losses_layers(reg_preds[:, batch_idx, src_idx], matched[:, 0:4], target_num)
+        return self._layer_terms(cls_l, l1_l, iou_l)
+
+    def _layer_terms(self, cls_l, l1_l, iou_l):
+        """[L] loss vectors -> the reference's dict of 3 L weighted scalars (losses.py:905-935).  The weights multiply the vectors and
+        the scalars are unbind() views: `w * v[idx]` per entry was 18 multiplications forward and, backward, 18 more plus a zero fill, a
+        copy and an accumulation per select -- same values, ~100 launches fewer per step."""
+        cls_w, l1_w, iou_w = self.cls_loss_weight * cls_l, self.box_l1_loss_weight * l1_l, self.iou_loss_weight * iou_l
         loss_dict = {}
-        for idx in range(cls_preds.shape[0]):
-            loss_dict[f'layer_{idx}_cls_loss'] = self.cls_loss_weight * cls_l[idx]
-            loss_dict[f'layer_{idx}_box_l1_loss'] = self.box_l1_loss_weight * l1_l[idx]
-            loss_dict[f'layer_{idx}_box_iou_loss'] = self.iou_loss_weight * iou_l[idx]
+        for idx, (c, a, g) in enumerate(zip(cls_w.unbind(0), l1_w.unbind(0), iou_w.unbind(0))):
+            loss_dict[f'layer_{idx}_cls_loss'] = c
+            loss_dict[f'layer_{idx}_box_l1_loss'] = a
+            loss_dict[f'layer_{idx}_box_iou_loss'] = g
         return loss_dict
 
     def _cls_loss_layers(self, cls_preds, batch_idx, src_idx, target_classes):
@@ -270,12 +277,7 @@ class DETRLoss(nn.Module):
             l1_l = ((pm - tb).abs().sum(dim=-1) * w).sum(dim=(1, 2)) / target_num
             giou = _giou(_cxcywh_to_xyxy(pm), _cxcywh_to_xyxy(tb))
             iou_l = ((1 - giou) * w).sum(dim=(1, 2)) / target_num
-        loss_dict = {}
-        for idx in range(l):
-            loss_dict[f'layer_{idx}_cls_loss'] = self.cls_loss_weight * cls_l[idx]
-            loss_dict[f'layer_{idx}_box_l1_loss'] = self.box_l1_loss_weight * l1_l[idx]
-            loss_dict[f'layer_{idx}_box_iou_loss'] = self.iou_loss_weight * iou_l[idx]
-        return loss_dict
+        return self._layer_terms(cls_l, l1_l, iou_l)
 
     # reference-named views of the same computations (used by its tests / tools)
     def compute_batch_cls_loss(self, cls_preds, annotations, indices):

@@ -318,8 +318,14 @@ def _epoch_loop(train_loader, model, optimizer, scheduler, epoch, logger, config
         if names['keys'] is None:
             names['keys'] = list(loss_value.keys())
         keys = names['keys']
-        loss = sum(loss_value.values())
-        terms = torch.stack([loss_value[k].detach().float() for k in keys]) / acc_steps
+        if len(keys) > 4:
+            # many terms (DETR: 18): one stack + one sum instead of a chain of adds and a second stack; d loss / d term is 1 either way
+            stacked = torch.stack([loss_value[k].float() for k in keys])
+            loss = stacked.sum()
+            terms = stacked.detach() / acc_steps
+        else:
+            loss = sum(loss_value.values())
+            terms = torch.stack([loss_value[k].detach().float() for k in keys]) / acc_steps
         bad = bad | (loss == 0.) | ~torch.isfinite(loss) | ~torch.isfinite(terms).all()
         loss = loss / acc_steps
         scaled = scaler.scale(loss) if scaler is not None else loss
