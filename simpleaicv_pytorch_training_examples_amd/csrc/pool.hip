@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
 // > 0) and fed straight into the BatchNorm backward: one pass for the two per-channel sums, one that writes d y.  Neither the
 // pooled gradient scattered to full resolution nor z's mask exist.  HBM per step at b256: forward 1.41 -> 0.57 GB, backward
 // 2.67 -> ~1.5 GB.
-template <typename T>
+// KT > 0: the window size as a compile-time constant (the stem's 3): the window's loads are issued back to back.  With a run-time K the
+// kh / kw loops stay rolled and every load waits for the previous one -- nine L2 round trips per pooled element: 148 us forward and 211 us
+// in the reduction pass against ~95 us of HBM time each (r06 trace).
+template <typename T, int KT>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, T* __restrict__ out,
                                                                   uint8_t* __restrict__ idx, int Nimg, int H, int W, int C, int OH,
@@ -206,26 +209,63 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
 #pragma unroll
         for (int j = 0; j < N; ++j) { best[j] = -INFINITY; bi[j] = 0; }
         bool first = true;
-        for (int kh = 0; kh < K; ++kh) {
-            const int ih = oh * stride - pad + kh;
-            if ((unsigned)ih >= (unsigned)H) continue;
-            for (int kw = 0; kw < K; ++kw) {
-                const int iw = ow * stride - pad + kw;
-                if ((unsigned)iw >= (unsigned)W) continue;
+        if constexpr (KT > 0) {
+            u32x4 raw[KT * KT];
+            bool ok[KT * KT];
+#pragma unroll
+            for (int kh = 0; kh < KT; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < KT; ++kw) {
+                    const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+                    ok[kh * KT + kw] = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+                    raw[kh * KT + kw] = ld_chunk(y + ((size_t)(n * H + ihc) * W + iwc) * C + cb * N);
+                }
+            }
+#pragma unroll
+            for (int pos = 0; pos < KT * KT; ++pos) {
+                if (!ok[pos]) continue;
                 float v[N];
-                Chunk<T>::unpack(ld_chunk(y + ((size_t)(n * H + ih) * W + iw) * C + cb * N), v);
+                Chunk<T>::unpack(raw[pos], v);
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const float z = round_through<T>(fmaxf(fmaf(sc[j], v[j], sh[j]), 0.f));
-                    if (first || z > best[j] || z != z) { best[j] = z; bi[j] = kh * K + kw; }
+                    if (first || z > best[j] || z != z) { best[j] = z; bi[j] = pos; }
                 }
                 first = false;
+            }
+        } else {
+            for (int kh = 0; kh < K; ++kh) {
+                const int ih = oh * stride - pad + kh;
+                if ((unsigned)ih >= (unsigned)H) continue;
+                for (int kw = 0; kw < K; ++kw) {
+                    const int iw = ow * stride - pad + kw;
+                    if ((unsigned)iw >= (unsigned)W) continue;
+                    float v[N];
+                    Chunk<T>::unpack(ld_chunk(y + ((size_t)(n * H + ih) * W + iw) * C + cb * N), v);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        const float z = round_through<T>(fmaxf(fmaf(sc[j], v[j], sh[j]), 0.f));
+                        if (first || z > best[j] || z != z) { best[j] = z; bi[j] = kh * K + kw; }
+                    }
+                    first = false;
+                }
             }
         }
         const size_t o = (((size_t)(n * OH + oh)) * OW + ow) * C + cb * N;
         st_chunk(out + o, Chunk<T>::pack(best));
+        uint8_t packed[N];                                  // one 8- / 4-byte store instead of N byte stores (o is a multiple of N)
 #pragma unroll
-        for (int j = 0; j < N; ++j) idx[o + j] = (uint8_t)bi[j];
+        for (int j = 0; j < N; ++j) packed[j] = (uint8_t)bi[j];
+        if (N == 8) {
+            uint2 raw;
+            __builtin_memcpy(&raw, packed, 8);
+            *reinterpret_cast<uint2*>(idx + o) = raw;
+        } else {
+            uint32_t raw;
+            __builtin_memcpy(&raw, packed, 4);
+            *reinterpret_cast<uint32_t*>(idx + o) = raw;
+        }
     }
 }
 
@@ -276,7 +316,7 @@ DEVINL void pooled_grad(float (&g)[Chunk<T>::N], const T* __restrict__ dout, con
 // Walks the POOLED tensor (a quarter of the pixels): every pooled element sends its gradient to exactly one input position, the
 // recorded maximum of its window, so the sums over input pixels are sums over pooled elements of d * [gate] * (1 | xhat) with y
 // taken at that position -- the window's chunks are re-read as in the forward pass (L2 hits), the per-channel position selects.
-template <typename T>
+template <typename T, int KT>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx,
                                                                          const T* __restrict__ y, const float* __restrict__ mean,
                                                                          const float* __restrict__ invstd, const float* __restrict__ scale,
@@ -313,17 +353,36 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_kernel(const T
         float ya[N];                                   // y at each channel's recorded maximum
 #pragma unroll
         for (int j = 0; j < N; ++j) ya[j] = 0.f;
-        for (int kh = 0; kh < K; ++kh) {
-            const int ih = oh * stride - pad + kh;
-            if ((unsigned)ih >= (unsigned)H) continue;
-            for (int kw = 0; kw < K; ++kw) {
-                const int iw = ow * stride - pad + kw;
-                if ((unsigned)iw >= (unsigned)W) continue;
+        if constexpr (KT > 0) {
+            u32x4 raw[KT * KT];
+#pragma unroll
+            for (int kh = 0; kh < KT; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < KT; ++kw) {                 // (a position outside the image is never a recorded maximum: its clamped load is ignored)
+                    const int ihc = min(max(oh * stride - pad + kh, 0), H - 1), iwc = min(max(ow * stride - pad + kw, 0), W - 1);
+                    raw[kh * KT + kw] = ld_chunk(y + ((size_t)(n * H + ihc) * W + iwc) * C + cb * N);
+                }
+            }
+#pragma unroll
+            for (int pos = 0; pos < KT * KT; ++pos) {
                 float v[N];
-                Chunk<T>::unpack(ld_chunk(y + ((size_t)(n * H + ih) * W + iw) * C + cb * N), v);
-                const int pos = kh * K + kw;
+                Chunk<T>::unpack(raw[pos], v);
 #pragma unroll
                 for (int j = 0; j < N; ++j) ya[j] = (ib[j] == pos) ? v[j] : ya[j];
+            }
+        } else {
+            for (int kh = 0; kh < K; ++kh) {
+                const int ih = oh * stride - pad + kh;
+                if ((unsigned)ih >= (unsigned)H) continue;
+                for (int kw = 0; kw < K; ++kw) {
+                    const int iw = ow * stride - pad + kw;
+                    if ((unsigned)iw >= (unsigned)W) continue;
+                    float v[N];
+                    Chunk<T>::unpack(ld_chunk(y + ((size_t)(n * H + ih) * W + iw) * C + cb * N), v);
+                    const int pos = kh * K + kw;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) ya[j] = (ib[j] == pos) ? v[j] : ya[j];
+                }
             }
         }
 #pragma unroll
@@ -435,10 +494,13 @@ int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const floa
     SAICV_REQUIRE(C % n == 0 && 256 % (C / n) == 0, "bn_relu_maxpool_fwd: C=%d must be %d x a power of two <= 256", C, n);
     SAICV_REQUIRE(K * K <= 255, "bn_relu_maxpool_fwd: window too large");
     const size_t total = (size_t)Nimg * OH * OW * (C / n);
-    if (dtype == SAICV_DTYPE_BF16)
-        hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (bf16_t*)out, idx, Nimg, H, W, C, OH, OW, K, stride, pad);
-    else
-        hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, (const float*)y, scale, shift, (float*)out, idx, Nimg, H, W, C, OH, OW, K, stride, pad);
+    if (dtype == SAICV_DTYPE_BF16) {
+        if (K == 3) hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<bf16_t, 3>), dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (bf16_t*)out, idx, Nimg, H, W, C, OH, OW, K, stride, pad);
+        else hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<bf16_t, 0>), dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (bf16_t*)out, idx, Nimg, H, W, C, OH, OW, K, stride, pad);
+    } else {
+        if (K == 3) hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<float, 3>), dim3(sgrid(total)), dim3(256), 0, st, (const float*)y, scale, shift, (float*)out, idx, Nimg, H, W, C, OH, OW, K, stride, pad);
+        else hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<float, 0>), dim3(sgrid(total)), dim3(256), 0, st, (const float*)y, scale, shift, (float*)out, idx, Nimg, H, W, C, OH, OW, K, stride, pad);
+    }
     return check_launch("bn_relu_maxpool_fwd");
 }
 
@@ -454,11 +516,13 @@ int bn_relu_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, const v
     DetParts det;
     if (det.begin(st, sgrid(ptotal), (size_t)2 * C, "bn_relu_maxpool_bwd")) return -1;
     if (dtype == SAICV_DTYPE_BF16) {
-        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<bf16_t>, dim3(sgrid(ptotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
+        if (K == 3) hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<bf16_t, 3>), dim3(sgrid(ptotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
+        else hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<bf16_t, 0>), dim3(sgrid(ptotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
         if (det.fold(ws, 0, (size_t)2 * C)) return -1;
         hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, gamma, mean, invstd, scale, shift, ws, (bf16_t*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
     } else {
-        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<float>, dim3(sgrid(ptotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
+        if (K == 3) hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<float, 3>), dim3(sgrid(ptotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
+        else hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<float, 0>), dim3(sgrid(ptotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
         if (det.fold(ws, 0, (size_t)2 * C)) return -1;
         hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, gamma, mean, invstd, scale, shift, ws, (float*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
     }
