@@ -452,6 +452,103 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_apply_kernel(const T*
     }
 }
 
+// pass 2 for the stem's own geometry (K = 3, stride 2, padding 1; late r06): one thread per 2 x 2 block of input pixels.  The four pixels
+// (2a, 2b) ... (2a + 1, 2b + 1) are covered by the same four windows (a, b) ... (a + 1, b + 1) -- by 1, 2, 2 and 4 of them -- so the
+// four gradient chunks and position words are fetched ONCE per block instead of four (clamped) times per pixel: 16 memory instructions
+// per four output chunks instead of 40.  Same sums in the same order as pooled_grad (windows ascending in oh, then ow).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_apply_k3s2_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                                             const T* __restrict__ y, const float* __restrict__ gamma,
+                                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                             const float* __restrict__ sums, T* __restrict__ dy,
+                                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                                             int Nimg, int H, int W, int C, int OH, int OW) {
+    constexpr int N = Chunk<T>::N;
+    const int cpr = C / N;
+    const int HB = (H + 1) / 2, WB = (W + 1) / 2;
+    const size_t total = (size_t)Nimg * HB * WB * cpr;
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    const int cb = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % cpr);
+    const float inv_m = 1.f / ((float)Nimg * (float)H * (float)W);
+    float sc[N], sh[N], mu[N], is[N], k0[N], mg[N], mx[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int c = cb * N + j;
+        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+        k0[j] = gamma[c] * is[j];
+        mg[j] = sums[c] * inv_m;
+        mx[j] = sums[C + c] * inv_m;
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            if (accumulate) { dbeta[c] += sums[c]; dgamma[c] += sums[C + c]; }
+            else { dbeta[c] = sums[c]; dgamma[c] = sums[C + c]; }
+        }
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        size_t blk = i / cpr;
+        const int b = (int)(blk % WB); blk /= WB;
+        const int a = (int)(blk % HB);
+        const int n = (int)(blk / HB);
+        // the four windows (a + dy, b + dx); one that does not exist is fetched clamped and ignored
+        u32x4 cg[4];
+        uint8_t ib[4][N];
+        bool wok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oh = a + (q >> 1), ow = b + (q & 1);
+            wok[q] = oh < OH && ow < OW;
+            const size_t o = (((size_t)(n * OH + min(oh, OH - 1))) * OW + min(ow, OW - 1)) * C + cb * N;
+            cg[q] = ld_chunk(dout + o);
+            if (N == 8) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(idx + o);
+                __builtin_memcpy(ib[q], &raw, 8);
+            } else {
+                const uint32_t raw = *reinterpret_cast<const uint32_t*>(idx + o);
+                __builtin_memcpy(ib[q], &raw, 4);
+            }
+        }
+        u32x4 yr[4];
+        bool pok[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int h = 2 * a + (p >> 1), w = 2 * b + (p & 1);
+            pok[p] = h < H && w < W;
+            yr[p] = ld_chunk(y + ((size_t)(n * H + min(h, H - 1)) * W + min(w, W - 1)) * C + cb * N);
+        }
+        float d[4][N];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Chunk<T>::unpack(cg[q], d[q]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!pok[p]) continue;
+            const int r = p >> 1, c = p & 1;
+            float yv[N], g[N], o[N];
+            Chunk<T>::unpack(yr[p], yv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) g[j] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int dyq = q >> 1, dxq = q & 1;
+                if ((r == 0 && dyq == 1) || (c == 0 && dxq == 1)) continue;        // an even row / column lies in window a (b) only
+                if (!wok[q]) continue;
+                const int kh = r == 0 ? 1 : (dyq == 0 ? 2 : 0), kw = c == 0 ? 1 : (dxq == 0 ? 2 : 0);
+                const int want = kh * 3 + kw;
+#pragma unroll
+                for (int j = 0; j < N; ++j) g[j] += (ib[q][j] == want) ? d[q][j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float gj = fmaf(sc[j], yv[j], sh[j]) > 0.f ? g[j] : 0.f;
+                o[j] = k0[j] * (gj - mg[j] - (yv[j] - mu[j]) * is[j] * mx[j]);
+            }
+            const int h = 2 * a + r, w = 2 * b + c;
+            st_chunk(dy + ((size_t)(n * H + h) * W + w) * C + cb * N, Chunk<T>::pack(o));
+        }
+    }
+}
+
 inline int sgrid(size_t total) {
     size_t b = (total + 255) / 256;
     if (b > 4096) b = 4096;
@@ -513,18 +610,24 @@ int bn_relu_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, const v
     SAICV_REQUIRE(K <= 2 * stride + 1, "bn_relu_maxpool_bwd: K=%d, stride=%d: more than 2 x 2 windows cover a pixel", K, stride);
     if (hipMemsetAsync(ws, 0, 2 * (size_t)C * sizeof(float), st) != hipSuccess) { set_error("bn_relu_maxpool_bwd: memset failed"); return -1; }
     const size_t total = (size_t)Nimg * H * W * (C / n), ptotal = (size_t)Nimg * OH * OW * (C / n);
+    // the stem's own geometry: one thread per 2 x 2 pixel block (SAICV_POOL_APPLY_QUAD=0: the per-pixel form, for the A/B)
+    static const bool quad_ok = !(getenv("SAICV_POOL_APPLY_QUAD") && atoi(getenv("SAICV_POOL_APPLY_QUAD")) == 0);
+    const bool k3s2 = quad_ok && K == 3 && stride == 2 && pad == 1 && OH == (H + 1) / 2 && OW == (W + 1) / 2;
+    const size_t qtotal = (size_t)Nimg * ((H + 1) / 2) * ((W + 1) / 2) * (C / n);
     DetParts det;
     if (det.begin(st, sgrid(ptotal), (size_t)2 * C, "bn_relu_maxpool_bwd")) return -1;
     if (dtype == SAICV_DTYPE_BF16) {
         if (K == 3) hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<bf16_t, 3>), dim3(sgrid(ptotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
         else hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<bf16_t, 0>), dim3(sgrid(ptotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
         if (det.fold(ws, 0, (size_t)2 * C)) return -1;
-        hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, gamma, mean, invstd, scale, shift, ws, (bf16_t*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
+        if (k3s2) hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_k3s2_kernel<bf16_t>, dim3(sgrid(qtotal)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, gamma, mean, invstd, scale, shift, ws, (bf16_t*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW);
+        else hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, st, (const bf16_t*)dout, idx, (const bf16_t*)y, gamma, mean, invstd, scale, shift, ws, (bf16_t*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
     } else {
         if (K == 3) hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<float, 3>), dim3(sgrid(ptotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
         else hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<float, 0>), dim3(sgrid(ptotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, mean, invstd, scale, shift, ws, Nimg, H, W, C, OH, OW, K, stride, pad, det.sink());
         if (det.fold(ws, 0, (size_t)2 * C)) return -1;
-        hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, gamma, mean, invstd, scale, shift, ws, (float*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
+        if (k3s2) hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_k3s2_kernel<float>, dim3(sgrid(qtotal)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, gamma, mean, invstd, scale, shift, ws, (float*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW);
+        else hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<float>, dim3(sgrid(total)), dim3(256), 0, st, (const float*)dout, idx, (const float*)y, gamma, mean, invstd, scale, shift, ws, (float*)dy, dgamma, dbeta, accumulate, Nimg, H, W, C, OH, OW, K, stride, pad);
     }
     return check_launch("bn_relu_maxpool_bwd");
 }
