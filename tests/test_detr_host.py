@@ -196,3 +196,28 @@ def test_detr_static_shape_loss_divides_by_the_boxes_of_the_batch():
             assert np.isnan(dyn[k]) and np.isnan(sta[k]), (k, dyn[k], sta[k])
         else:
             assert abs(dyn[k] - sta[k]) <= 1e-6 * max(1.0, abs(dyn[k])), (k, dyn[k], sta[k])
+
+
+def test_layer_terms_are_the_weighted_selects_and_their_gradients():
+    """DETRLoss._layer_terms (late r06): the reference's dict of 3 L weighted scalars (losses.py:905-935) as unbind() views of three
+    weighted vectors -- the same values and the same gradients as `weight * vector[idx]` entry by entry, bit for bit."""
+    import torch
+    from simpleaicv_pytorch_training_examples_amd.SimpleAICV.detection.losses import DETRLoss
+    crit = DETRLoss(cls_loss_weight=1.0, box_l1_loss_weight=5.0, iou_loss_weight=2.0)
+    g = torch.Generator().manual_seed(3)
+    vecs = [torch.randn(6, generator=g).requires_grad_(True) for _ in range(3)]
+    ref_vecs = [v.detach().clone().requires_grad_(True) for v in vecs]
+    terms = crit._layer_terms(*vecs)
+    ref = {}
+    for idx in range(6):
+        ref[f'layer_{idx}_cls_loss'] = 1.0 * ref_vecs[0][idx]
+        ref[f'layer_{idx}_box_l1_loss'] = 5.0 * ref_vecs[1][idx]
+        ref[f'layer_{idx}_box_iou_loss'] = 2.0 * ref_vecs[2][idx]
+    assert list(terms) == list(ref)
+    coeff = torch.randn(18, generator=g)
+    torch.stack(list(terms.values())).mul(coeff).sum().backward()
+    torch.stack(list(ref.values())).mul(coeff).sum().backward()
+    for k in ref:
+        assert torch.equal(terms[k], ref[k]), k
+    for a, b in zip(vecs, ref_vecs):
+        assert torch.equal(a.grad, b.grad)
